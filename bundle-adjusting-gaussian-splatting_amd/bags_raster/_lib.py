@@ -1,0 +1,97 @@
+"""ctypes binding of libbags_raster.so (include/bags_raster.h).  No torch types cross this boundary: only raw
+device pointers (``tensor.data_ptr()``), ints and floats.  The library is built in-tree by ``__graft_entry__.build()``
+(or ``make -C csrc``); importing this module without it raises -- there is no CPU or eager fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbags_raster.so")
+
+ABI_VERSION = 1
+DEPTH_Z, DEPTH_DISTANCE = 0, 1
+
+c_fp = C.c_void_p  # device pointers travel as integers
+
+
+class BagsSettings(C.Structure):
+    _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+                ("scale_modifier", C.c_float), ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32),
+                ("depth_key", C.c_int32), ("debug", C.c_int32), ("debug_iter", C.c_int32),
+                ("bg", c_fp), ("viewmatrix", c_fp), ("projmatrix", c_fp), ("intrinsic", c_fp), ("campos", c_fp)]
+
+
+class BagsInputs(C.Structure):
+    _fields_ = [("P", C.c_int32), ("means3D", c_fp), ("means2D", c_fp), ("shift_factors", c_fp), ("shs", c_fp),
+                ("colors_precomp", c_fp), ("opacities", c_fp), ("scales", c_fp), ("rotations", c_fp),
+                ("cov3D_precomp", c_fp)]
+
+
+class BagsState(C.Structure):
+    _fields_ = [("geom", c_fp), ("geom_bytes", C.c_size_t), ("binning", c_fp), ("binning_bytes", C.c_size_t),
+                ("image", c_fp), ("image_bytes", C.c_size_t)]
+
+
+class BagsForwardOut(C.Structure):
+    _fields_ = [("color", c_fp), ("radii", c_fp), ("depth", c_fp), ("weights", c_fp), ("mean2D", c_fp)]
+
+
+class BagsBackwardArgs(C.Structure):
+    _fields_ = [("grad_color", c_fp), ("num_rendered", C.c_int64), ("workspace", c_fp), ("workspace_bytes", C.c_size_t),
+                ("grad_means3D", c_fp), ("grad_means2D", c_fp), ("grad_means2D_densify", c_fp), ("grad_shs", c_fp),
+                ("grad_colors_precomp", c_fp), ("grad_opacities", c_fp), ("grad_scales", c_fp), ("grad_rotations", c_fp),
+                ("grad_cov3D_precomp", c_fp), ("grad_viewmatrix", c_fp), ("grad_projmatrix", c_fp),
+                ("grad_intrinsic", c_fp), ("grad_campos", c_fp), ("grad_shift_factors", c_fp)]
+
+
+class BagsDebugViews(C.Structure):
+    _fields_ = [("tiles_touched", c_fp), ("rect", c_fp), ("depth_bits", c_fp), ("point_list", c_fp),
+                ("keys_sorted", c_fp), ("ranges", c_fp), ("n_contrib", c_fp), ("final_T", c_fp)]
+
+
+# every symbol include/bags_raster.h declares: (restype, argtypes)
+SYMBOLS = {
+    "bags_abi_version": (C.c_int, []),
+    "bags_last_error": (C.c_char_p, []),
+    "bags_geom_size": (C.c_size_t, [C.c_int32]),
+    "bags_binning_size": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "bags_image_size": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "bags_backward_workspace_size": (C.c_size_t, [C.c_int32, C.c_int64]),
+    "bags_forward_prepare": (C.c_int, [C.POINTER(BagsSettings), C.POINTER(BagsInputs), C.POINTER(BagsState),
+                                       C.POINTER(BagsForwardOut), C.POINTER(C.c_int64), C.c_void_p]),
+    "bags_forward_finish": (C.c_int, [C.POINTER(BagsSettings), C.POINTER(BagsInputs), C.POINTER(BagsState),
+                                      C.POINTER(BagsForwardOut), C.c_int64, C.c_void_p]),
+    "bags_backward": (C.c_int, [C.POINTER(BagsSettings), C.POINTER(BagsInputs), C.POINTER(BagsState),
+                                C.POINTER(BagsBackwardArgs), C.c_void_p]),
+    "bags_debug_views": (C.c_int, [C.POINTER(BagsSettings), C.POINTER(BagsInputs), C.POINTER(BagsState), C.c_int64,
+                                   C.POINTER(BagsDebugViews), C.c_void_p]),
+    "bags_compute_relocation": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int32, C.c_int32, c_fp, c_fp, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen the HIP library (once).  Raises if it is absent or its ABI does not match."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"bags_raster: {LIB_PATH} is missing. Build the HIP extension first "
+            f"(python -c 'import __graft_entry__ as g; g.build()' or make -C csrc). There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)           # AttributeError if the .so lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.bags_abi_version() != ABI_VERSION:
+        raise ImportError(f"bags_raster: ABI {lib.bags_abi_version()} != expected {ABI_VERSION}; rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().bags_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what}: {msg} (code {rc})")

@@ -1,0 +1,283 @@
+"""Host-side mirror of the reference's rasterizer operator (the Python half of ``diff_gaussian_rasterization``).
+
+Reference interface reproduced here (the fork's own source is absent, so the contract is its call site):
+  * ``GaussianRasterizationSettings(image_height, image_width, tanfovx, tanfovy, bg, scale_modifier, viewmatrix,
+    projmatrix, intrinsic, sh_degree, campos, prefiltered, debug, debug_iter)``   gaussian_renderer/__init__.py:50-65
+  * ``GaussianRasterizer(raster_settings)(means3D=, means2D=, means2D_densify=, shift_factors=, shs=,
+    colors_precomp=, opacities=, scales=, rotations=, cov3D_precomp=)`` -> ``(rendered_image, radii, depth, weights,
+    mean2D)``                                                                      gaussian_renderer/__init__.py:110-121
+  * gradients flow to the Gaussian parameters AND to the tensors inside the settings (viewmatrix, projmatrix,
+    intrinsic, campos) plus shift_factors: that is how train.py:472-485 optimises the camera leaves.
+
+PyTorch is plumbing only: it owns device memory and the stream.  All compute is in libbags_raster.so through the
+C ABI (``_lib``); tensors must live on the AMD GPU ("cuda" device under ROCm).  There is no CPU or eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+
+from . import _lib as L
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    intrinsic: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool = False
+    debug: bool = False
+    debug_iter: Optional[int] = None
+    depth_key: str = "z"            # "distance" replaces the README.md:126 hand-edit + recompile for cubemaps
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _f32c(t: Optional[torch.Tensor], name: str, device: torch.device, shape=None) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    if not torch.is_tensor(t):
+        raise TypeError(f"{name} must be a tensor")
+    if t.numel() == 0 and shape is None:
+        return None                       # the fork's wrapper passes torch.Tensor([]) for "absent"
+    if t.device != device:
+        raise RuntimeError(f"{name} is on {t.device}, expected {device}")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    t = t.detach()
+    if not t.is_contiguous():
+        t = t.contiguous()
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+    return t
+
+
+class _Packed:
+    """C structs + the tensors that keep their pointers alive."""
+
+    def __init__(self, settings: GaussianRasterizationSettings, means3D, means2D, shift_factors, sh, colors_precomp,
+                 opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, intrinsic, campos):
+        dev = means3D.device
+        if dev.type != "cuda":
+            raise RuntimeError("bags_raster runs only on an AMD GPU: tensors must be on a 'cuda' (ROCm) device; "
+                               "there is no CPU path")
+        P = means3D.shape[0]
+        self.device, self.P = dev, P
+        k = {}
+        k["means3D"] = _f32c(means3D, "means3D", dev, (P, 3))
+        k["means2D"] = _f32c(means2D, "means2D", dev, (P, 3)) if means2D is not None else None
+        k["shift_factors"] = _f32c(shift_factors, "shift_factors", dev, (3,)) if shift_factors is not None else None
+        k["shs"] = _f32c(sh, "shs", dev)
+        k["colors_precomp"] = _f32c(colors_precomp, "colors_precomp", dev)
+        k["opacities"] = _f32c(opacities, "opacities", dev)
+        k["scales"] = _f32c(scales, "scales", dev)
+        k["rotations"] = _f32c(rotations, "rotations", dev)
+        k["cov3D_precomp"] = _f32c(cov3D_precomp, "cov3D_precomp", dev)
+        if (k["shs"] is None) == (k["colors_precomp"] is None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((k["scales"] is None or k["rotations"] is None) and k["cov3D_precomp"] is None) or \
+                ((k["scales"] is not None or k["rotations"] is not None) and k["cov3D_precomp"] is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        M = 0
+        if k["shs"] is not None:
+            if k["shs"].dim() != 3 or k["shs"].shape[0] != P or k["shs"].shape[2] != 3:
+                raise ValueError(f"shs must be (P,M,3), got {tuple(k['shs'].shape)}")
+            M = k["shs"].shape[1]
+        if k["colors_precomp"] is not None and tuple(k["colors_precomp"].shape) != (P, 3):
+            raise ValueError("colors_precomp must be (P,3)")
+        if k["opacities"] is None or k["opacities"].numel() != P:
+            raise ValueError("opacities must be (P,1)")
+        for nm, n in (("scales", 3), ("rotations", 4), ("cov3D_precomp", 6)):
+            if k[nm] is not None and tuple(k[nm].shape) != (P, n):
+                raise ValueError(f"{nm} must be (P,{n})")
+        k["bg"] = _f32c(settings.bg, "bg", dev, (3,))
+        k["viewmatrix"] = _f32c(viewmatrix, "viewmatrix", dev, (4, 4))
+        k["projmatrix"] = _f32c(projmatrix, "projmatrix", dev, (4, 4))
+        k["intrinsic"] = _f32c(intrinsic, "intrinsic", dev, (4, 4))
+        k["campos"] = _f32c(campos.reshape(3), "campos", dev, (3,))
+        self.keep = k
+        self.M = M
+        if settings.depth_key not in ("z", "distance"):
+            raise ValueError("depth_key must be 'z' or 'distance'")
+        self.settings = L.BagsSettings(
+            int(settings.image_height), int(settings.image_width), float(settings.tanfovx), float(settings.tanfovy),
+            float(settings.scale_modifier), int(settings.sh_degree), int(M),
+            L.DEPTH_DISTANCE if settings.depth_key == "distance" else L.DEPTH_Z, int(bool(settings.debug)),
+            int(settings.debug_iter) if settings.debug_iter is not None else -1,
+            _ptr(k["bg"]), _ptr(k["viewmatrix"]), _ptr(k["projmatrix"]), _ptr(k["intrinsic"]), _ptr(k["campos"]))
+        self.inputs = L.BagsInputs(P, _ptr(k["means3D"]), _ptr(k["means2D"]), _ptr(k["shift_factors"]), _ptr(k["shs"]),
+                                   _ptr(k["colors_precomp"]), _ptr(k["opacities"]), _ptr(k["scales"]),
+                                   _ptr(k["rotations"]), _ptr(k["cov3D_precomp"]))
+
+
+def _bytes(n: int, device) -> torch.Tensor:
+    return torch.empty(int(n), dtype=torch.uint8, device=device)
+
+
+class _Forwarded:
+    """Everything backward (and the parity tests) need from one forward call."""
+    __slots__ = ("packed", "geom", "binning", "image", "num_rendered", "H", "W")
+
+
+def _run_forward(lib, pk: _Packed, H: int, W: int):
+    dev, P = pk.device, pk.P
+    fw = _Forwarded()
+    fw.packed, fw.H, fw.W = pk, H, W
+    fw.geom = _bytes(lib.bags_geom_size(P), dev)
+    fw.image = _bytes(lib.bags_image_size(W, H), dev)
+    color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+    depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+    weights = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+    radii = torch.empty(P, dtype=torch.int32, device=dev)
+    mean2D = torch.empty(P, 2, dtype=torch.float32, device=dev)
+    out = L.BagsForwardOut(color.data_ptr(), radii.data_ptr(), depth.data_ptr(), weights.data_ptr(), mean2D.data_ptr())
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    state = L.BagsState(fw.geom.data_ptr(), fw.geom.numel(), None, 0, fw.image.data_ptr(), fw.image.numel())
+    n = C.c_int64(0)
+    L.check(lib.bags_forward_prepare(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(out),
+                                     C.byref(n), stream), "bags_forward_prepare")
+    fw.num_rendered = int(n.value)
+    fw.binning = _bytes(lib.bags_binning_size(fw.num_rendered, W, H), dev)
+    state.binning, state.binning_bytes = fw.binning.data_ptr(), fw.binning.numel()
+    L.check(lib.bags_forward_finish(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(out),
+                                    fw.num_rendered, stream), "bags_forward_finish")
+    return fw, (color, radii, depth, weights, mean2D)
+
+
+def _state_of(fw: _Forwarded) -> L.BagsState:
+    return L.BagsState(fw.geom.data_ptr(), fw.geom.numel(), fw.binning.data_ptr(), fw.binning.numel(),
+                       fw.image.data_ptr(), fw.image.numel())
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, means2D_densify, shift_factors, sh, colors_precomp, opacities, scales, rotations,
+                cov3Ds_precomp, viewmatrix, projmatrix, intrinsic, campos, raster_settings):
+        lib = L.load()
+        with torch.cuda.device(means3D.device):
+            pk = _Packed(raster_settings, means3D, means2D, shift_factors, sh, colors_precomp, opacities, scales,
+                         rotations, cov3Ds_precomp, viewmatrix, projmatrix, intrinsic, campos)
+            fw, outs = _run_forward(lib, pk, int(raster_settings.image_height), int(raster_settings.image_width))
+        ctx.fw = fw
+        ctx.shapes = dict(sh=None if sh is None else sh.shape, opac=opacities.shape, campos=campos.shape)
+        color, radii, depth, weights, mean2D = outs
+        ctx.mark_non_differentiable(radii, depth, weights, mean2D)
+        return color, radii, depth, weights, mean2D
+
+    @staticmethod
+    def backward(ctx, grad_color, _g_radii, _g_depth, _g_weights, _g_mean2D):
+        lib = L.load()
+        fw: _Forwarded = ctx.fw
+        pk, dev, P = fw.packed, fw.packed.device, fw.packed.P
+        need = ctx.needs_input_grad
+        with torch.cuda.device(dev):
+            gc = grad_color.detach()
+            if gc.dtype != torch.float32 or not gc.is_contiguous():
+                gc = gc.to(torch.float32).contiguous()
+
+            def new(shape, flag):
+                return torch.empty(shape, dtype=torch.float32, device=dev) if flag else None
+            k = pk.keep
+            g_means3D = new((P, 3), need[0])
+            g_means2D = new((P, 3), need[1])
+            g_densify = new((P, 3), need[2])
+            g_shift = new((3,), need[3])
+            g_sh = new(ctx.shapes["sh"], need[4] and k["shs"] is not None)
+            g_col = new((P, 3), need[5] and k["colors_precomp"] is not None)
+            g_opac = new(ctx.shapes["opac"], need[6])
+            g_scales = new((P, 3), need[7] and k["scales"] is not None)
+            g_rot = new((P, 4), need[8] and k["rotations"] is not None)
+            g_cov = new((P, 6), need[9] and k["cov3D_precomp"] is not None)
+            g_view = new((4, 4), need[10])
+            g_proj = new((4, 4), need[11])
+            g_intr = new((4, 4), need[12])
+            g_campos = new((3,), need[13])
+            ws = _bytes(lib.bags_backward_workspace_size(P, fw.num_rendered), dev)
+            args = L.BagsBackwardArgs(gc.data_ptr(), fw.num_rendered, ws.data_ptr(), ws.numel(), _ptr(g_means3D),
+                                      _ptr(g_means2D), _ptr(g_densify), _ptr(g_sh), _ptr(g_col), _ptr(g_opac),
+                                      _ptr(g_scales), _ptr(g_rot), _ptr(g_cov), _ptr(g_view), _ptr(g_proj),
+                                      _ptr(g_intr), _ptr(g_campos), _ptr(g_shift))
+            state = _state_of(fw)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            L.check(lib.bags_backward(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(args), stream),
+                    "bags_backward")
+        if g_campos is not None:
+            g_campos = g_campos.reshape(ctx.shapes["campos"])
+        return (g_means3D, g_means2D, g_densify, g_shift, g_sh, g_col, g_opac, g_scales, g_rot, g_cov, g_view, g_proj,
+                g_intr, g_campos, None)
+
+
+def rasterize_gaussians(means3D, means2D, means2D_densify, shift_factors, sh, colors_precomp, opacities, scales,
+                        rotations, cov3Ds_precomp, raster_settings: GaussianRasterizationSettings):
+    return _RasterizeGaussians.apply(means3D, means2D, means2D_densify, shift_factors, sh, colors_precomp, opacities,
+                                     scales, rotations, cov3Ds_precomp, raster_settings.viewmatrix,
+                                     raster_settings.projmatrix, raster_settings.intrinsic, raster_settings.campos,
+                                     raster_settings)
+
+
+class GaussianRasterizer(torch.nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """Near-plane frustum test of the stock package (p_view.z > 0.2)."""
+        with torch.no_grad():
+            v = self.raster_settings.viewmatrix
+            z = positions[:, 0] * v[0, 2] + positions[:, 1] * v[1, 2] + positions[:, 2] * v[2, 2] + v[3, 2]
+            return z > 0.2
+
+    def forward(self, means3D, means2D, opacities, means2D_densify=None, shift_factors=None, shs=None,
+                colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        return rasterize_gaussians(means3D, means2D, means2D_densify, shift_factors, shs, colors_precomp, opacities,
+                                   scales, rotations, cov3D_precomp, rs)
+
+
+def debug_views(settings: GaussianRasterizationSettings, means3D, means2D, shift_factors, shs, colors_precomp,
+                opacities, scales, rotations, cov3D_precomp):
+    """Forward pass that also returns the integer artefacts (tiles_touched, rect, depth bits, sorted instance list,
+    64-bit keys, tile ranges, n_contrib, final_T) for the bit-exact parity tests."""
+    lib = L.load()
+    dev = means3D.device
+    with torch.cuda.device(dev), torch.no_grad():
+        pk = _Packed(settings, means3D, means2D, shift_factors, shs, colors_precomp, opacities, scales, rotations,
+                     cov3D_precomp, settings.viewmatrix, settings.projmatrix, settings.intrinsic, settings.campos)
+        H, W = int(settings.image_height), int(settings.image_width)
+        fw, outs = _run_forward(lib, pk, H, W)
+        P, I = pk.P, fw.num_rendered
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        i32 = lambda *s: torch.empty(*s, dtype=torch.int32, device=dev)
+        v = dict(tiles_touched=i32(P), rect=i32(P, 4), depth_bits=i32(P), point_list=i32(max(I, 1)),
+                 keys_sorted=torch.empty(max(I, 1), dtype=torch.int64, device=dev), ranges=i32(T, 2),
+                 n_contrib=i32(H, W), final_T=torch.empty(H, W, dtype=torch.float32, device=dev))
+        views = L.BagsDebugViews(*[v[n].data_ptr() for n in ("tiles_touched", "rect", "depth_bits", "point_list",
+                                                             "keys_sorted", "ranges", "n_contrib", "final_T")])
+        state = _state_of(fw)
+        L.check(lib.bags_debug_views(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), I, C.byref(views),
+                                     torch.cuda.current_stream(dev).cuda_stream), "bags_debug_views")
+        v["point_list"], v["keys_sorted"] = v["point_list"][:I], v["keys_sorted"][:I]
+        v["num_rendered"] = I
+        v["outputs"] = outs
+    return v
+
+
+def compute_relocation(opacity_old, scale_old, N, binoms, n_max):
+    """utils/reloc_utils.py:11-13.  The reference's only caller is commented out (scene/gaussian_model.py:23,494-504)."""
+    raise NotImplementedError("compute_relocation is not part of the accelerated path (MCMC relocation is disabled in the reference)")

@@ -1,0 +1,246 @@
+// api.hip -- the extern "C" surface of libbags_raster.so (include/bags_raster.h) and the state-buffer layout.
+#include "bags_common.h"
+#include <stdio.h>
+#include <string.h>
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...)
+{
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do { hipError_t e_ = (expr);                                                                        \
+         if (e_ != hipSuccess) return fail(BAGS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// after a launcher when settings.debug is on: drain the stream so a faulting kernel is attributed correctly
+#define DEBUG_SYNC(s, st, what)                                                                         \
+    do { if ((s)->debug) { hipError_t e_ = hipStreamSynchronize(st);                                    \
+         if (e_ != hipSuccess) return fail(BAGS_ERR_HIP, "debug: %s failed at iteration %d: %s", what, (s)->debug_iter, hipGetErrorString(e_)); } \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------- buffer carving
+template <typename Tp>
+static inline void take(char*& p, Tp*& out, size_t count)
+{
+    out = reinterpret_cast<Tp*>(p);
+    p += align_up(count * sizeof(Tp), 256);
+}
+
+size_t carve_geom(void* base, int P, GeomView* v)
+{
+    char* p = reinterpret_cast<char*>(base);
+    GeomView g;
+    const size_t n = (size_t)(P > 0 ? P : 1);
+    g.nblocks_sort = cdiv((long long)n, SORT_TILE);
+    g.nblocks_scan = cdiv((long long)n, SCAN_TILE);
+    take(p, g.depth_key, n); take(p, g.xy, n); take(p, g.conic_opacity, n); take(p, g.rgbz, n); take(p, g.rect, n);
+    take(p, g.tiles_touched, n); take(p, g.inst_offset, n); take(p, g.clamped, n);
+    take(p, g.keys_a, n); take(p, g.keys_b, n); take(p, g.vals_a, n); take(p, g.vals_b, n);
+    take(p, g.rank_offset, n);
+    take(p, g.scan_partials, (size_t)g.nblocks_scan + 1);
+    take(p, g.radix_hist, (size_t)RADIX_BINS * g.nblocks_sort);
+    take(p, g.digit_totals, RADIX_BINS);
+    take(p, g.num_rendered, 64);
+    if (v) *v = g;
+    return (size_t)(p - reinterpret_cast<char*>(base));
+}
+
+static int tile_passes(int T) { return (bit_length((u32)(T > 1 ? T - 1 : 1)) + RADIX_BITS - 1) / RADIX_BITS; }
+
+size_t carve_binning(void* base, long long I, int W, int H, BinView* v)
+{
+    char* p = reinterpret_cast<char*>(base);
+    BinView b;
+    const size_t n = (size_t)(I > 0 ? I : 1);
+    const int T = cdiv(W, BAGS_TILE) * cdiv(H, BAGS_TILE);
+    b.nblocks_sort = cdiv((long long)n, SORT_TILE);
+    b.passes = tile_passes(T);
+    take(p, b.keys_a, n); take(p, b.vals_a, n); take(p, b.keys_b, n); take(p, b.vals_b, n);
+    take(p, b.ranges, (size_t)(T > 0 ? T : 1));
+    take(p, b.radix_hist, (size_t)RADIX_BINS * b.nblocks_sort);
+    take(p, b.digit_totals, RADIX_BINS);
+    // emission writes the *_b half; pass 0: b -> a, pass 1: a -> b, ...
+    b.point_list = (b.passes & 1) ? b.vals_a : b.vals_b;
+    b.tile_sorted = (b.passes & 1) ? b.keys_a : b.keys_b;
+    if (v) *v = b;
+    return (size_t)(p - reinterpret_cast<char*>(base));
+}
+
+size_t carve_image(void* base, int W, int H, ImgView* v)
+{
+    char* p = reinterpret_cast<char*>(base);
+    ImgView im;
+    const size_t n = (size_t)W * H > 0 ? (size_t)W * H : 1;
+    take(p, im.final_T, n); take(p, im.n_contrib, n);
+    if (v) *v = im;
+    return (size_t)(p - reinterpret_cast<char*>(base));
+}
+
+// ---------------------------------------------------------------------------------------------- validation
+static int check_common(const BagsSettings* s, const BagsInputs* in, const BagsState* stt)
+{
+    if (!s || !in || !stt) return fail(BAGS_ERR_ARG, "null argument struct");
+    if (in->P < 0) return fail(BAGS_ERR_ARG, "P < 0");
+    if (s->image_width <= 0 || s->image_height <= 0) return fail(BAGS_ERR_ARG, "empty image %dx%d", s->image_width, s->image_height);
+    if (cdiv(s->image_width, BAGS_TILE) > 65535 || cdiv(s->image_height, BAGS_TILE) > 65535)
+        return fail(BAGS_ERR_ARG, "image too large for 16-bit tile coordinates");
+    if (s->sh_degree < 0 || s->sh_degree > 3) return fail(BAGS_ERR_ARG, "sh_degree %d not in 0..3", s->sh_degree);
+    if (!s->bg || !s->viewmatrix || !s->projmatrix || !s->intrinsic || !s->campos)
+        return fail(BAGS_ERR_ARG, "bg/viewmatrix/projmatrix/intrinsic/campos must be given");
+    if (in->P > 0) {
+        if (!in->means3D || !in->opacities) return fail(BAGS_ERR_ARG, "means3D/opacities must be given");
+        if ((in->shs != nullptr) == (in->colors_precomp != nullptr))
+            return fail(BAGS_ERR_ARG, "Please provide excatly one of either SHs or precomputed colors!");
+        const bool sr = in->scales && in->rotations;
+        if ((in->scales != nullptr) != (in->rotations != nullptr) || sr == (in->cov3D_precomp != nullptr))
+            return fail(BAGS_ERR_ARG, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+        if (in->shs && (s->sh_degree + 1) * (s->sh_degree + 1) > s->sh_coeffs)
+            return fail(BAGS_ERR_ARG, "sh_degree %d needs %d coefficients, shs holds %d", s->sh_degree,
+                        (s->sh_degree + 1) * (s->sh_degree + 1), s->sh_coeffs);
+    }
+    if (!stt->geom || stt->geom_bytes < bags_geom_size(in->P)) return fail(BAGS_ERR_SIZE, "geom buffer too small");
+    if (!stt->image || stt->image_bytes < bags_image_size(s->image_width, s->image_height))
+        return fail(BAGS_ERR_SIZE, "image buffer too small");
+    return BAGS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- C ABI
+extern "C" {
+
+int bags_abi_version(void) { return BAGS_ABI_VERSION; }
+const char* bags_last_error(void) { return g_err; }
+
+size_t bags_geom_size(int32_t P) { return carve_geom(nullptr, P, nullptr) + 256; }
+size_t bags_binning_size(int64_t I, int32_t W, int32_t H) { return carve_binning(nullptr, I, W, H, nullptr) + 256; }
+size_t bags_image_size(int32_t W, int32_t H) { return carve_image(nullptr, W, H, nullptr) + 256; }
+size_t bags_backward_workspace_size(int32_t P, int64_t I)
+{
+    const size_t part = align_up((size_t)(I > 0 ? I : 1) * PART_FLOATS * sizeof(float), 256);
+    const size_t slab = align_up((size_t)(cdiv(P > 0 ? P : 1, 256)) * POSE_VALS * sizeof(float), 256);
+    return part + slab + 256;
+}
+
+static inline void* align256(void* p) { return reinterpret_cast<void*>(align_up(reinterpret_cast<size_t>(p), 256)); }
+
+int bags_forward_prepare(const BagsSettings* s, const BagsInputs* in, const BagsState* stt, const BagsForwardOut* out,
+                         int64_t* host_num_rendered, void* stream)
+{
+    int rc = check_common(s, in, stt);
+    if (rc) return rc;
+    if (!out || !out->radii || !host_num_rendered) return fail(BAGS_ERR_ARG, "radii / host_num_rendered must be given");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    GeomView g; carve_geom(align256(stt->geom), in->P, &g);
+    *host_num_rendered = 0;
+    if (in->P == 0) return BAGS_OK;
+    HIP_TRY(launch_preprocess_fwd(*s, *in, g, out->radii, out->mean2D, st));
+    DEBUG_SYNC(s, st, "preprocess_fwd");
+    // depth order of the Gaussians: 4 stable 8-bit passes over the float bits (positive floats order like u32)
+    HIP_TRY(launch_radix_sort(g.depth_key, nullptr, g.keys_a, g.vals_a, g.keys_b, g.vals_b, in->P, 32, true,
+                              g.radix_hist, g.digit_totals, g.nblocks_sort, st));
+    DEBUG_SYNC(s, st, "depth sort");
+    const u32* sorted_ids = g.vals_b;                     // 4 passes: src->a->b->a->b
+    HIP_TRY(launch_offsets_scan(g, sorted_ids, in->P, st));
+    DEBUG_SYNC(s, st, "offsets scan");
+    u32 host_I = 0;
+    HIP_TRY(hipMemcpyAsync(&host_I, g.num_rendered, sizeof(u32), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *host_num_rendered = (int64_t)host_I;
+    return BAGS_OK;
+}
+
+int bags_forward_finish(const BagsSettings* s, const BagsInputs* in, const BagsState* stt, const BagsForwardOut* out,
+                        int64_t I, void* stream)
+{
+    int rc = check_common(s, in, stt);
+    if (rc) return rc;
+    if (!out || !out->color) return fail(BAGS_ERR_ARG, "color output must be given");
+    if (I < 0 || I > 0xFFFFFFF0ll) return fail(BAGS_ERR_ARG, "num_rendered out of range");
+    const int W = s->image_width, H = s->image_height;
+    if (!stt->binning || stt->binning_bytes < bags_binning_size(I, W, H)) return fail(BAGS_ERR_SIZE, "binning buffer too small");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    GeomView g; carve_geom(align256(stt->geom), in->P, &g);
+    BinView b; carve_binning(align256(stt->binning), I, W, H, &b);
+    ImgView im; carve_image(align256(stt->image), W, H, &im);
+    const int gx = cdiv(W, BAGS_TILE), gy = cdiv(H, BAGS_TILE);
+    if (I > 0) {
+        HIP_TRY(launch_emit(g, g.vals_b, in->P, gx, b.keys_b, b.vals_b, st));
+        DEBUG_SYNC(s, st, "emit");
+        HIP_TRY(launch_radix_sort(b.keys_b, b.vals_b, b.keys_a, b.vals_a, b.keys_b, b.vals_b, I, b.passes * RADIX_BITS,
+                                  false, b.radix_hist, b.digit_totals, b.nblocks_sort, st));
+        DEBUG_SYNC(s, st, "tile sort");
+    }
+    HIP_TRY(launch_tile_ranges(b.tile_sorted, I, b.ranges, gx * gy, st));
+    DEBUG_SYNC(s, st, "tile ranges");
+    HIP_TRY(launch_blend_fwd(*s, g, b, im, *out, st));
+    DEBUG_SYNC(s, st, "blend_fwd");
+    return BAGS_OK;
+}
+
+int bags_backward(const BagsSettings* s, const BagsInputs* in, const BagsState* stt, const BagsBackwardArgs* a, void* stream)
+{
+    int rc = check_common(s, in, stt);
+    if (rc) return rc;
+    if (!a || !a->grad_color) return fail(BAGS_ERR_ARG, "grad_color must be given");
+    const int W = s->image_width, H = s->image_height;
+    const int64_t I = a->num_rendered;
+    if (I < 0) return fail(BAGS_ERR_ARG, "num_rendered < 0");
+    if (!stt->binning || stt->binning_bytes < bags_binning_size(I, W, H)) return fail(BAGS_ERR_SIZE, "binning buffer too small");
+    if (!a->workspace || a->workspace_bytes < bags_backward_workspace_size(in->P, I)) return fail(BAGS_ERR_SIZE, "backward workspace too small");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    GeomView g; carve_geom(align256(stt->geom), in->P, &g);
+    BinView b; carve_binning(align256(stt->binning), I, W, H, &b);
+    ImgView im; carve_image(align256(stt->image), W, H, &im);
+    char* ws = reinterpret_cast<char*>(align256(a->workspace));
+    float* partials = reinterpret_cast<float*>(ws);
+    float* slab = reinterpret_cast<float*>(ws + align_up((size_t)(I > 0 ? I : 1) * PART_FLOATS * sizeof(float), 256));
+    if (I > 0) {
+        HIP_TRY(launch_blend_bwd(*s, g, b, im, a->grad_color, partials, st));
+        DEBUG_SYNC(s, st, "blend_bwd");
+    }
+    int nblocks = 0;
+    HIP_TRY(launch_preprocess_bwd(*s, *in, g, nullptr, partials, slab, &nblocks, *a, st));
+    DEBUG_SYNC(s, st, "preprocess_bwd");
+    HIP_TRY(launch_pose_reduce(slab, nblocks, *a, st));
+    DEBUG_SYNC(s, st, "pose_reduce");
+    return BAGS_OK;
+}
+
+int bags_debug_views(const BagsSettings* s, const BagsInputs* in, const BagsState* stt, int64_t I,
+                     const BagsDebugViews* d, void* stream)
+{
+    int rc = check_common(s, in, stt);
+    if (rc) return rc;
+    if (!d) return fail(BAGS_ERR_ARG, "null views");
+    const int W = s->image_width, H = s->image_height;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    GeomView g; carve_geom(align256(stt->geom), in->P, &g);
+    ImgView im; carve_image(align256(stt->image), W, H, &im);
+    const size_t P = (size_t)in->P, T = (size_t)cdiv(W, BAGS_TILE) * cdiv(H, BAGS_TILE);
+    if (d->tiles_touched && P) HIP_TRY(hipMemcpyAsync(d->tiles_touched, g.tiles_touched, P * 4, hipMemcpyDeviceToDevice, st));
+    if (d->depth_bits && P) HIP_TRY(hipMemcpyAsync(d->depth_bits, g.depth_key, P * 4, hipMemcpyDeviceToDevice, st));
+    if (d->rect && P) HIP_TRY(launch_unpack_rect(g.rect, in->P, d->rect, st));
+    if (d->n_contrib) HIP_TRY(hipMemcpyAsync(d->n_contrib, im.n_contrib, (size_t)W * H * 4, hipMemcpyDeviceToDevice, st));
+    if (d->final_T) HIP_TRY(hipMemcpyAsync(d->final_T, im.final_T, (size_t)W * H * 4, hipMemcpyDeviceToDevice, st));
+    if (d->point_list || d->keys_sorted || d->ranges) {
+        if (!stt->binning || stt->binning_bytes < bags_binning_size(I, W, H)) return fail(BAGS_ERR_SIZE, "binning buffer too small");
+        BinView b; carve_binning(align256(stt->binning), I, W, H, &b);
+        if (d->point_list && I) HIP_TRY(hipMemcpyAsync(d->point_list, b.point_list, (size_t)I * 4, hipMemcpyDeviceToDevice, st));
+        if (d->keys_sorted && I) HIP_TRY(launch_debug_keys(b.tile_sorted, b.point_list, g.depth_key, I, d->keys_sorted, st));
+        if (d->ranges) HIP_TRY(hipMemcpyAsync(d->ranges, b.ranges, T * 8, hipMemcpyDeviceToDevice, st));
+    }
+    return BAGS_OK;
+}
+
+int bags_compute_relocation(const float*, const float*, const int32_t*, const float*, int32_t, int32_t, float*, float*, void*)
+{
+    return fail(BAGS_ERR_ARG, "compute_relocation: the reference's only caller is commented out (scene/gaussian_model.py:23,494-504); not implemented");
+}
+
+}  // extern "C"

@@ -1,0 +1,83 @@
+// Shared host/device declarations of libbags_raster.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/bags_raster.h"
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define BAGS_WAVE 64
+#define RADIX_BITS 8
+#define RADIX_BINS 256
+#define SORT_BLOCK 256
+#define SORT_ITEMS 16                     // keys per thread per radix pass
+#define SORT_TILE (SORT_BLOCK * SORT_ITEMS)   // 4096 keys per workgroup
+#define SCAN_BLOCK 256
+#define SCAN_ITEMS 8
+#define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)   // 2048 offsets per workgroup
+#define PART_FLOATS 16                    // one 64-byte partial-gradient record per sorted instance
+#define POSE_VALS 40                      // pose-gradient slab row (35 used)
+#define KEY_CULLED 0xFFFFFFFFu
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline int bit_length(u32 v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
+
+// ---- carved views of the three caller-owned state buffers -------------------------------------------------
+struct GeomView {            // per Gaussian, indexed by Gaussian id unless stated
+    u32*    depth_key;       // float bits of the sort depth, KEY_CULLED when not rendered
+    float2* xy;              // pixel centre
+    float4* conic_opacity;   // conic a,b,c + opacity
+    float4* rgbz;            // colour after clamp + view depth z
+    uint2*  rect;            // (minx | miny<<16, maxx | maxy<<16), max exclusive
+    u32*    tiles_touched;
+    u32*    inst_offset;     // first emission index of the Gaussian's instances
+    u32*    clamped;         // bit c set: SH colour channel c was clamped at 0
+    // scratch (dead after forward)
+    u32 *keys_a, *keys_b, *vals_a, *vals_b;   // depth ordering of Gaussians (ping-pong)
+    u32*    rank_offset;     // exclusive instance offset per depth rank
+    u32*    scan_partials;
+    u32*    radix_hist;      // [256][nblocks]
+    u32*    digit_totals;    // [256]
+    u32*    num_rendered;    // [1] (+ pad)
+    int     nblocks_sort;    // radix workgroups for P keys
+    int     nblocks_scan;
+};
+struct BinView {
+    u32 *keys_a, *keys_b, *vals_a, *vals_b;   // tile id / Gaussian id per instance (ping-pong)
+    uint2*  ranges;          // [T]
+    u32*    radix_hist;
+    u32*    digit_totals;
+    int     nblocks_sort;
+    int     passes;          // radix passes over the tile id
+    u32*    point_list;      // vals after the last pass
+    u32*    tile_sorted;     // keys after the last pass
+};
+struct ImgView {
+    float* final_T;          // [H*W]
+    u32*   n_contrib;        // [H*W]
+};
+
+size_t carve_geom(void* base, int P, GeomView* v);
+size_t carve_binning(void* base, long long I, int W, int H, BinView* v);
+size_t carve_image(void* base, int W, int H, ImgView* v);
+
+// ---- launchers (each enqueues on `st`; returns hipError_t) --------------------------------------------------
+hipError_t launch_preprocess_fwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, int32_t* radii,
+                                 float* mean2D, hipStream_t st);
+hipError_t launch_radix_sort(const u32* src_k, const u32* src_v, u32* a_k, u32* a_v, u32* b_k, u32* b_v, long long n,
+                             int bits, bool iota_vals, u32* hist, u32* totals, int nblocks, hipStream_t st);
+hipError_t launch_offsets_scan(const GeomView& g, const u32* sorted_ids, int P, hipStream_t st);
+hipError_t launch_emit(const GeomView& g, const u32* sorted_ids, int P, int grid_x, u32* keys, u32* vals, hipStream_t st);
+hipError_t launch_tile_ranges(const u32* tile_sorted, long long I, uint2* ranges, int T, hipStream_t st);
+hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
+                            const BagsForwardOut& out, hipStream_t st);
+hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
+                            const float* grad_color, float* partials, hipStream_t st);
+hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, const int32_t* radii_or_null,
+                                 const float* partials, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a, hipStream_t st);
+hipError_t launch_pose_reduce(const float* pose_slab, int nblocks, const BagsBackwardArgs& a, hipStream_t st);
+hipError_t launch_debug_keys(const u32* tile_sorted, const u32* point_list, const u32* depth_key, long long I, u64* out, hipStream_t st);
+hipError_t launch_unpack_rect(const uint2* rect, int P, u32* out, hipStream_t st);

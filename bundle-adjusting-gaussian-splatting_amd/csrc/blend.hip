@@ -1,0 +1,365 @@
+// blend.hip -- K6 / K7: front-to-back alpha compositing and its backward.
+//
+// MI355X mapping (not the CUDA "256 threads = 256 pixels" layout):
+//   * ONE wave64 per 16x16 tile; lane l owns FOUR pixels, one in each 8x8 quadrant, at (l&7, l>>3) inside the
+//     quadrant.  No workgroup barriers, no cross-wave reduction.
+//   * the tile's depth-ordered splat list is staged 64 at a time: every lane gathers one splat (id -> xy, conic,
+//     opacity, colour), derives which quadrants the splat's alpha >= 1/255 ellipse can reach, and the batch is
+//     ballot-compacted into LDS.  The inner loop then reads a splat as an LDS broadcast and skips whole quadrants
+//     with scalar branches.  Skipped pairs are exactly those the per-pixel test (alpha < 1/255) would reject, so the
+//     image is unchanged.
+//   * backward walks the list back to front with the same per-pixel recurrence as the reference design but never
+//     issues a global atomic: the 256 pixel contributions to one splat are summed in-lane (4 pixels), then across
+//     the wave with a transposed butterfly (17 shuffles for 11 sums), and written as ONE 64-byte record per sorted
+//     instance at the instance's emission slot.  preprocess_bwd sums each Gaussian's consecutive records: the
+//     result is bitwise reproducible.
+#include "bags_common.h"
+
+#define LOG2E 1.4426950408889634f
+#define ALPHA_MIN (1.0f / 255.0f)
+#define T_EPS 0.0001f
+
+struct __attribute__((aligned(16))) SplatRec {
+    float x, y, ap, bp;       // centre, pre-scaled conic: exp2(ap dx^2 + bp dx dy + cp dy^2) == exp(power)
+    float cp, o, r, g;
+    float b, z; u32 mask; u32 pos;   // mask: quadrants reachable; pos: 1-based position in the tile list
+};
+
+__device__ __forceinline__ int tile_of_block(int b, int T)
+{   // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous band of tiles so that
+    // neighbouring tiles, which share splats, hit the same L2.  Placement only affects speed.
+    const int chunk = (T + 7) / 8;
+    return (b & 7) * chunk + (b >> 3);
+}
+
+// quadrants of the tile whose pixels can reach alpha >= 1/255 for this splat (conservative)
+__device__ __forceinline__ u32 quadrant_mask(float x, float y, float a, float b, float c, float o, float X0, float Y0)
+{
+    const float vis = 255.0f * o;
+    if (!(vis >= 0.99f)) return 0u;
+    const float det = a * c - b * b;
+    if (!(det > 0.f) || !(a > 0.f) || !(c > 0.f)) return 0xFu;
+    const float tau2 = 2.0f * (fmaxf(__logf(vis), 0.f) + 1e-3f);
+    const float idet = 1.0f / det;
+    const float hx = sqrtf(tau2 * c * idet) * 1.001f + 0.05f;
+    const float hy = sqrtf(tau2 * a * idet) * 1.001f + 0.05f;
+    u32 m = 0;
+    const bool xl = (x + hx >= X0) && (x - hx <= X0 + 7.f);
+    const bool xr = (x + hx >= X0 + 8.f) && (x - hx <= X0 + 15.f);
+    const bool yt = (y + hy >= Y0) && (y - hy <= Y0 + 7.f);
+    const bool yb = (y + hy >= Y0 + 8.f) && (y - hy <= Y0 + 15.f);
+    if (xl && yt) m |= 1u;
+    if (xr && yt) m |= 2u;
+    if (xl && yb) m |= 4u;
+    if (xr && yb) m |= 8u;
+    return m;
+}
+
+// exp(power) for one (pixel, splat) pair: the SAME instruction sequence in forward and backward so both make the
+// same contribute / skip decision.
+__device__ __forceinline__ float pair_power2(float dx, float dy, float ap, float bp, float cp)
+{
+    const float t = __fmaf_rn(bp, dy, __fmul_rn(ap, dx));
+    const float u = __fmul_rn(__fmul_rn(cp, dy), dy);
+    return __fmaf_rn(dx, t, u);
+}
+
+__global__ void __launch_bounds__(64)
+blend_fwd_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ ranges, const u32* __restrict__ point_list,
+                 const float2* __restrict__ xy, const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbz,
+                 const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
+                 float* __restrict__ out_weights, float* __restrict__ final_T, u32* __restrict__ n_contrib)
+{
+    const int tile = tile_of_block(blockIdx.x, T);
+    if (tile >= T) return;
+    const int lane = threadIdx.x;
+    const int tile_x = tile % grid_x, tile_y = tile / grid_x;
+    const float X0 = (float)(tile_x * BAGS_TILE), Y0 = (float)(tile_y * BAGS_TILE);
+    const uint2 range = ranges[tile];
+
+    __shared__ SplatRec recs[64];
+
+    float pxf[4], pyf[4], Tq[4], Cr[4], Cg[4], Cb[4], Dq[4];
+    u32 last[4];
+    bool done[4], inside[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int px = tile_x * BAGS_TILE + (q & 1) * 8 + (lane & 7);
+        const int py = tile_y * BAGS_TILE + (q >> 1) * 8 + (lane >> 3);
+        pxf[q] = (float)px; pyf[q] = (float)py;
+        inside[q] = (px < W) && (py < H);
+        done[q] = !inside[q];
+        Tq[q] = 1.f; Cr[q] = Cg[q] = Cb[q] = Dq[q] = 0.f; last[q] = 0;
+    }
+    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+    for (u32 base = range.x; base < range.y; base += 64) {
+        // which quadrants still have live pixels (wave-uniform)
+        u32 live = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (__ballot(!done[q]) != 0ull) live |= (1u << q);
+        if (live == 0) break;
+        // ---- stage up to 64 splats
+        const u32 idx = base + lane;
+        SplatRec rec; rec.mask = 0;
+        if (idx < range.y) {
+            const u32 g = point_list[idx];
+            const float2 c2 = xy[g];
+            const float4 co = conic_opacity[g];
+            const float4 cz = rgbz[g];
+            rec.x = c2.x; rec.y = c2.y;
+            rec.ap = -0.5f * LOG2E * co.x; rec.bp = -LOG2E * co.y; rec.cp = -0.5f * LOG2E * co.z; rec.o = co.w;
+            rec.r = cz.x; rec.g = cz.y; rec.b = cz.z; rec.z = cz.w;
+            rec.pos = idx - range.x + 1;
+            rec.mask = quadrant_mask(c2.x, c2.y, co.x, co.y, co.z, co.w, X0, Y0) & live;
+        }
+        const u64 keep = __ballot(rec.mask != 0);
+        const int count = __popcll(keep);
+        __syncthreads();                      // previous batch fully consumed (single wave: orders LDS traffic)
+        if (rec.mask != 0) recs[__popcll(keep & lt_mask)] = rec;
+        __syncthreads();
+        // ---- composite
+        for (int k = 0; k < count; ++k) {
+            const SplatRec s = recs[k];
+            const u32 m = __builtin_amdgcn_readfirstlane(s.mask);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!((m >> q) & 1u)) continue;
+                const float dx = s.x - pxf[q], dy = s.y - pyf[q];
+                const float p2 = pair_power2(dx, dy, s.ap, s.bp, s.cp);
+                const float G = __builtin_amdgcn_exp2f(p2);
+                const float alpha = fminf(0.99f, s.o * G);
+                bool contrib = (p2 <= 0.f) && (alpha >= ALPHA_MIN) && !done[q];
+                if (__ballot(contrib) == 0ull) continue;
+                const float test_T = Tq[q] * (1.f - alpha);
+                const bool stop = contrib && (test_T < T_EPS);
+                done[q] = done[q] || stop;
+                contrib = contrib && !stop;
+                const float w = contrib ? alpha * Tq[q] : 0.f;
+                Cr[q] = __fmaf_rn(w, s.r, Cr[q]); Cg[q] = __fmaf_rn(w, s.g, Cg[q]); Cb[q] = __fmaf_rn(w, s.b, Cb[q]);
+                Dq[q] = __fmaf_rn(w, s.z, Dq[q]);
+                Tq[q] = contrib ? test_T : Tq[q];
+                last[q] = contrib ? s.pos : last[q];
+            }
+        }
+    }
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    const size_t HW = (size_t)W * H;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (!inside[q]) continue;
+        const size_t pix = (size_t)pyf[q] * W + (size_t)pxf[q];
+        out_color[pix] = Cr[q] + Tq[q] * bg0;
+        out_color[HW + pix] = Cg[q] + Tq[q] * bg1;
+        out_color[2 * HW + pix] = Cb[q] + Tq[q] * bg2;
+        if (out_depth) out_depth[pix] = Dq[q];
+        if (out_weights) out_weights[pix] = 1.f - Tq[q];
+        final_T[pix] = Tq[q];
+        n_contrib[pix] = last[q];
+    }
+}
+
+hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
+                            const BagsForwardOut& out, hipStream_t st)
+{
+    const int gx = cdiv(s.image_width, BAGS_TILE), gy = cdiv(s.image_height, BAGS_TILE);
+    const int T = gx * gy;
+    if (T == 0) return hipSuccess;
+    const int grid = ((T + 7) / 8) * 8;
+    hipLaunchKernelGGL(blend_fwd_kernel, dim3(grid), dim3(64), 0, st, s.image_width, s.image_height, gx, T, b.ranges,
+                       b.point_list, g.xy, g.conic_opacity, g.rgbz, s.bg, out.color, out.depth, out.weights,
+                       im.final_T, im.n_contrib);
+    return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------------------------- backward
+// 16 per-lane partial sums -> totals; on return lane L holds the wave total of value nib_rev(L & 15) in v[0].
+__device__ __forceinline__ void wave_reduce16(float (&v)[16], int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bool hi = lane & 1;
+        const float keep = hi ? v[i + 8] : v[i], send = hi ? v[i] : v[i + 8];
+        v[i] = keep + __shfl_xor(send, 1);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool hi = lane & 2;
+        const float keep = hi ? v[i + 4] : v[i], send = hi ? v[i] : v[i + 4];
+        v[i] = keep + __shfl_xor(send, 2);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const bool hi = lane & 4;
+        const float keep = hi ? v[i + 2] : v[i], send = hi ? v[i] : v[i + 2];
+        v[i] = keep + __shfl_xor(send, 4);
+    }
+    {
+        const bool hi = lane & 8;
+        const float keep = hi ? v[1] : v[0], send = hi ? v[0] : v[1];
+        v[0] = keep + __shfl_xor(send, 8);
+    }
+    v[0] += __shfl_xor(v[0], 16);
+    v[0] += __shfl_xor(v[0], 32);
+}
+
+// partial record layout (floats): 0..2 dL/drgb, 3 dL/dopacity, 4 Mx, 5 My, 6 Mxx, 7 Mxy, 8 Myy, 9 absx, 10 absy
+//   M* = sum over pixels of q d^k with q = dL/dG * G and d = centre - pixel;  abs* = sum |d L/d centre (pixel units)|
+__global__ void __launch_bounds__(64)
+blend_bwd_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ ranges, const u32* __restrict__ point_list,
+                 const float2* __restrict__ xy, const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbz,
+                 const uint2* __restrict__ rect, const u32* __restrict__ inst_offset, const float* __restrict__ bg,
+                 const float* __restrict__ final_T, const u32* __restrict__ n_contrib, const float* __restrict__ grad_color,
+                 float* __restrict__ partials)
+{
+    const int tile = tile_of_block(blockIdx.x, T);
+    if (tile >= T) return;
+    const int lane = threadIdx.x;
+    const int tile_x = tile % grid_x, tile_y = tile / grid_x;
+    const float X0 = (float)(tile_x * BAGS_TILE), Y0 = (float)(tile_y * BAGS_TILE);
+    const uint2 range = ranges[tile];
+    const u32 n = range.y - range.x;
+    if (n == 0) return;
+
+    __shared__ SplatRec recs[64];
+    __shared__ float acc[64][PART_FLOATS];
+
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    const size_t HW = (size_t)W * H;
+    float pxf[4], pyf[4], g0[4], g1[4], g2[4], Tq[4], Rq[4], la[4], ls[4], bgt[4];
+    u32 nc[4];
+    u32 maxc = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int px = tile_x * BAGS_TILE + (q & 1) * 8 + (lane & 7);
+        const int py = tile_y * BAGS_TILE + (q >> 1) * 8 + (lane >> 3);
+        pxf[q] = (float)px; pyf[q] = (float)py;
+        const bool in = (px < W) && (py < H);
+        const size_t pix = (size_t)py * W + px;
+        g0[q] = in ? grad_color[pix] : 0.f;
+        g1[q] = in ? grad_color[HW + pix] : 0.f;
+        g2[q] = in ? grad_color[2 * HW + pix] : 0.f;
+        const float Tf = in ? final_T[pix] : 1.f;
+        nc[q] = in ? n_contrib[pix] : 0u;
+        Tq[q] = Tf; Rq[q] = 0.f; la[q] = 0.f; ls[q] = 0.f;
+        bgt[q] = Tf * (bg0 * g0[q] + bg1 * g1[q] + bg2 * g2[q]);
+        maxc = max(maxc, nc[q]);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) maxc = max(maxc, (u32)__shfl_xor((int)maxc, d));
+    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+    // instances behind the last contributor of every pixel are never visited: their records are zero
+    for (u32 p = maxc + lane; p < n; p += 64) {
+        const u32 g = point_list[range.x + p];
+        const uint2 rc = rect[g];
+        const u32 e = inst_offset[g] + (u32)(tile_y - (int)(rc.x >> 16)) * ((rc.y & 0xFFFF) - (rc.x & 0xFFFF)) +
+                      (u32)(tile_x - (int)(rc.x & 0xFFFF));
+        float4* dst = reinterpret_cast<float4*>(partials + (size_t)e * PART_FLOATS);
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        dst[0] = z4; dst[1] = z4; dst[2] = z4; dst[3] = z4;
+    }
+
+    for (u32 hi = maxc; hi > 0;) {
+        const u32 cnt = min(hi, 64u);
+        const u32 lo = hi - cnt;
+        // ---- stage splats at list positions [lo, hi) (0-based), list order preserved
+        SplatRec rec; rec.mask = 0;
+        u32 e = 0;
+        const bool valid = (u32)lane < cnt;
+        if (valid) {
+            const u32 g = point_list[range.x + lo + lane];
+            const float2 c2 = xy[g];
+            const float4 co = conic_opacity[g];
+            const float4 cz = rgbz[g];
+            const uint2 rc = rect[g];
+            e = inst_offset[g] + (u32)(tile_y - (int)(rc.x >> 16)) * ((rc.y & 0xFFFF) - (rc.x & 0xFFFF)) +
+                (u32)(tile_x - (int)(rc.x & 0xFFFF));
+            rec.x = c2.x; rec.y = c2.y;
+            rec.ap = -0.5f * LOG2E * co.x; rec.bp = -LOG2E * co.y; rec.cp = -0.5f * LOG2E * co.z; rec.o = co.w;
+            rec.r = cz.x; rec.g = cz.y; rec.b = cz.z; rec.z = cz.w;
+            rec.pos = lo + lane + 1;
+            rec.mask = quadrant_mask(c2.x, c2.y, co.x, co.y, co.z, co.w, X0, Y0);
+        }
+        const u64 keep = __ballot(rec.mask != 0);
+        const int count = __popcll(keep);
+        const int slot = __popcll(keep & lt_mask);
+        __syncthreads();
+        if (rec.mask != 0) recs[slot] = rec;
+        {
+            float4* a4 = reinterpret_cast<float4*>(&acc[lane][0]);
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            a4[0] = z4; a4[1] = z4; a4[2] = z4; a4[3] = z4;
+        }
+        __syncthreads();
+        // ---- back to front
+        for (int k = count - 1; k >= 0; --k) {
+            const SplatRec s = recs[k];
+            const u32 m = __builtin_amdgcn_readfirstlane(s.mask);
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = 0.f;
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!((m >> q) & 1u)) continue;
+                const float dx = s.x - pxf[q], dy = s.y - pyf[q];
+                const float p2 = pair_power2(dx, dy, s.ap, s.bp, s.cp);
+                const float G = __builtin_amdgcn_exp2f(p2);
+                const float alpha = fminf(0.99f, s.o * G);
+                const bool contrib = (p2 <= 0.f) && (alpha >= ALPHA_MIN) && (s.pos <= nc[q]);
+                if (__ballot(contrib) == 0ull) continue;
+                any = true;
+                const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
+                const float Tn = Tq[q] * inv;                       // T before this splat
+                const float sdot = s.r * g0[q] + s.g * g1[q] + s.b * g2[q];
+                const float Rn = __fmaf_rn(la[q], ls[q] - Rq[q], Rq[q]);   // colour behind, dotted with dL/dC
+                float dLda = (sdot - Rn) * Tn - bgt[q] * inv;
+                float w = alpha * Tn;
+                if (contrib) { Tq[q] = Tn; Rq[q] = Rn; la[q] = alpha; ls[q] = sdot; }
+                else { dLda = 0.f; w = 0.f; }
+                v[0] = __fmaf_rn(w, g0[q], v[0]); v[1] = __fmaf_rn(w, g1[q], v[1]); v[2] = __fmaf_rn(w, g2[q], v[2]);
+                v[3] = __fmaf_rn(G, dLda, v[3]);
+                const float qv = s.o * dLda * G;
+                const float qdx = qv * dx, qdy = qv * dy;
+                v[4] += qdx; v[5] += qdy;
+                v[6] = __fmaf_rn(qdx, dx, v[6]); v[7] = __fmaf_rn(qdx, dy, v[7]); v[8] = __fmaf_rn(qdy, dy, v[8]);
+                v[9] += fabsf(__fmaf_rn(2.f * s.ap, qdx, s.bp * qdy));
+                v[10] += fabsf(__fmaf_rn(2.f * s.cp, qdy, s.bp * qdx));
+            }
+            if (any) {
+                wave_reduce16(v, lane);
+                if (lane < 16) {
+                    const int idxv = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
+                    acc[k][idxv] = v[0];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- one 64-byte record per staged instance, at its emission slot
+        if (valid) {
+            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
+            if (rec.mask != 0) {
+                const float4* a4 = reinterpret_cast<const float4*>(&acc[slot][0]);
+                r0 = a4[0]; r1 = a4[1]; r2 = a4[2]; r3 = a4[3];
+                r2.y *= (1.0f / LOG2E); r2.z *= (1.0f / LOG2E);      // abs sums were taken on the scaled conic
+            }
+            float4* dst = reinterpret_cast<float4*>(partials + (size_t)e * PART_FLOATS);
+            dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
+        }
+        hi = lo;
+    }
+}
+
+hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
+                            const float* grad_color, float* partials, hipStream_t st)
+{
+    const int gx = cdiv(s.image_width, BAGS_TILE), gy = cdiv(s.image_height, BAGS_TILE);
+    const int T = gx * gy;
+    if (T == 0) return hipSuccess;
+    const int grid = ((T + 7) / 8) * 8;
+    hipLaunchKernelGGL(blend_bwd_kernel, dim3(grid), dim3(64), 0, st, s.image_width, s.image_height, gx, T, b.ranges,
+                       b.point_list, g.xy, g.conic_opacity, g.rgbz, g.rect, g.inst_offset, s.bg, im.final_T,
+                       im.n_contrib, grad_color, partials);
+    return hipGetLastError();
+}

@@ -1,0 +1,346 @@
+// preprocess_bwd.hip -- K8/K9/K10: per-Gaussian backward + camera-pose Jacobians.
+//
+// One thread per Gaussian:
+//   1. sums the Gaussian's consecutive 64-byte partial records written by blend_bwd (no atomics anywhere);
+//   2. moments -> dL/d{mean2D, conic, opacity, rgb};
+//   3. conic -> cov2D -> (J, Wc, Sigma) -> dL/d{means3D, scales, rotations | cov3D_precomp};
+//   4. pixel centre -> p_hom -> dL/dmeans3D; colour -> dL/d{shs | colors_precomp}, view direction -> dL/dmeans3D;
+//   5. the camera side of every one of those products: dL/d{viewmatrix, projmatrix, intrinsic, campos,
+//      shift_factors} (35 non-zero scalars) reduced wave -> workgroup -> one slab row per workgroup; a second
+//      tiny kernel adds the rows in fp64, so pose gradients are deterministic and do not lose bits to a
+//      half-million-term fp32 chain.
+// The forward quantities are recomputed from the inputs (cheaper than 100+ B/Gaussian of saved state).
+#include "bags_common.h"
+#include "sh_basis.h"
+
+struct CamConstB {
+    float v[16], m[16], k[16];
+    float campos[3];
+    float sf[3];
+};
+
+__device__ __forceinline__ float wave_sum(float x)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+    return x;
+}
+
+__global__ void __launch_bounds__(256)
+preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod,
+                      const float* __restrict__ means3D, const float* __restrict__ shift_factors,
+                      const float* __restrict__ shs, const float* __restrict__ colors_precomp,
+                      const float* __restrict__ scales, const float* __restrict__ rotations,
+                      const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
+                      const float* __restrict__ projmatrix, const float* __restrict__ intrinsic,
+                      const float* __restrict__ campos_p,
+                      const float4* __restrict__ conic_opacity, const u32* __restrict__ tiles_touched,
+                      const u32* __restrict__ inst_offset, const u32* __restrict__ clamped,
+                      const float* __restrict__ partials, float* __restrict__ pose_slab,
+                      float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_densify,
+                      float* __restrict__ g_shs, float* __restrict__ g_colors, float* __restrict__ g_opac,
+                      float* __restrict__ g_scales, float* __restrict__ g_rot, float* __restrict__ g_cov3D)
+{
+    __shared__ CamConstB cam;
+    __shared__ float wpose[4][POSE_VALS];
+    if (threadIdx.x < 16) {
+        cam.v[threadIdx.x] = viewmatrix[threadIdx.x];
+        cam.m[threadIdx.x] = projmatrix[threadIdx.x];
+        cam.k[threadIdx.x] = intrinsic[threadIdx.x];
+    }
+    if (threadIdx.x < 3) {
+        cam.campos[threadIdx.x] = campos_p[threadIdx.x];
+        cam.sf[threadIdx.x] = shift_factors ? shift_factors[threadIdx.x] : 0.0f;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float* v = cam.v; const float* m = cam.m; const float* k = cam.k;
+
+    float pose[POSE_VALS];
+#pragma unroll
+    for (int t = 0; t < POSE_VALS; ++t) pose[t] = 0.f;
+    float dmx = 0.f, dmy = 0.f, dmz = 0.f;           // dL/dmeans3D
+    float gm2x = 0.f, gm2y = 0.f, gdx = 0.f, gdy = 0.f, gop = 0.f;
+    float gs0 = 0.f, gs1 = 0.f, gs2 = 0.f, gqr = 0.f, gqx = 0.f, gqy = 0.f, gqz = 0.f;
+    float gc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float drgb[3] = {0.f, 0.f, 0.f};
+    const bool live = (i < P) && (tiles_touched[i] > 0);
+
+    if (live) {
+        // ---- 1. sum the per-instance records
+        float s[12];
+#pragma unroll
+        for (int t = 0; t < 12; ++t) s[t] = 0.f;
+        const u32 nrec = tiles_touched[i];
+        const float4* rec = reinterpret_cast<const float4*>(partials + (size_t)inst_offset[i] * PART_FLOATS);
+        for (u32 r = 0; r < nrec; ++r) {
+            const float4 a = rec[4 * r], b = rec[4 * r + 1], c = rec[4 * r + 2];
+            s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
+            s[4] += b.x; s[5] += b.y; s[6] += b.z; s[7] += b.w;
+            s[8] += c.x; s[9] += c.y; s[10] += c.z;
+        }
+        drgb[0] = s[0]; drgb[1] = s[1]; drgb[2] = s[2];
+        gop = s[3];
+        const float Mx = s[4], My = s[5], Mxx = s[6], Mxy = s[7], Myy = s[8];
+        const float4 co = conic_opacity[i];
+        // ---- 2. moments -> screen-space gradients
+        const float dpx = -(co.x * Mx + co.y * My);         // dL/d centre (pixel units)
+        const float dpy = -(co.z * My + co.y * Mx);
+        const float gA = -0.5f * Mxx, gB = -Mxy, gC = -0.5f * Myy;   // dL/dconic
+        gm2x = dpx * (0.5f * (float)W); gm2y = dpy * (0.5f * (float)H);
+        gdx = s[9] * (0.5f * (float)W); gdy = s[10] * (0.5f * (float)H);
+
+        // ---- recompute the forward chain
+        const float x = means3D[3 * i + 0], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+        const float tx = x * v[0] + y * v[4] + z * v[8] + v[12];
+        const float ty = x * v[1] + y * v[5] + z * v[9] + v[13];
+        const float tz = x * v[2] + y * v[6] + z * v[10] + v[14];
+        const float rho = sqrtf(tx * tx + ty * ty + 1e-20f);
+        const float theta = atan2f(rho, tz);
+        const float th2 = theta * theta, th3 = th2 * theta;
+        const float shift = cam.sf[0] * th3 + cam.sf[1] * (th3 * th2) + cam.sf[2] * (th3 * th2 * th2);
+        const float tzs = tz + shift;
+        const float hx = x * m[0] + y * m[4] + z * m[8] + m[12] + shift * k[8];
+        const float hy = x * m[1] + y * m[5] + z * m[9] + m[13] + shift * k[9];
+        const float hw = x * m[3] + y * m[7] + z * m[11] + m[15] + shift * k[11];
+        const float pw = 1.0f / (hw + 1e-7f);
+
+        float c0, c1, c2, c3, c4, c5;
+        float s0 = 0, s1 = 0, s2 = 0, qr = 0, qx = 0, qy = 0, qz = 0;
+        float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
+        if (cov3D_precomp) {
+            const float* c = cov3D_precomp + 6 * (size_t)i;
+            c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3]; c4 = c[4]; c5 = c[5];
+        } else {
+            s0 = scales[3 * i + 0] * mod; s1 = scales[3 * i + 1] * mod; s2 = scales[3 * i + 2] * mod;
+            const float4 q = reinterpret_cast<const float4*>(rotations)[i];
+            qr = q.x; qx = q.y; qy = q.z; qz = q.w;
+            r00 = 1.0f - 2.0f * (qy * qy + qz * qz); r01 = 2.0f * (qx * qy - qr * qz); r02 = 2.0f * (qx * qz + qr * qy);
+            r10 = 2.0f * (qx * qy + qr * qz); r11 = 1.0f - 2.0f * (qx * qx + qz * qz); r12 = 2.0f * (qy * qz - qr * qx);
+            r20 = 2.0f * (qx * qz - qr * qy); r21 = 2.0f * (qy * qz + qr * qx); r22 = 1.0f - 2.0f * (qx * qx + qy * qy);
+            const float l00 = r00 * s0, l01 = r01 * s1, l02 = r02 * s2;
+            const float l10 = r10 * s0, l11 = r11 * s1, l12 = r12 * s2;
+            const float l20 = r20 * s0, l21 = r21 * s1, l22 = r22 * s2;
+            c0 = l00 * l00 + l01 * l01 + l02 * l02; c1 = l00 * l10 + l01 * l11 + l02 * l12;
+            c2 = l00 * l20 + l01 * l21 + l02 * l22; c3 = l10 * l10 + l11 * l11 + l12 * l12;
+            c4 = l10 * l20 + l11 * l21 + l12 * l22; c5 = l20 * l20 + l21 * l21 + l22 * l22;
+        }
+        const float fx = k[0] * (0.5f * (float)W), fy = k[5] * (0.5f * (float)H);
+        const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+        const float itz = 1.0f / tzs;
+        const float txtz = tx * itz, tytz = ty * itz;
+        const bool clx = (txtz < -limx) || (txtz > limx), cly = (tytz < -limy) || (tytz > limy);
+        const float ux = fminf(limx, fmaxf(-limx, txtz)), uy = fminf(limy, fmaxf(-limy, tytz));
+        const float j00 = fx * itz, j02 = -fx * ux * itz, j11 = fy * itz, j12 = -fy * uy * itz;
+        const float a00 = j00 * v[0] + j02 * v[2], a01 = j00 * v[4] + j02 * v[6], a02 = j00 * v[8] + j02 * v[10];
+        const float a10 = j11 * v[1] + j12 * v[2], a11 = j11 * v[5] + j12 * v[6], a12 = j11 * v[9] + j12 * v[10];
+        const float b00 = a00 * c0 + a01 * c1 + a02 * c2, b01 = a00 * c1 + a01 * c3 + a02 * c4, b02 = a00 * c2 + a01 * c4 + a02 * c5;
+        const float b10 = a10 * c0 + a11 * c1 + a12 * c2, b11 = a10 * c1 + a11 * c3 + a12 * c4, b12 = a10 * c2 + a11 * c4 + a12 * c5;
+        const float cxx = b00 * a00 + b01 * a01 + b02 * a02 + 0.3f;
+        const float cxy = b00 * a10 + b01 * a11 + b02 * a12;
+        const float cyy = b10 * a10 + b11 * a11 + b12 * a12 + 0.3f;
+        const float det = cxx * cyy - cxy * cxy;
+        const float di = 1.0f / det, di2 = di * di;
+
+        // ---- 3. conic -> cov2D
+        const float dcxx = di2 * (-gA * cyy * cyy + gB * cxy * cyy - gC * cxy * cxy);
+        const float dcyy = di2 * (-gA * cxy * cxy + gB * cxy * cxx - gC * cxx * cxx);
+        const float dcxy = di2 * (2.f * gA * cyy * cxy + 2.f * gC * cxx * cxy) - gB * (di + 2.f * cxy * cxy * di2);
+        // cov2D -> Sigma (unique entries)
+        gc[0] = dcxx * a00 * a00 + dcxy * a00 * a10 + dcyy * a10 * a10;
+        gc[3] = dcxx * a01 * a01 + dcxy * a01 * a11 + dcyy * a11 * a11;
+        gc[5] = dcxx * a02 * a02 + dcxy * a02 * a12 + dcyy * a12 * a12;
+        gc[1] = 2.f * dcxx * a00 * a01 + dcxy * (a00 * a11 + a01 * a10) + 2.f * dcyy * a10 * a11;
+        gc[2] = 2.f * dcxx * a00 * a02 + dcxy * (a00 * a12 + a02 * a10) + 2.f * dcyy * a10 * a12;
+        gc[4] = 2.f * dcxx * a01 * a02 + dcxy * (a01 * a12 + a02 * a11) + 2.f * dcyy * a11 * a12;
+        // cov2D -> A = J Wc
+        const float dA00 = 2.f * dcxx * b00 + dcxy * b10, dA01 = 2.f * dcxx * b01 + dcxy * b11, dA02 = 2.f * dcxx * b02 + dcxy * b12;
+        const float dA10 = 2.f * dcyy * b10 + dcxy * b00, dA11 = 2.f * dcyy * b11 + dcxy * b01, dA12 = 2.f * dcyy * b12 + dcxy * b02;
+        // A -> J, viewmatrix rotation block
+        const float dj00 = dA00 * v[0] + dA01 * v[4] + dA02 * v[8];
+        const float dj02 = dA00 * v[2] + dA01 * v[6] + dA02 * v[10];
+        const float dj11 = dA10 * v[1] + dA11 * v[5] + dA12 * v[9];
+        const float dj12 = dA10 * v[2] + dA11 * v[6] + dA12 * v[10];
+        // pose slab: [0..11] viewmatrix (rows 0..3 x cols 0..2), [12..23] projmatrix (rows 0..3 x cols 0,1,3),
+        //            [24] k0 [25] k5 [26] k8 [27] k9 [28] k11, [29..31] campos, [32..34] shift_factors
+        pose[0] = dA00 * j00; pose[1] = dA10 * j11; pose[2] = dA00 * j02 + dA10 * j12;      // v[0], v[1], v[2]
+        pose[3] = dA01 * j00; pose[4] = dA11 * j11; pose[5] = dA01 * j02 + dA11 * j12;      // v[4], v[5], v[6]
+        pose[6] = dA02 * j00; pose[7] = dA12 * j11; pose[8] = dA02 * j02 + dA12 * j12;      // v[8], v[9], v[10]
+        // J -> focal lengths, view-space point
+        const float dfx = dj00 * itz - dj02 * ux * itz;
+        const float dfy = dj11 * itz - dj12 * uy * itz;
+        pose[24] = dfx * (0.5f * (float)W);
+        pose[25] = dfy * (0.5f * (float)H);
+        const float dux = -dj02 * fx * itz, duy = -dj12 * fy * itz;
+        const float ditz = dj00 * fx - dj02 * fx * ux + dj11 * fy - dj12 * fy * uy;
+        float dtx = 0.f, dty = 0.f, dtz = 0.f;
+        float dtzs = -ditz * itz * itz;
+        if (!clx) { dtx += dux * itz; dtzs -= dux * tx * itz * itz; }
+        if (!cly) { dty += duy * itz; dtzs -= duy * ty * itz * itz; }
+
+        // ---- 4. pixel centre -> homogeneous point
+        const float dhx = gm2x * pw, dhy = gm2y * pw;
+        const float dhw = -(gm2x * hx + gm2y * hy) * pw * pw;
+        dmx = dhx * m[0] + dhy * m[1] + dhw * m[3];
+        dmy = dhx * m[4] + dhy * m[5] + dhw * m[7];
+        dmz = dhx * m[8] + dhy * m[9] + dhw * m[11];
+        pose[12] = dhx * x; pose[13] = dhy * x; pose[14] = dhw * x;       // m[0], m[1], m[3]
+        pose[15] = dhx * y; pose[16] = dhy * y; pose[17] = dhw * y;       // m[4], m[5], m[7]
+        pose[18] = dhx * z; pose[19] = dhy * z; pose[20] = dhw * z;       // m[8], m[9], m[11]
+        pose[21] = dhx;     pose[22] = dhy;     pose[23] = dhw;           // m[12], m[13], m[15]
+        float dshift = dhx * k[8] + dhy * k[9] + dhw * k[11] + dtzs;
+        pose[26] = dhx * shift; pose[27] = dhy * shift; pose[28] = dhw * shift;
+        dtz += dtzs;
+        // shift polynomial in theta = atan2(rho, tz)
+        pose[32] = dshift * th3; pose[33] = dshift * th3 * th2; pose[34] = dshift * th3 * th2 * th2;
+        const float dtheta = dshift * (3.f * cam.sf[0] * th2 + 5.f * cam.sf[1] * th2 * th2 + 7.f * cam.sf[2] * th2 * th2 * th2);
+        const float ir2 = 1.0f / (rho * rho + tz * tz);
+        const float drho = dtheta * tz * ir2;
+        dtz -= dtheta * rho * ir2;
+        dtx += drho * tx / rho; dty += drho * ty / rho;
+        // view-space point -> world point, viewmatrix
+        dmx += dtx * v[0] + dty * v[1] + dtz * v[2];
+        dmy += dtx * v[4] + dty * v[5] + dtz * v[6];
+        dmz += dtx * v[8] + dty * v[9] + dtz * v[10];
+        pose[0] += dtx * x; pose[1] += dty * x; pose[2] += dtz * x;
+        pose[3] += dtx * y; pose[4] += dty * y; pose[5] += dtz * y;
+        pose[6] += dtx * z; pose[7] += dty * z; pose[8] += dtz * z;
+        pose[9] = dtx; pose[10] = dty; pose[11] = dtz;                    // v[12], v[13], v[14]
+
+        // ---- Sigma -> scales, rotation
+        if (!cov3D_precomp) {
+            const float S00 = 2.f * gc[0], S01 = gc[1], S02 = gc[2], S11 = 2.f * gc[3], S12 = gc[4], S22 = 2.f * gc[5];
+            const float l00 = r00 * s0, l01 = r01 * s1, l02 = r02 * s2;
+            const float l10 = r10 * s0, l11 = r11 * s1, l12 = r12 * s2;
+            const float l20 = r20 * s0, l21 = r21 * s1, l22 = r22 * s2;
+            const float dl00 = S00 * l00 + S01 * l10 + S02 * l20, dl01 = S00 * l01 + S01 * l11 + S02 * l21, dl02 = S00 * l02 + S01 * l12 + S02 * l22;
+            const float dl10 = S01 * l00 + S11 * l10 + S12 * l20, dl11 = S01 * l01 + S11 * l11 + S12 * l21, dl12 = S01 * l02 + S11 * l12 + S12 * l22;
+            const float dl20 = S02 * l00 + S12 * l10 + S22 * l20, dl21 = S02 * l01 + S12 * l11 + S22 * l21, dl22 = S02 * l02 + S12 * l12 + S22 * l22;
+            gs0 = mod * (dl00 * r00 + dl10 * r10 + dl20 * r20);
+            gs1 = mod * (dl01 * r01 + dl11 * r11 + dl21 * r21);
+            gs2 = mod * (dl02 * r02 + dl12 * r12 + dl22 * r22);
+            const float d00 = dl00 * s0, d01 = dl01 * s1, d02 = dl02 * s2;
+            const float d10 = dl10 * s0, d11 = dl11 * s1, d12 = dl12 * s2;
+            const float d20 = dl20 * s0, d21 = dl21 * s1, d22 = dl22 * s2;
+            gqr = 2.f * (-qz * d01 + qy * d02 + qz * d10 - qx * d12 - qy * d20 + qx * d21);
+            gqx = 2.f * (qy * d01 + qz * d02 + qy * d10 - 2.f * qx * d11 - qr * d12 + qz * d20 + qr * d21 - 2.f * qx * d22);
+            gqy = 2.f * (-2.f * qy * d00 + qx * d01 + qr * d02 + qx * d10 + qz * d12 - qr * d20 + qz * d21 - 2.f * qy * d22);
+            gqz = 2.f * (-2.f * qz * d00 - qr * d01 + qx * d02 + qr * d10 - 2.f * qz * d11 + qy * d12 + qx * d20 + qy * d21);
+        }
+
+        // ---- colour
+        if (!colors_precomp) {
+            const u32 cl = clamped[i];
+            if (cl & 1u) drgb[0] = 0.f;
+            if (cl & 2u) drgb[1] = 0.f;
+            if (cl & 4u) drgb[2] = 0.f;
+            const float ex = x - cam.campos[0], ey = y - cam.campos[1], ez = z - cam.campos[2];
+            const float il = 1.0f / sqrtf(ex * ex + ey * ey + ez * ez);
+            const float ux_ = ex * il, uy_ = ey * il, uz_ = ez * il;
+            float bs[16], bx[16], by[16], bz[16];
+            sh_basis(deg, ux_, uy_, uz_, bs);
+            sh_basis_grad(deg, ux_, uy_, uz_, bx, by, bz);
+            const int nb = (deg + 1) * (deg + 1);
+            const float* sh = shs + (size_t)i * M * 3;
+            float* gsh = g_shs ? g_shs + (size_t)i * M * 3 : nullptr;
+            float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+            for (int t = 0; t < M; ++t) {
+                float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+                if (t < nb) {
+                    const float w = sh[3 * t] * drgb[0] + sh[3 * t + 1] * drgb[1] + sh[3 * t + 2] * drgb[2];
+                    ddx += bx[t] * w; ddy += by[t] * w; ddz += bz[t] * w;
+                    o0 = bs[t] * drgb[0]; o1 = bs[t] * drgb[1]; o2 = bs[t] * drgb[2];
+                }
+                if (gsh) { gsh[3 * t] = o0; gsh[3 * t + 1] = o1; gsh[3 * t + 2] = o2; }
+            }
+            const float dot = ux_ * ddx + uy_ * ddy + uz_ * ddz;
+            const float px_ = (ddx - ux_ * dot) * il, py_ = (ddy - uy_ * dot) * il, pz_ = (ddz - uz_ * dot) * il;
+            dmx += px_; dmy += py_; dmz += pz_;
+            pose[29] = -px_; pose[30] = -py_; pose[31] = -pz_;
+        }
+    } else if (i < P && g_shs && !colors_precomp) {
+        float* gsh = g_shs + (size_t)i * M * 3;
+        for (int t = 0; t < 3 * M; ++t) gsh[t] = 0.f;
+    }
+
+    if (i < P) {
+        if (g_means3D) { g_means3D[3 * i] = dmx; g_means3D[3 * i + 1] = dmy; g_means3D[3 * i + 2] = dmz; }
+        if (g_means2D) { g_means2D[3 * i] = gm2x; g_means2D[3 * i + 1] = gm2y; g_means2D[3 * i + 2] = 0.f; }
+        if (g_densify) { g_densify[3 * i] = gdx; g_densify[3 * i + 1] = gdy; g_densify[3 * i + 2] = 0.f; }
+        if (g_opac) g_opac[i] = gop;
+        if (g_colors) { g_colors[3 * i] = drgb[0]; g_colors[3 * i + 1] = drgb[1]; g_colors[3 * i + 2] = drgb[2]; }
+        if (g_scales) { g_scales[3 * i] = gs0; g_scales[3 * i + 1] = gs1; g_scales[3 * i + 2] = gs2; }
+        if (g_rot) reinterpret_cast<float4*>(g_rot)[i] = make_float4(gqr, gqx, gqy, gqz);
+        if (g_cov3D) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t) g_cov3D[6 * (size_t)i + t] = gc[t];
+        }
+    }
+
+    // ---- 5. pose Jacobians: wave -> workgroup -> slab row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < 35; ++t) {
+        const float r = wave_sum(pose[t]);
+        if (lane == 0) wpose[wave][t] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < POSE_VALS) {
+        const int t = threadIdx.x;
+        pose_slab[(size_t)blockIdx.x * POSE_VALS + t] =
+            (t < 35) ? (wpose[0][t] + wpose[1][t]) + (wpose[2][t] + wpose[3][t]) : 0.f;
+    }
+}
+
+// rows -> the five pose tensors, summed in fp64
+__global__ void __launch_bounds__(64)
+pose_reduce_kernel(const float* __restrict__ slab, int nblocks, float* __restrict__ g_view, float* __restrict__ g_proj,
+                   float* __restrict__ g_intr, float* __restrict__ g_campos, float* __restrict__ g_shift)
+{
+    const int t = threadIdx.x;
+    double acc = 0.0;
+    if (t < 35)
+        for (int b = 0; b < nblocks; ++b) acc += (double)slab[(size_t)b * POSE_VALS + t];
+    __shared__ float tot[64];
+    tot[t] = (float)acc;
+    __syncthreads();
+    if (t < 16) {
+        const int r = t >> 2, c = t & 3;
+        if (g_view) g_view[t] = (c < 3) ? tot[r * 3 + c] : 0.f;
+        if (g_proj) g_proj[t] = (c == 2) ? 0.f : tot[12 + r * 3 + (c == 3 ? 2 : c)];
+        if (g_intr) {
+            float val = 0.f;
+            if (t == 0) val = tot[24]; else if (t == 5) val = tot[25]; else if (t == 8) val = tot[26];
+            else if (t == 9) val = tot[27]; else if (t == 11) val = tot[28];
+            g_intr[t] = val;
+        }
+    }
+    if (t < 3) {
+        if (g_campos) g_campos[t] = tot[29 + t];
+        if (g_shift) g_shift[t] = tot[32 + t];
+    }
+}
+
+hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, const int32_t*,
+                                 const float* partials, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a,
+                                 hipStream_t st)
+{
+    const int P = in.P;
+    const int nb = cdiv(P, 256);
+    *nblocks_out = nb;
+    if (P == 0) return hipSuccess;
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nb), dim3(256), 0, st, P, s.sh_coeffs, s.sh_degree, s.image_width,
+                       s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, in.means3D, in.shift_factors, in.shs,
+                       in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, s.viewmatrix, s.projmatrix,
+                       s.intrinsic, s.campos, g.conic_opacity, g.tiles_touched, g.inst_offset, g.clamped, partials,
+                       pose_slab, a.grad_means3D, a.grad_means2D, a.grad_means2D_densify, a.grad_shs,
+                       a.grad_colors_precomp, a.grad_opacities, a.grad_scales, a.grad_rotations, a.grad_cov3D_precomp);
+    return hipGetLastError();
+}
+
+hipError_t launch_pose_reduce(const float* pose_slab, int nblocks, const BagsBackwardArgs& a, hipStream_t st)
+{
+    hipLaunchKernelGGL(pose_reduce_kernel, dim3(1), dim3(64), 0, st, pose_slab, nblocks, a.grad_viewmatrix,
+                       a.grad_projmatrix, a.grad_intrinsic, a.grad_campos, a.grad_shift_factors);
+    return hipGetLastError();
+}

@@ -1,0 +1,210 @@
+// preprocess_fwd.hip -- K1: per-Gaussian 3D->2D projection, EWA covariance, radius, tile rectangle, SH colour.
+//
+// COMPILED WITH -ffp-contract=off: the integer artefacts (radius, tile rectangle, depth key) must be bit-identical
+// to the fp32 oracle (oracle/raster_oracle.py: preprocess), so every expression here is the same sequence of
+// individually rounded IEEE fp32 mul/add/div/sqrt, left to right.  Algorithm: SURVEY.md Appendix A.1; conventions:
+// utils/graphics_utils.py:26-33 (row-vector transforms), utils/general_utils.py:130-163 (quaternion order, R.S),
+// utils/sh_utils.py:57-112 (SH basis), gaussian_renderer/__init__.py:92-95 (+0.5, clamp at 0).
+#include "bags_common.h"
+#include "sh_basis.h"
+
+struct CamConst {
+    float v[16], m[16], k[16];
+    float campos[3];
+    float sf[3];
+};
+
+__global__ void __launch_bounds__(256)
+preprocess_fwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod, int depth_mode,
+                      const float* __restrict__ means3D, const float* __restrict__ means2D,
+                      const float* __restrict__ shift_factors, const float* __restrict__ shs,
+                      const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
+                      const float* __restrict__ scales, const float* __restrict__ rotations,
+                      const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
+                      const float* __restrict__ projmatrix, const float* __restrict__ intrinsic,
+                      const float* __restrict__ campos_p,
+                      u32* __restrict__ depth_key, float2* __restrict__ xy_out, float4* __restrict__ conic_opacity,
+                      float4* __restrict__ rgbz, uint2* __restrict__ rect_out, u32* __restrict__ tiles_touched,
+                      u32* __restrict__ clamped_out, int32_t* __restrict__ radii, float* __restrict__ mean2D_out)
+{
+    __shared__ CamConst cam;
+    if (threadIdx.x < 16) {
+        cam.v[threadIdx.x] = viewmatrix[threadIdx.x];
+        cam.m[threadIdx.x] = projmatrix[threadIdx.x];
+        cam.k[threadIdx.x] = intrinsic[threadIdx.x];
+    }
+    if (threadIdx.x < 3) {
+        cam.campos[threadIdx.x] = campos_p[threadIdx.x];
+        cam.sf[threadIdx.x] = shift_factors ? shift_factors[threadIdx.x] : 0.0f;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float* v = cam.v; const float* m = cam.m; const float* k = cam.k;
+
+    // defaults for a culled Gaussian
+    u32 key = KEY_CULLED; u32 tiles = 0; int radius = 0;
+    uint2 rect = make_uint2(0u, 0u);
+    float2 pxy = make_float2(0.f, 0.f);
+
+    const float x = means3D[3 * i + 0], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+    const float tx = x * v[0] + y * v[4] + z * v[8] + v[12];
+    const float ty = x * v[1] + y * v[5] + z * v[9] + v[13];
+    const float tz = x * v[2] + y * v[6] + z * v[10] + v[14];
+    bool ok = tz > 0.2f;                                   // near-plane cull
+    if (ok) {
+        // D2: entrance-pupil shift (zero factors => exact identity)
+        const float rho = sqrtf(tx * tx + ty * ty + 1e-20f);
+        const float theta = atan2f(rho, tz);
+        const float th2 = theta * theta;
+        const float th3 = th2 * theta;
+        const float shift = cam.sf[0] * th3 + cam.sf[1] * (th3 * th2) + cam.sf[2] * (th3 * th2 * th2);
+        const float tzs = tz + shift;
+
+        const float hx = x * m[0] + y * m[4] + z * m[8] + m[12] + shift * k[8];
+        const float hy = x * m[1] + y * m[5] + z * m[9] + m[13] + shift * k[9];
+        const float hw = x * m[3] + y * m[7] + z * m[11] + m[15] + shift * k[11];
+        const float pw = 1.0f / (hw + 1e-7f);
+        float ndc_x = hx * pw, ndc_y = hy * pw;
+        if (means2D) { ndc_x = ndc_x + means2D[3 * i + 0]; ndc_y = ndc_y + means2D[3 * i + 1]; }
+        const float px = ((ndc_x + 1.0f) * (float)W - 1.0f) * 0.5f;
+        const float py = ((ndc_y + 1.0f) * (float)H - 1.0f) * 0.5f;
+
+        float c0, c1, c2, c3, c4, c5;
+        if (cov3D_precomp) {
+            const float* c = cov3D_precomp + 6 * (size_t)i;
+            c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3]; c4 = c[4]; c5 = c[5];
+        } else {
+            const float s0 = scales[3 * i + 0] * mod, s1 = scales[3 * i + 1] * mod, s2 = scales[3 * i + 2] * mod;
+            const float4 q = reinterpret_cast<const float4*>(rotations)[i];
+            const float qr = q.x, qx = q.y, qy = q.z, qz = q.w;
+            const float r00 = 1.0f - 2.0f * (qy * qy + qz * qz);
+            const float r01 = 2.0f * (qx * qy - qr * qz);
+            const float r02 = 2.0f * (qx * qz + qr * qy);
+            const float r10 = 2.0f * (qx * qy + qr * qz);
+            const float r11 = 1.0f - 2.0f * (qx * qx + qz * qz);
+            const float r12 = 2.0f * (qy * qz - qr * qx);
+            const float r20 = 2.0f * (qx * qz - qr * qy);
+            const float r21 = 2.0f * (qy * qz + qr * qx);
+            const float r22 = 1.0f - 2.0f * (qx * qx + qy * qy);
+            const float l00 = r00 * s0, l01 = r01 * s1, l02 = r02 * s2;
+            const float l10 = r10 * s0, l11 = r11 * s1, l12 = r12 * s2;
+            const float l20 = r20 * s0, l21 = r21 * s1, l22 = r22 * s2;
+            c0 = l00 * l00 + l01 * l01 + l02 * l02;
+            c1 = l00 * l10 + l01 * l11 + l02 * l12;
+            c2 = l00 * l20 + l01 * l21 + l02 * l22;
+            c3 = l10 * l10 + l11 * l11 + l12 * l12;
+            c4 = l10 * l20 + l11 * l21 + l12 * l22;
+            c5 = l20 * l20 + l21 * l21 + l22 * l22;
+        }
+        const float fx = k[0] * (0.5f * (float)W);          // D1
+        const float fy = k[5] * (0.5f * (float)H);
+        const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+        const float txtz = tx / tzs, tytz = ty / tzs;
+        const float cx_ = fminf(limx, fmaxf(-limx, txtz)) * tzs;
+        const float cy_ = fminf(limy, fmaxf(-limy, tytz)) * tzs;
+        const float itz = 1.0f / tzs;
+        const float itz2 = itz * itz;
+        const float j00 = fx * itz;
+        const float j02 = -(fx * cx_) * itz2;
+        const float j11 = fy * itz;
+        const float j12 = -(fy * cy_) * itz2;
+        const float a00 = j00 * v[0] + j02 * v[2];
+        const float a01 = j00 * v[4] + j02 * v[6];
+        const float a02 = j00 * v[8] + j02 * v[10];
+        const float a10 = j11 * v[1] + j12 * v[2];
+        const float a11 = j11 * v[5] + j12 * v[6];
+        const float a12 = j11 * v[9] + j12 * v[10];
+        const float b00 = a00 * c0 + a01 * c1 + a02 * c2;
+        const float b01 = a00 * c1 + a01 * c3 + a02 * c4;
+        const float b02 = a00 * c2 + a01 * c4 + a02 * c5;
+        const float b10 = a10 * c0 + a11 * c1 + a12 * c2;
+        const float b11 = a10 * c1 + a11 * c3 + a12 * c4;
+        const float b12 = a10 * c2 + a11 * c4 + a12 * c5;
+        const float cxx = b00 * a00 + b01 * a01 + b02 * a02 + 0.3f;
+        const float cxy = b00 * a10 + b01 * a11 + b02 * a12;
+        const float cyy = b10 * a10 + b11 * a11 + b12 * a12 + 0.3f;
+        const float det = cxx * cyy - cxy * cxy;
+        ok = (det != 0.0f);
+        if (ok) {
+            const float det_inv = 1.0f / det;
+            const float con_a = cyy * det_inv, con_b = -cxy * det_inv, con_c = cxx * det_inv;
+            const float mid = 0.5f * (cxx + cyy);
+            const float lam = mid + sqrtf(fmaxf(mid * mid - det, 0.1f));
+            const float rad_f = ceilf(3.0f * sqrtf(lam));
+            ok = isfinite(px) && isfinite(py) && isfinite(rad_f);
+            if (ok) {
+                const int gx = (W + BAGS_TILE - 1) / BAGS_TILE, gy = (H + BAGS_TILE - 1) / BAGS_TILE;
+                const float big = 1.0e9f;
+                const int minx = min(gx, max(0, (int)fminf(big, fmaxf(-big, (px - rad_f) / 16.0f))));
+                const int miny = min(gy, max(0, (int)fminf(big, fmaxf(-big, (py - rad_f) / 16.0f))));
+                const int maxx = min(gx, max(0, (int)fminf(big, fmaxf(-big, (px + rad_f + 15.0f) / 16.0f))));
+                const int maxy = min(gy, max(0, (int)fminf(big, fmaxf(-big, (py + rad_f + 15.0f) / 16.0f))));
+                const int nt = (maxx - minx) * (maxy - miny);
+                if (nt > 0) {
+                    tiles = (u32)nt;
+                    radius = (int)rad_f;
+                    rect = make_uint2((u32)minx | ((u32)miny << 16), (u32)maxx | ((u32)maxy << 16));
+                    pxy = make_float2(px, py);
+                    const float dsort = (depth_mode == BAGS_DEPTH_DISTANCE) ? sqrtf(tx * tx + ty * ty + tzs * tzs) : tzs;
+                    key = __float_as_uint(dsort);
+                    // colour
+                    float r, g, b; u32 cl = 0;
+                    if (colors_precomp) {
+                        r = colors_precomp[3 * i + 0]; g = colors_precomp[3 * i + 1]; b = colors_precomp[3 * i + 2];
+                    } else {
+                        const float dx = x - cam.campos[0], dy = y - cam.campos[1], dz = z - cam.campos[2];
+                        const float dl = sqrtf(dx * dx + dy * dy + dz * dz);
+                        float basis[16];
+                        sh_basis(deg, dx / dl, dy / dl, dz / dl, basis);
+                        const int nb = (deg + 1) * (deg + 1);
+                        const float* sh = shs + (size_t)i * M * 3;
+                        r = 0.f; g = 0.f; b = 0.f;
+                        if (M == 16) {             // 192 B per Gaussian, 16-byte aligned: 12 dwordx4 loads
+                            float c[48];
+                            const float4* s4 = reinterpret_cast<const float4*>(sh);
+#pragma unroll
+                            for (int t = 0; t < 12; ++t) {
+                                float4 w = s4[t];
+                                c[4 * t] = w.x; c[4 * t + 1] = w.y; c[4 * t + 2] = w.z; c[4 * t + 3] = w.w;
+                            }
+#pragma unroll
+                            for (int t = 0; t < 16; ++t)
+                                if (t < nb) { r += basis[t] * c[3 * t]; g += basis[t] * c[3 * t + 1]; b += basis[t] * c[3 * t + 2]; }
+                        } else {
+                            for (int t = 0; t < nb; ++t) {
+                                r += basis[t] * sh[3 * t]; g += basis[t] * sh[3 * t + 1]; b += basis[t] * sh[3 * t + 2];
+                            }
+                        }
+                        r += 0.5f; g += 0.5f; b += 0.5f;
+                        if (r < 0.f) { cl |= 1u; r = 0.f; }
+                        if (g < 0.f) { cl |= 2u; g = 0.f; }
+                        if (b < 0.f) { cl |= 4u; b = 0.f; }
+                    }
+                    conic_opacity[i] = make_float4(con_a, con_b, con_c, opacities[i]);
+                    rgbz[i] = make_float4(r, g, b, tzs);
+                    clamped_out[i] = cl;
+                }
+            }
+        }
+    }
+    depth_key[i] = key;
+    tiles_touched[i] = tiles;
+    rect_out[i] = rect;
+    xy_out[i] = pxy;
+    radii[i] = radius;
+    if (mean2D_out) { mean2D_out[2 * i] = pxy.x; mean2D_out[2 * i + 1] = pxy.y; }
+}
+
+hipError_t launch_preprocess_fwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, int32_t* radii,
+                                 float* mean2D, hipStream_t st)
+{
+    const int P = in.P;
+    if (P == 0) return hipSuccess;
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, P, s.sh_coeffs, s.sh_degree,
+                       s.image_width, s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, s.depth_key,
+                       in.means3D, in.means2D, in.shift_factors, in.shs, in.colors_precomp, in.opacities, in.scales,
+                       in.rotations, in.cov3D_precomp, s.viewmatrix, s.projmatrix, s.intrinsic, s.campos,
+                       g.depth_key, g.xy, g.conic_opacity, g.rgbz, g.rect, g.tiles_touched, g.clamped, radii, mean2D);
+    return hipGetLastError();
+}

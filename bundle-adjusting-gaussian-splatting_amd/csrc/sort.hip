@@ -1,0 +1,350 @@
+// sort.hip -- K2..K5: depth ordering of Gaussians, instance offsets, instance emission, stable per-tile ordering,
+// tile ranges.
+//
+// The stock pipeline sorts I (tile<<32 | depth) 64-bit keys in 6+ radix passes.  Here the same total order
+// (tile ascending, depth ascending, Gaussian id ascending among equal depths) is produced with far less traffic:
+//   1. sort the P Gaussians once by their 32-bit depth key (stable, ids ascending among ties)        [P items]
+//   2. exclusive-scan tiles_touched in that depth order -> emission offsets, instance count I
+//   3. emit (tile id, Gaussian id) instances in depth order
+//   4. stable LSD radix sort of the instances by tile id only (ceil(bit_length(T-1)/8) passes)         [I items]
+// Since step 4 is stable and its input is depth-ordered, each tile's run is depth-ordered: bit-identical to the
+// stable sort of the 64-bit keys (checked against oracle/raster_oracle.py: bin_and_sort).
+//
+// All radix passes are deterministic: ranks come from wave64 ballots and per-wave LDS counters, never atomics
+// that race for order.
+#include "bags_common.h"
+
+// ------------------------------------------------------------------------------------------------ radix: histogram
+__global__ void __launch_bounds__(SORT_BLOCK)
+radix_hist_kernel(const u32* __restrict__ keys, long long n, int shift, int nblocks, u32* __restrict__ hist)
+{
+    __shared__ u32 h[RADIX_BINS];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * SORT_TILE;
+#pragma unroll 4
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const long long idx = base + (long long)r * SORT_BLOCK + threadIdx.x;
+        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & (RADIX_BINS - 1)], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// one workgroup per digit: exclusive scan of that digit's per-block counts (in place) + digit total
+__global__ void __launch_bounds__(256)
+radix_scan_kernel(u32* __restrict__ hist, int nblocks, u32* __restrict__ totals)
+{
+    __shared__ u32 wsum[4];
+    __shared__ u32 carry_s;
+    u32* row = hist + (size_t)blockIdx.x * nblocks;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += 256) {
+        const int i = base + threadIdx.x;
+        const u32 v = (i < nblocks) ? row[i] : 0u;
+        u32 incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        u32 wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += wsum[w];
+        const u32 carry = carry_s;
+        if (i < nblocks) row[i] = carry + wbase + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = carry + wbase + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
+}
+
+// ------------------------------------------------------------------------------------------------ radix: scatter
+// Item order inside a workgroup is (wave, round, lane) == ascending index, so ranks computed as
+//   [digits of earlier waves] + [same-digit items of earlier rounds of this wave] + [same-digit lower lanes]
+// make the pass stable.
+template <bool IOTA>
+__global__ void __launch_bounds__(SORT_BLOCK)
+radix_scatter_kernel(const u32* __restrict__ keys_in, const u32* __restrict__ vals_in, u32* __restrict__ keys_out,
+                     u32* __restrict__ vals_out, long long n, int shift, int nblocks, const u32* __restrict__ hist,
+                     const u32* __restrict__ totals)
+{
+    constexpr int WAVES = SORT_BLOCK / 64;
+    constexpr int ROUNDS = SORT_TILE / SORT_BLOCK;           // rounds of 64 keys per wave
+    __shared__ u32 whist[WAVES][RADIX_BINS];
+    __shared__ u32 dbase[RADIX_BINS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int w = 0; w < WAVES; ++w) whist[w][threadIdx.x] = 0;
+    // exclusive scan of the 256 digit totals (every workgroup repeats this 1 KB scan)
+    {
+        const u32 v = totals[threadIdx.x];
+        u32 incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        __shared__ u32 ws[WAVES];
+        if (lane == 63) ws[wave] = incl;
+        __syncthreads();
+        u32 wb = 0;
+        for (int w = 0; w < wave; ++w) wb += ws[w];
+        dbase[threadIdx.x] = wb + incl - v + hist[(size_t)threadIdx.x * nblocks + blockIdx.x];
+    }
+    __syncthreads();
+
+    const long long seg = (long long)blockIdx.x * SORT_TILE + (long long)wave * (ROUNDS * 64);
+    u32 key[ROUNDS];
+    u32 rank[ROUNDS];
+    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const long long idx = seg + r * 64 + lane;
+        const bool valid = idx < n;
+        const u32 k = valid ? keys_in[idx] : 0xFFFFFFFFu;
+        const u32 d = (k >> shift) & (RADIX_BINS - 1);
+        u64 m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < RADIX_BITS; ++b) {
+            const u64 bb = __ballot((d >> b) & 1u);
+            m &= ((d >> b) & 1u) ? bb : ~bb;
+        }
+        const u32 below = (u32)__popcll(m & lt_mask);
+        const u32 pre = whist[wave][d];
+        if (valid && below == 0) whist[wave][d] = pre + (u32)__popcll(m);
+        key[r] = k;
+        rank[r] = pre + below;
+    }
+    __syncthreads();
+    // digit t: turn the per-wave counts into per-wave bases on top of the workgroup's global base
+    {
+        u32 run = dbase[threadIdx.x];
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const u32 c = whist[w][threadIdx.x];
+            whist[w][threadIdx.x] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const long long idx = seg + r * 64 + lane;
+        if (idx < n) {
+            const u32 d = (key[r] >> shift) & (RADIX_BINS - 1);
+            const u32 pos = whist[wave][d] + rank[r];
+            keys_out[pos] = key[r];
+            vals_out[pos] = IOTA ? (u32)idx : vals_in[idx];
+        }
+    }
+}
+
+// Sorts (keys, vals) by key bits [0, bits) with stable 8-bit passes.  Pass 0 reads (src_k, src_v) and writes the A
+// half, pass 1 reads A and writes B, pass 2 reads B and writes A, ...  The result is in A when the number of passes is
+// odd and in B when it is even.  src may alias B (it is consumed by pass 0 before pass 1 overwrites it).
+hipError_t launch_radix_sort(const u32* src_k, const u32* src_v, u32* a_k, u32* a_v, u32* b_k, u32* b_v, long long n,
+                             int bits, bool iota_vals, u32* hist, u32* totals, int nblocks, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const int passes = (bits + RADIX_BITS - 1) / RADIX_BITS;
+    const u32* ik = src_k; const u32* iv = src_v;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = p * RADIX_BITS;
+        u32* ok = (p & 1) ? b_k : a_k; u32* ov = (p & 1) ? b_v : a_v;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(SORT_BLOCK), 0, st, ik, n, shift, nblocks, hist);
+        hipLaunchKernelGGL(radix_scan_kernel, dim3(RADIX_BINS), dim3(256), 0, st, hist, nblocks, totals);
+        if (p == 0 && iota_vals)
+            hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nblocks), dim3(SORT_BLOCK), 0, st, ik, iv, ok, ov, n,
+                               shift, nblocks, hist, totals);
+        else
+            hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nblocks), dim3(SORT_BLOCK), 0, st, ik, iv, ok, ov, n,
+                               shift, nblocks, hist, totals);
+        ik = ok; iv = ov;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ offsets scan
+// Exclusive scan of tiles_touched in depth order.  Three small kernels: workgroup sums, scan of the sums (+ total),
+// rescan with the carried prefix.
+__global__ void __launch_bounds__(SCAN_BLOCK)
+offsets_partial_kernel(const u32* __restrict__ sorted_ids, const u32* __restrict__ tiles_touched, int P,
+                       u32* __restrict__ partials)
+{
+    __shared__ u32 ws[SCAN_BLOCK / 64];
+    const int base = blockIdx.x * SCAN_TILE;
+    u32 s = 0;
+#pragma unroll
+    for (int r = 0; r < SCAN_ITEMS; ++r) {
+        const int j = base + r * SCAN_BLOCK + threadIdx.x;
+        if (j < P) s += tiles_touched[sorted_ids[j]];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 t = 0;
+        for (int w = 0; w < SCAN_BLOCK / 64; ++w) t += ws[w];
+        partials[blockIdx.x] = t;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+offsets_top_kernel(u32* __restrict__ partials, int nparts, u32* __restrict__ total)
+{
+    __shared__ u32 wsum[4];
+    __shared__ u32 carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nparts; base += 256) {
+        const int i = base + threadIdx.x;
+        const u32 v = (i < nparts) ? partials[i] : 0u;
+        u32 incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        u32 wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += wsum[w];
+        const u32 carry = carry_s;
+        if (i < nparts) partials[i] = carry + wbase + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = carry + wbase + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[0] = carry_s;
+}
+
+// item order inside a workgroup here is (thread, item) with SCAN_ITEMS consecutive ranks per thread
+__global__ void __launch_bounds__(SCAN_BLOCK)
+offsets_final_kernel(const u32* __restrict__ sorted_ids, const u32* __restrict__ tiles_touched, int P,
+                     const u32* __restrict__ partials, u32* __restrict__ rank_offset, u32* __restrict__ inst_offset)
+{
+    __shared__ u32 wsum[SCAN_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j0 = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    u32 id[SCAN_ITEMS], t[SCAN_ITEMS];
+    u32 s = 0;
+#pragma unroll
+    for (int r = 0; r < SCAN_ITEMS; ++r) {
+        const int j = j0 + r;
+        id[r] = (j < P) ? sorted_ids[j] : 0u;
+        t[r] = (j < P) ? tiles_touched[id[r]] : 0u;
+        s += t[r];
+    }
+    u32 incl = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 u = __shfl_up(incl, d);
+        if (lane >= d) incl += u;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    u32 run = partials[blockIdx.x] + incl - s;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+    for (int r = 0; r < SCAN_ITEMS; ++r) {
+        const int j = j0 + r;
+        if (j < P) { rank_offset[j] = run; inst_offset[id[r]] = run; }
+        run += t[r];
+    }
+}
+
+hipError_t launch_offsets_scan(const GeomView& g, const u32* sorted_ids, int P, hipStream_t st)
+{
+    if (P == 0) { return hipMemsetAsync(g.num_rendered, 0, sizeof(u32), st); }
+    const int nb = g.nblocks_scan;
+    hipLaunchKernelGGL(offsets_partial_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, st, sorted_ids, g.tiles_touched, P, g.scan_partials);
+    hipLaunchKernelGGL(offsets_top_kernel, dim3(1), dim3(256), 0, st, g.scan_partials, nb, g.num_rendered);
+    hipLaunchKernelGGL(offsets_final_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, st, sorted_ids, g.tiles_touched, P,
+                       g.scan_partials, g.rank_offset, g.inst_offset);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ emission
+// One thread per depth rank: writes the Gaussian's rectangle of tiles (y outer, x inner) at its offset.
+__global__ void __launch_bounds__(256)
+emit_kernel(const u32* __restrict__ sorted_ids, const u32* __restrict__ rank_offset, const uint2* __restrict__ rect,
+            const u32* __restrict__ tiles_touched, int P, int grid_x, u32* __restrict__ keys, u32* __restrict__ vals)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P) return;
+    const u32 g = sorted_ids[j];
+    if (tiles_touched[g] == 0) return;
+    const uint2 rc = rect[g];
+    const int minx = rc.x & 0xFFFF, miny = rc.x >> 16, maxx = rc.y & 0xFFFF, maxy = rc.y >> 16;
+    u32 off = rank_offset[j];
+    for (int y = miny; y < maxy; ++y)
+        for (int x = minx; x < maxx; ++x) {
+            keys[off] = (u32)(y * grid_x + x);
+            vals[off] = g;
+            ++off;
+        }
+}
+
+hipError_t launch_emit(const GeomView& g, const u32* sorted_ids, int P, int grid_x, u32* keys, u32* vals, hipStream_t st)
+{
+    if (P == 0) return hipSuccess;
+    hipLaunchKernelGGL(emit_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, sorted_ids, g.rank_offset, g.rect,
+                       g.tiles_touched, P, grid_x, keys, vals);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ tile ranges
+__global__ void __launch_bounds__(256)
+tile_ranges_kernel(const u32* __restrict__ tile_sorted, long long I, uint2* __restrict__ ranges)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= I) return;
+    const u32 t = tile_sorted[i];
+    if (i == 0) ranges[t].x = 0;
+    else {
+        const u32 p = tile_sorted[i - 1];
+        if (p != t) { ranges[p].y = (u32)i; ranges[t].x = (u32)i; }
+    }
+    if (i == I - 1) ranges[t].y = (u32)I;
+}
+
+hipError_t launch_tile_ranges(const u32* tile_sorted, long long I, uint2* ranges, int T, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, st);
+    if (e != hipSuccess || I == 0) return e;
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(cdiv(I, 256)), dim3(256), 0, st, tile_sorted, I, ranges);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ debug views
+__global__ void debug_keys_kernel(const u32* tile_sorted, const u32* point_list, const u32* depth_key, long long I, u64* out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < I) out[i] = ((u64)tile_sorted[i] << 32) | (u64)depth_key[point_list[i]];
+}
+hipError_t launch_debug_keys(const u32* tile_sorted, const u32* point_list, const u32* depth_key, long long I, u64* out, hipStream_t st)
+{
+    if (I == 0) return hipSuccess;
+    hipLaunchKernelGGL(debug_keys_kernel, dim3(cdiv(I, 256)), dim3(256), 0, st, tile_sorted, point_list, depth_key, I, out);
+    return hipGetLastError();
+}
+__global__ void unpack_rect_kernel(const uint2* rect, int P, u32* out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P) {
+        const uint2 r = rect[i];
+        out[4 * i] = r.x & 0xFFFF; out[4 * i + 1] = r.x >> 16; out[4 * i + 2] = r.y & 0xFFFF; out[4 * i + 3] = r.y >> 16;
+    }
+}
+hipError_t launch_unpack_rect(const uint2* rect, int P, u32* out, hipStream_t st)
+{
+    if (P == 0) return hipSuccess;
+    hipLaunchKernelGGL(unpack_rect_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, rect, P, out);
+    return hipGetLastError();
+}

@@ -1,0 +1,150 @@
+/* bags_raster.h -- C ABI of libbags_raster.so, the MI355X (gfx950) pose-differentiable Gaussian rasterizer.
+ *
+ * Drop-in boundary.  The reference reaches its rasterizer through the Python package
+ * `diff_gaussian_rasterization` (gaussian_renderer/__init__.py:14), whose native half is a pybind11 torch
+ * extension living in the (empty) `3dgs-pose` submodule (.gitmodules:4-6, README.md:126).  That extension's
+ * entry points -- rasterize forward, rasterize backward -- are what this header replaces, as plain C:
+ *
+ *   reference call site                                              replaced by
+ *   ---------------------------------------------------------------  ----------------------------------
+ *   GaussianRasterizer.forward(...)  gaussian_renderer/__init__.py:110-121   bags_forward_prepare + bags_forward_finish
+ *   autograd backward of that call   train.py:331 (loss.backward)            bags_backward
+ *   GaussianRasterizationSettings    gaussian_renderer/__init__.py:50-65     BagsSettings (POD)
+ *   state kept between fwd and bwd   (fork: geom/binning/image byte tensors)  caller-owned buffers sized by bags_*_size
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless named host_*; fp32, contiguous, row-major;
+ *   - the library allocates nothing that outlives a call, keeps no per-call state, never frees caller memory;
+ *   - all work is enqueued on `stream` (a hipStream_t; NULL = default stream) of the current device;
+ *     bags_forward_prepare performs ONE stream synchronisation (to hand the instance count to the host);
+ *   - return value: 0 = ok, negative = error; bags_last_error() gives a thread-local message;
+ *   - matrices follow the reference's row-vector convention: p_view = [x y z 1] * viewmatrix
+ *     (utils/graphics_utils.py:26-33, scene/cameras.py:107-108), 16 floats row-major.
+ */
+#ifndef BAGS_RASTER_H
+#define BAGS_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BAGS_ABI_VERSION 1
+#define BAGS_TILE 16
+
+enum { BAGS_OK = 0, BAGS_ERR_ARG = -1, BAGS_ERR_HIP = -2, BAGS_ERR_SIZE = -3, BAGS_ERR_DEVICE = -4 };
+enum { BAGS_DEPTH_Z = 0, BAGS_DEPTH_DISTANCE = 1 };   /* README.md:126: sort key is view z, or distance for cubemaps */
+
+/* GaussianRasterizationSettings (gaussian_renderer/__init__.py:50-65) */
+typedef struct BagsSettings {
+    int32_t image_height, image_width;
+    float tanfovx, tanfovy;          /* from the camera's STATIC fov (gaussian_renderer/__init__.py:47-48) */
+    float scale_modifier;
+    int32_t sh_degree;               /* active degree 0..3 */
+    int32_t sh_coeffs;               /* M: coefficients stored per Gaussian in `shs` ((max_sh_degree+1)^2) */
+    int32_t depth_key;               /* BAGS_DEPTH_Z | BAGS_DEPTH_DISTANCE */
+    int32_t debug;                   /* !=0: synchronise + check after every kernel */
+    int32_t debug_iter;              /* carried for error messages only */
+    const float* bg;                 /* (3)   */
+    const float* viewmatrix;         /* (4,4) world->view, transposed (W2C^T) */
+    const float* projmatrix;         /* (4,4) viewmatrix * intrinsic */
+    const float* intrinsic;          /* (4,4) projection^T; [0][0],[1][1] give the focal lengths, row 2 the shift direction */
+    const float* campos;             /* (3)   */
+} BagsSettings;
+
+/* the keyword tensors of GaussianRasterizer.forward (gaussian_renderer/__init__.py:110-121) */
+typedef struct BagsInputs {
+    int32_t P;
+    const float* means3D;            /* (P,3) */
+    const float* means2D;            /* (P,3) additive NDC offset, normally zeros; may be NULL */
+    const float* shift_factors;      /* (3) entrance-pupil polynomial; may be NULL (= zeros) */
+    const float* shs;                /* (P,M,3) or NULL */
+    const float* colors_precomp;     /* (P,3)   or NULL  (exactly one of shs / colors_precomp) */
+    const float* opacities;          /* (P,1) */
+    const float* scales;             /* (P,3) or NULL */
+    const float* rotations;          /* (P,4) (w,x,y,z) or NULL */
+    const float* cov3D_precomp;      /* (P,6) xx,xy,xz,yy,yz,zz or NULL (exactly one of scales+rotations / cov3D) */
+} BagsInputs;
+
+/* caller-owned state that survives from forward to backward */
+typedef struct BagsState {
+    void* geom;    size_t geom_bytes;     /* >= bags_geom_size(P)            */
+    void* binning; size_t binning_bytes;  /* >= bags_binning_size(I, W, H)   */
+    void* image;   size_t image_bytes;    /* >= bags_image_size(W, H)        */
+} BagsState;
+
+typedef struct BagsForwardOut {
+    float*   color;      /* (3,H,W) */
+    int32_t* radii;      /* (P)     */
+    float*   depth;      /* (1,H,W) expected view-space z            */
+    float*   weights;    /* (1,H,W) accumulated alpha = 1 - T_final  */
+    float*   mean2D;     /* (P,2)   pixel centres (0 for culled)     */
+} BagsForwardOut;
+
+typedef struct BagsBackwardArgs {
+    const float* grad_color;         /* (3,H,W) dL/dimage */
+    int64_t num_rendered;            /* I returned by bags_forward_prepare */
+    void* workspace; size_t workspace_bytes;   /* >= bags_backward_workspace_size(P, I) */
+    /* outputs; any may be NULL when not needed.  All are fully overwritten (not accumulated). */
+    float* grad_means3D;             /* (P,3)   */
+    float* grad_means2D;             /* (P,3)   NDC units, z = 0 */
+    float* grad_means2D_densify;     /* (P,3)   sum over pixels of |per-pixel NDC gradient|, z = 0 */
+    float* grad_shs;                 /* (P,M,3) */
+    float* grad_colors_precomp;      /* (P,3)   */
+    float* grad_opacities;           /* (P,1)   */
+    float* grad_scales;              /* (P,3)   */
+    float* grad_rotations;           /* (P,4)   */
+    float* grad_cov3D_precomp;       /* (P,6)   */
+    float* grad_viewmatrix;          /* (4,4)   */
+    float* grad_projmatrix;          /* (4,4)   */
+    float* grad_intrinsic;           /* (4,4)   */
+    float* grad_campos;              /* (3)     */
+    float* grad_shift_factors;       /* (3)     */
+} BagsBackwardArgs;
+
+/* integer artefacts for bit-exact parity checks (all device pointers, any may be NULL) */
+typedef struct BagsDebugViews {
+    uint32_t* tiles_touched;         /* (P) */
+    uint32_t* rect;                  /* (P,4) minx,miny,maxx,maxy */
+    uint32_t* depth_bits;            /* (P) float bits of the sort depth (0xFFFFFFFF if culled) */
+    uint32_t* point_list;            /* (I) Gaussian id per sorted instance */
+    uint64_t* keys_sorted;           /* (I) (tile<<32)|depth_bits per sorted instance */
+    uint32_t* ranges;                /* (T,2) */
+    uint32_t* n_contrib;             /* (H,W) */
+    float*    final_T;               /* (H,W) */
+} BagsDebugViews;
+
+int         bags_abi_version(void);
+const char* bags_last_error(void);
+
+size_t bags_geom_size(int32_t P);
+size_t bags_binning_size(int64_t num_rendered, int32_t width, int32_t height);
+size_t bags_image_size(int32_t width, int32_t height);
+size_t bags_backward_workspace_size(int32_t P, int64_t num_rendered);
+
+/* Phase 1: per-Gaussian projection/covariance/colour, depth ordering of the Gaussians, instance offsets.
+ * Writes radii and mean2D.  Synchronises `stream` once and returns the instance count in *host_num_rendered. */
+int bags_forward_prepare(const BagsSettings*, const BagsInputs*, const BagsState*, const BagsForwardOut*,
+                         int64_t* host_num_rendered, void* stream);
+/* Phase 2: instance emission, per-tile stable sort, tile ranges, front-to-back blend.  state.binning must hold
+ * bags_binning_size(num_rendered, W, H) bytes. */
+int bags_forward_finish(const BagsSettings*, const BagsInputs*, const BagsState*, const BagsForwardOut*,
+                        int64_t num_rendered, void* stream);
+/* Backward of the whole op from dL/dimage. */
+int bags_backward(const BagsSettings*, const BagsInputs*, const BagsState*, const BagsBackwardArgs*, void* stream);
+
+/* Copies integer artefacts out of the state buffers (parity tests / debugging). */
+int bags_debug_views(const BagsSettings*, const BagsInputs*, const BagsState*, int64_t num_rendered,
+                     const BagsDebugViews*, void* stream);
+
+/* compute_relocation of the fork's MCMC path (utils/reloc_utils.py:11-13): its only caller is commented out in
+ * the reference (scene/gaussian_model.py:23,494-504); exported so the symbol exists, returns BAGS_ERR_ARG. */
+int bags_compute_relocation(const float* opacity_old, const float* scale_old, const int32_t* N, const float* binoms,
+                            int32_t n_max, int32_t P, float* opacity_new, float* scale_new, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BAGS_RASTER_H */

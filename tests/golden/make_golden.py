@@ -1,0 +1,82 @@
+"""Generates the committed golden vectors from the REFERENCE's own Python functions (run in the authoring
+container only: /root/reference does not exist on the GPU box, and no reference source is copied here -- only
+inputs and expected outputs are stored).
+
+  sh_basis.npz      utils/sh_utils.py:57-112   eval_sh deg 0..3 on seeded coefficients/directions
+  camera_chain.npz  utils/graphics_utils.py:83-107 getProjectionMatrix (values + d/dfov),
+                    scene/cameras.py:399-416 quaternion_to_rotation_matrix (values + Jacobian)
+  loss.npz          utils/loss_utils.py l1_loss / ssim on seeded images (the loss that produces dL/dimage)
+
+Functions whose modules cannot be imported off-GPU (default arguments call .cuda()) are extracted by name from the
+module AST and exec'd in isolation.
+"""
+import ast, math, os, sys
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+
+
+def extract(path, names):
+    src = open(os.path.join(REF, path)).read()
+    tree = ast.parse(src)
+    ns = {"torch": torch, "math": math, "np": np}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            exec(compile(ast.Module([node], []), path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def main():
+    g = torch.Generator().manual_seed(1234)
+    # ---- SH basis
+    from utils.sh_utils import eval_sh, RGB2SH, SH2RGB
+    sh = torch.randn(64, 3, 16, generator=g)
+    d = torch.randn(64, 3, generator=g)
+    d = d / d.norm(dim=1, keepdim=True)
+    out = {"sh": sh.numpy(), "dirs": d.numpy()}
+    for deg in range(4):
+        out[f"rgb_deg{deg}"] = eval_sh(deg, sh, d).numpy()
+    rgb = torch.rand(8, 3, generator=g)
+    out["rgb_in"] = rgb.numpy(); out["rgb2sh"] = RGB2SH(rgb).numpy(); out["sh2rgb"] = SH2RGB(RGB2SH(rgb)).numpy()
+    np.savez(os.path.join(OUT, "sh_basis.npz"), **out)
+
+    # ---- camera chain pieces
+    (getProjectionMatrix,) = extract("utils/graphics_utils.py", ["getProjectionMatrix"])
+    (quaternion_to_rotation_matrix,) = extract("scene/cameras.py", ["quaternion_to_rotation_matrix"])
+    cam = {}
+    fovs = torch.tensor([[0.6911112, 1.0], [1.2, 0.9], [2.0, 1.7]])
+    Ps, dPx, dPy = [], [], []
+    for fx, fy in fovs:
+        fx = fx.clone().requires_grad_(True); fy = fy.clone().requires_grad_(True)
+        P = getProjectionMatrix(znear=0.01, zfar=100.0, fovX=fx, fovY=fy)
+        Ps.append(P.detach().numpy())
+        jx = torch.autograd.functional.jacobian(lambda a: getProjectionMatrix(0.01, 100.0, a, fy.detach()), fx.detach())
+        jy = torch.autograd.functional.jacobian(lambda a: getProjectionMatrix(0.01, 100.0, fx.detach(), a), fy.detach())
+        dPx.append(jx.numpy()); dPy.append(jy.numpy())
+    cam["fovs"] = fovs.numpy(); cam["P"] = np.stack(Ps); cam["dP_dfovx"] = np.stack(dPx); cam["dP_dfovy"] = np.stack(dPy)
+    cam["P_float"] = getProjectionMatrix(0.01, 100.0, 0.6911112, 1.0).numpy()
+    qs = torch.randn(6, 4, generator=g)
+    Rs, Js = [], []
+    for q in qs:
+        Rs.append(quaternion_to_rotation_matrix(q).numpy())
+        Js.append(torch.autograd.functional.jacobian(quaternion_to_rotation_matrix, q).numpy())
+    cam["q"] = qs.numpy(); cam["R"] = np.stack(Rs); cam["dR_dq"] = np.stack(Js)
+    np.savez(os.path.join(OUT, "camera_chain.npz"), **cam)
+
+    # ---- photometric loss
+    from utils.loss_utils import l1_loss, ssim
+    a = torch.rand(3, 48, 64, generator=g); b = torch.rand(3, 48, 64, generator=g)
+    a.requires_grad_(True)
+    l1 = l1_loss(a, b); s = ssim(a, b)
+    loss = 0.8 * l1 + 0.2 * (1.0 - s)
+    (ga,) = torch.autograd.grad(loss, a)
+    np.savez(os.path.join(OUT, "loss.npz"), a=a.detach().numpy(), b=b.numpy(), l1=l1.item(), ssim=s.item(),
+             loss=loss.item(), dloss_da=ga.numpy())
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

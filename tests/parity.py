@@ -1,0 +1,114 @@
+"""HIP-vs-oracle comparison used by the -m gpu tests and __graft_entry__.smoke()."""
+import torch
+
+from oracle import raster_oracle as O
+from scenes import camera_tensors, hip_settings, oracle_settings, rel_err
+
+GRAD_NAMES = ("means3D", "means2D", "means2D_densify", "shift_factors", "shs", "colors_precomp", "opacities", "scales",
+              "rotations", "cov3D_precomp", "viewmatrix", "projmatrix", "intrinsic", "campos")
+
+
+def run_hip(scene, cam, deg, grad_image=None, device="cuda", bg=None, shift=None, colors=None, cov3D=None,
+            scale_modifier=1.0, depth_key="z", debug=False, means2D=None):
+    """Forward (+ backward) through the product op.  Returns (outputs, grads dict, views dict)."""
+    from bags_raster import GaussianRasterizer, debug_views
+    dev = torch.device(device)
+    want = grad_image is not None
+    t = {k: v.to(dev).clone().requires_grad_(want) for k, v in scene.items()}
+    ct = {k: v.clone().requires_grad_(want) for k, v in camera_tensors(cam, dev).items()}
+    P = t["means3D"].shape[0]
+    m2 = (torch.zeros(P, 3) if means2D is None else means2D).to(dev).requires_grad_(want)
+    m2d = torch.zeros(P, 3, device=dev, requires_grad=want)
+    sf = (torch.zeros(3) if shift is None else shift).to(dev).requires_grad_(want)
+    col = None if colors is None else colors.to(dev).clone().requires_grad_(want)
+    cov = None if cov3D is None else cov3D.to(dev).clone().requires_grad_(want)
+    st = hip_settings(cam, deg, dev, bg=bg, scale_modifier=scale_modifier, depth_key=depth_key, tensors=ct, debug=debug)
+    rast = GaussianRasterizer(st)
+    kw = dict(means3D=t["means3D"], means2D=m2, means2D_densify=m2d, shift_factors=sf,
+              shs=None if col is not None else t["shs"], colors_precomp=col, opacities=t["opacities"],
+              scales=None if cov is not None else t["scales"], rotations=None if cov is not None else t["rotations"],
+              cov3D_precomp=cov)
+    outs = rast(**kw)
+    grads = None
+    if want:
+        outs[0].backward(grad_image.to(dev))
+        src = dict(means3D=t["means3D"], means2D=m2, means2D_densify=m2d, shift_factors=sf, shs=t["shs"],
+                   colors_precomp=col, opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"],
+                   cov3D_precomp=cov, **ct)
+        grads = {k: (None if v is None or v.grad is None else v.grad.detach().cpu()) for k, v in src.items()}
+    with torch.no_grad():
+        views = debug_views(st, *[None if kw[k] is None else kw[k].detach() for k in
+                                  ("means3D", "means2D", "shift_factors", "shs", "colors_precomp", "opacities",
+                                   "scales", "rotations", "cov3D_precomp")])
+    views = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in views.items() if k != "outputs"}
+    return [o.detach().cpu() for o in outs], grads, views
+
+
+def run_oracle(scene, cam, deg, grad_image=None, dtype=torch.float32, bg=None, shift=None, colors=None, cov3D=None,
+               scale_modifier=1.0, depth_key="z", discrete=None, means2D=None):
+    s = oracle_settings(cam, deg, bg=bg, scale_modifier=scale_modifier, depth_key=depth_key)
+    inp = dict(scene)
+    inp["shift_factors"] = torch.zeros(3) if shift is None else shift
+    if means2D is not None:
+        inp["means2D"] = means2D
+    if colors is not None:
+        inp["colors_precomp"] = colors; inp["shs"] = None
+    if cov3D is not None:
+        inp["cov3D_precomp"] = cov3D; inp["scales"] = None; inp["rotations"] = None
+    return O.render_and_grad(inp, s, grad_image, dtype=dtype, discrete=discrete)
+
+
+def compare(scene, cam, deg, seed=1, check_fp64=True, **kw):
+    """Full parity report of one case.  Integer artefacts are compared bit for bit, floats by tolerance."""
+    H, W = cam.image_height, cam.image_width
+    g = torch.randn(3, H, W, generator=torch.Generator().manual_seed(seed))
+    outs, grads, views = run_hip(scene, cam, deg, g, **kw)
+    st32, gr32 = run_oracle(scene, cam, deg, g, torch.float32, **kw)
+    rep = {}
+    # ---- integers: bit-exact
+    rep["radii_equal"] = bool(torch.equal(outs[1], st32.radii))
+    rep["tiles_touched_equal"] = bool(torch.equal(views["tiles_touched"], st32.pre.tiles_touched))
+    rep["rect_equal"] = bool(torch.equal(views["rect"], st32.pre.rect))
+    vis = st32.pre.visible
+    d32 = st32.pre.depth.detach().float().contiguous().view(torch.int32)
+    rep["depth_bits_equal"] = bool(torch.equal(views["depth_bits"][vis], d32[vis]))
+    rep["num_rendered"] = (views["num_rendered"], int(st32.point_list.numel()))
+    same_I = views["num_rendered"] == st32.point_list.numel()
+    rep["point_list_equal"] = same_I and bool(torch.equal(views["point_list"], st32.point_list))
+    rep["keys_equal"] = same_I and bool(torch.equal(views["keys_sorted"], st32.keys_sorted))
+    cnt_h = views["ranges"][:, 1] - views["ranges"][:, 0]
+    cnt_o = st32.ranges[:, 1] - st32.ranges[:, 0]
+    nz = cnt_o > 0
+    rep["ranges_equal"] = bool(torch.equal(cnt_h, cnt_o)) and bool(torch.equal(views["ranges"][nz], st32.ranges[nz]))
+    nc_mis = (views["n_contrib"] != st32.n_contrib).float().mean().item()
+    rep["n_contrib_mismatch_frac"] = nc_mis
+    # ---- floats
+    img_err = (outs[0] - st32.image).abs() / (1.0 + st32.image.abs())
+    rep["image_max_err"] = img_err.max().item()
+    rep["depth_max_err"] = ((outs[2] - st32.depth_img).abs() / (1.0 + st32.depth_img.abs())).max().item()
+    rep["weights_max_err"] = (outs[3] - st32.weights).abs().max().item()
+    rep["mean2D_max_err"] = (outs[4] - st32.mean2D).abs().max().item()
+    rep["grad_rel_fp32"] = {k: rel_err(grads[k], gr32[k]) for k in GRAD_NAMES if grads.get(k) is not None and k in gr32}
+    if check_fp64:
+        st64, gr64 = run_oracle(scene, cam, deg, g, torch.float64, discrete=O.discrete_of(st32), **kw)
+        rep["grad_rel_fp64"] = {k: rel_err(grads[k], gr64[k]) for k in GRAD_NAMES if grads.get(k) is not None and k in gr64}
+        rep["oracle32_vs_64"] = {k: rel_err(gr32[k], gr64[k]) for k in GRAD_NAMES if k in gr32 and k in gr64}
+    return rep
+
+
+INT_KEYS = ("radii_equal", "tiles_touched_equal", "rect_equal", "depth_bits_equal", "point_list_equal", "keys_equal",
+            "ranges_equal")
+
+
+def assert_report(rep, grad_tol=1e-4, img_tol=1e-5, skip_zero=()):
+    for k in INT_KEYS:
+        assert rep[k], f"{k} failed: {rep}"
+    assert rep["num_rendered"][0] == rep["num_rendered"][1]
+    assert rep["n_contrib_mismatch_frac"] <= 1e-4, rep["n_contrib_mismatch_frac"]
+    assert rep["image_max_err"] <= img_tol, rep["image_max_err"]
+    assert rep["depth_max_err"] <= 1e-4 and rep["weights_max_err"] <= 1e-4 and rep["mean2D_max_err"] <= 1e-3
+    for name in ("grad_rel_fp32", "grad_rel_fp64"):
+        for k, e in rep.get(name, {}).items():
+            if k in skip_zero:
+                continue
+            assert e <= grad_tol, f"{name}[{k}] = {e:.3e} > {grad_tol}: {rep}"

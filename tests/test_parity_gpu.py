@@ -1,0 +1,122 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (BASELINE.json north_star): tile/splat indices bit-exact; gradients <= 1e-4 relative (L2 per tensor) to the
+fp32 oracle and to the fp64 oracle replaying the fp32 run's discrete decisions; image |d| <= 1e-5 (1+|x|)."""
+import pytest
+import torch
+
+from parity import assert_report, compare, run_hip, run_oracle
+from scenes import make_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _report(rep):
+    print({k: v for k, v in rep.items()})
+
+
+@pytest.mark.parametrize("P,W,H,sm,deg", [(1000, 128, 96, 2.0, 3), (3000, 200, 136, 1.5, 3), (2000, 100, 70, 2.0, 0),
+                                          (4000, 160, 160, 1.0, 2), (2500, 131, 77, 2.0, 1)])
+def test_parity_synthetic(P, W, H, sm, deg):
+    scene, cam = make_case(P, W, H, sm, deg, seed=P)
+    rep = compare(scene, cam, deg)
+    _report(rep)
+    assert_report(rep, skip_zero=("campos",) if deg == 0 else ())
+
+
+def test_parity_config1_plumbing():
+    """BASELINE config 1: 10k Gaussians, 400x400, SH degree 0."""
+    scene, cam = make_case(10000, 400, 400, 1.0, 0, seed=0)
+    rep = compare(scene, cam, 0, check_fp64=False)
+    _report(rep)
+    assert rep["num_rendered"][0] == 270130          # G = 9 936, I = 0.27 M
+    assert_report(rep, skip_zero=("campos",))
+
+
+def test_parity_background_and_scale_modifier():
+    scene, cam = make_case(1500, 96, 64, 2.0, 3, seed=3)
+    rep = compare(scene, cam, 3, bg=torch.tensor([0.3, 0.6, 0.9]), scale_modifier=0.7)
+    _report(rep)
+    assert_report(rep)
+
+
+def test_parity_precomputed_colors_and_cov3D():
+    scene, cam = make_case(1200, 96, 80, 2.0, 0, seed=5)
+    g = torch.Generator().manual_seed(7)
+    colors = torch.rand(1200, 3, generator=g)
+    L = torch.randn(1200, 3, 3, generator=g) * 0.03
+    cov = L @ L.transpose(1, 2)
+    cov6 = torch.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], 1)
+    rep = compare(scene, cam, 0, colors=colors, cov3D=cov6)
+    _report(rep)
+    assert_report(rep, skip_zero=("campos",))
+
+
+def test_parity_shift_factors_extension():
+    """Non-zero entrance-pupil polynomial (BASELINE config 5's distortion parameters): indices are no longer
+    bit-comparable (atan2 differs by ulps between CPU and GPU), values and gradients still are."""
+    scene, cam = make_case(1500, 128, 96, 2.0, 2, seed=9)
+    sf = torch.tensor([0.05, -0.02, 0.01])
+    H, W = cam.image_height, cam.image_width
+    g = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1))
+    outs, grads, _ = run_hip(scene, cam, 2, g, shift=sf)
+    st, gr = run_oracle(scene, cam, 2, g, torch.float32, shift=sf)
+    assert ((outs[0] - st.image).abs() / (1 + st.image.abs())).max().item() < 1e-3
+    for k in ("means3D", "shift_factors", "viewmatrix", "projmatrix", "intrinsic", "opacities"):
+        assert rel_err(grads[k], gr[k]) < 2e-3, (k, rel_err(grads[k], gr[k]))
+
+
+def test_edge_cases_empty_behind_and_single():
+    from bags_raster.synth import look_at_origin_camera
+    cam = look_at_origin_camera(64, 48)
+    g = torch.randn(3, 48, 64, generator=torch.Generator().manual_seed(0))
+    # everything behind the camera -> background only, zero gradients, I == 0
+    scene, _ = make_case(50, 64, 48, 1.0, 1, seed=1)
+    scene["means3D"] = scene["means3D"] + torch.tensor([0.0, 0.0, -10.0])
+    bg = torch.tensor([0.2, 0.4, 0.6])
+    outs, grads, views = run_hip(scene, cam, 1, g, bg=bg)
+    assert views["num_rendered"] == 0 and int(outs[1].max()) == 0
+    assert torch.allclose(outs[0], bg[:, None, None].expand(3, 48, 64))
+    assert all(v is None or float(v.abs().max()) == 0.0 for v in grads.values())
+    # a single Gaussian on the optical axis
+    one = dict(means3D=torch.zeros(1, 3), scales=torch.full((1, 3), 0.2), rotations=torch.tensor([[1.0, 0, 0, 0]]),
+               opacities=torch.tensor([[0.8]]), shs=torch.randn(1, 16, 3, generator=torch.Generator().manual_seed(2)) * 0.3)
+    rep = compare(one, cam, 3)
+    _report(rep)
+    assert_report(rep)
+
+
+def test_saturated_alpha_and_early_termination():
+    """Opaque, overlapping splats: exercises alpha clamp 0.99 and the T < 1e-4 stop."""
+    scene, cam = make_case(800, 96, 96, 6.0, 1, seed=11)
+    scene["opacities"] = torch.full_like(scene["opacities"], 0.999)
+    rep = compare(scene, cam, 1)
+    _report(rep)
+    assert_report(rep, grad_tol=2e-4)
+
+
+def test_depth_key_distance_mode():
+    scene, cam = make_case(1500, 128, 96, 2.0, 1, seed=13)
+    rep = compare(scene, cam, 1, depth_key="distance", check_fp64=False)
+    _report(rep)
+    assert_report(rep)
+
+
+def test_backward_is_bitwise_reproducible():
+    scene, cam = make_case(3000, 160, 128, 1.5, 3, seed=21)
+    g = torch.randn(3, 128, 160, generator=torch.Generator().manual_seed(4))
+    _, g1, _ = run_hip(scene, cam, 3, g)
+    _, g2, _ = run_hip(scene, cam, 3, g)
+    for k in g1:
+        if g1[k] is not None:
+            assert torch.equal(g1[k], g2[k]), k
+
+
+def test_cpu_tensors_fail_loudly():
+    from bags_raster import GaussianRasterizer
+    from scenes import hip_settings
+    scene, cam = make_case(10, 32, 32, 1.0, 0, seed=0)
+    st = hip_settings(cam, 0, "cpu")
+    with pytest.raises(RuntimeError, match="AMD GPU"):
+        GaussianRasterizer(st)(means3D=scene["means3D"], means2D=torch.zeros(10, 3), shs=scene["shs"],
+                               opacities=scene["opacities"], scales=scene["scales"], rotations=scene["rotations"])
