@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- composited Gaussians/s (fwd+bwd) @1080p of the MI355X rasterizer (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one pass of the hot path over one view: the C-ABI forward (bags_forward_prepare + bags_forward_finish) and
+backward (bags_backward) of BASELINE config 2 -- synth(500 000 Gaussians, seed 0, sm 0.5), one pinhole camera at
+1920x1080, SH degree 3 -- with every input already resident in HBM and a fixed seeded dL/dimage cotangent.  At N > 1
+the views are sharded (rank r renders its own perturbed-pose view of the same replicated scene) and the step ends
+with the RCCL all-reduce of the Gaussian-parameter gradients (59 floats per Gaussian), the path's one exchange step;
+value = N * P * K / max-over-ranks time ("weak" scaling: per-GPU work is fixed).
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (blend_bwd): algorithmic bytes per launch / mean launch time, timed with hipEvents on the
+                launch stream inside the timed region (bags_profile_*), against the 8 TB/s HBM peak
+  op_roofline   the same for the whole fwd+bwd with SURVEY.md 8d's B_alg = G*850 + (P-G)*28 + I*168 + H*W*40
+  cpu_baseline  the CPU oracle (oracle/raster_oracle.py, PyTorch autograd, fp32) on a bounded sample of the same workload
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "bundle-adjusting-gaussian-splatting_amd")
+for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: 8 TB/s spec
+P_DEFAULT, W_DEFAULT, H_DEFAULT, SM_DEFAULT, DEG = 500_000, 1920, 1080, 0.5, 3
+
+
+def build_case(P, W, H, sm, rank, dev):
+    from bags_raster.synth import synth_scene, look_at_origin_camera, sphere_views
+    scene = synth_scene(P, 0, sm, DEG, device=dev)
+    if rank == 0:
+        cam = look_at_origin_camera(W, H)
+    else:   # view sharding: rank r looks at the same scene from its own perturbed pose (scene/__init__.py:121-148)
+        cam = sphere_views(rank + 1, W, H, noise=0.05)[rank]
+    return scene, cam
+
+
+def make_step(scene, cam, dev, pose_grads=True):
+    from bags_raster import GaussianRasterizationSettings, GaussianRasterizer
+    from scenes import camera_tensors
+    P = scene["means3D"].shape[0]
+    leaves = {k: v.clone().requires_grad_(True) for k, v in scene.items()}
+    ct = {k: v.clone().requires_grad_(pose_grads) for k, v in camera_tensors(cam, dev).items()}
+    means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
+    densify = torch.zeros(P, 3, device=dev, requires_grad=True)
+    shift = torch.zeros(3, device=dev, requires_grad=True)
+    st = GaussianRasterizationSettings(image_height=cam.image_height, image_width=cam.image_width,
+                                       tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+                                       bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=ct["viewmatrix"],
+                                       projmatrix=ct["projmatrix"], intrinsic=ct["intrinsic"], sh_degree=DEG,
+                                       campos=ct["campos"], prefiltered=False, debug=False, debug_iter=0)
+    rast = GaussianRasterizer(st)
+    cot = torch.randn(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(1)).to(dev)
+    params = list(leaves.values())
+    every = params + list(ct.values()) + [means2D, densify, shift]
+
+    def step():
+        for t in every:
+            t.grad = None
+        img, radii, _, _, _ = rast(means3D=leaves["means3D"], means2D=means2D, means2D_densify=densify,
+                                   shift_factors=shift, shs=leaves["shs"], colors_precomp=None,
+                                   opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"],
+                                   cov3D_precomp=None)
+        img.backward(cot)
+        return radii
+
+    return step, params, ct
+
+
+def cpu_baseline(P, W, H, sm, budget_tiles=None):
+    """Oracle fwd+bwd on host cores: preprocess + binning on all P, blending on every `stride`-th tile (scaled back)."""
+    from bags_raster.synth import synth_scene, look_at_origin_camera
+    from oracle import raster_oracle as O
+    from scenes import oracle_settings
+    torch.set_num_threads(os.cpu_count() or 1)
+    scene = synth_scene(P, 0, sm, DEG)
+    cam = look_at_origin_camera(W, H)
+    s = oracle_settings(cam, DEG)
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    stride = max(1, T // (budget_tiles or 384))
+    tiles = torch.arange(0, T, stride)
+    g = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1))
+    inp = dict(scene); inp["shift_factors"] = torch.zeros(3)
+    t0 = time.perf_counter()
+    st, _ = O.render_and_grad(inp, s, None, tiles=tiles[:1])            # preprocess + sort (+1 tile)
+    t_pre = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    st, gr = O.render_and_grad(inp, s, g, tiles=tiles)
+    t_all = time.perf_counter() - t0
+    # t_all = (preprocess + sort + its backward) + blend(fwd+bwd) on len(tiles) tiles
+    t_blend = max(t_all - t_pre, 0.0)
+    est = t_pre + t_blend * (T / len(tiles))
+    return dict(value=P / est, unit="Gaussians/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle/raster_oracle.py fp32 autograd: preprocess+sort of all {P} Gaussians ({t_pre:.1f}s) + "
+                       f"blend fwd+bwd on {len(tiles)} of {T} tiles ({t_blend:.1f}s), tile time scaled x{T / len(tiles):.1f}",
+                seconds_measured=round(t_all + t_pre, 2), est_seconds_full=round(est, 1))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--P", type=int, default=P_DEFAULT)
+    ap.add_argument("--width", type=int, default=W_DEFAULT)
+    ap.add_argument("--height", type=int, default=H_DEFAULT)
+    ap.add_argument("--sm", type=float, default=SM_DEFAULT)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-stage hipEvents in the timed region")
+    ap.add_argument("--fixed-pose", action="store_true", help="config 2 exactly: no pose/intrinsic gradients requested")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the rasterizer has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from bags_raster import _lib
+    from bags_raster.sharding import GradAllReducer
+    P, W, H = args.P, args.width, args.height
+    scene, cam = build_case(P, W, H, args.sm, rank, dev)
+    step, params, ct = make_step(scene, cam, dev, pose_grads=not args.fixed_pose)
+    reducer = GradAllReducer(params) if world > 1 else None
+
+    def full_step():
+        radii = step()
+        if reducer is not None:
+            reducer.all_reduce()
+        return radii
+
+    for _ in range(args.warmup):
+        radii = full_step()
+    torch.cuda.synchronize()
+    G = int((radii > 0).sum())
+    _lib.profile_read()
+    _lib.profile_enable(not args.no_profile)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full_step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    prof = _lib.profile_read()
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        from bags_raster import rasterizer as R
+        I = int(getattr(R, "LAST_NUM_RENDERED", 0))
+        ms_step = elapsed / args.steps * 1e3
+        value = world * P * args.steps / elapsed
+        stages = {k: (ms / max(c, 1)) for k, (ms, c) in prof.items() if c > 0}
+        HWp = H * W
+        alg = {  # algorithmic bytes per launch (DESIGN.md "Kernels"): SURVEY.md 8d split per stage
+            "blend_bwd": I * 84 + HWp * 20,
+            "blend_fwd": I * 40 + HWp * 20,
+            "preprocess_fwd": G * 284 + (P - G) * 28,
+            "preprocess_bwd": G * 566,
+            "tile_sort": I * 36,
+            "emit": I * 12,
+        }
+        b_alg = G * 850 + (P - G) * 28 + I * 168 + HWp * 40
+        out = {
+            "metric": "composited Gaussians/s (fwd+bwd) @1080p", "value": value, "unit": "Gaussians/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE config {'2' if args.fixed_pose else '3'}: synth({P}, seed 0, sm {args.sm}), "
+                                   f"1 camera/rank @{W}x{H}, SH deg 3, fwd+bwd"
+                                   f"{'' if args.fixed_pose else ' incl. pose/intrinsic gradients'}",
+                       "P": P, "visible_G": G, "instances_I": I, "width": W, "height": H,
+                       "parallelism": f"view-sharded x{world}" + (", RCCL all-reduce of Gaussian grads" if world > 1 else "")},
+            "instances_per_s": world * I * args.steps / elapsed,
+        }
+        if stages:
+            dom = max(stages, key=lambda k: stages[k])
+            if dom in alg:
+                ach = alg[dom] / (stages[dom] * 1e-3)
+                out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
+                                   "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": None,
+                                   "alg_bytes_per_launch": alg[dom], "mean_launch_ms": stages[dom]}
+            dev_ms = sum(stages.values())
+            out["op_roofline"] = {"bound": "hbm", "alg_bytes_per_step": b_alg, "device_ms_per_step": dev_ms,
+                                  "achieved": b_alg / (dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                  "frac": b_alg / (dev_ms * 1e-3) / HBM_PEAK,
+                                  "frac_wall": b_alg / (ms_step * 1e-3) / HBM_PEAK}
+            out["stage_ms"] = {k: round(v, 4) for k, v in stages.items()}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(P, W, H, args.sm)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -66,6 +66,8 @@ SYMBOLS = {
                                 C.POINTER(BagsBackwardArgs), C.c_void_p]),
     "bags_debug_views": (C.c_int, [C.POINTER(BagsSettings), C.POINTER(BagsInputs), C.POINTER(BagsState), C.c_int64,
                                    C.POINTER(BagsDebugViews), C.c_void_p]),
+    "bags_profile_enable": (C.c_int, [C.c_int]),
+    "bags_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "bags_compute_relocation": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int32, C.c_int32, c_fp, c_fp, C.c_void_p]),
 }
 
@@ -95,3 +97,17 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().bags_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{what}: {msg} (code {rc})")
+
+
+def profile_enable(on: bool) -> None:
+    load().bags_profile_enable(1 if on else 0)
+
+
+def profile_read():
+    """{stage: (total_ms, intervals)} since the last read; synchronises on the recorded events."""
+    n = 16
+    names = (C.c_char_p * n)()
+    ms = (C.c_double * n)()
+    calls = (C.c_int64 * n)()
+    k = load().bags_profile_read(n, names, ms, calls)
+    return {names[i].decode(): (ms[i], calls[i]) for i in range(min(k, n))}

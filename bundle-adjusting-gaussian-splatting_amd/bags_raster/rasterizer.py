@@ -121,8 +121,17 @@ class _Packed:
                                    _ptr(k["rotations"]), _ptr(k["cov3D_precomp"]))
 
 
+def _require_gpu(t: torch.Tensor) -> None:
+    if not torch.is_tensor(t) or t.device.type != "cuda":
+        raise RuntimeError("bags_raster runs only on an AMD GPU: tensors must be on a 'cuda' (ROCm) device; "
+                           "there is no CPU path")
+
+
 def _bytes(n: int, device) -> torch.Tensor:
     return torch.empty(int(n), dtype=torch.uint8, device=device)
+
+
+LAST_NUM_RENDERED = 0      # instance count of the most recent forward (bench/diagnostics)
 
 
 class _Forwarded:
@@ -148,6 +157,8 @@ def _run_forward(lib, pk: _Packed, H: int, W: int):
     L.check(lib.bags_forward_prepare(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(out),
                                      C.byref(n), stream), "bags_forward_prepare")
     fw.num_rendered = int(n.value)
+    global LAST_NUM_RENDERED
+    LAST_NUM_RENDERED = fw.num_rendered
     fw.binning = _bytes(lib.bags_binning_size(fw.num_rendered, W, H), dev)
     state.binning, state.binning_bytes = fw.binning.data_ptr(), fw.binning.numel()
     L.check(lib.bags_forward_finish(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(out),
@@ -165,6 +176,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     def forward(ctx, means3D, means2D, means2D_densify, shift_factors, sh, colors_precomp, opacities, scales, rotations,
                 cov3Ds_precomp, viewmatrix, projmatrix, intrinsic, campos, raster_settings):
         lib = L.load()
+        _require_gpu(means3D)
         with torch.cuda.device(means3D.device):
             pk = _Packed(raster_settings, means3D, means2D, shift_factors, sh, colors_precomp, opacities, scales,
                          rotations, cov3Ds_precomp, viewmatrix, projmatrix, intrinsic, campos)
@@ -255,6 +267,7 @@ def debug_views(settings: GaussianRasterizationSettings, means3D, means2D, shift
     """Forward pass that also returns the integer artefacts (tiles_touched, rect, depth bits, sorted instance list,
     64-bit keys, tile ranges, n_contrib, final_T) for the bit-exact parity tests."""
     lib = L.load()
+    _require_gpu(means3D)
     dev = means3D.device
     with torch.cuda.device(dev), torch.no_grad():
         pk = _Packed(settings, means3D, means2D, shift_factors, shs, colors_precomp, opacities, scales, rotations,

@@ -25,6 +25,31 @@ static int fail(int code, const char* fmt, ...)
          if (e_ != hipSuccess) return fail(BAGS_ERR_HIP, "debug: %s failed at iteration %d: %s", what, (s)->debug_iter, hipGetErrorString(e_)); } \
     } while (0)
 
+// ---------------------------------------------------------------------------------------------- stage profiler
+// Opt-in (bags_profile_enable): a start/stop hipEvent pair per stage per call, resolved in bags_profile_read.
+#include <vector>
+enum Stage { ST_PRE_FWD, ST_DEPTH_SORT, ST_OFFSETS, ST_EMIT, ST_TILE_SORT, ST_RANGES, ST_BLEND_FWD, ST_BLEND_BWD,
+             ST_PRE_BWD, ST_POSE_REDUCE, ST_COUNT };
+static const char* kStageNames[ST_COUNT] = {"preprocess_fwd", "depth_sort", "offsets_scan", "emit", "tile_sort",
+                                            "tile_ranges", "blend_fwd", "blend_bwd", "preprocess_bwd", "pose_reduce"};
+struct ProfInterval { int stage; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfInterval> g_prof_pending;
+static std::vector<hipEvent_t> g_prof_free;
+static double g_prof_ms[ST_COUNT];
+static long long g_prof_calls[ST_COUNT];
+
+static hipEvent_t prof_event()
+{
+    if (!g_prof_free.empty()) { hipEvent_t e = g_prof_free.back(); g_prof_free.pop_back(); return e; }
+    hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
+}
+struct ProfScope {
+    hipStream_t st; int stage; hipEvent_t a = nullptr;
+    ProfScope(int stage_, hipStream_t st_) : st(st_), stage(stage_) { if (g_prof_on) { a = prof_event(); (void)hipEventRecord(a, st); } }
+    ~ProfScope() { if (a) { hipEvent_t b = prof_event(); (void)hipEventRecord(b, st); g_prof_pending.push_back({stage, a, b}); } }
+};
+
 // ---------------------------------------------------------------------------------------------- buffer carving
 template <typename Tp>
 static inline void take(char*& p, Tp*& out, size_t count)
@@ -139,14 +164,15 @@ int bags_forward_prepare(const BagsSettings* s, const BagsInputs* in, const Bags
     GeomView g; carve_geom(align256(stt->geom), in->P, &g);
     *host_num_rendered = 0;
     if (in->P == 0) return BAGS_OK;
-    HIP_TRY(launch_preprocess_fwd(*s, *in, g, out->radii, out->mean2D, st));
+    { ProfScope ps(ST_PRE_FWD, st); HIP_TRY(launch_preprocess_fwd(*s, *in, g, out->radii, out->mean2D, st)); }
     DEBUG_SYNC(s, st, "preprocess_fwd");
     // depth order of the Gaussians: 4 stable 8-bit passes over the float bits (positive floats order like u32)
-    HIP_TRY(launch_radix_sort(g.depth_key, nullptr, g.keys_a, g.vals_a, g.keys_b, g.vals_b, in->P, 32, true,
-                              g.radix_hist, g.digit_totals, g.nblocks_sort, st));
+    { ProfScope ps(ST_DEPTH_SORT, st);
+      HIP_TRY(launch_radix_sort(g.depth_key, nullptr, g.keys_a, g.vals_a, g.keys_b, g.vals_b, in->P, 32, true,
+                                g.radix_hist, g.digit_totals, g.nblocks_sort, st)); }
     DEBUG_SYNC(s, st, "depth sort");
     const u32* sorted_ids = g.vals_b;                     // 4 passes: src->a->b->a->b
-    HIP_TRY(launch_offsets_scan(g, sorted_ids, in->P, st));
+    { ProfScope ps(ST_OFFSETS, st); HIP_TRY(launch_offsets_scan(g, sorted_ids, in->P, st)); }
     DEBUG_SYNC(s, st, "offsets scan");
     u32 host_I = 0;
     HIP_TRY(hipMemcpyAsync(&host_I, g.num_rendered, sizeof(u32), hipMemcpyDeviceToHost, st));
@@ -170,15 +196,16 @@ int bags_forward_finish(const BagsSettings* s, const BagsInputs* in, const BagsS
     ImgView im; carve_image(align256(stt->image), W, H, &im);
     const int gx = cdiv(W, BAGS_TILE), gy = cdiv(H, BAGS_TILE);
     if (I > 0) {
-        HIP_TRY(launch_emit(g, g.vals_b, in->P, gx, b.keys_b, b.vals_b, st));
+        { ProfScope ps(ST_EMIT, st); HIP_TRY(launch_emit(g, g.vals_b, in->P, gx, b.keys_b, b.vals_b, st)); }
         DEBUG_SYNC(s, st, "emit");
-        HIP_TRY(launch_radix_sort(b.keys_b, b.vals_b, b.keys_a, b.vals_a, b.keys_b, b.vals_b, I, b.passes * RADIX_BITS,
-                                  false, b.radix_hist, b.digit_totals, b.nblocks_sort, st));
+        { ProfScope ps(ST_TILE_SORT, st);
+          HIP_TRY(launch_radix_sort(b.keys_b, b.vals_b, b.keys_a, b.vals_a, b.keys_b, b.vals_b, I, b.passes * RADIX_BITS,
+                                    false, b.radix_hist, b.digit_totals, b.nblocks_sort, st)); }
         DEBUG_SYNC(s, st, "tile sort");
     }
-    HIP_TRY(launch_tile_ranges(b.tile_sorted, I, b.ranges, gx * gy, st));
+    { ProfScope ps(ST_RANGES, st); HIP_TRY(launch_tile_ranges(b.tile_sorted, I, b.ranges, gx * gy, st)); }
     DEBUG_SYNC(s, st, "tile ranges");
-    HIP_TRY(launch_blend_fwd(*s, g, b, im, *out, st));
+    { ProfScope ps(ST_BLEND_FWD, st); HIP_TRY(launch_blend_fwd(*s, g, b, im, *out, st)); }
     DEBUG_SYNC(s, st, "blend_fwd");
     return BAGS_OK;
 }
@@ -201,13 +228,13 @@ int bags_backward(const BagsSettings* s, const BagsInputs* in, const BagsState* 
     float* partials = reinterpret_cast<float*>(ws);
     float* slab = reinterpret_cast<float*>(ws + align_up((size_t)(I > 0 ? I : 1) * PART_FLOATS * sizeof(float), 256));
     if (I > 0) {
-        HIP_TRY(launch_blend_bwd(*s, g, b, im, a->grad_color, partials, st));
+        { ProfScope ps(ST_BLEND_BWD, st); HIP_TRY(launch_blend_bwd(*s, g, b, im, a->grad_color, partials, st)); }
         DEBUG_SYNC(s, st, "blend_bwd");
     }
     int nblocks = 0;
-    HIP_TRY(launch_preprocess_bwd(*s, *in, g, nullptr, partials, slab, &nblocks, *a, st));
+    { ProfScope ps(ST_PRE_BWD, st); HIP_TRY(launch_preprocess_bwd(*s, *in, g, nullptr, partials, slab, &nblocks, *a, st)); }
     DEBUG_SYNC(s, st, "preprocess_bwd");
-    HIP_TRY(launch_pose_reduce(slab, nblocks, *a, st));
+    { ProfScope ps(ST_POSE_REDUCE, st); HIP_TRY(launch_pose_reduce(slab, nblocks, *a, st)); }
     DEBUG_SYNC(s, st, "pose_reduce");
     return BAGS_OK;
 }
@@ -236,6 +263,32 @@ int bags_debug_views(const BagsSettings* s, const BagsInputs* in, const BagsStat
         if (d->ranges) HIP_TRY(hipMemcpyAsync(d->ranges, b.ranges, T * 8, hipMemcpyDeviceToDevice, st));
     }
     return BAGS_OK;
+}
+
+int bags_profile_enable(int on)
+{
+    g_prof_on = on != 0;
+    return BAGS_OK;
+}
+
+int bags_profile_read(int max_stages, const char** names, double* total_ms, int64_t* calls)
+{
+    for (const ProfInterval& iv : g_prof_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(iv.b) == hipSuccess && hipEventElapsedTime(&ms, iv.a, iv.b) == hipSuccess) {
+            g_prof_ms[iv.stage] += ms; g_prof_calls[iv.stage] += 1;
+        }
+        g_prof_free.push_back(iv.a); g_prof_free.push_back(iv.b);
+    }
+    g_prof_pending.clear();
+    const int n = max_stages < ST_COUNT ? max_stages : (int)ST_COUNT;
+    for (int i = 0; i < n; ++i) {
+        if (names) names[i] = kStageNames[i];
+        if (total_ms) total_ms[i] = g_prof_ms[i];
+        if (calls) calls[i] = g_prof_calls[i];
+    }
+    for (int i = 0; i < ST_COUNT; ++i) { g_prof_ms[i] = 0.0; g_prof_calls[i] = 0; }
+    return (int)ST_COUNT;
 }
 
 int bags_compute_relocation(const float*, const float*, const int32_t*, const float*, int32_t, int32_t, float*, float*, void*)

@@ -139,6 +139,14 @@ int bags_backward(const BagsSettings*, const BagsInputs*, const BagsState*, cons
 int bags_debug_views(const BagsSettings*, const BagsInputs*, const BagsState*, int64_t num_rendered,
                      const BagsDebugViews*, void* stream);
 
+/* Opt-in per-stage device timing (hipEvents recorded on the caller's stream around each kernel group):
+ * bench.py's roofline leg.  Off by default; the hot path records nothing unless enabled.
+ * bags_profile_read synchronises on the recorded events, returns the number of stages, fills up to `max_stages`
+ * entries (stage name, summed milliseconds, number of timed intervals) and clears the accumulators. */
+#define BAGS_PROFILE_MAX_STAGES 16
+int bags_profile_enable(int on);
+int bags_profile_read(int max_stages, const char** names, double* total_ms, int64_t* calls);
+
 /* compute_relocation of the fork's MCMC path (utils/reloc_utils.py:11-13): its only caller is commented out in
  * the reference (scene/gaussian_model.py:23,494-504); exported so the symbol exists, returns BAGS_ERR_ARG. */
 int bags_compute_relocation(const float* opacity_old, const float* scale_old, const int32_t* N, const float* binoms,

@@ -1,0 +1,85 @@
+"""No-GPU checks of the drop-in boundary: the library loads, exports every symbol include/bags_raster.h declares,
+reports sane buffer sizes, and the host shim refuses CPU tensors / bad argument combinations like the reference op."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from bags_raster import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    header = open(os.path.join(ROOT, "include", "bags_raster.h")).read()
+    declared = set(re.findall(r"\b(bags_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.bags_abi_version() == _lib.ABI_VERSION
+
+
+def test_buffer_sizes_grow_with_problem(lib):
+    assert lib.bags_geom_size(0) > 0
+    assert lib.bags_geom_size(500_000) > 500_000 * 80
+    assert lib.bags_geom_size(1000) < lib.bags_geom_size(100_000)
+    assert lib.bags_binning_size(3_700_000, 1920, 1080) >= 3_700_000 * 16
+    assert lib.bags_image_size(1920, 1080) >= 1920 * 1080 * 8
+    assert lib.bags_backward_workspace_size(500_000, 3_700_000) >= 3_700_000 * 64
+
+
+def test_struct_layout_matches_header(lib):
+    # field counts and pointer-size packing of the POD structs (a mismatch would corrupt every call)
+    assert C.sizeof(_lib.BagsSettings) == 10 * 4 + 5 * 8
+    assert C.sizeof(_lib.BagsInputs) == 8 + 9 * 8
+    assert C.sizeof(_lib.BagsState) == 6 * 8
+    assert C.sizeof(_lib.BagsForwardOut) == 5 * 8
+    assert C.sizeof(_lib.BagsBackwardArgs) == 4 * 8 + 14 * 8
+    assert C.sizeof(_lib.BagsDebugViews) == 8 * 8
+
+
+def test_error_path_reports_message(lib):
+    rc = lib.bags_compute_relocation(None, None, None, None, 51, 0, None, None, None)
+    assert rc != 0 and b"compute_relocation" in lib.bags_last_error()
+    s = _lib.BagsSettings(); i = _lib.BagsInputs(); st = _lib.BagsState(); o = _lib.BagsForwardOut()
+    n = C.c_int64(0)
+    rc = lib.bags_forward_prepare(C.byref(s), C.byref(i), C.byref(st), C.byref(o), C.byref(n), None)
+    assert rc == -1 and b"empty image" in lib.bags_last_error()      # argument validation, no GPU touched
+
+
+def test_operator_api_surface_and_argument_errors():
+    import inspect
+    import diff_gaussian_rasterization as dgr
+    from bags_raster import GaussianRasterizationSettings, GaussianRasterizer
+    assert dgr.GaussianRasterizer is GaussianRasterizer and dgr.GaussianRasterizationSettings is GaussianRasterizationSettings
+    # the 14 settings keywords of gaussian_renderer/__init__.py:50-65, in order
+    assert GaussianRasterizationSettings._fields[:14] == (
+        "image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix",
+        "intrinsic", "sh_degree", "campos", "prefiltered", "debug", "debug_iter")
+    # the 10 call keywords of gaussian_renderer/__init__.py:110-121
+    params = set(inspect.signature(GaussianRasterizer.forward).parameters)
+    assert {"means3D", "means2D", "means2D_densify", "shift_factors", "shs", "colors_precomp", "opacities", "scales",
+            "rotations", "cov3D_precomp"} <= params
+    eye = torch.eye(4)
+    st = GaussianRasterizationSettings(32, 32, 0.5, 0.5, torch.zeros(3), 1.0, eye, eye, eye, 0, torch.zeros(3), False, False, 0)
+    r = GaussianRasterizer(st)
+    x = torch.zeros(4, 3)
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        r(means3D=x, means2D=x, opacities=torch.ones(4, 1), scales=x, rotations=torch.zeros(4, 4))
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair or precomputed 3D covariance"):
+        r(means3D=x, means2D=x, opacities=torch.ones(4, 1), shs=torch.zeros(4, 1, 3))
+    with pytest.raises(RuntimeError, match="AMD GPU"):     # no silent CPU fallback
+        r(means3D=x, means2D=x, opacities=torch.ones(4, 1), shs=torch.zeros(4, 1, 3), scales=x, rotations=torch.zeros(4, 4))
+    with pytest.raises(NotImplementedError):
+        dgr.compute_relocation(None, None, None, None, 51)
