@@ -292,32 +292,42 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     }
 }
 
-// rows -> the five pose tensors, summed in fp64
-__global__ void __launch_bounds__(64)
+// rows -> the five pose tensors, summed in fp64 (25 row-groups x 40 values in flight, fixed order: deterministic)
+#define POSE_GROUPS 25
+__global__ void __launch_bounds__(1024)
 pose_reduce_kernel(const float* __restrict__ slab, int nblocks, float* __restrict__ g_view, float* __restrict__ g_proj,
                    float* __restrict__ g_intr, float* __restrict__ g_campos, float* __restrict__ g_shift)
 {
-    const int t = threadIdx.x;
-    double acc = 0.0;
-    if (t < 35)
-        for (int b = 0; b < nblocks; ++b) acc += (double)slab[(size_t)b * POSE_VALS + t];
-    __shared__ float tot[64];
-    tot[t] = (float)acc;
+    __shared__ double part[POSE_GROUPS][POSE_VALS];
+    __shared__ float tot[POSE_VALS];
+    const int t = threadIdx.x % POSE_VALS, grp = threadIdx.x / POSE_VALS;
+    if (grp < POSE_GROUPS) {
+        double acc = 0.0;
+        for (int b = grp; b < nblocks; b += POSE_GROUPS) acc += (double)slab[(size_t)b * POSE_VALS + t];
+        part[grp][t] = acc;
+    }
     __syncthreads();
-    if (t < 16) {
-        const int r = t >> 2, c = t & 3;
-        if (g_view) g_view[t] = (c < 3) ? tot[r * 3 + c] : 0.f;
-        if (g_proj) g_proj[t] = (c == 2) ? 0.f : tot[12 + r * 3 + (c == 3 ? 2 : c)];
+    if (threadIdx.x < POSE_VALS) {
+        double acc = 0.0;
+        for (int g = 0; g < POSE_GROUPS; ++g) acc += part[g][threadIdx.x];
+        tot[threadIdx.x] = (float)acc;
+    }
+    __syncthreads();
+    const int i = threadIdx.x;
+    if (i < 16) {
+        const int r = i >> 2, c = i & 3;
+        if (g_view) g_view[i] = (c < 3) ? tot[r * 3 + c] : 0.f;
+        if (g_proj) g_proj[i] = (c == 2) ? 0.f : tot[12 + r * 3 + (c == 3 ? 2 : c)];
         if (g_intr) {
             float val = 0.f;
-            if (t == 0) val = tot[24]; else if (t == 5) val = tot[25]; else if (t == 8) val = tot[26];
-            else if (t == 9) val = tot[27]; else if (t == 11) val = tot[28];
-            g_intr[t] = val;
+            if (i == 0) val = tot[24]; else if (i == 5) val = tot[25]; else if (i == 8) val = tot[26];
+            else if (i == 9) val = tot[27]; else if (i == 11) val = tot[28];
+            g_intr[i] = val;
         }
     }
-    if (t < 3) {
-        if (g_campos) g_campos[t] = tot[29 + t];
-        if (g_shift) g_shift[t] = tot[32 + t];
+    if (i < 3) {
+        if (g_campos) g_campos[i] = tot[29 + i];
+        if (g_shift) g_shift[i] = tot[32 + i];
     }
 }
 
@@ -340,7 +350,7 @@ hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, co
 
 hipError_t launch_pose_reduce(const float* pose_slab, int nblocks, const BagsBackwardArgs& a, hipStream_t st)
 {
-    hipLaunchKernelGGL(pose_reduce_kernel, dim3(1), dim3(64), 0, st, pose_slab, nblocks, a.grad_viewmatrix,
+    hipLaunchKernelGGL(pose_reduce_kernel, dim3(1), dim3(1024), 0, st, pose_slab, nblocks, a.grad_viewmatrix,
                        a.grad_projmatrix, a.grad_intrinsic, a.grad_campos, a.grad_shift_factors);
     return hipGetLastError();
 }

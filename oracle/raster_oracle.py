@@ -121,6 +121,15 @@ def _f(v, like):
     return torch.as_tensor(v, dtype=like.dtype)
 
 
+def _sqrt(x: torch.Tensor) -> torch.Tensor:
+    """Correctly rounded sqrt.  torch's vectorised fp32 CPU sqrt is NOT correctly rounded (0.6 % of inputs are 1 ulp
+    off numpy / the GPU's IEEE sqrt), which would break bit-exact depth keys and radii; sqrt in fp64 rounded once to
+    fp32 is exact (53 >= 2*24+2 bits makes the double rounding innocuous)."""
+    if x.dtype == torch.float32:
+        return torch.sqrt(x.double()).float()
+    return torch.sqrt(x)
+
+
 def preprocess(means3D, means2D, shift_factors, shs, colors_precomp, opacities, scales, rotations,
                cov3D_precomp, s: OracleSettings, dtype=torch.float32,
                discrete: Optional[Dict[str, torch.Tensor]] = None) -> Preprocessed:
@@ -162,7 +171,7 @@ def preprocess(means3D, means2D, shift_factors, shs, colors_precomp, opacities, 
     tz = x * v[2] + y * v[6] + z * v[10] + v[14]
 
     # D2: entrance-pupil shift along the optical axis (identity when shift_factors == 0)
-    rho = torch.sqrt(tx * tx + ty * ty + 1e-20)
+    rho = _sqrt(tx * tx + ty * ty + 1e-20)
     theta = torch.atan2(rho, tz)
     th2 = theta * theta
     th3 = th2 * theta
@@ -242,8 +251,8 @@ def preprocess(means3D, means2D, shift_factors, shs, colors_precomp, opacities, 
     con_b = -cxy * det_inv
     con_c = cxx * det_inv
     mid = 0.5 * (cxx + cyy)
-    lam = mid + torch.sqrt(torch.clamp_min(mid * mid - det, 0.1))
-    radius_f = torch.ceil(3.0 * torch.sqrt(lam))
+    lam = mid + _sqrt(torch.clamp_min(mid * mid - det, 0.1))
+    radius_f = torch.ceil(3.0 * _sqrt(lam))
 
     # colour
     if col_s is not None:
@@ -251,14 +260,14 @@ def preprocess(means3D, means2D, shift_factors, shs, colors_precomp, opacities, 
         clamped_s = torch.zeros(n, 3, dtype=torch.bool)
     else:
         dx_, dy_, dz_ = x - campos[0], y - campos[1], z - campos[2]
-        dl = torch.sqrt(dx_ * dx_ + dy_ * dy_ + dz_ * dz_)
+        dl = _sqrt(dx_ * dx_ + dy_ * dy_ + dz_ * dz_)
         d = torch.stack([dx_ / dl, dy_ / dl, dz_ / dl], 1)
         raw = eval_sh_rgb(int(s.sh_degree), shs_s, d) + 0.5
         clamped_s = raw.detach() < 0
         rgb = torch.clamp_min(raw, 0.0)
 
     if s.depth_key == "distance":
-        depth = torch.sqrt(tx * tx + ty * ty + tzs * tzs)
+        depth = _sqrt(tx * tx + ty * ty + tzs * tzs)
     else:
         depth = tzs
 
