@@ -228,7 +228,7 @@ int bags_backward(const BagsSettings* s, const BagsInputs* in, const BagsState* 
     float* partials = reinterpret_cast<float*>(ws);
     float* slab = reinterpret_cast<float*>(ws + align_up((size_t)(I > 0 ? I : 1) * PART_FLOATS * sizeof(float), 256));
     if (I > 0) {
-        { ProfScope ps(ST_BLEND_BWD, st); HIP_TRY(launch_blend_bwd(*s, g, b, im, a->grad_color, partials, st)); }
+        { ProfScope ps(ST_BLEND_BWD, st); HIP_TRY(launch_blend_bwd(*s, g, b, im, a->grad_color, partials, a->grad_means2D_densify != nullptr, st)); }
         DEBUG_SYNC(s, st, "blend_bwd");
     }
     int nblocks = 0;

@@ -75,7 +75,7 @@ hipError_t launch_tile_ranges(const u32* tile_sorted, long long I, uint2* ranges
 hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
                             const BagsForwardOut& out, hipStream_t st);
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
-                            const float* grad_color, float* partials, hipStream_t st);
+                            const float* grad_color, float* partials, bool want_abs, hipStream_t st);
 hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, const int32_t* radii_or_null,
                                  const float* partials, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a, hipStream_t st);
 hipError_t launch_pose_reduce(const float* pose_slab, int nblocks, const BagsBackwardArgs& a, hipStream_t st);

@@ -15,6 +15,24 @@
 //     result is bitwise reproducible.
 #include "bags_common.h"
 
+// tuning knobs (tools/variants.sh sweeps them with -D...)
+#ifndef FWD_WAVES
+#define FWD_WAVES 5        // __launch_bounds__ waves/SIMD for blend_fwd
+#endif
+#ifndef BWD_WAVES
+#define BWD_WAVES 3
+#endif
+#ifndef BWD_REDUCE_DPP
+#define BWD_REDUCE_DPP 0   // 1: DPP row/wave sums, 0: ds_bpermute butterfly
+#endif
+#ifndef PREFETCH_REC
+#define PREFETCH_REC 0     // fetch splat k+1 from LDS while splat k is processed
+#endif
+
+#ifndef ABLATE
+#define ABLATE 0           // timing-only builds (wrong results): 1 no reduce, 2 no contributing body, 3 no quadrant loop
+#endif
+
 #define LOG2E 1.4426950408889634f
 #define ALPHA_MIN (1.0f / 255.0f)
 #define T_EPS 0.0001f
@@ -64,7 +82,7 @@ __device__ __forceinline__ float pair_power2(float dx, float dy, float ap, float
     return __fmaf_rn(dx, t, u);
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, FWD_WAVES)
 blend_fwd_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ ranges, const u32* __restrict__ point_list,
                  const float2* __restrict__ xy, const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbz,
                  const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
@@ -79,6 +97,7 @@ blend_fwd_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ rang
 
     __shared__ SplatRec recs[64];
 
+    const float lx = X0 + (float)(lane & 7), ly = Y0 + (float)(lane >> 3);      // this lane's pixel in quadrant 0
     float pxf[4], pyf[4], Tq[4], Cr[4], Cg[4], Cb[4], Dq[4];
     u32 last[4];
     bool done[4], inside[4];
@@ -118,29 +137,43 @@ blend_fwd_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ rang
         __syncthreads();                      // previous batch fully consumed (single wave: orders LDS traffic)
         if (rec.mask != 0) recs[__popcll(keep & lt_mask)] = rec;
         __syncthreads();
-        // ---- composite
+        // ---- composite; the next record is fetched from LDS while the current one is processed
+#if PREFETCH_REC
+        SplatRec s = recs[0];
+#endif
         for (int k = 0; k < count; ++k) {
+#if PREFETCH_REC
+            const SplatRec nxt = recs[k + 1 < count ? k + 1 : k];
+#else
             const SplatRec s = recs[k];
+#endif
             const u32 m = __builtin_amdgcn_readfirstlane(s.mask);
+            const float sx = s.x - lx, sy = s.y - ly;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (!((m >> q) & 1u)) continue;
-                const float dx = s.x - pxf[q], dy = s.y - pyf[q];
+                const float dx = sx - (float)((q & 1) * 8), dy = sy - (float)((q >> 1) * 8);
                 const float p2 = pair_power2(dx, dy, s.ap, s.bp, s.cp);
                 const float G = __builtin_amdgcn_exp2f(p2);
                 const float alpha = fminf(0.99f, s.o * G);
-                bool contrib = (p2 <= 0.f) && (alpha >= ALPHA_MIN) && !done[q];
+                const bool contrib = (p2 <= 0.f) && (alpha >= ALPHA_MIN) && !done[q];
                 if (__ballot(contrib) == 0ull) continue;
-                const float test_T = Tq[q] * (1.f - alpha);
-                const bool stop = contrib && (test_T < T_EPS);
-                done[q] = done[q] || stop;
-                contrib = contrib && !stop;
-                const float w = contrib ? alpha * Tq[q] : 0.f;
-                Cr[q] = __fmaf_rn(w, s.r, Cr[q]); Cg[q] = __fmaf_rn(w, s.g, Cg[q]); Cb[q] = __fmaf_rn(w, s.b, Cb[q]);
-                Dq[q] = __fmaf_rn(w, s.z, Dq[q]);
-                Tq[q] = contrib ? test_T : Tq[q];
-                last[q] = contrib ? s.pos : last[q];
+                if (contrib) {
+                    const float test_T = Tq[q] * (1.f - alpha);
+                    if (test_T < T_EPS) {
+                        done[q] = true;
+                    } else {
+                        const float w = alpha * Tq[q];
+                        Cr[q] = __fmaf_rn(w, s.r, Cr[q]); Cg[q] = __fmaf_rn(w, s.g, Cg[q]); Cb[q] = __fmaf_rn(w, s.b, Cb[q]);
+                        Dq[q] = __fmaf_rn(w, s.z, Dq[q]);
+                        Tq[q] = test_T;
+                        last[q] = s.pos;
+                    }
+                }
             }
+#if PREFETCH_REC
+            s = nxt;
+#endif
         }
     }
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
@@ -173,7 +206,26 @@ hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinV
 }
 
 // --------------------------------------------------------------------------------------------------- backward
-// 16 per-lane partial sums -> totals; on return lane L holds the wave total of value nib_rev(L & 15) in v[0].
+// DPP cross-lane adds: full-rate VALU, no LDS crossbar round trip (ds_bpermute costs ~60 exposed cycles per step).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v)
+{   // v + (v moved by the DPP pattern); lanes outside ROW_MASK keep v
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+    return v + __int_as_float(moved);
+}
+// Sum over the 64 lanes in a FIXED order (bitwise reproducible); the total lands in lanes 48..63.
+__device__ __forceinline__ float wave_total_row3(float v)
+{
+    v = dpp_add<0x121, 0xF>(v);      // row_ror:1   -> pairs
+    v = dpp_add<0x122, 0xF>(v);      // row_ror:2   -> quads
+    v = dpp_add<0x124, 0xF>(v);      // row_ror:4   -> 8
+    v = dpp_add<0x128, 0xF>(v);      // row_ror:8   -> every lane of a 16-lane row holds the row total
+    v = dpp_add<0x142, 0xA>(v);      // row_bcast15 -> rows 1,3 += previous row
+    v = dpp_add<0x143, 0xC>(v);      // row_bcast31 -> rows 2,3 += lane 31 (rows 0+1)
+    return v;
+}
+
+// ds_bpermute alternative: 16 per-lane partial sums -> totals; lane L ends with the total of value nib_rev(L & 15)
 __device__ __forceinline__ void wave_reduce16(float (&v)[16], int lane)
 {
 #pragma unroll
@@ -205,7 +257,9 @@ __device__ __forceinline__ void wave_reduce16(float (&v)[16], int lane)
 
 // partial record layout (floats): 0..2 dL/drgb, 3 dL/dopacity, 4 Mx, 5 My, 6 Mxx, 7 Mxy, 8 Myy, 9 absx, 10 absy
 //   M* = sum over pixels of q d^k with q = dL/dG * G and d = centre - pixel;  abs* = sum |d L/d centre (pixel units)|
-__global__ void __launch_bounds__(64)
+#define NSUM 11
+template <bool ABS>
+__global__ void __launch_bounds__(64, BWD_WAVES)
 blend_bwd_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ ranges, const u32* __restrict__ point_list,
                  const float2* __restrict__ xy, const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbz,
                  const uint2* __restrict__ rect, const u32* __restrict__ inst_offset, const float* __restrict__ bg,
@@ -226,14 +280,14 @@ blend_bwd_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ rang
 
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const size_t HW = (size_t)W * H;
-    float pxf[4], pyf[4], g0[4], g1[4], g2[4], Tq[4], Rq[4], la[4], ls[4], bgt[4];
+    const float lx = X0 + (float)(lane & 7), ly = Y0 + (float)(lane >> 3);      // this lane's pixel in quadrant 0
+    float g0[4], g1[4], g2[4], Tq[4], Rq[4], la[4], ls[4], bgt[4];
     u32 nc[4];
     u32 maxc = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int px = tile_x * BAGS_TILE + (q & 1) * 8 + (lane & 7);
         const int py = tile_y * BAGS_TILE + (q >> 1) * 8 + (lane >> 3);
-        pxf[q] = (float)px; pyf[q] = (float)py;
         const bool in = (px < W) && (py < H);
         const size_t pix = (size_t)py * W + px;
         g0[q] = in ? grad_color[pix] : 0.f;
@@ -248,6 +302,7 @@ blend_bwd_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ rang
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) maxc = max(maxc, (u32)__shfl_xor((int)maxc, d));
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int sel = lane - 48;                 // lanes 48..58 publish sum 0..10 of a splat
 
     // instances behind the last contributor of every pixel are never visited: their records are zero
     for (u32 p = maxc + lane; p < n; p += 64) {
@@ -257,7 +312,7 @@ blend_bwd_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ rang
                       (u32)(tile_x - (int)(rc.x & 0xFFFF));
         float4* dst = reinterpret_cast<float4*>(partials + (size_t)e * PART_FLOATS);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        dst[0] = z4; dst[1] = z4; dst[2] = z4; dst[3] = z4;
+        dst[0] = z4; dst[1] = z4; dst[2] = z4;
     }
 
     for (u32 hi = maxc; hi > 0;) {
@@ -289,77 +344,114 @@ blend_bwd_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ rang
         {
             float4* a4 = reinterpret_cast<float4*>(&acc[lane][0]);
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            a4[0] = z4; a4[1] = z4; a4[2] = z4; a4[3] = z4;
+            a4[0] = z4; a4[1] = z4; a4[2] = z4;
         }
         __syncthreads();
-        // ---- back to front
+        // ---- back to front; the next record is fetched from LDS while the current one is processed
+#if PREFETCH_REC
+        SplatRec s = recs[count > 0 ? count - 1 : 0];
+#endif
         for (int k = count - 1; k >= 0; --k) {
+#if PREFETCH_REC
+            const SplatRec nxt = recs[k > 0 ? k - 1 : 0];
+#else
             const SplatRec s = recs[k];
+#endif
             const u32 m = __builtin_amdgcn_readfirstlane(s.mask);
-            float v[16];
+            float v[NSUM];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = 0.f;
+            for (int i = 0; i < NSUM; ++i) v[i] = 0.f;
             bool any = false;
+            const float sx = s.x - lx, sy = s.y - ly;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (!((m >> q) & 1u)) continue;
-                const float dx = s.x - pxf[q], dy = s.y - pyf[q];
+                if (!((m >> q) & 1u) || ABLATE == 3) continue;
+                const float dx = sx - (float)((q & 1) * 8), dy = sy - (float)((q >> 1) * 8);
                 const float p2 = pair_power2(dx, dy, s.ap, s.bp, s.cp);
                 const float G = __builtin_amdgcn_exp2f(p2);
                 const float alpha = fminf(0.99f, s.o * G);
                 const bool contrib = (p2 <= 0.f) && (alpha >= ALPHA_MIN) && (s.pos <= nc[q]);
                 if (__ballot(contrib) == 0ull) continue;
                 any = true;
-                const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
-                const float Tn = Tq[q] * inv;                       // T before this splat
-                const float sdot = s.r * g0[q] + s.g * g1[q] + s.b * g2[q];
-                const float Rn = __fmaf_rn(la[q], ls[q] - Rq[q], Rq[q]);   // colour behind, dotted with dL/dC
-                float dLda = (sdot - Rn) * Tn - bgt[q] * inv;
-                float w = alpha * Tn;
-                if (contrib) { Tq[q] = Tn; Rq[q] = Rn; la[q] = alpha; ls[q] = sdot; }
-                else { dLda = 0.f; w = 0.f; }
-                v[0] = __fmaf_rn(w, g0[q], v[0]); v[1] = __fmaf_rn(w, g1[q], v[1]); v[2] = __fmaf_rn(w, g2[q], v[2]);
-                v[3] = __fmaf_rn(G, dLda, v[3]);
-                const float qv = s.o * dLda * G;
-                const float qdx = qv * dx, qdy = qv * dy;
-                v[4] += qdx; v[5] += qdy;
-                v[6] = __fmaf_rn(qdx, dx, v[6]); v[7] = __fmaf_rn(qdx, dy, v[7]); v[8] = __fmaf_rn(qdy, dy, v[8]);
-                v[9] += fabsf(__fmaf_rn(2.f * s.ap, qdx, s.bp * qdy));
-                v[10] += fabsf(__fmaf_rn(2.f * s.cp, qdy, s.bp * qdx));
-            }
-            if (any) {
-                wave_reduce16(v, lane);
-                if (lane < 16) {
-                    const int idxv = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
-                    acc[k][idxv] = v[0];
+                if (contrib && ABLATE != 2) {
+                    const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
+                    const float Tn = Tq[q] * inv;                               // T before this splat
+                    const float sdot = s.r * g0[q] + s.g * g1[q] + s.b * g2[q];
+                    const float Rn = __fmaf_rn(la[q], ls[q] - Rq[q], Rq[q]);    // colour behind, dotted with dL/dC
+                    const float dLda = __fmaf_rn(-bgt[q], inv, (sdot - Rn) * Tn);
+                    const float w = alpha * Tn;
+                    Tq[q] = Tn; Rq[q] = Rn; la[q] = alpha; ls[q] = sdot;
+                    v[0] = __fmaf_rn(w, g0[q], v[0]); v[1] = __fmaf_rn(w, g1[q], v[1]); v[2] = __fmaf_rn(w, g2[q], v[2]);
+                    const float gd = G * dLda;
+                    v[3] += gd;
+                    const float qv = s.o * gd;
+                    const float qdx = qv * dx, qdy = qv * dy;
+                    v[4] += qdx; v[5] += qdy;
+                    v[6] = __fmaf_rn(qdx, dx, v[6]); v[7] = __fmaf_rn(qdx, dy, v[7]); v[8] = __fmaf_rn(qdy, dy, v[8]);
+                    if (ABS) {
+                        v[9] += fabsf(__fmaf_rn(2.f * s.ap, qdx, s.bp * qdy));
+                        v[10] += fabsf(__fmaf_rn(2.f * s.cp, qdy, s.bp * qdx));
+                    }
                 }
             }
+            if (ABLATE == 1 || ABLATE == 2) { float keepalive = 0.f;
+#pragma unroll
+                for (int i = 0; i < NSUM; ++i) keepalive += v[i];
+                if (keepalive == 123.456f) acc[k][0] = keepalive; }
+            if (any && ABLATE != 1 && ABLATE != 2) {
+#if BWD_REDUCE_DPP
+                float out = 0.f;
+#pragma unroll
+                for (int i = 0; i < (ABS ? NSUM : NSUM - 2); ++i) {
+                    const float t = wave_total_row3(v[i]);
+                    out = (sel == i) ? t : out;
+                }
+                if (sel >= 0 && sel < NSUM) acc[k][sel] = out;
+#else
+                float v16[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v16[i] = (i < NSUM) ? v[i] : 0.f;
+                wave_reduce16(v16, lane);
+                if (lane < 16) {
+                    const int idxv = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
+                    acc[k][idxv] = v16[0];
+                }
+#endif
+            }
+#if PREFETCH_REC
+            s = nxt;
+#endif
         }
         __syncthreads();
-        // ---- one 64-byte record per staged instance, at its emission slot
+        // ---- one record per staged instance, at its emission slot (48 of its 64 bytes carry data)
         if (valid) {
-            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
+            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
             if (rec.mask != 0) {
                 const float4* a4 = reinterpret_cast<const float4*>(&acc[slot][0]);
-                r0 = a4[0]; r1 = a4[1]; r2 = a4[2]; r3 = a4[3];
+                r0 = a4[0]; r1 = a4[1]; r2 = a4[2];
                 r2.y *= (1.0f / LOG2E); r2.z *= (1.0f / LOG2E);      // abs sums were taken on the scaled conic
             }
             float4* dst = reinterpret_cast<float4*>(partials + (size_t)e * PART_FLOATS);
-            dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
+            dst[0] = r0; dst[1] = r1; dst[2] = r2;
         }
         hi = lo;
     }
 }
 
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
-                            const float* grad_color, float* partials, hipStream_t st)
+                            const float* grad_color, float* partials, bool want_abs, hipStream_t st)
 {
     const int gx = cdiv(s.image_width, BAGS_TILE), gy = cdiv(s.image_height, BAGS_TILE);
     const int T = gx * gy;
     if (T == 0) return hipSuccess;
     const int grid = ((T + 7) / 8) * 8;
-    hipLaunchKernelGGL(blend_bwd_kernel, dim3(grid), dim3(64), 0, st, s.image_width, s.image_height, gx, T, b.ranges,
-                       b.point_list, g.xy, g.conic_opacity, g.rgbz, g.rect, g.inst_offset, s.bg, im.final_T,
-                       im.n_contrib, grad_color, partials);
+    if (want_abs)
+        hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(grid), dim3(64), 0, st, s.image_width, s.image_height, gx, T,
+                           b.ranges, b.point_list, g.xy, g.conic_opacity, g.rgbz, g.rect, g.inst_offset, s.bg,
+                           im.final_T, im.n_contrib, grad_color, partials);
+    else
+        hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(grid), dim3(64), 0, st, s.image_width, s.image_height, gx, T,
+                           b.ranges, b.point_list, g.xy, g.conic_opacity, g.rgbz, g.rect, g.inst_offset, s.bg,
+                           im.final_T, im.n_contrib, grad_color, partials);
     return hipGetLastError();
 }

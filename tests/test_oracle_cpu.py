@@ -1,0 +1,97 @@
+"""CPU checks of the oracle itself (no GPU): internal consistency, finite differences of the pose gradients in fp64,
+binning invariants, edge cases.  The oracle cannot be pinned against the CUDA fork (source absent, see its header);
+these tests pin what can be: its own mathematics."""
+import math
+
+import pytest
+import torch
+
+from oracle import raster_oracle as O
+from parity import run_oracle
+from scenes import make_case, oracle_settings, rel_err
+
+
+def test_config1_counts_match_survey():
+    """BASELINE config 1 (10k Gaussians, 400x400): SURVEY.md 8d measured G = 9 936 visible, I = 270 130 instances."""
+    scene, cam = make_case(10000, 400, 400, 1.0, 0, seed=0)
+    pre = O.preprocess(scene["means3D"], torch.zeros(10000, 3), torch.zeros(3), scene["shs"], None, scene["opacities"],
+                       scene["scales"], scene["rotations"], None, oracle_settings(cam, 0))
+    assert int(pre.visible.sum()) == 9936
+    assert int(pre.tiles_touched.sum()) == 270130
+
+
+def test_binning_is_sorted_stable_and_ranges_partition():
+    scene, cam = make_case(800, 96, 64, 2.0, 0, seed=2)
+    st, _ = run_oracle(scene, cam, 0)
+    keys = st.keys_sorted
+    assert torch.all(keys[1:] >= keys[:-1])
+    # ties (same tile, same depth bits) keep Gaussian-id order = stability of the sort over emission order
+    same = keys[1:] == keys[:-1]
+    assert torch.all(st.point_list[1:][same] > st.point_list[:-1][same])
+    T = st.gx * st.gy
+    cnt = (st.ranges[:, 1] - st.ranges[:, 0]).to(torch.int64)
+    assert int(cnt.sum()) == keys.numel() and st.ranges.shape[0] == T
+    tiles = (keys >> 32)
+    for t in (0, T // 2, T - 1):
+        lo, hi = int(st.ranges[t, 0]), int(st.ranges[t, 1])
+        assert torch.all(tiles[lo:hi] == t)
+    assert int(st.pre.tiles_touched.sum()) == keys.numel()
+
+
+def test_fp32_and_fp64_modes_agree():
+    scene, cam = make_case(600, 80, 64, 2.0, 2, seed=4)
+    g = torch.randn(3, 64, 80, generator=torch.Generator().manual_seed(0))
+    st32, g32 = run_oracle(scene, cam, 2, g, torch.float32)
+    st64, g64 = run_oracle(scene, cam, 2, g, torch.float64, discrete=O.discrete_of(st32))
+    assert (st32.image.double() - st64.image).abs().max() < 5e-5
+    for k in ("means3D", "scales", "rotations", "opacities", "shs", "viewmatrix", "projmatrix", "intrinsic", "campos"):
+        assert rel_err(g32[k], g64[k]) < 2e-3, (k, rel_err(g32[k], g64[k]))
+
+
+def test_pose_gradients_match_finite_differences_fp64():
+    """d loss / d{viewmatrix, projmatrix, intrinsic, campos, shift_factors}: autograd (what the HIP kernel is held to)
+    against central differences, in fp64, on a smooth scene (large splats, no threshold pair near a flip)."""
+    scene, cam = make_case(40, 48, 32, 6.0, 2, seed=7)
+    scene = {k: v.double() for k, v in scene.items()}
+    s = oracle_settings(cam, 2)
+    g = torch.randn(3, 32, 48, generator=torch.Generator().manual_seed(3)).double()
+    base = dict(scene); base["shift_factors"] = torch.tensor([0.01, 0.0, 0.0], dtype=torch.float64)
+    st0, gr = O.render_and_grad(base, s, g, dtype=torch.float64)
+    disc = O.discrete_of(st0)
+
+    def loss_with(name, tensor):
+        s2 = O.OracleSettings(**{**s.__dict__})
+        inp = dict(base)
+        if name in ("viewmatrix", "projmatrix", "intrinsic", "campos"):
+            setattr(s2, name, tensor)
+        else:
+            inp[name] = tensor
+        st, _ = O.render_and_grad(inp, s2, None, dtype=torch.float64, discrete=disc)
+        return float((st.image * g).sum())
+
+    eps = 1e-6
+    for name in ("viewmatrix", "projmatrix", "intrinsic", "campos", "shift_factors"):
+        ref = (getattr(s, name) if name != "shift_factors" else base[name]).double().clone()
+        flat = ref.reshape(-1)
+        picks = [i for i in range(flat.numel())][:: max(1, flat.numel() // 6)]
+        for i in picks:
+            d = torch.zeros_like(flat); d[i] = eps
+            fd = (loss_with(name, (flat + d).reshape(ref.shape)) - loss_with(name, (flat - d).reshape(ref.shape))) / (2 * eps)
+            an = float(gr[name].reshape(-1)[i])
+            assert abs(fd - an) <= 2e-4 * max(1.0, abs(fd), abs(an)), (name, i, fd, an)
+
+
+def test_empty_and_all_culled_inputs():
+    scene, cam = make_case(20, 32, 32, 1.0, 0, seed=1)
+    scene["means3D"] = scene["means3D"] - torch.tensor([0.0, 0.0, 10.0])      # all behind the camera
+    g = torch.randn(3, 32, 32)
+    st, gr = run_oracle(scene, cam, 0, g, bg=torch.tensor([0.1, 0.2, 0.3]))
+    assert st.point_list.numel() == 0 and int(st.radii.max()) == 0
+    assert torch.allclose(st.image[1], torch.full((32, 32), 0.2))
+    assert float(gr["means3D"].abs().max()) == 0.0 and float(gr["viewmatrix"].abs().max()) == 0.0
+
+
+def test_exact_sqrt_helper_is_correctly_rounded():
+    import numpy as np
+    x = torch.rand(200000, generator=torch.Generator().manual_seed(0)) * 50
+    assert (O._sqrt(x).numpy() == np.sqrt(x.numpy())).all()

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Sweeps compile-time tuning knobs on the GPU box: rebuilds the library per variant and prints the bench stage times.
+# usage: tools/variants.sh "<-D flags of variant 1>" "<-D flags of variant 2>" ...
+cd "$(dirname "$0")/.."
+CS=bundle-adjusting-gaussian-splatting_amd/csrc
+for v in "$@"; do
+  rm -rf $CS/build
+  make -C $CS -j8 DEFS="$v" > /tmp/build.log 2>&1 || { echo "BUILD FAILED: $v"; tail -5 /tmp/build.log; continue; }
+  echo "== $v"
+  timeout 200 python bench.py --no-cpu-baseline --steps ${STEPS:-15} --warmup 3 ${BENCH_ARGS} 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); s=d['stage_ms']
+print('  ms/step %.3f  fwd %.3f bwd %.3f pre_bwd %.3f sort %.3f  all:'%(d['ms_per_step'], s['blend_fwd'], s['blend_bwd'], s['preprocess_bwd'], s['depth_sort']+s['tile_sort']), s)"
+done
+rm -rf $CS/build; make -C $CS -j8 > /dev/null 2>&1
