@@ -98,6 +98,7 @@ blend_fwd_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ rang
     __shared__ SplatRec recs[64];
 
     const float lx = X0 + (float)(lane & 7), ly = Y0 + (float)(lane >> 3);      // this lane's pixel in quadrant 0
+    const float lx8 = lx + 8.f, ly8 = ly + 8.f;                                  // ... in the other quadrants (exact)
     float pxf[4], pyf[4], Tq[4], Cr[4], Cg[4], Cb[4], Dq[4];
     u32 last[4];
     bool done[4], inside[4];
@@ -148,11 +149,10 @@ blend_fwd_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ rang
             const SplatRec s = recs[k];
 #endif
             const u32 m = __builtin_amdgcn_readfirstlane(s.mask);
-            const float sx = s.x - lx, sy = s.y - ly;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (!((m >> q) & 1u)) continue;
-                const float dx = sx - (float)((q & 1) * 8), dy = sy - (float)((q >> 1) * 8);
+                const float dx = s.x - ((q & 1) ? lx8 : lx), dy = s.y - ((q >> 1) ? ly8 : ly);   // centre - exact pixel
                 const float p2 = pair_power2(dx, dy, s.ap, s.bp, s.cp);
                 const float G = __builtin_amdgcn_exp2f(p2);
                 const float alpha = fminf(0.99f, s.o * G);
@@ -281,6 +281,7 @@ blend_bwd_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ rang
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const size_t HW = (size_t)W * H;
     const float lx = X0 + (float)(lane & 7), ly = Y0 + (float)(lane >> 3);      // this lane's pixel in quadrant 0
+    const float lx8 = lx + 8.f, ly8 = ly + 8.f;
     float g0[4], g1[4], g2[4], Tq[4], Rq[4], la[4], ls[4], bgt[4];
     u32 nc[4];
     u32 maxc = 0;
@@ -362,11 +363,10 @@ blend_bwd_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ rang
 #pragma unroll
             for (int i = 0; i < NSUM; ++i) v[i] = 0.f;
             bool any = false;
-            const float sx = s.x - lx, sy = s.y - ly;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (!((m >> q) & 1u) || ABLATE == 3) continue;
-                const float dx = sx - (float)((q & 1) * 8), dy = sy - (float)((q >> 1) * 8);
+                const float dx = s.x - ((q & 1) ? lx8 : lx), dy = s.y - ((q >> 1) ? ly8 : ly);
                 const float p2 = pair_power2(dx, dy, s.ap, s.bp, s.cp);
                 const float G = __builtin_amdgcn_exp2f(p2);
                 const float alpha = fminf(0.99f, s.o * G);
@@ -438,6 +438,306 @@ blend_bwd_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ rang
     }
 }
 
+// ================================================================================================================
+// Scan-based backward ("lane = splat").  PMC showed the lane = pixel backward saturates VALU issue (96 % of SIMD cycles)
+// and spends most of it on 64-wide work where a third of the lanes contribute, plus an 11-value cross-lane reduction
+// per (tile, splat).  Here the roles are swapped:
+//   * a 256-thread workgroup owns a tile; the tile list is consumed back to front in chunks of 256 splats, staged once
+//     in LDS together with a 16-bit mask of the 4x4-pixel blocks each splat's alpha >= 1/255 ellipse can reach
+//     (Mahalanobis triangle-inequality test, conservative);
+//   * each wave owns four of the sixteen blocks and ballot-compacts, per block, the chunk's splats that reach it;
+//   * 64 lanes = 64 splats of one block list (deepest in lane 0); the block's pixels are visited two at a time with
+//     packed fp32 math.  The per-pixel recurrences of alpha compositing become wave64 DPP scans:
+//         B_i = prod_{j at or behind i} (1 - alpha_j)          T_i = T_final / B_i        (transmittance in front of i)
+//         S_i = sum_{j behind i} alpha_j T_j (c_j . dL/dC)                                  (colour behind i)
+//     carried across groups / chunks through one (B, S) pair per pixel in LDS;
+//   * every lane then owns its splat's 11 sums outright: no cross-lane reduction, no atomics.  Each wave adds into its
+//     own LDS copy of the chunk's records; the four copies are added in fixed order => bitwise reproducible.
+// ================================================================================================================
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_src(float identity, float v)
+{   // v moved by the DPP pattern; lanes without a source (or in rows outside ROW_MASK) get `identity`
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+// Inclusive prefix scans over the 64 lanes for TWO independent values at once (the two pixels of a pair).  One
+// VOP2-DPP instruction per step and value: lanes without a source (bound_ctrl:0) or outside row_mask keep their
+// value, which is exactly the scan semantics.  The two chains are interleaved and padded with s_nop so that the
+// "VALU write -> DPP read: 2 wait states" hazard of gfx9 is respected (the compiler cannot see inside the asm).
+#define SCAN2(OP)                                                                                        \
+    asm volatile(                                                                                        \
+        "s_nop 1\n\t"                                                                                    \
+        OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                        \
+        OP " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                        \
+        "s_nop 0\n\t"                                                                                    \
+        OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                                        \
+        OP " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                                        \
+        "s_nop 0\n\t"                                                                                    \
+        OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                                        \
+        OP " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                                        \
+        "s_nop 0\n\t"                                                                                    \
+        OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                                        \
+        OP " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                                        \
+        "s_nop 0\n\t"                                                                                    \
+        OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                                     \
+        OP " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                                     \
+        "s_nop 0\n\t"                                                                                    \
+        OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                                     \
+        OP " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                                     \
+        "s_nop 1"                                                                                        \
+        : "+v"(a), "+v"(b))
+__device__ __forceinline__ void scan_mul64x2(float& a, float& b) { SCAN2("v_mul_f32_dpp"); }
+__device__ __forceinline__ void scan_add64x2(float& a, float& b) { SCAN2("v_add_f32_dpp"); }
+
+#define CHUNK 256
+struct __attribute__((aligned(16))) ChunkRec {
+    float x, y, ap, bp;
+    float cp, o, r, g;
+    float b; u32 pos; u32 mask; u32 e;         // mask: 4x4 blocks reachable (bit by*4+bx); e: emission slot
+};
+// per pixel PAIR (two horizontally adjacent pixels A,B of one block row), 16 floats:
+//   [g0A g0B g1A g1B] [g2A g2B TfA TfB] [bgtA bgtB ncA ncB] [BcA BcB ScA ScB]
+struct __attribute__((aligned(16))) PixPair { float4 q0, q1, q2, q3; };
+
+// blocks of the tile a splat can reach with alpha >= 1/255 (conservative; exactness comes from the per-pixel test)
+__device__ __forceinline__ u32 block_mask16(float x, float y, float a, float b, float c, float o, float X0, float Y0)
+{
+    const float vis = 255.0f * o;
+    if (!(vis >= 0.99f)) return 0u;
+    const float det = a * c - b * b;
+    if (!(det > 0.f) || !(a > 0.f) || !(c > 0.f)) return 0xFFFFu;
+    const float tau2 = 2.0f * (fmaxf(__logf(vis), 0.f) + 1e-3f);
+    const float idet = 1.0f / det;
+    const float hx = sqrtf(tau2 * c * idet) * 1.001f + 0.05f;
+    const float hy = sqrtf(tau2 * a * idet) * 1.001f + 0.05f;
+    // Q-norm radius of a 4x4 block around its centre: corners at (+-1.5, +-1.5)
+    const float qd = 2.25f * (a + c), qo = 4.5f * b;
+    const float rb = sqrtf(fmaxf(qd + qo, qd - qo));
+    const float lim = sqrtf(tau2) * 1.001f + rb + 1e-3f;
+    const float lim2 = lim * lim;
+    u32 m = 0;
+#pragma unroll
+    for (int by = 0; by < 4; ++by) {
+        const float y0 = Y0 + 4.f * by;
+        if (!((y + hy >= y0) && (y - hy <= y0 + 3.f))) continue;
+        const float dy = (y0 + 1.5f) - y;
+#pragma unroll
+        for (int bx = 0; bx < 4; ++bx) {
+            const float x0 = X0 + 4.f * bx;
+            if (!((x + hx >= x0) && (x - hx <= x0 + 3.f))) continue;
+            const float dx = (x0 + 1.5f) - x;
+            const float Q = a * dx * dx + 2.f * b * dx * dy + c * dy * dy;      // squared Q-norm of centre offset
+            if (Q <= lim2) m |= 1u << (by * 4 + bx);
+        }
+    }
+    return m;
+}
+
+template <bool ABS>
+__global__ void __launch_bounds__(256, 2)
+blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ ranges, const u32* __restrict__ point_list,
+                      const float2* __restrict__ xy, const float4* __restrict__ conic_opacity,
+                      const float4* __restrict__ rgbz, const uint2* __restrict__ rect, const u32* __restrict__ inst_offset,
+                      const float* __restrict__ bg, const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
+                      const float* __restrict__ grad_color, float* __restrict__ partials)
+{
+    const int tile = tile_of_block(blockIdx.x, T);
+    if (tile >= T) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile_x = tile % grid_x, tile_y = tile / grid_x;
+    const float X0 = (float)(tile_x * BAGS_TILE), Y0 = (float)(tile_y * BAGS_TILE);
+    const uint2 range = ranges[tile];
+    const u32 n = range.y - range.x;
+    if (n == 0) return;
+
+    __shared__ ChunkRec recs[CHUNK];                 // 12 KB
+    __shared__ PixPair pix[128];                     //  8 KB
+    __shared__ unsigned char lists[16][CHUNK];       //  4 KB
+    __shared__ float acc[4][CHUNK][12];              // 48 KB, one copy per wave
+    __shared__ u32 wmax[4];
+
+    // ---- per-pixel constants: thread tid <-> block tid>>4, pixel tid&15 (ix = &3, iy = >>2)
+    u32 maxc;
+    {
+        const int b = tid >> 4, i = tid & 15;
+        const int px = tile_x * BAGS_TILE + (b & 3) * 4 + (i & 3);
+        const int py = tile_y * BAGS_TILE + (b >> 2) * 4 + (i >> 2);
+        const bool in = (px < W) && (py < H);
+        const size_t HW = (size_t)W * H, pixi = (size_t)py * W + px;
+        const float g0 = in ? grad_color[pixi] : 0.f, g1 = in ? grad_color[HW + pixi] : 0.f, g2 = in ? grad_color[2 * HW + pixi] : 0.f;
+        const float Tf = in ? final_T[pixi] : 1.f;
+        const u32 nc = in ? n_contrib[pixi] : 0u;
+        const float bgt = Tf * (bg[0] * g0 + bg[1] * g1 + bg[2] * g2);
+        float* pp = reinterpret_cast<float*>(&pix[tid >> 1]);
+        const int h = tid & 1;                        // A or B of the pair
+        pp[0 + h] = g0; pp[2 + h] = g1; pp[4 + h] = g2; pp[6 + h] = Tf;
+        pp[8 + h] = bgt; pp[10 + h] = __uint_as_float(nc); pp[12 + h] = 1.f; pp[14 + h] = 0.f;
+        u32 m = nc;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = max(m, (u32)__shfl_xor((int)m, d));
+        if (lane == 0) wmax[wave] = m;
+        __syncthreads();
+        maxc = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+    }
+
+    // instances behind the last contributor of every pixel are never visited: their records are zero
+    for (u32 p = maxc + tid; p < n; p += 256) {
+        const u32 g = point_list[range.x + p];
+        const uint2 rc = rect[g];
+        const u32 e = inst_offset[g] + (u32)(tile_y - (int)(rc.x >> 16)) * ((rc.y & 0xFFFF) - (rc.x & 0xFFFF)) +
+                      (u32)(tile_x - (int)(rc.x & 0xFFFF));
+        float4* dst = reinterpret_cast<float4*>(partials + (size_t)e * PART_FLOATS);
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        dst[0] = z4; dst[1] = z4; dst[2] = z4;
+    }
+    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+    for (u32 hi = maxc; hi > 0;) {
+        const u32 cnt = min(hi, (u32)CHUNK);
+        const u32 lo = hi - cnt;
+        // ---- stage the chunk [lo, hi): slot s <-> list position lo + s (front to back)
+        ChunkRec rec; rec.mask = 0; rec.e = 0;
+        if ((u32)tid < cnt) {
+            const u32 g = point_list[range.x + lo + tid];
+            const float2 c2 = xy[g];
+            const float4 co = conic_opacity[g];
+            const float4 cz = rgbz[g];
+            const uint2 rc = rect[g];
+            rec.e = inst_offset[g] + (u32)(tile_y - (int)(rc.x >> 16)) * ((rc.y & 0xFFFF) - (rc.x & 0xFFFF)) +
+                    (u32)(tile_x - (int)(rc.x & 0xFFFF));
+            rec.x = c2.x; rec.y = c2.y;
+            rec.ap = -0.5f * LOG2E * co.x; rec.bp = -LOG2E * co.y; rec.cp = -0.5f * LOG2E * co.z; rec.o = co.w;
+            rec.r = cz.x; rec.g = cz.y; rec.b = cz.z;
+            rec.pos = lo + tid + 1;
+            rec.mask = block_mask16(c2.x, c2.y, co.x, co.y, co.z, co.w, X0, Y0);
+        }
+        recs[tid] = rec;
+        {
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                float4* a4 = reinterpret_cast<float4*>(&acc[w][tid][0]);
+                a4[0] = z4; a4[1] = z4; a4[2] = z4;
+            }
+        }
+        __syncthreads();
+
+        // ---- this wave's four blocks: one per block row, column = wave
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            const int blk = j * 4 + wave;
+            // ballot-compact the chunk's slots that reach this block (list order = depth order)
+            int L = 0;
+#pragma unroll
+            for (int r = 0; r < CHUNK / 64; ++r) {
+                const int slot = r * 64 + lane;
+                const bool hit = (recs[slot].mask >> blk) & 1u;
+                const u64 bal = __ballot(hit);
+                if (hit) lists[blk][L + __popcll(bal & lt_mask)] = (unsigned char)slot;
+                L += __popcll(bal);
+            }
+            if (L == 0) continue;
+            const float bx0 = X0 + 4.f * (float)(blk & 3), by0 = Y0 + 4.f * (float)(blk >> 2);
+            // groups of 64 list entries, deepest group first; inside a group lane 0 holds the deepest entry
+            for (int gend = L; gend > 0; gend -= 64) {
+                const int gcnt = min(gend, 64);
+                const bool live = lane < gcnt;
+                const int slot = live ? (int)lists[blk][gend - 1 - lane] : 0;
+                const ChunkRec s = recs[slot];
+                f2 a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0, a4 = a0, a5 = a0, a6 = a0, a7 = a0, a8 = a0, a9 = a0, a10 = a0;
+#ifndef SCAN_UNROLL
+#define SCAN_UNROLL 1
+#endif
+#pragma unroll SCAN_UNROLL
+                for (int it = 0; it < 8; ++it) {
+                    const int iy = it >> 1, ixp = (it & 1) * 2;
+                    PixPair& P = pix[blk * 8 + it];
+                    const float4 q0 = P.q0, q1 = P.q1, q2 = P.q2, q3 = P.q3;
+                    const f2 g0 = {q0.x, q0.y}, g1 = {q0.z, q0.w}, g2 = {q1.x, q1.y}, Tf = {q1.z, q1.w};
+                    const f2 bgt = {q2.x, q2.y}, Bc = {q3.x, q3.y}, Sc = {q3.z, q3.w};
+                    const u32 ncA = __float_as_uint(q2.z), ncB = __float_as_uint(q2.w);
+                    // same arithmetic as pair_power2 on d = centre - pixel (pixel coordinates are exact floats)
+                    const f2 dx = {s.x - (bx0 + (float)ixp), s.x - (bx0 + (float)(ixp + 1))};
+                    const float dy = s.y - (by0 + (float)iy);
+                    const f2 m2 = s.ap * dx;
+                    const f2 t2 = __builtin_elementwise_fma((f2){s.bp, s.bp}, (f2){dy, dy}, m2);
+                    const float u = __fmul_rn(__fmul_rn(s.cp, dy), dy);
+                    const f2 p2 = __builtin_elementwise_fma(dx, t2, (f2){u, u});
+                    f2 G = {__builtin_amdgcn_exp2f(p2.x), __builtin_amdgcn_exp2f(p2.y)};
+                    f2 al = s.o * G;
+                    al.x = fminf(0.99f, al.x); al.y = fminf(0.99f, al.y);
+                    const bool vA = live && (p2.x <= 0.f) && (al.x >= ALPHA_MIN) && (s.pos <= ncA);
+                    const bool vB = live && (p2.y <= 0.f) && (al.y >= ALPHA_MIN) && (s.pos <= ncB);
+                    al.x = vA ? al.x : 0.f; al.y = vB ? al.y : 0.f;
+                    G.x = vA ? G.x : 0.f;   G.y = vB ? G.y : 0.f;
+                    const f2 om = 1.f - al;
+                    // B_i: product over this and deeper splats (incl. everything behind the group, carried in Bc)
+                    float Bx = om.x, By = om.y;
+                    scan_mul64x2(Bx, By);
+                    const f2 B = (f2){Bx, By} * Bc;
+                    const f2 Tn = {Tf.x * __builtin_amdgcn_rcpf(B.x), Tf.y * __builtin_amdgcn_rcpf(B.y)};   // T in front of i
+                    const f2 w = al * Tn;
+                    const f2 sd = __builtin_elementwise_fma((f2){s.b, s.b}, g2, __builtin_elementwise_fma((f2){s.g, s.g}, g1, s.r * g0));
+                    const f2 ws = w * sd;
+                    float Sx = ws.x, Sy = ws.y;
+                    scan_add64x2(Sx, Sy);
+                    const f2 Si = (f2){Sx, Sy} + Sc;                                           // inclusive: this and everything behind
+                    if (lane == 63) { P.q3 = make_float4(B.x, B.y, Si.x, Si.y); }   // carries for the next (shallower) group
+                    const f2 Sex = Si - ws;                                 // strictly behind i
+                    const f2 iom = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+                    const f2 dLda = __builtin_elementwise_fma(Tn, sd, -((Sex + bgt) * iom));
+                    a0 = __builtin_elementwise_fma(w, g0, a0); a1 = __builtin_elementwise_fma(w, g1, a1); a2 = __builtin_elementwise_fma(w, g2, a2);
+                    const f2 gd = G * dLda;                                 // G == 0 for non-contributing pairs
+                    a3 = a3 + gd;
+                    const f2 qv = s.o * gd;
+                    const f2 qdx = qv * dx, qdy = qv * dy;
+                    a4 = a4 + qdx; a5 = a5 + qdy;
+                    a6 = __builtin_elementwise_fma(qdx, dx, a6); a7 = __builtin_elementwise_fma(qdx, (f2){dy, dy}, a7);
+                    a8 = __builtin_elementwise_fma(qdy, (f2){dy, dy}, a8);
+                    if (ABS) {
+                        const f2 tx = __builtin_elementwise_fma((f2){2.f * s.ap, 2.f * s.ap}, qdx, s.bp * qdy);
+                        const f2 ty = __builtin_elementwise_fma((f2){2.f * s.cp, 2.f * s.cp}, qdy, s.bp * qdx);
+                        a9 = a9 + __builtin_elementwise_abs(tx); a10 = a10 + __builtin_elementwise_abs(ty);
+                    }
+                }
+                if (live) {      // distinct lanes hold distinct slots: plain read-modify-write of the wave's own copy
+                    float4* d4 = reinterpret_cast<float4*>(&acc[wave][slot][0]);
+                    float4 r0 = d4[0], r1 = d4[1], r2 = d4[2];
+                    r0.x += a0.x + a0.y; r0.y += a1.x + a1.y; r0.z += a2.x + a2.y; r0.w += a3.x + a3.y;
+                    r1.x += a4.x + a4.y; r1.y += a5.x + a5.y; r1.z += a6.x + a6.y; r1.w += a7.x + a7.y;
+                    r2.x += a8.x + a8.y; r2.y += a9.x + a9.y; r2.z += a10.x + a10.y;
+                    d4[0] = r0; d4[1] = r1; d4[2] = r2;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- one record per staged instance: the four wave copies added in fixed order
+        if ((u32)tid < cnt) {
+            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+            if (rec.mask != 0) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float4* a4 = reinterpret_cast<const float4*>(&acc[w][tid][0]);
+                    const float4 x0 = a4[0], x1 = a4[1], x2 = a4[2];
+                    r0.x += x0.x; r0.y += x0.y; r0.z += x0.z; r0.w += x0.w;
+                    r1.x += x1.x; r1.y += x1.y; r1.z += x1.z; r1.w += x1.w;
+                    r2.x += x2.x; r2.y += x2.y; r2.z += x2.z;
+                }
+                r2.y *= (1.0f / LOG2E); r2.z *= (1.0f / LOG2E);      // abs sums were taken on the scaled conic
+            }
+            float4* dst = reinterpret_cast<float4*>(partials + (size_t)rec.e * PART_FLOATS);
+            dst[0] = r0; dst[1] = r1; dst[2] = r2;
+        }
+        __syncthreads();
+        hi = lo;
+    }
+}
+
+#ifndef BWD_SCAN
+#define BWD_SCAN 1          // 1: scan-based backward (lane = splat), 0: lane = pixel backward
+#endif
+
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
                             const float* grad_color, float* partials, bool want_abs, hipStream_t st)
 {
@@ -445,6 +745,16 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     const int T = gx * gy;
     if (T == 0) return hipSuccess;
     const int grid = ((T + 7) / 8) * 8;
+#if BWD_SCAN
+    if (want_abs)
+        hipLaunchKernelGGL(blend_bwd_scan_kernel<true>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
+                           b.ranges, b.point_list, g.xy, g.conic_opacity, g.rgbz, g.rect, g.inst_offset, s.bg,
+                           im.final_T, im.n_contrib, grad_color, partials);
+    else
+        hipLaunchKernelGGL(blend_bwd_scan_kernel<false>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
+                           b.ranges, b.point_list, g.xy, g.conic_opacity, g.rgbz, g.rect, g.inst_offset, s.bg,
+                           im.final_T, im.n_contrib, grad_color, partials);
+#else
     if (want_abs)
         hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(grid), dim3(64), 0, st, s.image_width, s.image_height, gx, T,
                            b.ranges, b.point_list, g.xy, g.conic_opacity, g.rgbz, g.rect, g.inst_offset, s.bg,
@@ -453,5 +763,6 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
         hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(grid), dim3(64), 0, st, s.image_width, s.image_height, gx, T,
                            b.ranges, b.point_list, g.xy, g.conic_opacity, g.rgbz, g.rect, g.inst_offset, s.bg,
                            im.final_T, im.n_contrib, grad_color, partials);
+#endif
     return hipGetLastError();
 }
