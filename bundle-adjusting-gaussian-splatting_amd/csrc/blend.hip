@@ -490,7 +490,12 @@ __device__ __forceinline__ float dpp_src(float identity, float v)
 __device__ __forceinline__ void scan_mul64x2(float& a, float& b) { SCAN2("v_mul_f32_dpp"); }
 __device__ __forceinline__ void scan_add64x2(float& a, float& b) { SCAN2("v_add_f32_dpp"); }
 
+#ifndef CHUNK
 #define CHUNK 256
+#endif
+#ifndef SCAN_WG_PER_CU
+#define SCAN_WG_PER_CU 2
+#endif
 struct __attribute__((aligned(16))) ChunkRec {
     float x, y, ap, bp;
     float cp, o, r, g;
@@ -535,7 +540,7 @@ __device__ __forceinline__ u32 block_mask16(float x, float y, float a, float b, 
 }
 
 template <bool ABS>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, SCAN_WG_PER_CU)
 blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ ranges, const u32* __restrict__ point_list,
                       const float2* __restrict__ xy, const float4* __restrict__ conic_opacity,
                       const float4* __restrict__ rgbz, const uint2* __restrict__ rect, const u32* __restrict__ inst_offset,
@@ -593,18 +598,29 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
     }
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
+    // Software pipeline over chunks: Gaussian ids are fetched TWO chunks ahead and the per-splat gathers ONE chunk
+    // ahead, so neither the id load nor the dependent gathers sit on the critical path of a chunk.
+    struct Raw { float2 c2; float4 co; float4 cz; uint2 rc; u32 io; };
+    auto fetch_id = [&](u32 hi_) -> u32 {            // id of this thread's slot in the chunk that ends at hi_
+        const u32 c_ = min(hi_, (u32)CHUNK);
+        return ((u32)tid < c_) ? point_list[range.x + (hi_ - c_) + tid] : 0xFFFFFFFFu;
+    };
+    auto fetch = [&](u32 g) {
+        Raw r; r.c2 = make_float2(0.f, 0.f); r.co = make_float4(0.f, 0.f, 0.f, 0.f); r.cz = r.co; r.rc = make_uint2(0u, 0u); r.io = 0u;
+        if (g != 0xFFFFFFFFu) { r.c2 = xy[g]; r.co = conic_opacity[g]; r.cz = rgbz[g]; r.rc = rect[g]; r.io = inst_offset[g]; }
+        return r;
+    };
+    Raw raw = fetch(fetch_id(maxc));
+    u32 gid_next = (maxc > CHUNK) ? fetch_id(maxc - CHUNK) : 0xFFFFFFFFu;
+
     for (u32 hi = maxc; hi > 0;) {
         const u32 cnt = min(hi, (u32)CHUNK);
         const u32 lo = hi - cnt;
         // ---- stage the chunk [lo, hi): slot s <-> list position lo + s (front to back)
         ChunkRec rec; rec.mask = 0; rec.e = 0;
         if ((u32)tid < cnt) {
-            const u32 g = point_list[range.x + lo + tid];
-            const float2 c2 = xy[g];
-            const float4 co = conic_opacity[g];
-            const float4 cz = rgbz[g];
-            const uint2 rc = rect[g];
-            rec.e = inst_offset[g] + (u32)(tile_y - (int)(rc.x >> 16)) * ((rc.y & 0xFFFF) - (rc.x & 0xFFFF)) +
+            const float2 c2 = raw.c2; const float4 co = raw.co, cz = raw.cz; const uint2 rc = raw.rc;
+            rec.e = raw.io + (u32)(tile_y - (int)(rc.x >> 16)) * ((rc.y & 0xFFFF) - (rc.x & 0xFFFF)) +
                     (u32)(tile_x - (int)(rc.x & 0xFFFF));
             rec.x = c2.x; rec.y = c2.y;
             rec.ap = -0.5f * LOG2E * co.x; rec.bp = -LOG2E * co.y; rec.cp = -0.5f * LOG2E * co.z; rec.o = co.w;
@@ -612,8 +628,12 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
             rec.pos = lo + tid + 1;
             rec.mask = block_mask16(c2.x, c2.y, co.x, co.y, co.z, co.w, X0, Y0);
         }
-        recs[tid] = rec;
-        {
+        if (lo > 0) {
+            raw = fetch(gid_next);                                       // gathers for the next chunk
+            gid_next = (lo > CHUNK) ? fetch_id(lo - CHUNK) : 0xFFFFFFFFu;   // ids for the one after
+        }
+        if (tid < CHUNK) {
+            recs[tid] = rec;
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
@@ -637,7 +657,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
                 if (hit) lists[blk][L + __popcll(bal & lt_mask)] = (unsigned char)slot;
                 L += __popcll(bal);
             }
-            if (L == 0) continue;
+            if (L == 0 || ABLATE == 4) continue;
             const float bx0 = X0 + 4.f * (float)(blk & 3), by0 = Y0 + 4.f * (float)(blk >> 2);
             // groups of 64 list entries, deepest group first; inside a group lane 0 holds the deepest entry
             for (int gend = L; gend > 0; gend -= 64) {
@@ -647,10 +667,10 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
                 const ChunkRec s = recs[slot];
                 f2 a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0, a4 = a0, a5 = a0, a6 = a0, a7 = a0, a8 = a0, a9 = a0, a10 = a0;
 #ifndef SCAN_UNROLL
-#define SCAN_UNROLL 1
+#define SCAN_UNROLL 2
 #endif
 #pragma unroll SCAN_UNROLL
-                for (int it = 0; it < 8; ++it) {
+                for (int it = 0; it < (ABLATE == 5 ? 2 : 8); ++it) {
                     const int iy = it >> 1, ixp = (it & 1) * 2;
                     PixPair& P = pix[blk * 8 + it];
                     const float4 q0 = P.q0, q1 = P.q1, q2 = P.q2, q3 = P.q3;
