@@ -149,7 +149,8 @@ size_t bags_backward_workspace_size(int32_t P, int64_t I)
 {
     const size_t part = align_up((size_t)(I > 0 ? I : 1) * PART_FLOATS * sizeof(float), 256);
     const size_t slab = align_up((size_t)(cdiv(P > 0 ? P : 1, 256)) * POSE_VALS * sizeof(float), 256);
-    return part + slab + 256;
+    const size_t sums = align_up((size_t)(P > 0 ? P : 1) * 12 * sizeof(float), 256);
+    return part + slab + sums + 256;
 }
 
 static inline void* align256(void* p) { return reinterpret_cast<void*>(align_up(reinterpret_cast<size_t>(p), 256)); }
@@ -227,12 +228,14 @@ int bags_backward(const BagsSettings* s, const BagsInputs* in, const BagsState* 
     char* ws = reinterpret_cast<char*>(align256(a->workspace));
     float* partials = reinterpret_cast<float*>(ws);
     float* slab = reinterpret_cast<float*>(ws + align_up((size_t)(I > 0 ? I : 1) * PART_FLOATS * sizeof(float), 256));
+    float* sums = reinterpret_cast<float*>(reinterpret_cast<char*>(slab) +
+                                           align_up((size_t)(cdiv(in->P > 0 ? in->P : 1, 256)) * POSE_VALS * sizeof(float), 256));
     if (I > 0) {
         { ProfScope ps(ST_BLEND_BWD, st); HIP_TRY(launch_blend_bwd(*s, g, b, im, a->grad_color, partials, a->grad_means2D_densify != nullptr, st)); }
         DEBUG_SYNC(s, st, "blend_bwd");
     }
     int nblocks = 0;
-    { ProfScope ps(ST_PRE_BWD, st); HIP_TRY(launch_preprocess_bwd(*s, *in, g, nullptr, partials, slab, &nblocks, *a, st)); }
+    { ProfScope ps(ST_PRE_BWD, st); HIP_TRY(launch_preprocess_bwd(*s, *in, g, nullptr, partials, slab, &nblocks, *a, st, sums)); }
     DEBUG_SYNC(s, st, "preprocess_bwd");
     { ProfScope ps(ST_POSE_REDUCE, st); HIP_TRY(launch_pose_reduce(slab, nblocks, *a, st)); }
     DEBUG_SYNC(s, st, "pose_reduce");

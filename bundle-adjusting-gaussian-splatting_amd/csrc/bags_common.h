@@ -77,7 +77,7 @@ hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinV
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
                             const float* grad_color, float* partials, bool want_abs, hipStream_t st);
 hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, const int32_t* radii_or_null,
-                                 const float* partials, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a, hipStream_t st);
+                                 const float* partials, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a, hipStream_t st, float* sums);
 hipError_t launch_pose_reduce(const float* pose_slab, int nblocks, const BagsBackwardArgs& a, hipStream_t st);
 hipError_t launch_debug_keys(const u32* tile_sorted, const u32* point_list, const u32* depth_key, long long I, u64* out, hipStream_t st);
 hipError_t launch_unpack_rect(const uint2* rect, int P, u32* out, hipStream_t st);

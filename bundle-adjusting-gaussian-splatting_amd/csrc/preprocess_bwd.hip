@@ -26,6 +26,39 @@ __device__ __forceinline__ float wave_sum(float x)
     return x;
 }
 
+// K8a: each Gaussian's consecutive partial records (written by blend_bwd at its emission slots) summed in list order.
+// Light kernel (high occupancy, two records in flight per lane): the record stream is the only traffic.
+__global__ void __launch_bounds__(256)
+sum_partials_kernel(int P, const u32* __restrict__ tiles_touched, const u32* __restrict__ inst_offset,
+                    const float* __restrict__ partials, float4* __restrict__ sums)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
+    const u32 nrec = tiles_touched[i];
+    if (nrec) {
+        const float4* rec = reinterpret_cast<const float4*>(partials + (size_t)inst_offset[i] * PART_FLOATS);
+        u32 r = 0;
+        for (; r + 1 < nrec; r += 2) {
+            const float4 a0 = rec[4 * r], b0 = rec[4 * r + 1], c0 = rec[4 * r + 2];
+            const float4 a1 = rec[4 * r + 4], b1 = rec[4 * r + 5], c1 = rec[4 * r + 6];
+            s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+            s1.x += b0.x; s1.y += b0.y; s1.z += b0.z; s1.w += b0.w;
+            s2.x += c0.x; s2.y += c0.y; s2.z += c0.z;
+            s0.x += a1.x; s0.y += a1.y; s0.z += a1.z; s0.w += a1.w;
+            s1.x += b1.x; s1.y += b1.y; s1.z += b1.z; s1.w += b1.w;
+            s2.x += c1.x; s2.y += c1.y; s2.z += c1.z;
+        }
+        if (r < nrec) {
+            const float4 a0 = rec[4 * r], b0 = rec[4 * r + 1], c0 = rec[4 * r + 2];
+            s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+            s1.x += b0.x; s1.y += b0.y; s1.z += b0.z; s1.w += b0.w;
+            s2.x += c0.x; s2.y += c0.y; s2.z += c0.z;
+        }
+    }
+    sums[3 * (size_t)i] = s0; sums[3 * (size_t)i + 1] = s1; sums[3 * (size_t)i + 2] = s2;
+}
+
 __global__ void __launch_bounds__(256)
 preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod,
                       const float* __restrict__ means3D, const float* __restrict__ shift_factors,
@@ -69,15 +102,11 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     if (live) {
         // ---- 1. sum the per-instance records
         float s[12];
-#pragma unroll
-        for (int t = 0; t < 12; ++t) s[t] = 0.f;
-        const u32 nrec = tiles_touched[i];
-        const float4* rec = reinterpret_cast<const float4*>(partials + (size_t)inst_offset[i] * PART_FLOATS);
-        for (u32 r = 0; r < nrec; ++r) {
-            const float4 a = rec[4 * r], b = rec[4 * r + 1], c = rec[4 * r + 2];
-            s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
-            s[4] += b.x; s[5] += b.y; s[6] += b.z; s[7] += b.w;
-            s[8] += c.x; s[9] += c.y; s[10] += c.z;
+        {
+            const float4* sm = reinterpret_cast<const float4*>(partials) + 3 * (size_t)i;   // K8a's per-Gaussian sums
+            const float4 a = sm[0], b = sm[1], c = sm[2];
+            s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+            s[8] = c.x; s[9] = c.y; s[10] = c.z; s[11] = 0.f;
         }
         drgb[0] = s[0]; drgb[1] = s[1]; drgb[2] = s[2];
         gop = s[3];
@@ -244,6 +273,36 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
             const float* sh = shs + (size_t)i * M * 3;
             float* gsh = g_shs ? g_shs + (size_t)i * M * 3 : nullptr;
             float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+            if (M == 16) {
+                // 192-byte rows, 16-byte aligned: four coefficients (12 floats) per step as 3 dwordx4 loads / stores
+                const float4* s4 = reinterpret_cast<const float4*>(sh);
+                float4* g4 = reinterpret_cast<float4*>(gsh);
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb) {
+                    float c[12], o[12];
+                    if (tb * 4 < nb) {
+                        const float4 w0 = s4[3 * tb], w1 = s4[3 * tb + 1], w2 = s4[3 * tb + 2];
+                        c[0] = w0.x; c[1] = w0.y; c[2] = w0.z; c[3] = w0.w; c[4] = w1.x; c[5] = w1.y; c[6] = w1.z; c[7] = w1.w;
+                        c[8] = w2.x; c[9] = w2.y; c[10] = w2.z; c[11] = w2.w;
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 12; ++u) c[u] = 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int t = tb * 4 + u;
+                        const bool on = t < nb;
+                        const float w = c[3 * u] * drgb[0] + c[3 * u + 1] * drgb[1] + c[3 * u + 2] * drgb[2];
+                        if (on) { ddx += bx[t] * w; ddy += by[t] * w; ddz += bz[t] * w; }
+                        o[3 * u] = on ? bs[t] * drgb[0] : 0.f; o[3 * u + 1] = on ? bs[t] * drgb[1] : 0.f; o[3 * u + 2] = on ? bs[t] * drgb[2] : 0.f;
+                    }
+                    if (g4) {
+                        g4[3 * tb] = make_float4(o[0], o[1], o[2], o[3]);
+                        g4[3 * tb + 1] = make_float4(o[4], o[5], o[6], o[7]);
+                        g4[3 * tb + 2] = make_float4(o[8], o[9], o[10], o[11]);
+                    }
+                }
+            } else
             for (int t = 0; t < M; ++t) {
                 float o0 = 0.f, o1 = 0.f, o2 = 0.f;
                 if (t < nb) {
@@ -260,7 +319,12 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         }
     } else if (i < P && g_shs && !colors_precomp) {
         float* gsh = g_shs + (size_t)i * M * 3;
-        for (int t = 0; t < 3 * M; ++t) gsh[t] = 0.f;
+        if (M == 16) {
+            float4* g4 = reinterpret_cast<float4*>(gsh);
+#pragma unroll
+            for (int t = 0; t < 12; ++t) g4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else
+            for (int t = 0; t < 3 * M; ++t) gsh[t] = 0.f;
     }
 
     if (i < P) {
@@ -332,13 +396,16 @@ pose_reduce_kernel(const float* __restrict__ slab, int nblocks, float* __restric
 }
 
 hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, const int32_t*,
-                                 const float* partials, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a,
-                                 hipStream_t st)
+                                 const float* partials_records, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a,
+                                 hipStream_t st, float* sums)
 {
     const int P = in.P;
     const int nb = cdiv(P, 256);
     *nblocks_out = nb;
     if (P == 0) return hipSuccess;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(nb), dim3(256), 0, st, P, g.tiles_touched, g.inst_offset,
+                       partials_records, reinterpret_cast<float4*>(sums));
+    const float* partials = sums;
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nb), dim3(256), 0, st, P, s.sh_coeffs, s.sh_degree, s.image_width,
                        s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, in.means3D, in.shift_factors, in.shs,
                        in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, s.viewmatrix, s.projmatrix,
