@@ -63,7 +63,7 @@ size_t carve_geom(void* base, int P, GeomView* v)
     char* p = reinterpret_cast<char*>(base);
     GeomView g;
     const size_t n = (size_t)(P > 0 ? P : 1);
-    g.nblocks_sort = cdiv((long long)n, SORT_TILE);
+    g.nblocks_sort = radix_blocks_for((long long)n);
     g.nblocks_scan = cdiv((long long)n, SCAN_TILE);
     take(p, g.depth_key, n); take(p, g.xy, n); take(p, g.conic_opacity, n); take(p, g.rgbz, n); take(p, g.rect, n);
     take(p, g.tiles_touched, n); take(p, g.inst_offset, n); take(p, g.clamped, n);
@@ -85,7 +85,7 @@ size_t carve_binning(void* base, long long I, int W, int H, BinView* v)
     BinView b;
     const size_t n = (size_t)(I > 0 ? I : 1);
     const int T = cdiv(W, BAGS_TILE) * cdiv(H, BAGS_TILE);
-    b.nblocks_sort = cdiv((long long)n, SORT_TILE);
+    b.nblocks_sort = radix_blocks_for((long long)n);
     b.passes = tile_passes(T);
     take(p, b.keys_a, n); take(p, b.vals_a, n); take(p, b.keys_b, n); take(p, b.vals_b, n);
     take(p, b.ranges, (size_t)(T > 0 ? T : 1));

@@ -12,8 +12,12 @@ typedef uint64_t u64;
 #define RADIX_BITS 8
 #define RADIX_BINS 256
 #define SORT_BLOCK 256
-#define SORT_ITEMS 16                     // keys per thread per radix pass
-#define SORT_TILE (SORT_BLOCK * SORT_ITEMS)   // 4096 keys per workgroup
+#ifndef SORT_ITEMS
+#define SORT_ITEMS 8                      // keys per thread per radix pass (large inputs)
+#endif
+#ifndef SORT_ITEMS_SMALL
+#define SORT_ITEMS_SMALL 4                // ... for inputs up to 2M keys
+#endif
 #define SCAN_BLOCK 256
 #define SCAN_ITEMS 8
 #define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)   // 2048 offsets per workgroup
@@ -60,6 +64,8 @@ struct ImgView {
     u32*   n_contrib;        // [H*W]
 };
 
+int radix_items_for(long long n);
+int radix_blocks_for(long long n);
 size_t carve_geom(void* base, int P, GeomView* v);
 size_t carve_binning(void* base, long long I, int W, int H, BinView* v);
 size_t carve_image(void* base, int W, int H, ImgView* v);

@@ -15,15 +15,16 @@
 #include "bags_common.h"
 
 // ------------------------------------------------------------------------------------------------ radix: histogram
+template <int ITEMS>
 __global__ void __launch_bounds__(SORT_BLOCK)
 radix_hist_kernel(const u32* __restrict__ keys, long long n, int shift, int nblocks, u32* __restrict__ hist)
 {
     __shared__ u32 h[RADIX_BINS];
     h[threadIdx.x] = 0;
     __syncthreads();
-    const long long base = (long long)blockIdx.x * SORT_TILE;
+    const long long base = (long long)blockIdx.x * (SORT_BLOCK * ITEMS);
 #pragma unroll 4
-    for (int r = 0; r < SORT_ITEMS; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         const long long idx = base + (long long)r * SORT_BLOCK + threadIdx.x;
         if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & (RADIX_BINS - 1)], 1u);
     }
@@ -67,14 +68,14 @@ radix_scan_kernel(u32* __restrict__ hist, int nblocks, u32* __restrict__ totals)
 // Item order inside a workgroup is (wave, round, lane) == ascending index, so ranks computed as
 //   [digits of earlier waves] + [same-digit items of earlier rounds of this wave] + [same-digit lower lanes]
 // make the pass stable.
-template <bool IOTA>
+template <bool IOTA, int ITEMS>
 __global__ void __launch_bounds__(SORT_BLOCK)
 radix_scatter_kernel(const u32* __restrict__ keys_in, const u32* __restrict__ vals_in, u32* __restrict__ keys_out,
                      u32* __restrict__ vals_out, long long n, int shift, int nblocks, const u32* __restrict__ hist,
                      const u32* __restrict__ totals)
 {
     constexpr int WAVES = SORT_BLOCK / 64;
-    constexpr int ROUNDS = SORT_TILE / SORT_BLOCK;           // rounds of 64 keys per wave
+    constexpr int ROUNDS = ITEMS;                            // rounds of 64 keys per wave
     __shared__ u32 whist[WAVES][RADIX_BINS];
     __shared__ u32 dbase[RADIX_BINS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -97,7 +98,7 @@ radix_scatter_kernel(const u32* __restrict__ keys_in, const u32* __restrict__ va
     }
     __syncthreads();
 
-    const long long seg = (long long)blockIdx.x * SORT_TILE + (long long)wave * (ROUNDS * 64);
+    const long long seg = (long long)blockIdx.x * (SORT_BLOCK * ITEMS) + (long long)wave * (ROUNDS * 64);
     u32 key[ROUNDS];
     u32 rank[ROUNDS];
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -146,26 +147,40 @@ radix_scatter_kernel(const u32* __restrict__ keys_in, const u32* __restrict__ va
 // Sorts (keys, vals) by key bits [0, bits) with stable 8-bit passes.  Pass 0 reads (src_k, src_v) and writes the A
 // half, pass 1 reads A and writes B, pass 2 reads B and writes A, ...  The result is in A when the number of passes is
 // odd and in B when it is even.  src may alias B (it is consumed by pass 0 before pass 1 overwrites it).
-hipError_t launch_radix_sort(const u32* src_k, const u32* src_v, u32* a_k, u32* a_v, u32* b_k, u32* b_v, long long n,
-                             int bits, bool iota_vals, u32* hist, u32* totals, int nblocks, hipStream_t st)
+template <int ITEMS>
+static hipError_t radix_sort_impl(const u32* src_k, const u32* src_v, u32* a_k, u32* a_v, u32* b_k, u32* b_v, long long n,
+                                  int bits, bool iota_vals, u32* hist, u32* totals, hipStream_t st)
 {
-    if (n <= 0) return hipSuccess;
+    const int nblocks = cdiv(n, SORT_BLOCK * ITEMS);
     const int passes = (bits + RADIX_BITS - 1) / RADIX_BITS;
     const u32* ik = src_k; const u32* iv = src_v;
     for (int p = 0; p < passes; ++p) {
         const int shift = p * RADIX_BITS;
         u32* ok = (p & 1) ? b_k : a_k; u32* ov = (p & 1) ? b_v : a_v;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(SORT_BLOCK), 0, st, ik, n, shift, nblocks, hist);
+        hipLaunchKernelGGL(radix_hist_kernel<ITEMS>, dim3(nblocks), dim3(SORT_BLOCK), 0, st, ik, n, shift, nblocks, hist);
         hipLaunchKernelGGL(radix_scan_kernel, dim3(RADIX_BINS), dim3(256), 0, st, hist, nblocks, totals);
         if (p == 0 && iota_vals)
-            hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nblocks), dim3(SORT_BLOCK), 0, st, ik, iv, ok, ov, n,
+            hipLaunchKernelGGL((radix_scatter_kernel<true, ITEMS>), dim3(nblocks), dim3(SORT_BLOCK), 0, st, ik, iv, ok, ov, n,
                                shift, nblocks, hist, totals);
         else
-            hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nblocks), dim3(SORT_BLOCK), 0, st, ik, iv, ok, ov, n,
+            hipLaunchKernelGGL((radix_scatter_kernel<false, ITEMS>), dim3(nblocks), dim3(SORT_BLOCK), 0, st, ik, iv, ok, ov, n,
                                shift, nblocks, hist, totals);
         ik = ok; iv = ov;
     }
     return hipGetLastError();
+}
+
+// keys per workgroup: small inputs get small tiles (more workgroups, shorter dependent chains), large inputs big ones
+int radix_items_for(long long n) { return n <= (1ll << 21) ? SORT_ITEMS_SMALL : SORT_ITEMS; }
+int radix_blocks_for(long long n) { return cdiv(n > 0 ? n : 1, (long long)SORT_BLOCK * radix_items_for(n)); }
+
+hipError_t launch_radix_sort(const u32* src_k, const u32* src_v, u32* a_k, u32* a_v, u32* b_k, u32* b_v, long long n,
+                             int bits, bool iota_vals, u32* hist, u32* totals, int /*nblocks*/, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    if (radix_items_for(n) == SORT_ITEMS_SMALL)
+        return radix_sort_impl<SORT_ITEMS_SMALL>(src_k, src_v, a_k, a_v, b_k, b_v, n, bits, iota_vals, hist, totals, st);
+    return radix_sort_impl<SORT_ITEMS>(src_k, src_v, a_k, a_v, b_k, b_v, n, bits, iota_vals, hist, totals, st);
 }
 
 // ------------------------------------------------------------------------------------------------ offsets scan
