@@ -192,7 +192,7 @@ blend_fwd_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ rang
     }
 }
 
-hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
+static hipError_t launch_blend_fwd_quadrants(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
                             const BagsForwardOut& out, hipStream_t st)
 {
     const int gx = cdiv(s.image_width, BAGS_TILE), gy = cdiv(s.image_height, BAGS_TILE);
@@ -785,4 +785,144 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
                            im.final_T, im.n_contrib, grad_color, partials);
 #endif
     return hipGetLastError();
+}
+
+
+// ================================================================================================================
+// Forward, "one DPP row per 4x4 block".  The quadrant forward above is latency-bound: one wave per tile leaves ~3.7
+// busy waves per SIMD on a scene whose splats cluster in half of the tiles, and each of them serialises on
+// LDS-read -> exp -> compare -> scalar-branch chains.  Here a 256-thread workgroup owns the tile:
+//   * the list is staged 256 splats at a time with the same 16-bit reach mask of 4x4 blocks as the backward;
+//   * wave w owns quadrant w; each of its four 16-lane rows owns one 4x4 block and walks ITS OWN ballot-compacted list
+//     of the chunk (one splat per row per step, 16 pixels each): ~1.8x fewer (pixel, splat) evaluations than 8x8
+//     quadrants, four times as many waves to hide latency, no scalar branch inside the walk.
+// Compositing arithmetic is unchanged (same pair_power2 / exp2 / thresholds), so images match the quadrant kernel.
+// ================================================================================================================
+template <int DUMMY>
+__global__ void __launch_bounds__(256)
+blend_fwd_rows_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ ranges, const u32* __restrict__ point_list,
+                      const float2* __restrict__ xy, const float4* __restrict__ conic_opacity,
+                      const float4* __restrict__ rgbz, const float* __restrict__ bg, float* __restrict__ out_color,
+                      float* __restrict__ out_depth, float* __restrict__ out_weights, float* __restrict__ final_T,
+                      u32* __restrict__ n_contrib)
+{
+    const int tile = tile_of_block(blockIdx.x, T);
+    if (tile >= T) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4, li = lane & 15;
+    const int tile_x = tile % grid_x, tile_y = tile / grid_x;
+    const float X0 = (float)(tile_x * BAGS_TILE), Y0 = (float)(tile_y * BAGS_TILE);
+    const uint2 range = ranges[tile];
+    const u32 n = range.y - range.x;
+
+    __shared__ SplatRec recs[CHUNK];                 // x y ap bp | cp o r g | b z mask pos
+    __shared__ unsigned char lists[16][CHUNK];
+    __shared__ int s_live[4];
+
+    const int bx = (wave & 1) * 2 + (row & 1), by = (wave >> 1) * 2 + (row >> 1), blk = by * 4 + bx;
+    const int px = tile_x * BAGS_TILE + bx * 4 + (li & 3), py = tile_y * BAGS_TILE + by * 4 + (li >> 2);
+    const float pxf = (float)px, pyf = (float)py;
+    const bool inside = (px < W) && (py < H);
+    bool done = !inside;
+    float Tq = 1.f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dq = 0.f;
+    u32 last = 0;
+    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // blocks of this wave's rows 0..3
+    const int qb = (wave >> 1) * 8 + (wave & 1) * 2;         // block index of row 0; rows: +0, +1, +4, +5
+
+    for (u32 base = 0; base < n; base += CHUNK) {
+        const u64 live_b = __ballot(!done);
+        if (lane == 0) s_live[wave] = (live_b != 0ull);
+        __syncthreads();                                     // previous chunk consumed by every wave
+        if (!(s_live[0] | s_live[1] | s_live[2] | s_live[3])) break;
+        const u32 cnt = min((u32)CHUNK, n - base);
+        SplatRec rec; rec.mask = 0; rec.x = rec.y = rec.ap = rec.bp = rec.cp = rec.o = rec.r = rec.g = rec.b = rec.z = 0.f; rec.pos = 0;
+        if ((u32)tid < cnt) {
+            const u32 g = point_list[range.x + base + tid];
+            const float2 c2 = xy[g];
+            const float4 co = conic_opacity[g];
+            const float4 cz = rgbz[g];
+            rec.x = c2.x; rec.y = c2.y;
+            rec.ap = -0.5f * LOG2E * co.x; rec.bp = -LOG2E * co.y; rec.cp = -0.5f * LOG2E * co.z; rec.o = co.w;
+            rec.r = cz.x; rec.g = cz.y; rec.b = cz.z; rec.z = cz.w;
+            rec.pos = base + tid + 1;
+            rec.mask = block_mask16(c2.x, c2.y, co.x, co.y, co.z, co.w, X0, Y0);
+        }
+        if (tid < CHUNK) recs[tid] = rec;
+        __syncthreads();
+        if (live_b == 0ull) continue;                        // this quadrant is finished; keep pace at the barriers
+        // ---- per-row lists (rows whose 16 pixels are all done take nothing)
+        int L0 = 0, L1 = 0, L2 = 0, L3 = 0;
+        const bool r0 = (live_b & 0xFFFFull) != 0, r1 = (live_b & 0xFFFF0000ull) != 0,
+                   r2 = (live_b & 0xFFFF00000000ull) != 0, r3 = (live_b & 0xFFFF000000000000ull) != 0;
+#pragma unroll
+        for (int rnd = 0; rnd < CHUNK / 64; ++rnd) {
+            const int slot = rnd * 64 + lane;
+            const u32 m = recs[slot].mask >> qb;             // bits 0,1,4,5 = this wave's rows 0..3
+            const bool h0 = r0 && (m & 1u), h1 = r1 && (m & 2u), h2 = r2 && (m & 16u), h3 = r3 && (m & 32u);
+            const u64 b0 = __ballot(h0), b1 = __ballot(h1), b2 = __ballot(h2), b3 = __ballot(h3);
+            if (h0) lists[qb][L0 + __popcll(b0 & lt_mask)] = (unsigned char)slot;
+            if (h1) lists[qb + 1][L1 + __popcll(b1 & lt_mask)] = (unsigned char)slot;
+            if (h2) lists[qb + 4][L2 + __popcll(b2 & lt_mask)] = (unsigned char)slot;
+            if (h3) lists[qb + 5][L3 + __popcll(b3 & lt_mask)] = (unsigned char)slot;
+            L0 += __popcll(b0); L1 += __popcll(b1); L2 += __popcll(b2); L3 += __popcll(b3);
+        }
+        const int Lrow = (row == 0) ? L0 : (row == 1) ? L1 : (row == 2) ? L2 : L3;
+        const int Lmax = max(max(L0, L1), max(L2, L3));
+        __builtin_amdgcn_wave_barrier();
+        // ---- every row walks its own list; the next list entry is fetched while the current splat is composited
+        const unsigned char* mylist = &lists[blk][0];
+        int slot = (Lrow > 0) ? (int)mylist[0] : 0;
+        for (int i = 0; i < Lmax; ++i) {
+            const bool act = i < Lrow;
+            const SplatRec s = recs[slot];
+            slot = (i + 1 < Lrow) ? (int)mylist[i + 1] : 0;
+            const float dx = s.x - pxf, dy = s.y - pyf;
+            const float p2 = pair_power2(dx, dy, s.ap, s.bp, s.cp);
+            const float G = __builtin_amdgcn_exp2f(p2);
+            const float alpha = fminf(0.99f, s.o * G);
+            const bool contrib = act && (p2 <= 0.f) && (alpha >= ALPHA_MIN) && !done;
+            if (contrib) {
+                const float test_T = Tq * (1.f - alpha);
+                if (test_T < T_EPS) {
+                    done = true;
+                } else {
+                    const float w = alpha * Tq;
+                    Cr = __fmaf_rn(w, s.r, Cr); Cg = __fmaf_rn(w, s.g, Cg); Cb = __fmaf_rn(w, s.b, Cb);
+                    Dq = __fmaf_rn(w, s.z, Dq);
+                    Tq = test_T;
+                    last = s.pos;
+                }
+            }
+        }
+    }
+    if (inside) {
+        const size_t HW = (size_t)W * H, pix = (size_t)py * W + px;
+        out_color[pix] = Cr + Tq * bg[0];
+        out_color[HW + pix] = Cg + Tq * bg[1];
+        out_color[2 * HW + pix] = Cb + Tq * bg[2];
+        if (out_depth) out_depth[pix] = Dq;
+        if (out_weights) out_weights[pix] = 1.f - Tq;
+        final_T[pix] = Tq;
+        n_contrib[pix] = last;
+    }
+}
+
+#ifndef FWD_ROWS
+#define FWD_ROWS 1          // 1: row-per-block forward, 0: quadrant forward
+#endif
+hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
+                            const BagsForwardOut& out, hipStream_t st)
+{
+#if FWD_ROWS
+    const int gx = cdiv(s.image_width, BAGS_TILE), gy = cdiv(s.image_height, BAGS_TILE);
+    const int T = gx * gy;
+    if (T == 0) return hipSuccess;
+    const int grid = ((T + 7) / 8) * 8;
+    hipLaunchKernelGGL(blend_fwd_rows_kernel<0>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
+                       b.ranges, b.point_list, g.xy, g.conic_opacity, g.rgbz, s.bg, out.color, out.depth, out.weights,
+                       im.final_T, im.n_contrib);
+    return hipGetLastError();
+#else
+    return launch_blend_fwd_quadrants(s, g, b, im, out, st);
+#endif
 }
