@@ -487,6 +487,21 @@ __device__ __forceinline__ float dpp_src(float identity, float v)
         OP " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                                     \
         "s_nop 1"                                                                                        \
         : "+v"(a), "+v"(b))
+#define SCAN4_STEP(OP, PAT)                                                                              \
+        OP " %0, %0, %0 " PAT "\n\t" OP " %1, %1, %1 " PAT "\n\t" OP " %2, %2, %2 " PAT "\n\t" OP " %3, %3, %3 " PAT "\n\t"
+#define SCAN4(OP)                                                                                        \
+    asm volatile(                                                                                        \
+        "s_nop 1\n\t"                                                                                    \
+        SCAN4_STEP(OP, "row_shr:1 row_mask:0xf bank_mask:0xf")                                           \
+        SCAN4_STEP(OP, "row_shr:2 row_mask:0xf bank_mask:0xf")                                           \
+        SCAN4_STEP(OP, "row_shr:4 row_mask:0xf bank_mask:0xf")                                           \
+        SCAN4_STEP(OP, "row_shr:8 row_mask:0xf bank_mask:0xf")                                           \
+        SCAN4_STEP(OP, "row_bcast:15 row_mask:0xa bank_mask:0xf")                                        \
+        SCAN4_STEP(OP, "row_bcast:31 row_mask:0xc bank_mask:0xf")                                        \
+        "s_nop 1"                                                                                        \
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+__device__ __forceinline__ void scan_mul64x4(float& a, float& b, float& c, float& d) { SCAN4("v_mul_f32_dpp"); }
+__device__ __forceinline__ void scan_add64x4(float& a, float& b, float& c, float& d) { SCAN4("v_add_f32_dpp"); }
 __device__ __forceinline__ void scan_mul64x2(float& a, float& b) { SCAN2("v_mul_f32_dpp"); }
 __device__ __forceinline__ void scan_add64x2(float& a, float& b) { SCAN2("v_add_f32_dpp"); }
 
@@ -667,58 +682,75 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
                 const ChunkRec s = recs[slot];
                 f2 a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0, a4 = a0, a5 = a0, a6 = a0, a7 = a0, a8 = a0, a9 = a0, a10 = a0;
 #ifndef SCAN_UNROLL
-#define SCAN_UNROLL 2
+#define SCAN_UNROLL 1
 #endif
+                // one block row (4 pixels = two packed pairs) per step: four independent scan chains interleave
+                // without pipeline bubbles
 #pragma unroll SCAN_UNROLL
-                for (int it = 0; it < (ABLATE == 5 ? 2 : 8); ++it) {
-                    const int iy = it >> 1, ixp = (it & 1) * 2;
-                    PixPair& P = pix[blk * 8 + it];
-                    const float4 q0 = P.q0, q1 = P.q1, q2 = P.q2, q3 = P.q3;
-                    const f2 g0 = {q0.x, q0.y}, g1 = {q0.z, q0.w}, g2 = {q1.x, q1.y}, Tf = {q1.z, q1.w};
-                    const f2 bgt = {q2.x, q2.y}, Bc = {q3.x, q3.y}, Sc = {q3.z, q3.w};
-                    const u32 ncA = __float_as_uint(q2.z), ncB = __float_as_uint(q2.w);
-                    // same arithmetic as pair_power2 on d = centre - pixel (pixel coordinates are exact floats)
-                    const f2 dx = {s.x - (bx0 + (float)ixp), s.x - (bx0 + (float)(ixp + 1))};
+                for (int iy = 0; iy < 4; ++iy) {
+                    PixPair& P0 = pix[blk * 8 + iy * 2];
+                    PixPair& P1 = pix[blk * 8 + iy * 2 + 1];
+                    const float4 q00 = P0.q0, q01 = P0.q1, q02 = P0.q2, q03 = P0.q3;
+                    const float4 q10 = P1.q0, q11 = P1.q1, q12 = P1.q2, q13 = P1.q3;
                     const float dy = s.y - (by0 + (float)iy);
-                    const f2 m2 = s.ap * dx;
-                    const f2 t2 = __builtin_elementwise_fma((f2){s.bp, s.bp}, (f2){dy, dy}, m2);
                     const float u = __fmul_rn(__fmul_rn(s.cp, dy), dy);
-                    const f2 p2 = __builtin_elementwise_fma(dx, t2, (f2){u, u});
-                    f2 G = {__builtin_amdgcn_exp2f(p2.x), __builtin_amdgcn_exp2f(p2.y)};
-                    f2 al = s.o * G;
-                    al.x = fminf(0.99f, al.x); al.y = fminf(0.99f, al.y);
-                    const bool vA = live && (p2.x <= 0.f) && (al.x >= ALPHA_MIN) && (s.pos <= ncA);
-                    const bool vB = live && (p2.y <= 0.f) && (al.y >= ALPHA_MIN) && (s.pos <= ncB);
-                    al.x = vA ? al.x : 0.f; al.y = vB ? al.y : 0.f;
-                    G.x = vA ? G.x : 0.f;   G.y = vB ? G.y : 0.f;
-                    const f2 om = 1.f - al;
-                    // B_i: product over this and deeper splats (incl. everything behind the group, carried in Bc)
-                    float Bx = om.x, By = om.y;
-                    scan_mul64x2(Bx, By);
-                    const f2 B = (f2){Bx, By} * Bc;
-                    const f2 Tn = {Tf.x * __builtin_amdgcn_rcpf(B.x), Tf.y * __builtin_amdgcn_rcpf(B.y)};   // T in front of i
-                    const f2 w = al * Tn;
-                    const f2 sd = __builtin_elementwise_fma((f2){s.b, s.b}, g2, __builtin_elementwise_fma((f2){s.g, s.g}, g1, s.r * g0));
-                    const f2 ws = w * sd;
-                    float Sx = ws.x, Sy = ws.y;
-                    scan_add64x2(Sx, Sy);
-                    const f2 Si = (f2){Sx, Sy} + Sc;                                           // inclusive: this and everything behind
-                    if (lane == 63) { P.q3 = make_float4(B.x, B.y, Si.x, Si.y); }   // carries for the next (shallower) group
-                    const f2 Sex = Si - ws;                                 // strictly behind i
-                    const f2 iom = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
-                    const f2 dLda = __builtin_elementwise_fma(Tn, sd, -((Sex + bgt) * iom));
-                    a0 = __builtin_elementwise_fma(w, g0, a0); a1 = __builtin_elementwise_fma(w, g1, a1); a2 = __builtin_elementwise_fma(w, g2, a2);
-                    const f2 gd = G * dLda;                                 // G == 0 for non-contributing pairs
-                    a3 = a3 + gd;
-                    const f2 qv = s.o * gd;
-                    const f2 qdx = qv * dx, qdy = qv * dy;
-                    a4 = a4 + qdx; a5 = a5 + qdy;
-                    a6 = __builtin_elementwise_fma(qdx, dx, a6); a7 = __builtin_elementwise_fma(qdx, (f2){dy, dy}, a7);
-                    a8 = __builtin_elementwise_fma(qdy, (f2){dy, dy}, a8);
+                    const f2 dyy = {dy, dy};
+                    // ---- part 1: alpha of the four pixels (same arithmetic as pair_power2 on d = centre - pixel)
+                    const f2 dxa = {s.x - bx0, s.x - (bx0 + 1.f)}, dxb = {s.x - (bx0 + 2.f), s.x - (bx0 + 3.f)};
+                    const f2 ta = __builtin_elementwise_fma((f2){s.bp, s.bp}, dyy, s.ap * dxa);
+                    const f2 tb = __builtin_elementwise_fma((f2){s.bp, s.bp}, dyy, s.ap * dxb);
+                    const f2 pa = __builtin_elementwise_fma(dxa, ta, (f2){u, u});
+                    const f2 pb = __builtin_elementwise_fma(dxb, tb, (f2){u, u});
+                    f2 Ga = {__builtin_amdgcn_exp2f(pa.x), __builtin_amdgcn_exp2f(pa.y)};
+                    f2 Gb = {__builtin_amdgcn_exp2f(pb.x), __builtin_amdgcn_exp2f(pb.y)};
+                    f2 ala = s.o * Ga, alb = s.o * Gb;
+                    ala.x = fminf(0.99f, ala.x); ala.y = fminf(0.99f, ala.y); alb.x = fminf(0.99f, alb.x); alb.y = fminf(0.99f, alb.y);
+                    const bool v0 = live && (pa.x <= 0.f) && (ala.x >= ALPHA_MIN) && (s.pos <= __float_as_uint(q02.z));
+                    const bool v1 = live && (pa.y <= 0.f) && (ala.y >= ALPHA_MIN) && (s.pos <= __float_as_uint(q02.w));
+                    const bool v2 = live && (pb.x <= 0.f) && (alb.x >= ALPHA_MIN) && (s.pos <= __float_as_uint(q12.z));
+                    const bool v3 = live && (pb.y <= 0.f) && (alb.y >= ALPHA_MIN) && (s.pos <= __float_as_uint(q12.w));
+                    ala.x = v0 ? ala.x : 0.f; ala.y = v1 ? ala.y : 0.f; alb.x = v2 ? alb.x : 0.f; alb.y = v3 ? alb.y : 0.f;
+                    Ga.x = v0 ? Ga.x : 0.f; Ga.y = v1 ? Ga.y : 0.f; Gb.x = v2 ? Gb.x : 0.f; Gb.y = v3 ? Gb.y : 0.f;
+                    const f2 oma = 1.f - ala, omb = 1.f - alb;
+                    // ---- B_i: product over this and deeper splats (x what lies behind the group, carried in q*3.xy)
+                    float B0 = oma.x, B1 = oma.y, B2 = omb.x, B3 = omb.y;
+                    scan_mul64x4(B0, B1, B2, B3);
+                    const f2 Ba = (f2){B0, B1} * (f2){q03.x, q03.y}, Bb = (f2){B2, B3} * (f2){q13.x, q13.y};
+                    const f2 Tna = {q01.z * __builtin_amdgcn_rcpf(Ba.x), q01.w * __builtin_amdgcn_rcpf(Ba.y)};   // T in front of i
+                    const f2 Tnb = {q11.z * __builtin_amdgcn_rcpf(Bb.x), q11.w * __builtin_amdgcn_rcpf(Bb.y)};
+                    const f2 wa = ala * Tna, wb = alb * Tnb;
+                    const f2 g0a = {q00.x, q00.y}, g1a = {q00.z, q00.w}, g2a = {q01.x, q01.y};
+                    const f2 g0b = {q10.x, q10.y}, g1b = {q10.z, q10.w}, g2b = {q11.x, q11.y};
+                    const f2 sda = __builtin_elementwise_fma((f2){s.b, s.b}, g2a, __builtin_elementwise_fma((f2){s.g, s.g}, g1a, s.r * g0a));
+                    const f2 sdb = __builtin_elementwise_fma((f2){s.b, s.b}, g2b, __builtin_elementwise_fma((f2){s.g, s.g}, g1b, s.r * g0b));
+                    const f2 wsa = wa * sda, wsb = wb * sdb;
+                    float S0 = wsa.x, S1 = wsa.y, S2 = wsb.x, S3 = wsb.y;
+                    scan_add64x4(S0, S1, S2, S3);
+                    const f2 Sia = (f2){S0, S1} + (f2){q03.z, q03.w}, Sib = (f2){S2, S3} + (f2){q13.z, q13.w};
+                    if (lane == 63) {                                       // carries for the next (shallower) group
+                        P0.q3 = make_float4(Ba.x, Ba.y, Sia.x, Sia.y);
+                        P1.q3 = make_float4(Bb.x, Bb.y, Sib.x, Sib.y);
+                    }
+                    const f2 ioma = {__builtin_amdgcn_rcpf(oma.x), __builtin_amdgcn_rcpf(oma.y)};
+                    const f2 iomb = {__builtin_amdgcn_rcpf(omb.x), __builtin_amdgcn_rcpf(omb.y)};
+                    const f2 dLa = __builtin_elementwise_fma(Tna, sda, -(((Sia - wsa) + (f2){q02.x, q02.y}) * ioma));
+                    const f2 dLb = __builtin_elementwise_fma(Tnb, sdb, -(((Sib - wsb) + (f2){q12.x, q12.y}) * iomb));
+                    a0 = __builtin_elementwise_fma(wa, g0a, a0); a1 = __builtin_elementwise_fma(wa, g1a, a1); a2 = __builtin_elementwise_fma(wa, g2a, a2);
+                    a0 = __builtin_elementwise_fma(wb, g0b, a0); a1 = __builtin_elementwise_fma(wb, g1b, a1); a2 = __builtin_elementwise_fma(wb, g2b, a2);
+                    const f2 gda = Ga * dLa, gdb = Gb * dLb;                // G == 0 for non-contributing pairs
+                    a3 = a3 + gda; a3 = a3 + gdb;
+                    const f2 qva = s.o * gda, qvb = s.o * gdb;
+                    const f2 qdxa = qva * dxa, qdxb = qvb * dxb, qdya = qva * dy, qdyb = qvb * dy;
+                    a4 = a4 + qdxa; a4 = a4 + qdxb; a5 = a5 + qdya; a5 = a5 + qdyb;
+                    a6 = __builtin_elementwise_fma(qdxa, dxa, a6); a6 = __builtin_elementwise_fma(qdxb, dxb, a6);
+                    a7 = __builtin_elementwise_fma(qdxa, dyy, a7); a7 = __builtin_elementwise_fma(qdxb, dyy, a7);
+                    a8 = __builtin_elementwise_fma(qdya, dyy, a8); a8 = __builtin_elementwise_fma(qdyb, dyy, a8);
                     if (ABS) {
-                        const f2 tx = __builtin_elementwise_fma((f2){2.f * s.ap, 2.f * s.ap}, qdx, s.bp * qdy);
-                        const f2 ty = __builtin_elementwise_fma((f2){2.f * s.cp, 2.f * s.cp}, qdy, s.bp * qdx);
-                        a9 = a9 + __builtin_elementwise_abs(tx); a10 = a10 + __builtin_elementwise_abs(ty);
+                        const f2 ap2 = {2.f * s.ap, 2.f * s.ap}, cp2 = {2.f * s.cp, 2.f * s.cp};
+                        a9 = a9 + __builtin_elementwise_abs(__builtin_elementwise_fma(ap2, qdxa, s.bp * qdya));
+                        a9 = a9 + __builtin_elementwise_abs(__builtin_elementwise_fma(ap2, qdxb, s.bp * qdyb));
+                        a10 = a10 + __builtin_elementwise_abs(__builtin_elementwise_fma(cp2, qdya, s.bp * qdxa));
+                        a10 = a10 + __builtin_elementwise_abs(__builtin_elementwise_fma(cp2, qdyb, s.bp * qdxb));
                     }
                 }
                 if (live) {      // distinct lanes hold distinct slots: plain read-modify-write of the wave's own copy
