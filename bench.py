@@ -191,13 +191,14 @@ def main():
         value = world * P * args.steps / elapsed
         stages = {k: (ms / max(c, 1)) for k, (ms, c) in prof.items() if c > 0}
         HWp = H * W
-        alg = {  # algorithmic bytes per launch (DESIGN.md "Kernels"): SURVEY.md 8d split per stage
+        alg = {  # algorithmic bytes per launch: SURVEY.md 8d split per stage
             "blend_bwd": I * 84 + HWp * 20,
             "blend_fwd": I * 40 + HWp * 20,
             "preprocess_fwd": G * 284 + (P - G) * 28,
             "preprocess_bwd": G * 566,
             "tile_sort": I * 36,
             "emit": I * 12,
+            "depth_sort": P * 96,
         }
         b_alg = G * 850 + (P - G) * 28 + I * 168 + HWp * 40
         out = {
