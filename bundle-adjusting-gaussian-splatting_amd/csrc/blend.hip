@@ -456,6 +456,12 @@ blend_bwd_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ rang
 // ================================================================================================================
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter
+// (s_waitcnt vmcnt(0)), which would stall every wave on the gathers it has just put in flight for the NEXT chunk
+// (measured: 23 % of the wave time parked at the first barrier).  Nothing exchanged between waves here lives in
+// global memory, so lgkmcnt(0) + s_barrier is sufficient.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_src(float identity, float v)
 {   // v moved by the DPP pattern; lanes without a source (or in rows outside ROW_MASK) get `identity`
@@ -554,6 +560,12 @@ __device__ __forceinline__ u32 block_mask16(float x, float y, float a, float b, 
     return m;
 }
 
+#ifdef DIAG_PHASES
+__device__ unsigned long long g_phase_cycles[8];
+#define PH_MARK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define PH_MARK(i) do {} while (0)
+#endif
 template <bool ABS>
 __global__ void __launch_bounds__(256, SCAN_WG_PER_CU)
 blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ ranges, const u32* __restrict__ point_list,
@@ -574,9 +586,20 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
     __shared__ ChunkRec recs[CHUNK];                 // 12 KB
     __shared__ PixPair pix[128];                     //  8 KB
     __shared__ unsigned char lists[16][CHUNK];       //  4 KB
+#ifndef ACC_ATOMIC
+#define ACC_ATOMIC 0        // 1: one shared copy + LDS float atomics (faster? but summation order then depends on timing)
+#endif
+#if ACC_ATOMIC
+    __shared__ float acc[1][CHUNK][12];
+#else
     __shared__ float acc[4][CHUNK][12];              // 48 KB, one copy per wave
+#endif
     __shared__ u32 wmax[4];
 
+#ifdef DIAG_PHASES
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
     // ---- per-pixel constants: thread tid <-> block tid>>4, pixel tid&15 (ix = &3, iy = >>2)
     u32 maxc;
     {
@@ -625,38 +648,52 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
         if (g != 0xFFFFFFFFu) { r.c2 = xy[g]; r.co = conic_opacity[g]; r.cz = rgbz[g]; r.rc = rect[g]; r.io = inst_offset[g]; }
         return r;
     };
-    Raw raw = fetch(fetch_id(maxc));
-    u32 gid_next = (maxc > CHUNK) ? fetch_id(maxc - CHUNK) : 0xFFFFFFFFu;
-
-    for (u32 hi = maxc; hi > 0;) {
-        const u32 cnt = min(hi, (u32)CHUNK);
-        const u32 lo = hi - cnt;
-        // ---- stage the chunk [lo, hi): slot s <-> list position lo + s (front to back)
+    if (tid < CHUNK) {
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w = 0; w < (ACC_ATOMIC ? 1 : 4); ++w) {
+            float4* a4 = reinterpret_cast<float4*>(&acc[w][tid][0]);
+            a4[0] = z4; a4[1] = z4; a4[2] = z4;
+        }
+    }
+    PH_MARK(0);        // prologue
+    auto make_rec = [&](const Raw& rw, u32 lo_, u32 cnt_) {
         ChunkRec rec; rec.mask = 0; rec.e = 0;
-        if ((u32)tid < cnt) {
-            const float2 c2 = raw.c2; const float4 co = raw.co, cz = raw.cz; const uint2 rc = raw.rc;
-            rec.e = raw.io + (u32)(tile_y - (int)(rc.x >> 16)) * ((rc.y & 0xFFFF) - (rc.x & 0xFFFF)) +
+        rec.x = rec.y = rec.ap = rec.bp = rec.cp = rec.o = rec.r = rec.g = rec.b = 0.f; rec.pos = 0;
+        if ((u32)tid < cnt_) {
+            const float2 c2 = rw.c2; const float4 co = rw.co, cz = rw.cz; const uint2 rc = rw.rc;
+            rec.e = rw.io + (u32)(tile_y - (int)(rc.x >> 16)) * ((rc.y & 0xFFFF) - (rc.x & 0xFFFF)) +
                     (u32)(tile_x - (int)(rc.x & 0xFFFF));
             rec.x = c2.x; rec.y = c2.y;
             rec.ap = -0.5f * LOG2E * co.x; rec.bp = -LOG2E * co.y; rec.cp = -0.5f * LOG2E * co.z; rec.o = co.w;
             rec.r = cz.x; rec.g = cz.y; rec.b = cz.z;
-            rec.pos = lo + tid + 1;
+            rec.pos = lo_ + tid + 1;
             rec.mask = block_mask16(c2.x, c2.y, co.x, co.y, co.z, co.w, X0, Y0);
         }
-        if (lo > 0) {
-            raw = fetch(gid_next);                                       // gathers for the next chunk
-            gid_next = (lo > CHUNK) ? fetch_id(lo - CHUNK) : 0xFFFFFFFFu;   // ids for the one after
-        }
-        if (tid < CHUNK) {
-            recs[tid] = rec;
-            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                float4* a4 = reinterpret_cast<float4*>(&acc[w][tid][0]);
-                a4[0] = z4; a4[1] = z4; a4[2] = z4;
-            }
-        }
-        __syncthreads();
+        return rec;
+    };
+    // Chunk pipeline.  Every value carried around the loop is COMPLETE (the compiler copies loop-carried registers at
+    // the loop head, and copying the destination of an in-flight load stalls on it -- measured: 23 % of the wave time):
+    //   top      publish rec(k) to LDS, barrier
+    //   then     issue the gathers of chunk k+1 (ids known) and the id load of chunk k+2
+    //   ...      lists + groups of chunk k            <- the loads land underneath
+    //   barrier  consume gathers -> rec(k+1), ids(k+2); only then store the records of chunk k
+    ChunkRec rec = make_rec(fetch(fetch_id(maxc)), maxc - min(maxc, (u32)CHUNK), min(maxc, (u32)CHUNK));
+    u32 gid1 = (maxc > CHUNK) ? fetch_id(maxc - CHUNK) : 0xFFFFFFFFu;       // ids of chunk 1
+
+    for (u32 hi = maxc; hi > 0;) {
+        const u32 cnt = min(hi, (u32)CHUNK);
+        const u32 lo = hi - cnt;
+        // ---- publish the staged chunk [lo, hi): slot s <-> list position lo + s (front to back)
+        if (tid < CHUNK) recs[tid] = rec;        // safe without a barrier: after the previous chunk's second barrier nobody reads recs
+        lds_barrier();
+        PH_MARK(2);    // barrier 1
+#ifndef SCAN_PRIO
+#define SCAN_PRIO 1
+#endif
+        if (SCAN_PRIO) __builtin_amdgcn_s_setprio(0);
+        Raw raw_n = fetch(lo > 0 ? gid1 : 0xFFFFFFFFu);                             // gathers of chunk k+1
+        const u32 gid2 = (lo > CHUNK) ? fetch_id(lo - CHUNK) : 0xFFFFFFFFu;          // ids of chunk k+2
 
         // ---- this wave's four blocks: one per block row, column = wave
 #pragma unroll 1
@@ -672,6 +709,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
                 if (hit) lists[blk][L + __popcll(bal & lt_mask)] = (unsigned char)slot;
                 L += __popcll(bal);
             }
+            PH_MARK(3);    // list building
             if (L == 0 || ABLATE == 4) continue;
             const float bx0 = X0 + 4.f * (float)(blk & 3), by0 = Y0 + 4.f * (float)(blk >> 2);
             // groups of 64 list entries, deepest group first; inside a group lane 0 holds the deepest entry
@@ -753,6 +791,15 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
                         a10 = a10 + __builtin_elementwise_abs(__builtin_elementwise_fma(cp2, qdyb, s.bp * qdxb));
                     }
                 }
+#if ACC_ATOMIC
+                if (live) {
+                    float* d = &acc[0][slot][0];
+                    atomicAdd(d + 0, a0.x + a0.y); atomicAdd(d + 1, a1.x + a1.y); atomicAdd(d + 2, a2.x + a2.y);
+                    atomicAdd(d + 3, a3.x + a3.y); atomicAdd(d + 4, a4.x + a4.y); atomicAdd(d + 5, a5.x + a5.y);
+                    atomicAdd(d + 6, a6.x + a6.y); atomicAdd(d + 7, a7.x + a7.y); atomicAdd(d + 8, a8.x + a8.y);
+                    if (ABS) { atomicAdd(d + 9, a9.x + a9.y); atomicAdd(d + 10, a10.x + a10.y); }
+                }
+#else
                 if (live) {      // distinct lanes hold distinct slots: plain read-modify-write of the wave's own copy
                     float4* d4 = reinterpret_cast<float4*>(&acc[wave][slot][0]);
                     float4 r0 = d4[0], r1 = d4[1], r2 = d4[2];
@@ -761,30 +808,51 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
                     r2.x += a8.x + a8.y; r2.y += a9.x + a9.y; r2.z += a10.x + a10.y;
                     d4[0] = r0; d4[1] = r1; d4[2] = r2;
                 }
+#endif
+                PH_MARK(4);    // groups
             }
         }
-        __syncthreads();
+        PH_MARK(3);
+        lds_barrier();
+        PH_MARK(5);    // barrier 2
+        // The short serial section between the two barriers shares its SIMDs with another workgroup that is usually in
+        // its VALU-saturated group phase; without priority the four waves crawl through it at different speeds and
+        // the skew is paid at the next barrier.
+        if (SCAN_PRIO) __builtin_amdgcn_s_setprio(3);
+        // ---- next chunk: its gathers were issued before the groups; turn them into the staged record
+        const ChunkRec cur = rec;
+        if (lo > 0) { const u32 ncnt = min(lo, (u32)CHUNK); rec = make_rec(raw_n, lo - ncnt, ncnt); }
+        gid1 = gid2;
+        PH_MARK(1);
         // ---- one record per staged instance: the four wave copies added in fixed order
         if ((u32)tid < cnt) {
             float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-            if (rec.mask != 0) {
+            if (cur.mask != 0) {
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const float4* a4 = reinterpret_cast<const float4*>(&acc[w][tid][0]);
+                for (int w = 0; w < (ACC_ATOMIC ? 1 : 4); ++w) {
+                    float4* a4 = reinterpret_cast<float4*>(&acc[w][tid][0]);
                     const float4 x0 = a4[0], x1 = a4[1], x2 = a4[2];
+                    a4[0] = z4; a4[1] = z4; a4[2] = z4;               // owner re-zeroes its slot for the next chunk
                     r0.x += x0.x; r0.y += x0.y; r0.z += x0.z; r0.w += x0.w;
                     r1.x += x1.x; r1.y += x1.y; r1.z += x1.z; r1.w += x1.w;
                     r2.x += x2.x; r2.y += x2.y; r2.z += x2.z;
                 }
                 r2.y *= (1.0f / LOG2E); r2.z *= (1.0f / LOG2E);      // abs sums were taken on the scaled conic
             }
-            float4* dst = reinterpret_cast<float4*>(partials + (size_t)rec.e * PART_FLOATS);
+            float4* dst = reinterpret_cast<float4*>(partials + (size_t)cur.e * PART_FLOATS);
             dst[0] = r0; dst[1] = r1; dst[2] = r2;
         }
-        __syncthreads();
-        hi = lo;
+        PH_MARK(6);    // record sums + stores
+        hi = lo;          // no barrier here: the next chunk's first barrier orders these LDS accesses before any reuse
     }
+#ifdef DIAG_PHASES
+    if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_cycles[i], ph[i]);
+#endif
 }
+#ifdef DIAG_PHASES
+extern "C" void bags_diag_phases(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 8); }
+#endif
 
 #ifndef BWD_SCAN
 #define BWD_SCAN 1          // 1: scan-based backward (lane = splat), 0: lane = pixel backward
