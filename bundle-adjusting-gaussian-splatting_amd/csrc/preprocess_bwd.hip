@@ -366,8 +366,17 @@ pose_reduce_kernel(const float* __restrict__ slab, int nblocks, float* __restric
     __shared__ float tot[POSE_VALS];
     const int t = threadIdx.x % POSE_VALS, grp = threadIdx.x / POSE_VALS;
     if (grp < POSE_GROUPS) {
+        // rows grp, grp+25, ...: eight independent loads in flight, added in row order (fixed => deterministic)
         double acc = 0.0;
-        for (int b = grp; b < nblocks; b += POSE_GROUPS) acc += (double)slab[(size_t)b * POSE_VALS + t];
+        int b = grp;
+        for (; b + 7 * POSE_GROUPS < nblocks; b += 8 * POSE_GROUPS) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(b + u * POSE_GROUPS) * POSE_VALS + t];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (double)v[u];
+        }
+        for (; b < nblocks; b += POSE_GROUPS) acc += (double)slab[(size_t)b * POSE_VALS + t];
         part[grp][t] = acc;
     }
     __syncthreads();

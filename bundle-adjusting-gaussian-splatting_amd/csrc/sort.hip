@@ -76,11 +76,15 @@ radix_scatter_kernel(const u32* __restrict__ keys_in, const u32* __restrict__ va
 {
     constexpr int WAVES = SORT_BLOCK / 64;
     constexpr int ROUNDS = ITEMS;                            // rounds of 64 keys per wave
-    __shared__ u32 whist[WAVES][RADIX_BINS];
-    __shared__ u32 dbase[RADIX_BINS];
+    constexpr int TILE = SORT_BLOCK * ITEMS;
+    __shared__ u32 whist[WAVES][RADIX_BINS];                 // per-wave digit counts -> per-wave local bases
+    __shared__ u32 gbase[RADIX_BINS];                        // global position of this workgroup's first key of digit d
+    __shared__ u32 lbase[RADIX_BINS];                        // local (in-workgroup) position of the first key of digit d
+    __shared__ u32 skey[TILE], sval[TILE];                   // the workgroup's keys in digit order
+    __shared__ u32 ws[WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int w = 0; w < WAVES; ++w) whist[w][threadIdx.x] = 0;
-    // exclusive scan of the 256 digit totals (every workgroup repeats this 1 KB scan)
+    // exclusive scan of the 256 digit totals (every workgroup repeats this 1 KB scan) + this workgroup's offset
     {
         const u32 v = totals[threadIdx.x];
         u32 incl = v;
@@ -89,16 +93,15 @@ radix_scatter_kernel(const u32* __restrict__ keys_in, const u32* __restrict__ va
             const u32 t = __shfl_up(incl, d);
             if (lane >= d) incl += t;
         }
-        __shared__ u32 ws[WAVES];
         if (lane == 63) ws[wave] = incl;
         __syncthreads();
         u32 wb = 0;
         for (int w = 0; w < wave; ++w) wb += ws[w];
-        dbase[threadIdx.x] = wb + incl - v + hist[(size_t)threadIdx.x * nblocks + blockIdx.x];
+        gbase[threadIdx.x] = wb + incl - v + hist[(size_t)threadIdx.x * nblocks + blockIdx.x];
     }
     __syncthreads();
 
-    const long long seg = (long long)blockIdx.x * (SORT_BLOCK * ITEMS) + (long long)wave * (ROUNDS * 64);
+    const long long seg = (long long)blockIdx.x * TILE + (long long)wave * (ROUNDS * 64);
     u32 key[ROUNDS];
     u32 rank[ROUNDS];
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -121,32 +124,56 @@ radix_scatter_kernel(const u32* __restrict__ keys_in, const u32* __restrict__ va
         rank[r] = pre + below;
     }
     __syncthreads();
-    // digit t: turn the per-wave counts into per-wave bases on top of the workgroup's global base
+    // digit t: workgroup total -> exclusive scan over digits (lbase); per-wave counts -> per-wave local bases
     {
-        u32 run = dbase[threadIdx.x];
+        u32 c[WAVES], tot = 0;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            const u32 c = whist[w][threadIdx.x];
-            whist[w][threadIdx.x] = run;
-            run += c;
+        for (int w = 0; w < WAVES; ++w) { c[w] = whist[w][threadIdx.x]; tot += c[w]; }
+        u32 incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
         }
+        __syncthreads();                                     // ws reuse
+        if (lane == 63) ws[wave] = incl;
+        __syncthreads();
+        u32 wb = 0;
+        for (int w = 0; w < wave; ++w) wb += ws[w];
+        u32 run = wb + incl - tot;
+        lbase[threadIdx.x] = run;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) { whist[w][threadIdx.x] = run; run += c[w]; }
     }
     __syncthreads();
+    // stage in digit order (stable: waves, rounds, lanes in ascending index order inside every digit)
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         const long long idx = seg + r * 64 + lane;
         if (idx < n) {
             const u32 d = (key[r] >> shift) & (RADIX_BINS - 1);
-            const u32 pos = whist[wave][d] + rank[r];
-            keys_out[pos] = key[r];
-            vals_out[pos] = IOTA ? (u32)idx : vals_in[idx];
+            const u32 lp = whist[wave][d] + rank[r];
+            skey[lp] = key[r];
+            sval[lp] = IOTA ? (u32)idx : vals_in[idx];
+        }
+    }
+    __syncthreads();
+    // coalesced write-out: consecutive threads hold consecutive keys of the same digit run
+    const long long left = n - (long long)blockIdx.x * TILE;
+    const int cnt = left < TILE ? (int)left : TILE;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int i = r * SORT_BLOCK + threadIdx.x;
+        if (i < cnt) {
+            const u32 k = skey[i];
+            const u32 d = (k >> shift) & (RADIX_BINS - 1);
+            const u32 pos = gbase[d] + ((u32)i - lbase[d]);
+            keys_out[pos] = k;
+            vals_out[pos] = sval[i];
         }
     }
 }
 
-// Sorts (keys, vals) by key bits [0, bits) with stable 8-bit passes.  Pass 0 reads (src_k, src_v) and writes the A
-// half, pass 1 reads A and writes B, pass 2 reads B and writes A, ...  The result is in A when the number of passes is
-// odd and in B when it is even.  src may alias B (it is consumed by pass 0 before pass 1 overwrites it).
 template <int ITEMS>
 static hipError_t radix_sort_impl(const u32* src_k, const u32* src_v, u32* a_k, u32* a_v, u32* b_k, u32* b_v, long long n,
                                   int bits, bool iota_vals, u32* hist, u32* totals, hipStream_t st)
