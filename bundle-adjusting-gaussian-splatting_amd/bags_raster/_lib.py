@@ -62,6 +62,10 @@ SYMBOLS = {
                                        C.POINTER(BagsForwardOut), C.POINTER(C.c_int64), C.c_void_p]),
     "bags_forward_finish": (C.c_int, [C.POINTER(BagsSettings), C.POINTER(BagsInputs), C.POINTER(BagsState),
                                       C.POINTER(BagsForwardOut), C.c_int64, C.c_void_p]),
+    "bags_forward_prepare_async": (C.c_int, [C.POINTER(BagsSettings), C.POINTER(BagsInputs), C.POINTER(BagsState),
+                                             C.POINTER(BagsForwardOut), C.c_void_p, C.c_void_p]),
+    "bags_forward_finish_speculative": (C.c_int, [C.POINTER(BagsSettings), C.POINTER(BagsInputs), C.POINTER(BagsState),
+                                                  C.POINTER(BagsForwardOut), C.c_int64, C.c_void_p]),
     "bags_backward": (C.c_int, [C.POINTER(BagsSettings), C.POINTER(BagsInputs), C.POINTER(BagsState),
                                 C.POINTER(BagsBackwardArgs), C.c_void_p]),
     "bags_debug_views": (C.c_int, [C.POINTER(BagsSettings), C.POINTER(BagsInputs), C.POINTER(BagsState), C.c_int64,

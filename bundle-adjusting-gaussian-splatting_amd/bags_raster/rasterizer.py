@@ -136,10 +136,17 @@ LAST_NUM_RENDERED = 0      # instance count of the most recent forward (bench/di
 
 class _Forwarded:
     """Everything backward (and the parity tests) need from one forward call."""
-    __slots__ = ("packed", "geom", "binning", "image", "num_rendered", "H", "W")
+    __slots__ = ("packed", "geom", "binning", "image", "num_rendered", "capacity", "H", "W")
 
 
-def _run_forward(lib, pk: _Packed, H: int, W: int):
+# Speculative forward (bags_forward_speculative): the instance count of the previous call with the same problem shape
+# is the capacity guess for the next one, so the steady state has no host round trip in the middle of the forward.
+SPECULATE = True
+_capacity_hint = {}          # (device index, P, W, H) -> last instance count
+_pinned_count = {}           # device index -> pinned int32[1] receiving the asynchronous count
+
+
+def _run_forward(lib, pk: _Packed, H: int, W: int, speculate: bool = True):
     dev, P = pk.device, pk.P
     fw = _Forwarded()
     fw.packed, fw.H, fw.W = pk, H, W
@@ -153,12 +160,42 @@ def _run_forward(lib, pk: _Packed, H: int, W: int):
     out = L.BagsForwardOut(color.data_ptr(), radii.data_ptr(), depth.data_ptr(), weights.data_ptr(), mean2D.data_ptr())
     stream = torch.cuda.current_stream(dev).cuda_stream
     state = L.BagsState(fw.geom.data_ptr(), fw.geom.numel(), None, 0, fw.image.data_ptr(), fw.image.numel())
+    global LAST_NUM_RENDERED
+    key = (dev.index, P, W, H)
+    hint = _capacity_hint.get(key) if (SPECULATE and speculate and not pk.settings.debug) else None
+    if hint is not None:
+        cap = int(hint * 1.2) + 8192
+        fw.binning = _bytes(lib.bags_binning_size(cap, W, H), dev)
+        state.binning, state.binning_bytes = fw.binning.data_ptr(), fw.binning.numel()
+        pinned = _pinned_count.get(dev.index)
+        if pinned is None:
+            pinned = _pinned_count[dev.index] = torch.zeros(1, dtype=torch.int32).pin_memory()
+        L.check(lib.bags_forward_prepare_async(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(out),
+                                               pinned.data_ptr(), stream), "bags_forward_prepare_async")
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        L.check(lib.bags_forward_finish_speculative(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(out),
+                                                    cap, stream), "bags_forward_finish_speculative")
+        ev.synchronize()                      # phase 2 is already queued behind the count: the GPU does not wait for us
+        n = int(pinned[0].item()) & 0xFFFFFFFF
+        _capacity_hint[key] = n
+        fw.num_rendered = LAST_NUM_RENDERED = n
+        if n <= cap:
+            fw.capacity = cap
+            return fw, (color, radii, depth, weights, mean2D)
+        # guess too small (scene changed abruptly): redo the second phase on an exact buffer; phase 1 results stay valid
+        fw.binning = _bytes(lib.bags_binning_size(n, W, H), dev)
+        state.binning, state.binning_bytes = fw.binning.data_ptr(), fw.binning.numel()
+        L.check(lib.bags_forward_finish(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(out), n, stream),
+                "bags_forward_finish")
+        fw.capacity = n
+        return fw, (color, radii, depth, weights, mean2D)
     n = C.c_int64(0)
     L.check(lib.bags_forward_prepare(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(out),
                                      C.byref(n), stream), "bags_forward_prepare")
-    fw.num_rendered = int(n.value)
-    global LAST_NUM_RENDERED
+    fw.num_rendered = fw.capacity = int(n.value)
     LAST_NUM_RENDERED = fw.num_rendered
+    _capacity_hint[key] = fw.num_rendered
     fw.binning = _bytes(lib.bags_binning_size(fw.num_rendered, W, H), dev)
     state.binning, state.binning_bytes = fw.binning.data_ptr(), fw.binning.numel()
     L.check(lib.bags_forward_finish(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(out),
@@ -215,8 +252,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_proj = new((4, 4), need[11])
             g_intr = new((4, 4), need[12])
             g_campos = new((3,), need[13])
-            ws = _bytes(lib.bags_backward_workspace_size(P, fw.num_rendered), dev)
-            args = L.BagsBackwardArgs(gc.data_ptr(), fw.num_rendered, ws.data_ptr(), ws.numel(), _ptr(g_means3D),
+            ws = _bytes(lib.bags_backward_workspace_size(P, fw.capacity), dev)
+            args = L.BagsBackwardArgs(gc.data_ptr(), fw.capacity, ws.data_ptr(), ws.numel(), _ptr(g_means3D),
                                       _ptr(g_means2D), _ptr(g_densify), _ptr(g_sh), _ptr(g_col), _ptr(g_opac),
                                       _ptr(g_scales), _ptr(g_rot), _ptr(g_cov), _ptr(g_view), _ptr(g_proj),
                                       _ptr(g_intr), _ptr(g_campos), _ptr(g_shift))
@@ -273,7 +310,7 @@ def debug_views(settings: GaussianRasterizationSettings, means3D, means2D, shift
         pk = _Packed(settings, means3D, means2D, shift_factors, shs, colors_precomp, opacities, scales, rotations,
                      cov3D_precomp, settings.viewmatrix, settings.projmatrix, settings.intrinsic, settings.campos)
         H, W = int(settings.image_height), int(settings.image_width)
-        fw, outs = _run_forward(lib, pk, H, W)
+        fw, outs = _run_forward(lib, pk, H, W, speculate=False)
         P, I = pk.P, fw.num_rendered
         T = ((W + 15) // 16) * ((H + 15) // 16)
         i32 = lambda *s: torch.empty(*s, dtype=torch.int32, device=dev)

@@ -155,16 +155,9 @@ size_t bags_backward_workspace_size(int32_t P, int64_t I)
 
 static inline void* align256(void* p) { return reinterpret_cast<void*>(align_up(reinterpret_cast<size_t>(p), 256)); }
 
-int bags_forward_prepare(const BagsSettings* s, const BagsInputs* in, const BagsState* stt, const BagsForwardOut* out,
-                         int64_t* host_num_rendered, void* stream)
+// K1 + depth ordering + offsets; leaves the instance count in g.num_rendered (device)
+static int enqueue_prepare(const BagsSettings* s, const BagsInputs* in, const GeomView& g, const BagsForwardOut* out, hipStream_t st)
 {
-    int rc = check_common(s, in, stt);
-    if (rc) return rc;
-    if (!out || !out->radii || !host_num_rendered) return fail(BAGS_ERR_ARG, "radii / host_num_rendered must be given");
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    GeomView g; carve_geom(align256(stt->geom), in->P, &g);
-    *host_num_rendered = 0;
-    if (in->P == 0) return BAGS_OK;
     { ProfScope ps(ST_PRE_FWD, st); HIP_TRY(launch_preprocess_fwd(*s, *in, g, out->radii, out->mean2D, st)); }
     DEBUG_SYNC(s, st, "preprocess_fwd");
     // depth order of the Gaussians: 4 stable 8-bit passes over the float bits (positive floats order like u32)
@@ -175,6 +168,43 @@ int bags_forward_prepare(const BagsSettings* s, const BagsInputs* in, const Bags
     const u32* sorted_ids = g.vals_b;                     // 4 passes: src->a->b->a->b
     { ProfScope ps(ST_OFFSETS, st); HIP_TRY(launch_offsets_scan(g, sorted_ids, in->P, st)); }
     DEBUG_SYNC(s, st, "offsets scan");
+    return BAGS_OK;
+}
+
+// emission, per-tile ordering, ranges, blend.  n_dev != nullptr: the instance count is read on the device and
+// clamped to `I` (the capacity the binning buffer was sized for)
+static int enqueue_finish(const BagsSettings* s, const BagsInputs* in, const GeomView& g, const BinView& b, const ImgView& im,
+                          const BagsForwardOut* out, int64_t I, const u32* n_dev, hipStream_t st)
+{
+    const int W = s->image_width, H = s->image_height;
+    const int gx = cdiv(W, BAGS_TILE), gy = cdiv(H, BAGS_TILE);
+    if (I > 0) {
+        { ProfScope ps(ST_EMIT, st); HIP_TRY(launch_emit(g, g.vals_b, in->P, gx, b.keys_b, b.vals_b, (u32)I, st, n_dev)); }
+        DEBUG_SYNC(s, st, "emit");
+        { ProfScope ps(ST_TILE_SORT, st);
+          HIP_TRY(launch_radix_sort(b.keys_b, b.vals_b, b.keys_a, b.vals_a, b.keys_b, b.vals_b, I, b.passes * RADIX_BITS,
+                                    false, b.radix_hist, b.digit_totals, b.nblocks_sort, st, n_dev)); }
+        DEBUG_SYNC(s, st, "tile sort");
+    }
+    { ProfScope ps(ST_RANGES, st); HIP_TRY(launch_tile_ranges(b.tile_sorted, I, b.ranges, gx * gy, st, n_dev)); }
+    DEBUG_SYNC(s, st, "tile ranges");
+    { ProfScope ps(ST_BLEND_FWD, st); HIP_TRY(launch_blend_fwd(*s, g, b, im, *out, st)); }
+    DEBUG_SYNC(s, st, "blend_fwd");
+    return BAGS_OK;
+}
+
+int bags_forward_prepare(const BagsSettings* s, const BagsInputs* in, const BagsState* stt, const BagsForwardOut* out,
+                         int64_t* host_num_rendered, void* stream)
+{
+    int rc = check_common(s, in, stt);
+    if (rc) return rc;
+    if (!out || !out->radii || !host_num_rendered) return fail(BAGS_ERR_ARG, "radii / host_num_rendered must be given");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    GeomView g; carve_geom(align256(stt->geom), in->P, &g);
+    *host_num_rendered = 0;
+    if (in->P == 0) return BAGS_OK;
+    rc = enqueue_prepare(s, in, g, out, st);
+    if (rc) return rc;
     u32 host_I = 0;
     HIP_TRY(hipMemcpyAsync(&host_I, g.num_rendered, sizeof(u32), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -195,20 +225,41 @@ int bags_forward_finish(const BagsSettings* s, const BagsInputs* in, const BagsS
     GeomView g; carve_geom(align256(stt->geom), in->P, &g);
     BinView b; carve_binning(align256(stt->binning), I, W, H, &b);
     ImgView im; carve_image(align256(stt->image), W, H, &im);
-    const int gx = cdiv(W, BAGS_TILE), gy = cdiv(H, BAGS_TILE);
-    if (I > 0) {
-        { ProfScope ps(ST_EMIT, st); HIP_TRY(launch_emit(g, g.vals_b, in->P, gx, b.keys_b, b.vals_b, st)); }
-        DEBUG_SYNC(s, st, "emit");
-        { ProfScope ps(ST_TILE_SORT, st);
-          HIP_TRY(launch_radix_sort(b.keys_b, b.vals_b, b.keys_a, b.vals_a, b.keys_b, b.vals_b, I, b.passes * RADIX_BITS,
-                                    false, b.radix_hist, b.digit_totals, b.nblocks_sort, st)); }
-        DEBUG_SYNC(s, st, "tile sort");
+    return enqueue_finish(s, in, g, b, im, out, I, nullptr, st);
+}
+
+int bags_forward_prepare_async(const BagsSettings* s, const BagsInputs* in, const BagsState* stt, const BagsForwardOut* out,
+                               uint32_t* host_num_rendered, void* stream)
+{
+    int rc = check_common(s, in, stt);
+    if (rc) return rc;
+    if (!out || !out->radii || !host_num_rendered) return fail(BAGS_ERR_ARG, "radii / host_num_rendered must be given");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    GeomView g; carve_geom(align256(stt->geom), in->P, &g);
+    if (in->P == 0) {
+        HIP_TRY(hipMemsetAsync(g.num_rendered, 0, sizeof(u32), st));
+    } else {
+        rc = enqueue_prepare(s, in, g, out, st);
+        if (rc) return rc;
     }
-    { ProfScope ps(ST_RANGES, st); HIP_TRY(launch_tile_ranges(b.tile_sorted, I, b.ranges, gx * gy, st)); }
-    DEBUG_SYNC(s, st, "tile ranges");
-    { ProfScope ps(ST_BLEND_FWD, st); HIP_TRY(launch_blend_fwd(*s, g, b, im, *out, st)); }
-    DEBUG_SYNC(s, st, "blend_fwd");
+    HIP_TRY(hipMemcpyAsync(host_num_rendered, g.num_rendered, sizeof(u32), hipMemcpyDeviceToHost, st));
     return BAGS_OK;
+}
+
+int bags_forward_finish_speculative(const BagsSettings* s, const BagsInputs* in, const BagsState* stt,
+                                    const BagsForwardOut* out, int64_t capacity, void* stream)
+{
+    int rc = check_common(s, in, stt);
+    if (rc) return rc;
+    if (!out || !out->color) return fail(BAGS_ERR_ARG, "color output must be given");
+    if (capacity < 1 || capacity > 0xFFFFFFF0ll) return fail(BAGS_ERR_ARG, "capacity out of range");
+    const int W = s->image_width, H = s->image_height;
+    if (!stt->binning || stt->binning_bytes < bags_binning_size(capacity, W, H)) return fail(BAGS_ERR_SIZE, "binning buffer too small");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    GeomView g; carve_geom(align256(stt->geom), in->P, &g);
+    BinView b; carve_binning(align256(stt->binning), capacity, W, H, &b);
+    ImgView im; carve_image(align256(stt->image), W, H, &im);
+    return enqueue_finish(s, in, g, b, im, out, capacity, g.num_rendered, st);
 }
 
 int bags_backward(const BagsSettings* s, const BagsInputs* in, const BagsState* stt, const BagsBackwardArgs* a, void* stream)

@@ -74,10 +74,13 @@ size_t carve_image(void* base, int W, int H, ImgView* v);
 hipError_t launch_preprocess_fwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, int32_t* radii,
                                  float* mean2D, hipStream_t st);
 hipError_t launch_radix_sort(const u32* src_k, const u32* src_v, u32* a_k, u32* a_v, u32* b_k, u32* b_v, long long n,
-                             int bits, bool iota_vals, u32* hist, u32* totals, int nblocks, hipStream_t st);
+                             int bits, bool iota_vals, u32* hist, u32* totals, int nblocks, hipStream_t st,
+                             const u32* n_dev = nullptr);
 hipError_t launch_offsets_scan(const GeomView& g, const u32* sorted_ids, int P, hipStream_t st);
-hipError_t launch_emit(const GeomView& g, const u32* sorted_ids, int P, int grid_x, u32* keys, u32* vals, hipStream_t st);
-hipError_t launch_tile_ranges(const u32* tile_sorted, long long I, uint2* ranges, int T, hipStream_t st);
+hipError_t launch_emit(const GeomView& g, const u32* sorted_ids, int P, int grid_x, u32* keys, u32* vals, u32 capacity,
+                       hipStream_t st, const u32* n_dev = nullptr);
+hipError_t launch_tile_ranges(const u32* tile_sorted, long long I, uint2* ranges, int T, hipStream_t st,
+                              const u32* n_dev = nullptr);
 hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
                             const BagsForwardOut& out, hipStream_t st);
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,

@@ -17,8 +17,11 @@
 // ------------------------------------------------------------------------------------------------ radix: histogram
 template <int ITEMS>
 __global__ void __launch_bounds__(SORT_BLOCK)
-radix_hist_kernel(const u32* __restrict__ keys, long long n, int shift, int nblocks, u32* __restrict__ hist)
+radix_hist_kernel(const u32* __restrict__ keys, long long n_cap, const u32* __restrict__ n_dev, int shift, int nblocks,
+                  u32* __restrict__ hist)
 {
+    // speculative forward: the count lives on the device; a count above the capacity turns the pass into a no-op
+    const long long n = n_dev ? ((long long)*n_dev <= n_cap ? (long long)*n_dev : 0ll) : n_cap;
     __shared__ u32 h[RADIX_BINS];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -71,9 +74,10 @@ radix_scan_kernel(u32* __restrict__ hist, int nblocks, u32* __restrict__ totals)
 template <bool IOTA, int ITEMS>
 __global__ void __launch_bounds__(SORT_BLOCK)
 radix_scatter_kernel(const u32* __restrict__ keys_in, const u32* __restrict__ vals_in, u32* __restrict__ keys_out,
-                     u32* __restrict__ vals_out, long long n, int shift, int nblocks, const u32* __restrict__ hist,
-                     const u32* __restrict__ totals)
+                     u32* __restrict__ vals_out, long long n_cap, const u32* __restrict__ n_dev, int shift, int nblocks,
+                     const u32* __restrict__ hist, const u32* __restrict__ totals)
 {
+    const long long n = n_dev ? ((long long)*n_dev <= n_cap ? (long long)*n_dev : 0ll) : n_cap;
     constexpr int WAVES = SORT_BLOCK / 64;
     constexpr int ROUNDS = ITEMS;                            // rounds of 64 keys per wave
     constexpr int TILE = SORT_BLOCK * ITEMS;
@@ -176,7 +180,7 @@ radix_scatter_kernel(const u32* __restrict__ keys_in, const u32* __restrict__ va
 
 template <int ITEMS>
 static hipError_t radix_sort_impl(const u32* src_k, const u32* src_v, u32* a_k, u32* a_v, u32* b_k, u32* b_v, long long n,
-                                  int bits, bool iota_vals, u32* hist, u32* totals, hipStream_t st)
+                                  int bits, bool iota_vals, u32* hist, u32* totals, hipStream_t st, const u32* n_dev)
 {
     const int nblocks = cdiv(n, SORT_BLOCK * ITEMS);
     const int passes = (bits + RADIX_BITS - 1) / RADIX_BITS;
@@ -184,14 +188,14 @@ static hipError_t radix_sort_impl(const u32* src_k, const u32* src_v, u32* a_k, 
     for (int p = 0; p < passes; ++p) {
         const int shift = p * RADIX_BITS;
         u32* ok = (p & 1) ? b_k : a_k; u32* ov = (p & 1) ? b_v : a_v;
-        hipLaunchKernelGGL(radix_hist_kernel<ITEMS>, dim3(nblocks), dim3(SORT_BLOCK), 0, st, ik, n, shift, nblocks, hist);
+        hipLaunchKernelGGL(radix_hist_kernel<ITEMS>, dim3(nblocks), dim3(SORT_BLOCK), 0, st, ik, n, n_dev, shift, nblocks, hist);
         hipLaunchKernelGGL(radix_scan_kernel, dim3(RADIX_BINS), dim3(256), 0, st, hist, nblocks, totals);
         if (p == 0 && iota_vals)
             hipLaunchKernelGGL((radix_scatter_kernel<true, ITEMS>), dim3(nblocks), dim3(SORT_BLOCK), 0, st, ik, iv, ok, ov, n,
-                               shift, nblocks, hist, totals);
+                               n_dev, shift, nblocks, hist, totals);
         else
             hipLaunchKernelGGL((radix_scatter_kernel<false, ITEMS>), dim3(nblocks), dim3(SORT_BLOCK), 0, st, ik, iv, ok, ov, n,
-                               shift, nblocks, hist, totals);
+                               n_dev, shift, nblocks, hist, totals);
         ik = ok; iv = ov;
     }
     return hipGetLastError();
@@ -202,12 +206,13 @@ int radix_items_for(long long n) { return n <= (1ll << 21) ? SORT_ITEMS_SMALL : 
 int radix_blocks_for(long long n) { return cdiv(n > 0 ? n : 1, (long long)SORT_BLOCK * radix_items_for(n)); }
 
 hipError_t launch_radix_sort(const u32* src_k, const u32* src_v, u32* a_k, u32* a_v, u32* b_k, u32* b_v, long long n,
-                             int bits, bool iota_vals, u32* hist, u32* totals, int /*nblocks*/, hipStream_t st)
+                             int bits, bool iota_vals, u32* hist, u32* totals, int /*nblocks*/, hipStream_t st,
+                             const u32* n_dev)
 {
     if (n <= 0) return hipSuccess;
     if (radix_items_for(n) == SORT_ITEMS_SMALL)
-        return radix_sort_impl<SORT_ITEMS_SMALL>(src_k, src_v, a_k, a_v, b_k, b_v, n, bits, iota_vals, hist, totals, st);
-    return radix_sort_impl<SORT_ITEMS>(src_k, src_v, a_k, a_v, b_k, b_v, n, bits, iota_vals, hist, totals, st);
+        return radix_sort_impl<SORT_ITEMS_SMALL>(src_k, src_v, a_k, a_v, b_k, b_v, n, bits, iota_vals, hist, totals, st, n_dev);
+    return radix_sort_impl<SORT_ITEMS>(src_k, src_v, a_k, a_v, b_k, b_v, n, bits, iota_vals, hist, totals, st, n_dev);
 }
 
 // ------------------------------------------------------------------------------------------------ offsets scan
@@ -316,7 +321,8 @@ hipError_t launch_offsets_scan(const GeomView& g, const u32* sorted_ids, int P, 
 // One thread per depth rank: writes the Gaussian's rectangle of tiles (y outer, x inner) at its offset.
 __global__ void __launch_bounds__(256)
 emit_kernel(const u32* __restrict__ sorted_ids, const u32* __restrict__ rank_offset, const uint2* __restrict__ rect,
-            const u32* __restrict__ tiles_touched, int P, int grid_x, u32* __restrict__ keys, u32* __restrict__ vals)
+            const u32* __restrict__ tiles_touched, int P, int grid_x, u32* __restrict__ keys, u32* __restrict__ vals,
+            u32 capacity, const u32* __restrict__ n_dev)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= P) return;
@@ -325,6 +331,8 @@ emit_kernel(const u32* __restrict__ sorted_ids, const u32* __restrict__ rank_off
     const uint2 rc = rect[g];
     const int minx = rc.x & 0xFFFF, miny = rc.x >> 16, maxx = rc.y & 0xFFFF, maxy = rc.y >> 16;
     u32 off = rank_offset[j];
+    if (n_dev && *n_dev > capacity) return;                 // speculative capacity exceeded: nothing is emitted, the caller reruns
+    if ((unsigned long long)off + tiles_touched[g] > (unsigned long long)capacity) return;
     for (int y = miny; y < maxy; ++y)
         for (int x = minx; x < maxx; ++x) {
             keys[off] = (u32)(y * grid_x + x);
@@ -333,18 +341,20 @@ emit_kernel(const u32* __restrict__ sorted_ids, const u32* __restrict__ rank_off
         }
 }
 
-hipError_t launch_emit(const GeomView& g, const u32* sorted_ids, int P, int grid_x, u32* keys, u32* vals, hipStream_t st)
+hipError_t launch_emit(const GeomView& g, const u32* sorted_ids, int P, int grid_x, u32* keys, u32* vals, u32 capacity,
+                       hipStream_t st, const u32* n_dev)
 {
     if (P == 0) return hipSuccess;
     hipLaunchKernelGGL(emit_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, sorted_ids, g.rank_offset, g.rect,
-                       g.tiles_touched, P, grid_x, keys, vals);
+                       g.tiles_touched, P, grid_x, keys, vals, capacity, n_dev);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------ tile ranges
 __global__ void __launch_bounds__(256)
-tile_ranges_kernel(const u32* __restrict__ tile_sorted, long long I, uint2* __restrict__ ranges)
+tile_ranges_kernel(const u32* __restrict__ tile_sorted, long long I_cap, const u32* __restrict__ n_dev, uint2* __restrict__ ranges)
 {
+    const long long I = n_dev ? ((long long)*n_dev <= I_cap ? (long long)*n_dev : 0ll) : I_cap;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= I) return;
     const u32 t = tile_sorted[i];
@@ -356,11 +366,11 @@ tile_ranges_kernel(const u32* __restrict__ tile_sorted, long long I, uint2* __re
     if (i == I - 1) ranges[t].y = (u32)I;
 }
 
-hipError_t launch_tile_ranges(const u32* tile_sorted, long long I, uint2* ranges, int T, hipStream_t st)
+hipError_t launch_tile_ranges(const u32* tile_sorted, long long I, uint2* ranges, int T, hipStream_t st, const u32* n_dev)
 {
     hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, st);
     if (e != hipSuccess || I == 0) return e;
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(cdiv(I, 256)), dim3(256), 0, st, tile_sorted, I, ranges);
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(cdiv(I, 256)), dim3(256), 0, st, tile_sorted, I, n_dev, ranges);
     return hipGetLastError();
 }
 

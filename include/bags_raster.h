@@ -132,6 +132,20 @@ int bags_forward_prepare(const BagsSettings*, const BagsInputs*, const BagsState
  * bags_binning_size(num_rendered, W, H) bytes. */
 int bags_forward_finish(const BagsSettings*, const BagsInputs*, const BagsState*, const BagsForwardOut*,
                         int64_t num_rendered, void* stream);
+/* Forward without a host round trip in the middle (speculative instance capacity).
+ *   1. bags_forward_prepare_async: phase 1 as above, but instead of synchronising it enqueues an asynchronous copy of
+ *      the instance count into *host_num_rendered (caller-owned PINNED host word).  The caller records an event here.
+ *   2. bags_forward_finish_speculative: phase 2 enqueued immediately, sized for a caller-guessed upper bound `capacity`
+ *      (e.g. 1.2 x the previous frame's count; state.binning holds bags_binning_size(capacity, W, H) bytes); the
+ *      kernels read the true count on the device and clamp it to `capacity`.
+ *   3. The caller waits for the event of step 1 (the GPU is already busy with step 2) and compares: if
+ *      *host_num_rendered > capacity the outputs are invalid and phase 2 must be redone with bags_forward_finish on a
+ *      larger buffer (phase 1 results in state.geom stay valid).  When it fits, `capacity` plays the role of
+ *      num_rendered for bags_backward / bags_backward_workspace_size buffer sizing. */
+int bags_forward_prepare_async(const BagsSettings*, const BagsInputs*, const BagsState*, const BagsForwardOut*,
+                               uint32_t* host_num_rendered, void* stream);
+int bags_forward_finish_speculative(const BagsSettings*, const BagsInputs*, const BagsState*, const BagsForwardOut*,
+                                    int64_t capacity, void* stream);
 /* Backward of the whole op from dL/dimage. */
 int bags_backward(const BagsSettings*, const BagsInputs*, const BagsState*, const BagsBackwardArgs*, void* stream);
 

@@ -120,3 +120,31 @@ def test_cpu_tensors_fail_loudly():
     with pytest.raises(RuntimeError, match="AMD GPU"):
         GaussianRasterizer(st)(means3D=scene["means3D"], means2D=torch.zeros(10, 3), shs=scene["shs"],
                                opacities=scene["opacities"], scales=scene["scales"], rotations=scene["rotations"])
+
+
+def test_speculative_forward_matches_exact_and_recovers_from_overflow():
+    """Second and later calls of a problem shape skip the mid-forward host round trip by guessing the instance
+    capacity from the previous call; a too-small guess must transparently redo phase 2."""
+    from bags_raster import rasterizer as R
+    scene, cam = make_case(3000, 160, 128, 1.0, 2, seed=31)
+    g = torch.randn(3, 128, 160, generator=torch.Generator().manual_seed(5))
+    R._capacity_hint.clear()
+    o_exact, g_exact, v1 = run_hip(scene, cam, 2, g)                 # no hint yet: exact two-phase path
+    assert R._capacity_hint, "hint not recorded"
+    o_spec, g_spec, _ = run_hip(scene, cam, 2, g)                    # hint present: speculative path
+    for a, b in zip(o_exact, o_spec):
+        assert torch.equal(a, b)
+    for k in g_exact:
+        if g_exact[k] is not None:
+            assert torch.equal(g_exact[k], g_spec[k]), k
+    # same shape, 3x larger splats => several times more instances than the hint allows
+    big = dict(scene); big["scales"] = scene["scales"] * 3.0
+    o_big, g_big, v_big = run_hip(big, cam, 2, g)
+    assert v_big["num_rendered"] > 1.5 * v1["num_rendered"]
+    R._capacity_hint.clear()
+    o_ref, g_ref, _ = run_hip(big, cam, 2, g)
+    for a, b in zip(o_big, o_ref):
+        assert torch.equal(a, b)
+    for k in g_ref:
+        if g_ref[k] is not None:
+            assert torch.equal(g_big[k], g_ref[k]), k
