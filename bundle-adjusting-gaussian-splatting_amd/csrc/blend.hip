@@ -1,46 +1,41 @@
 // blend.hip -- K6 / K7: front-to-back alpha compositing and its backward.
 //
-// MI355X mapping (not the CUDA "256 threads = 256 pixels" layout):
-//   * ONE wave64 per 16x16 tile; lane l owns FOUR pixels, one in each 8x8 quadrant, at (l&7, l>>3) inside the
-//     quadrant.  No workgroup barriers, no cross-wave reduction.
-//   * the tile's depth-ordered splat list is staged 64 at a time: every lane gathers one splat (id -> xy, conic,
-//     opacity, colour), derives which quadrants the splat's alpha >= 1/255 ellipse can reach, and the batch is
-//     ballot-compacted into LDS.  The inner loop then reads a splat as an LDS broadcast and skips whole quadrants
-//     with scalar branches.  Skipped pairs are exactly those the per-pixel test (alpha < 1/255) would reject, so the
-//     image is unchanged.
-//   * backward walks the list back to front with the same per-pixel recurrence as the reference design but never
-//     issues a global atomic: the 256 pixel contributions to one splat are summed in-lane (4 pixels), then across
-//     the wave with a transposed butterfly (17 shuffles for 11 sums), and written as ONE 64-byte record per sorted
-//     instance at the instance's emission slot.  preprocess_bwd sums each Gaussian's consecutive records: the
-//     result is bitwise reproducible.
+// MI355X mapping (none of this is the CUDA "256 threads = 256 pixels, atomicAdd per (pixel, splat)" layout):
+//   * a 256-thread workgroup (4 wave64) owns a 16x16 tile and consumes its depth-ordered splat list in chunks of 256:
+//     every thread gathers one splat (id -> xy, conic, opacity, colour) and computes a 16-bit mask of the 4x4-pixel
+//     blocks whose pixels can reach alpha >= 1/255 (conservative: Mahalanobis triangle inequality), so the inner
+//     loops only ever touch (block, splat) pairs that can contribute.  Skipped pairs are exactly those the per-pixel
+//     test would reject => images and gradients are unchanged by the culling.
+//   * FORWARD  (blend_fwd_rows_kernel): lane = pixel.  Each 16-lane DPP row owns one 4x4 block and walks its own
+//     ballot-compacted list; no scalar branches inside the walk.
+//   * BACKWARD (blend_bwd_scan_kernel): lane = splat.  The per-pixel recurrences of compositing (transmittance in
+//     front of a splat, colour behind it) are wave64 DPP prefix scans over a block's list, so every lane owns its
+//     splat's 11 gradient sums outright: no cross-lane reduction and NO atomics.  One 64-byte record per sorted
+//     instance is written at the instance's emission slot; preprocess_bwd sums each Gaussian's consecutive records.
+//     Gradients are bitwise reproducible run to run.
+// PMC history that led here is in profiles/r01 and DESIGN.md section 5 (the first lane = pixel kernels saturated VALU
+// issue at 96 % with a third of the lanes contributing; they are in the git history).
 #include "bags_common.h"
-
-// tuning knobs (tools/variants.sh sweeps them with -D...)
-#ifndef FWD_WAVES
-#define FWD_WAVES 5        // __launch_bounds__ waves/SIMD for blend_fwd
-#endif
-#ifndef BWD_WAVES
-#define BWD_WAVES 3
-#endif
-#ifndef BWD_REDUCE_DPP
-#define BWD_REDUCE_DPP 0   // 1: DPP row/wave sums, 0: ds_bpermute butterfly
-#endif
-#ifndef PREFETCH_REC
-#define PREFETCH_REC 0     // fetch splat k+1 from LDS while splat k is processed
-#endif
-
-#ifndef ABLATE
-#define ABLATE 0           // timing-only builds (wrong results): 1 no reduce, 2 no contributing body, 3 no quadrant loop
-#endif
 
 #define LOG2E 1.4426950408889634f
 #define ALPHA_MIN (1.0f / 255.0f)
 #define T_EPS 0.0001f
 
+// tuning knobs (tools/variants.sh sweeps them with -D...)
+#ifndef CHUNK
+#define CHUNK 256           // splats staged per step (LDS: 48 B record + 4 x 48 B accumulator copies + 16 list bytes each)
+#endif
+#ifndef SCAN_WG_PER_CU
+#define SCAN_WG_PER_CU 2    // backward workgroups per CU (LDS-limited: 72 KB each)
+#endif
+#ifndef SCAN_UNROLL
+#define SCAN_UNROLL 1
+#endif
+
 struct __attribute__((aligned(16))) SplatRec {
     float x, y, ap, bp;       // centre, pre-scaled conic: exp2(ap dx^2 + bp dx dy + cp dy^2) == exp(power)
     float cp, o, r, g;
-    float b, z; u32 mask; u32 pos;   // mask: quadrants reachable; pos: 1-based position in the tile list
+    float b, z; u32 mask; u32 pos;   // mask: 4x4 blocks reachable (bit by*4+bx); pos: 1-based position in the tile list
 };
 
 __device__ __forceinline__ int tile_of_block(int b, int T)
@@ -48,29 +43,6 @@ __device__ __forceinline__ int tile_of_block(int b, int T)
     // neighbouring tiles, which share splats, hit the same L2.  Placement only affects speed.
     const int chunk = (T + 7) / 8;
     return (b & 7) * chunk + (b >> 3);
-}
-
-// quadrants of the tile whose pixels can reach alpha >= 1/255 for this splat (conservative)
-__device__ __forceinline__ u32 quadrant_mask(float x, float y, float a, float b, float c, float o, float X0, float Y0)
-{
-    const float vis = 255.0f * o;
-    if (!(vis >= 0.99f)) return 0u;
-    const float det = a * c - b * b;
-    if (!(det > 0.f) || !(a > 0.f) || !(c > 0.f)) return 0xFu;
-    const float tau2 = 2.0f * (fmaxf(__logf(vis), 0.f) + 1e-3f);
-    const float idet = 1.0f / det;
-    const float hx = sqrtf(tau2 * c * idet) * 1.001f + 0.05f;
-    const float hy = sqrtf(tau2 * a * idet) * 1.001f + 0.05f;
-    u32 m = 0;
-    const bool xl = (x + hx >= X0) && (x - hx <= X0 + 7.f);
-    const bool xr = (x + hx >= X0 + 8.f) && (x - hx <= X0 + 15.f);
-    const bool yt = (y + hy >= Y0) && (y - hy <= Y0 + 7.f);
-    const bool yb = (y + hy >= Y0 + 8.f) && (y - hy <= Y0 + 15.f);
-    if (xl && yt) m |= 1u;
-    if (xr && yt) m |= 2u;
-    if (xl && yb) m |= 4u;
-    if (xr && yb) m |= 8u;
-    return m;
 }
 
 // exp(power) for one (pixel, splat) pair: the SAME instruction sequence in forward and backward so both make the
@@ -82,378 +54,6 @@ __device__ __forceinline__ float pair_power2(float dx, float dy, float ap, float
     return __fmaf_rn(dx, t, u);
 }
 
-__global__ void __launch_bounds__(64, FWD_WAVES)
-blend_fwd_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ ranges, const u32* __restrict__ point_list,
-                 const float2* __restrict__ xy, const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbz,
-                 const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
-                 float* __restrict__ out_weights, float* __restrict__ final_T, u32* __restrict__ n_contrib)
-{
-    const int tile = tile_of_block(blockIdx.x, T);
-    if (tile >= T) return;
-    const int lane = threadIdx.x;
-    const int tile_x = tile % grid_x, tile_y = tile / grid_x;
-    const float X0 = (float)(tile_x * BAGS_TILE), Y0 = (float)(tile_y * BAGS_TILE);
-    const uint2 range = ranges[tile];
-
-    __shared__ SplatRec recs[64];
-
-    const float lx = X0 + (float)(lane & 7), ly = Y0 + (float)(lane >> 3);      // this lane's pixel in quadrant 0
-    const float lx8 = lx + 8.f, ly8 = ly + 8.f;                                  // ... in the other quadrants (exact)
-    float pxf[4], pyf[4], Tq[4], Cr[4], Cg[4], Cb[4], Dq[4];
-    u32 last[4];
-    bool done[4], inside[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int px = tile_x * BAGS_TILE + (q & 1) * 8 + (lane & 7);
-        const int py = tile_y * BAGS_TILE + (q >> 1) * 8 + (lane >> 3);
-        pxf[q] = (float)px; pyf[q] = (float)py;
-        inside[q] = (px < W) && (py < H);
-        done[q] = !inside[q];
-        Tq[q] = 1.f; Cr[q] = Cg[q] = Cb[q] = Dq[q] = 0.f; last[q] = 0;
-    }
-    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-
-    for (u32 base = range.x; base < range.y; base += 64) {
-        // which quadrants still have live pixels (wave-uniform)
-        u32 live = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) if (__ballot(!done[q]) != 0ull) live |= (1u << q);
-        if (live == 0) break;
-        // ---- stage up to 64 splats
-        const u32 idx = base + lane;
-        SplatRec rec; rec.mask = 0;
-        if (idx < range.y) {
-            const u32 g = point_list[idx];
-            const float2 c2 = xy[g];
-            const float4 co = conic_opacity[g];
-            const float4 cz = rgbz[g];
-            rec.x = c2.x; rec.y = c2.y;
-            rec.ap = -0.5f * LOG2E * co.x; rec.bp = -LOG2E * co.y; rec.cp = -0.5f * LOG2E * co.z; rec.o = co.w;
-            rec.r = cz.x; rec.g = cz.y; rec.b = cz.z; rec.z = cz.w;
-            rec.pos = idx - range.x + 1;
-            rec.mask = quadrant_mask(c2.x, c2.y, co.x, co.y, co.z, co.w, X0, Y0) & live;
-        }
-        const u64 keep = __ballot(rec.mask != 0);
-        const int count = __popcll(keep);
-        __syncthreads();                      // previous batch fully consumed (single wave: orders LDS traffic)
-        if (rec.mask != 0) recs[__popcll(keep & lt_mask)] = rec;
-        __syncthreads();
-        // ---- composite; the next record is fetched from LDS while the current one is processed
-#if PREFETCH_REC
-        SplatRec s = recs[0];
-#endif
-        for (int k = 0; k < count; ++k) {
-#if PREFETCH_REC
-            const SplatRec nxt = recs[k + 1 < count ? k + 1 : k];
-#else
-            const SplatRec s = recs[k];
-#endif
-            const u32 m = __builtin_amdgcn_readfirstlane(s.mask);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (!((m >> q) & 1u)) continue;
-                const float dx = s.x - ((q & 1) ? lx8 : lx), dy = s.y - ((q >> 1) ? ly8 : ly);   // centre - exact pixel
-                const float p2 = pair_power2(dx, dy, s.ap, s.bp, s.cp);
-                const float G = __builtin_amdgcn_exp2f(p2);
-                const float alpha = fminf(0.99f, s.o * G);
-                const bool contrib = (p2 <= 0.f) && (alpha >= ALPHA_MIN) && !done[q];
-                if (__ballot(contrib) == 0ull) continue;
-                if (contrib) {
-                    const float test_T = Tq[q] * (1.f - alpha);
-                    if (test_T < T_EPS) {
-                        done[q] = true;
-                    } else {
-                        const float w = alpha * Tq[q];
-                        Cr[q] = __fmaf_rn(w, s.r, Cr[q]); Cg[q] = __fmaf_rn(w, s.g, Cg[q]); Cb[q] = __fmaf_rn(w, s.b, Cb[q]);
-                        Dq[q] = __fmaf_rn(w, s.z, Dq[q]);
-                        Tq[q] = test_T;
-                        last[q] = s.pos;
-                    }
-                }
-            }
-#if PREFETCH_REC
-            s = nxt;
-#endif
-        }
-    }
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    const size_t HW = (size_t)W * H;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (!inside[q]) continue;
-        const size_t pix = (size_t)pyf[q] * W + (size_t)pxf[q];
-        out_color[pix] = Cr[q] + Tq[q] * bg0;
-        out_color[HW + pix] = Cg[q] + Tq[q] * bg1;
-        out_color[2 * HW + pix] = Cb[q] + Tq[q] * bg2;
-        if (out_depth) out_depth[pix] = Dq[q];
-        if (out_weights) out_weights[pix] = 1.f - Tq[q];
-        final_T[pix] = Tq[q];
-        n_contrib[pix] = last[q];
-    }
-}
-
-static hipError_t launch_blend_fwd_quadrants(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
-                            const BagsForwardOut& out, hipStream_t st)
-{
-    const int gx = cdiv(s.image_width, BAGS_TILE), gy = cdiv(s.image_height, BAGS_TILE);
-    const int T = gx * gy;
-    if (T == 0) return hipSuccess;
-    const int grid = ((T + 7) / 8) * 8;
-    hipLaunchKernelGGL(blend_fwd_kernel, dim3(grid), dim3(64), 0, st, s.image_width, s.image_height, gx, T, b.ranges,
-                       b.point_list, g.xy, g.conic_opacity, g.rgbz, s.bg, out.color, out.depth, out.weights,
-                       im.final_T, im.n_contrib);
-    return hipGetLastError();
-}
-
-// --------------------------------------------------------------------------------------------------- backward
-// DPP cross-lane adds: full-rate VALU, no LDS crossbar round trip (ds_bpermute costs ~60 exposed cycles per step).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v)
-{   // v + (v moved by the DPP pattern); lanes outside ROW_MASK keep v
-    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
-    return v + __int_as_float(moved);
-}
-// Sum over the 64 lanes in a FIXED order (bitwise reproducible); the total lands in lanes 48..63.
-__device__ __forceinline__ float wave_total_row3(float v)
-{
-    v = dpp_add<0x121, 0xF>(v);      // row_ror:1   -> pairs
-    v = dpp_add<0x122, 0xF>(v);      // row_ror:2   -> quads
-    v = dpp_add<0x124, 0xF>(v);      // row_ror:4   -> 8
-    v = dpp_add<0x128, 0xF>(v);      // row_ror:8   -> every lane of a 16-lane row holds the row total
-    v = dpp_add<0x142, 0xA>(v);      // row_bcast15 -> rows 1,3 += previous row
-    v = dpp_add<0x143, 0xC>(v);      // row_bcast31 -> rows 2,3 += lane 31 (rows 0+1)
-    return v;
-}
-
-// ds_bpermute alternative: 16 per-lane partial sums -> totals; lane L ends with the total of value nib_rev(L & 15)
-__device__ __forceinline__ void wave_reduce16(float (&v)[16], int lane)
-{
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const bool hi = lane & 1;
-        const float keep = hi ? v[i + 8] : v[i], send = hi ? v[i] : v[i + 8];
-        v[i] = keep + __shfl_xor(send, 1);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const bool hi = lane & 2;
-        const float keep = hi ? v[i + 4] : v[i], send = hi ? v[i] : v[i + 4];
-        v[i] = keep + __shfl_xor(send, 2);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const bool hi = lane & 4;
-        const float keep = hi ? v[i + 2] : v[i], send = hi ? v[i] : v[i + 2];
-        v[i] = keep + __shfl_xor(send, 4);
-    }
-    {
-        const bool hi = lane & 8;
-        const float keep = hi ? v[1] : v[0], send = hi ? v[0] : v[1];
-        v[0] = keep + __shfl_xor(send, 8);
-    }
-    v[0] += __shfl_xor(v[0], 16);
-    v[0] += __shfl_xor(v[0], 32);
-}
-
-// partial record layout (floats): 0..2 dL/drgb, 3 dL/dopacity, 4 Mx, 5 My, 6 Mxx, 7 Mxy, 8 Myy, 9 absx, 10 absy
-//   M* = sum over pixels of q d^k with q = dL/dG * G and d = centre - pixel;  abs* = sum |d L/d centre (pixel units)|
-#define NSUM 11
-template <bool ABS>
-__global__ void __launch_bounds__(64, BWD_WAVES)
-blend_bwd_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ ranges, const u32* __restrict__ point_list,
-                 const float2* __restrict__ xy, const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbz,
-                 const uint2* __restrict__ rect, const u32* __restrict__ inst_offset, const float* __restrict__ bg,
-                 const float* __restrict__ final_T, const u32* __restrict__ n_contrib, const float* __restrict__ grad_color,
-                 float* __restrict__ partials)
-{
-    const int tile = tile_of_block(blockIdx.x, T);
-    if (tile >= T) return;
-    const int lane = threadIdx.x;
-    const int tile_x = tile % grid_x, tile_y = tile / grid_x;
-    const float X0 = (float)(tile_x * BAGS_TILE), Y0 = (float)(tile_y * BAGS_TILE);
-    const uint2 range = ranges[tile];
-    const u32 n = range.y - range.x;
-    if (n == 0) return;
-
-    __shared__ SplatRec recs[64];
-    __shared__ float acc[64][PART_FLOATS];
-
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    const size_t HW = (size_t)W * H;
-    const float lx = X0 + (float)(lane & 7), ly = Y0 + (float)(lane >> 3);      // this lane's pixel in quadrant 0
-    const float lx8 = lx + 8.f, ly8 = ly + 8.f;
-    float g0[4], g1[4], g2[4], Tq[4], Rq[4], la[4], ls[4], bgt[4];
-    u32 nc[4];
-    u32 maxc = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int px = tile_x * BAGS_TILE + (q & 1) * 8 + (lane & 7);
-        const int py = tile_y * BAGS_TILE + (q >> 1) * 8 + (lane >> 3);
-        const bool in = (px < W) && (py < H);
-        const size_t pix = (size_t)py * W + px;
-        g0[q] = in ? grad_color[pix] : 0.f;
-        g1[q] = in ? grad_color[HW + pix] : 0.f;
-        g2[q] = in ? grad_color[2 * HW + pix] : 0.f;
-        const float Tf = in ? final_T[pix] : 1.f;
-        nc[q] = in ? n_contrib[pix] : 0u;
-        Tq[q] = Tf; Rq[q] = 0.f; la[q] = 0.f; ls[q] = 0.f;
-        bgt[q] = Tf * (bg0 * g0[q] + bg1 * g1[q] + bg2 * g2[q]);
-        maxc = max(maxc, nc[q]);
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) maxc = max(maxc, (u32)__shfl_xor((int)maxc, d));
-    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int sel = lane - 48;                 // lanes 48..58 publish sum 0..10 of a splat
-
-    // instances behind the last contributor of every pixel are never visited: their records are zero
-    for (u32 p = maxc + lane; p < n; p += 64) {
-        const u32 g = point_list[range.x + p];
-        const uint2 rc = rect[g];
-        const u32 e = inst_offset[g] + (u32)(tile_y - (int)(rc.x >> 16)) * ((rc.y & 0xFFFF) - (rc.x & 0xFFFF)) +
-                      (u32)(tile_x - (int)(rc.x & 0xFFFF));
-        float4* dst = reinterpret_cast<float4*>(partials + (size_t)e * PART_FLOATS);
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        dst[0] = z4; dst[1] = z4; dst[2] = z4;
-    }
-
-    for (u32 hi = maxc; hi > 0;) {
-        const u32 cnt = min(hi, 64u);
-        const u32 lo = hi - cnt;
-        // ---- stage splats at list positions [lo, hi) (0-based), list order preserved
-        SplatRec rec; rec.mask = 0;
-        u32 e = 0;
-        const bool valid = (u32)lane < cnt;
-        if (valid) {
-            const u32 g = point_list[range.x + lo + lane];
-            const float2 c2 = xy[g];
-            const float4 co = conic_opacity[g];
-            const float4 cz = rgbz[g];
-            const uint2 rc = rect[g];
-            e = inst_offset[g] + (u32)(tile_y - (int)(rc.x >> 16)) * ((rc.y & 0xFFFF) - (rc.x & 0xFFFF)) +
-                (u32)(tile_x - (int)(rc.x & 0xFFFF));
-            rec.x = c2.x; rec.y = c2.y;
-            rec.ap = -0.5f * LOG2E * co.x; rec.bp = -LOG2E * co.y; rec.cp = -0.5f * LOG2E * co.z; rec.o = co.w;
-            rec.r = cz.x; rec.g = cz.y; rec.b = cz.z; rec.z = cz.w;
-            rec.pos = lo + lane + 1;
-            rec.mask = quadrant_mask(c2.x, c2.y, co.x, co.y, co.z, co.w, X0, Y0);
-        }
-        const u64 keep = __ballot(rec.mask != 0);
-        const int count = __popcll(keep);
-        const int slot = __popcll(keep & lt_mask);
-        __syncthreads();
-        if (rec.mask != 0) recs[slot] = rec;
-        {
-            float4* a4 = reinterpret_cast<float4*>(&acc[lane][0]);
-            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            a4[0] = z4; a4[1] = z4; a4[2] = z4;
-        }
-        __syncthreads();
-        // ---- back to front; the next record is fetched from LDS while the current one is processed
-#if PREFETCH_REC
-        SplatRec s = recs[count > 0 ? count - 1 : 0];
-#endif
-        for (int k = count - 1; k >= 0; --k) {
-#if PREFETCH_REC
-            const SplatRec nxt = recs[k > 0 ? k - 1 : 0];
-#else
-            const SplatRec s = recs[k];
-#endif
-            const u32 m = __builtin_amdgcn_readfirstlane(s.mask);
-            float v[NSUM];
-#pragma unroll
-            for (int i = 0; i < NSUM; ++i) v[i] = 0.f;
-            bool any = false;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (!((m >> q) & 1u) || ABLATE == 3) continue;
-                const float dx = s.x - ((q & 1) ? lx8 : lx), dy = s.y - ((q >> 1) ? ly8 : ly);
-                const float p2 = pair_power2(dx, dy, s.ap, s.bp, s.cp);
-                const float G = __builtin_amdgcn_exp2f(p2);
-                const float alpha = fminf(0.99f, s.o * G);
-                const bool contrib = (p2 <= 0.f) && (alpha >= ALPHA_MIN) && (s.pos <= nc[q]);
-                if (__ballot(contrib) == 0ull) continue;
-                any = true;
-                if (contrib && ABLATE != 2) {
-                    const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
-                    const float Tn = Tq[q] * inv;                               // T before this splat
-                    const float sdot = s.r * g0[q] + s.g * g1[q] + s.b * g2[q];
-                    const float Rn = __fmaf_rn(la[q], ls[q] - Rq[q], Rq[q]);    // colour behind, dotted with dL/dC
-                    const float dLda = __fmaf_rn(-bgt[q], inv, (sdot - Rn) * Tn);
-                    const float w = alpha * Tn;
-                    Tq[q] = Tn; Rq[q] = Rn; la[q] = alpha; ls[q] = sdot;
-                    v[0] = __fmaf_rn(w, g0[q], v[0]); v[1] = __fmaf_rn(w, g1[q], v[1]); v[2] = __fmaf_rn(w, g2[q], v[2]);
-                    const float gd = G * dLda;
-                    v[3] += gd;
-                    const float qv = s.o * gd;
-                    const float qdx = qv * dx, qdy = qv * dy;
-                    v[4] += qdx; v[5] += qdy;
-                    v[6] = __fmaf_rn(qdx, dx, v[6]); v[7] = __fmaf_rn(qdx, dy, v[7]); v[8] = __fmaf_rn(qdy, dy, v[8]);
-                    if (ABS) {
-                        v[9] += fabsf(__fmaf_rn(2.f * s.ap, qdx, s.bp * qdy));
-                        v[10] += fabsf(__fmaf_rn(2.f * s.cp, qdy, s.bp * qdx));
-                    }
-                }
-            }
-            if (ABLATE == 1 || ABLATE == 2) { float keepalive = 0.f;
-#pragma unroll
-                for (int i = 0; i < NSUM; ++i) keepalive += v[i];
-                if (keepalive == 123.456f) acc[k][0] = keepalive; }
-            if (any && ABLATE != 1 && ABLATE != 2) {
-#if BWD_REDUCE_DPP
-                float out = 0.f;
-#pragma unroll
-                for (int i = 0; i < (ABS ? NSUM : NSUM - 2); ++i) {
-                    const float t = wave_total_row3(v[i]);
-                    out = (sel == i) ? t : out;
-                }
-                if (sel >= 0 && sel < NSUM) acc[k][sel] = out;
-#else
-                float v16[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v16[i] = (i < NSUM) ? v[i] : 0.f;
-                wave_reduce16(v16, lane);
-                if (lane < 16) {
-                    const int idxv = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
-                    acc[k][idxv] = v16[0];
-                }
-#endif
-            }
-#if PREFETCH_REC
-            s = nxt;
-#endif
-        }
-        __syncthreads();
-        // ---- one record per staged instance, at its emission slot (48 of its 64 bytes carry data)
-        if (valid) {
-            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-            if (rec.mask != 0) {
-                const float4* a4 = reinterpret_cast<const float4*>(&acc[slot][0]);
-                r0 = a4[0]; r1 = a4[1]; r2 = a4[2];
-                r2.y *= (1.0f / LOG2E); r2.z *= (1.0f / LOG2E);      // abs sums were taken on the scaled conic
-            }
-            float4* dst = reinterpret_cast<float4*>(partials + (size_t)e * PART_FLOATS);
-            dst[0] = r0; dst[1] = r1; dst[2] = r2;
-        }
-        hi = lo;
-    }
-}
-
-// ================================================================================================================
-// Scan-based backward ("lane = splat").  PMC showed the lane = pixel backward saturates VALU issue (96 % of SIMD cycles)
-// and spends most of it on 64-wide work where a third of the lanes contribute, plus an 11-value cross-lane reduction
-// per (tile, splat).  Here the roles are swapped:
-//   * a 256-thread workgroup owns a tile; the tile list is consumed back to front in chunks of 256 splats, staged once
-//     in LDS together with a 16-bit mask of the 4x4-pixel blocks each splat's alpha >= 1/255 ellipse can reach
-//     (Mahalanobis triangle-inequality test, conservative);
-//   * each wave owns four of the sixteen blocks and ballot-compacts, per block, the chunk's splats that reach it;
-//   * 64 lanes = 64 splats of one block list (deepest in lane 0); the block's pixels are visited two at a time with
-//     packed fp32 math.  The per-pixel recurrences of alpha compositing become wave64 DPP scans:
-//         B_i = prod_{j at or behind i} (1 - alpha_j)          T_i = T_final / B_i        (transmittance in front of i)
-//         S_i = sum_{j behind i} alpha_j T_j (c_j . dL/dC)                                  (colour behind i)
-//     carried across groups / chunks through one (B, S) pair per pixel in LDS;
-//   * every lane then owns its splat's 11 sums outright: no cross-lane reduction, no atomics.  Each wave adds into its
-//     own LDS copy of the chunk's records; the four copies are added in fixed order => bitwise reproducible.
-// ================================================================================================================
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter
@@ -462,37 +62,6 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // global memory, so lgkmcnt(0) + s_barrier is sufficient.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_src(float identity, float v)
-{   // v moved by the DPP pattern; lanes without a source (or in rows outside ROW_MASK) get `identity`
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
-}
-// Inclusive prefix scans over the 64 lanes for TWO independent values at once (the two pixels of a pair).  One
-// VOP2-DPP instruction per step and value: lanes without a source (bound_ctrl:0) or outside row_mask keep their
-// value, which is exactly the scan semantics.  The two chains are interleaved and padded with s_nop so that the
-// "VALU write -> DPP read: 2 wait states" hazard of gfx9 is respected (the compiler cannot see inside the asm).
-#define SCAN2(OP)                                                                                        \
-    asm volatile(                                                                                        \
-        "s_nop 1\n\t"                                                                                    \
-        OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                        \
-        OP " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                        \
-        "s_nop 0\n\t"                                                                                    \
-        OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                                        \
-        OP " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                                        \
-        "s_nop 0\n\t"                                                                                    \
-        OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                                        \
-        OP " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                                        \
-        "s_nop 0\n\t"                                                                                    \
-        OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                                        \
-        OP " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                                        \
-        "s_nop 0\n\t"                                                                                    \
-        OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                                     \
-        OP " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                                     \
-        "s_nop 0\n\t"                                                                                    \
-        OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                                     \
-        OP " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                                     \
-        "s_nop 1"                                                                                        \
-        : "+v"(a), "+v"(b))
 #define SCAN4_STEP(OP, PAT)                                                                              \
         OP " %0, %0, %0 " PAT "\n\t" OP " %1, %1, %1 " PAT "\n\t" OP " %2, %2, %2 " PAT "\n\t" OP " %3, %3, %3 " PAT "\n\t"
 #define SCAN4(OP)                                                                                        \
@@ -508,15 +77,24 @@ __device__ __forceinline__ float dpp_src(float identity, float v)
         : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 __device__ __forceinline__ void scan_mul64x4(float& a, float& b, float& c, float& d) { SCAN4("v_mul_f32_dpp"); }
 __device__ __forceinline__ void scan_add64x4(float& a, float& b, float& c, float& d) { SCAN4("v_add_f32_dpp"); }
-__device__ __forceinline__ void scan_mul64x2(float& a, float& b) { SCAN2("v_mul_f32_dpp"); }
-__device__ __forceinline__ void scan_add64x2(float& a, float& b) { SCAN2("v_add_f32_dpp"); }
 
-#ifndef CHUNK
-#define CHUNK 256
-#endif
-#ifndef SCAN_WG_PER_CU
-#define SCAN_WG_PER_CU 2
-#endif
+// ================================================================================================================
+// backward
+// Scan-based backward ("lane = splat").  PMC showed a lane = pixel backward saturates VALU issue (96 % of SIMD cycles)
+// and spends most of it on 64-wide work where a third of the lanes contribute, plus an 11-value cross-lane reduction
+// per (tile, splat).  Here the roles are swapped:
+//   * a 256-thread workgroup owns a tile; the tile list is consumed back to front in chunks of 256 splats, staged once
+//     in LDS together with a 16-bit mask of the 4x4-pixel blocks each splat's alpha >= 1/255 ellipse can reach
+//     (Mahalanobis triangle-inequality test, conservative);
+//   * each wave owns four of the sixteen blocks and ballot-compacts, per block, the chunk's splats that reach it;
+//   * 64 lanes = 64 splats of one block list (deepest in lane 0); the block's pixels are visited two at a time with
+//     packed fp32 math.  The per-pixel recurrences of alpha compositing become wave64 DPP scans:
+//         B_i = prod_{j at or behind i} (1 - alpha_j)          T_i = T_final / B_i        (transmittance in front of i)
+//         S_i = sum_{j behind i} alpha_j T_j (c_j . dL/dC)                                  (colour behind i)
+//     carried across groups / chunks through one (B, S) pair per pixel in LDS;
+//   * every lane then owns its splat's 11 sums outright: no cross-lane reduction, no atomics.  Each wave adds into its
+//     own LDS copy of the chunk's records; the four copies are added in fixed order => bitwise reproducible.
+// ================================================================================================================
 struct __attribute__((aligned(16))) ChunkRec {
     float x, y, ap, bp;
     float cp, o, r, g;
@@ -586,14 +164,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
     __shared__ ChunkRec recs[CHUNK];                 // 12 KB
     __shared__ PixPair pix[128];                     //  8 KB
     __shared__ unsigned char lists[16][CHUNK];       //  4 KB
-#ifndef ACC_ATOMIC
-#define ACC_ATOMIC 0        // 1: one shared copy + LDS float atomics (faster? but summation order then depends on timing)
-#endif
-#if ACC_ATOMIC
-    __shared__ float acc[1][CHUNK][12];
-#else
-    __shared__ float acc[4][CHUNK][12];              // 48 KB, one copy per wave
-#endif
+    __shared__ float acc[4][CHUNK][12];              // 48 KB, one copy per wave (LDS float atomics on a shared copy were 1.6x slower)
     __shared__ u32 wmax[4];
 
 #ifdef DIAG_PHASES
@@ -651,7 +222,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
     if (tid < CHUNK) {
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int w = 0; w < (ACC_ATOMIC ? 1 : 4); ++w) {
+        for (int w = 0; w < 4; ++w) {
             float4* a4 = reinterpret_cast<float4*>(&acc[w][tid][0]);
             a4[0] = z4; a4[1] = z4; a4[2] = z4;
         }
@@ -688,10 +259,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
         if (tid < CHUNK) recs[tid] = rec;        // safe without a barrier: after the previous chunk's second barrier nobody reads recs
         lds_barrier();
         PH_MARK(2);    // barrier 1
-#ifndef SCAN_PRIO
-#define SCAN_PRIO 1
-#endif
-        if (SCAN_PRIO) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
         Raw raw_n = fetch(lo > 0 ? gid1 : 0xFFFFFFFFu);                             // gathers of chunk k+1
         const u32 gid2 = (lo > CHUNK) ? fetch_id(lo - CHUNK) : 0xFFFFFFFFu;          // ids of chunk k+2
 
@@ -710,7 +278,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
                 L += __popcll(bal);
             }
             PH_MARK(3);    // list building
-            if (L == 0 || ABLATE == 4) continue;
+            if (L == 0) continue;
             const float bx0 = X0 + 4.f * (float)(blk & 3), by0 = Y0 + 4.f * (float)(blk >> 2);
             // groups of 64 list entries, deepest group first; inside a group lane 0 holds the deepest entry
             for (int gend = L; gend > 0; gend -= 64) {
@@ -719,9 +287,6 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
                 const int slot = live ? (int)lists[blk][gend - 1 - lane] : 0;
                 const ChunkRec s = recs[slot];
                 f2 a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0, a4 = a0, a5 = a0, a6 = a0, a7 = a0, a8 = a0, a9 = a0, a10 = a0;
-#ifndef SCAN_UNROLL
-#define SCAN_UNROLL 1
-#endif
                 // one block row (4 pixels = two packed pairs) per step: four independent scan chains interleave
                 // without pipeline bubbles
 #pragma unroll SCAN_UNROLL
@@ -791,15 +356,6 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
                         a10 = a10 + __builtin_elementwise_abs(__builtin_elementwise_fma(cp2, qdyb, s.bp * qdxb));
                     }
                 }
-#if ACC_ATOMIC
-                if (live) {
-                    float* d = &acc[0][slot][0];
-                    atomicAdd(d + 0, a0.x + a0.y); atomicAdd(d + 1, a1.x + a1.y); atomicAdd(d + 2, a2.x + a2.y);
-                    atomicAdd(d + 3, a3.x + a3.y); atomicAdd(d + 4, a4.x + a4.y); atomicAdd(d + 5, a5.x + a5.y);
-                    atomicAdd(d + 6, a6.x + a6.y); atomicAdd(d + 7, a7.x + a7.y); atomicAdd(d + 8, a8.x + a8.y);
-                    if (ABS) { atomicAdd(d + 9, a9.x + a9.y); atomicAdd(d + 10, a10.x + a10.y); }
-                }
-#else
                 if (live) {      // distinct lanes hold distinct slots: plain read-modify-write of the wave's own copy
                     float4* d4 = reinterpret_cast<float4*>(&acc[wave][slot][0]);
                     float4 r0 = d4[0], r1 = d4[1], r2 = d4[2];
@@ -808,7 +364,6 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
                     r2.x += a8.x + a8.y; r2.y += a9.x + a9.y; r2.z += a10.x + a10.y;
                     d4[0] = r0; d4[1] = r1; d4[2] = r2;
                 }
-#endif
                 PH_MARK(4);    // groups
             }
         }
@@ -818,7 +373,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
         // The short serial section between the two barriers shares its SIMDs with another workgroup that is usually in
         // its VALU-saturated group phase; without priority the four waves crawl through it at different speeds and
         // the skew is paid at the next barrier.
-        if (SCAN_PRIO) __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(3);
         // ---- next chunk: its gathers were issued before the groups; turn them into the staged record
         const ChunkRec cur = rec;
         if (lo > 0) { const u32 ncnt = min(lo, (u32)CHUNK); rec = make_rec(raw_n, lo - ncnt, ncnt); }
@@ -830,7 +385,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
             if (cur.mask != 0) {
                 const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int w = 0; w < (ACC_ATOMIC ? 1 : 4); ++w) {
+                for (int w = 0; w < 4; ++w) {
                     float4* a4 = reinterpret_cast<float4*>(&acc[w][tid][0]);
                     const float4 x0 = a4[0], x1 = a4[1], x2 = a4[2];
                     a4[0] = z4; a4[1] = z4; a4[2] = z4;               // owner re-zeroes its slot for the next chunk
@@ -854,10 +409,6 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
 extern "C" void bags_diag_phases(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 8); }
 #endif
 
-#ifndef BWD_SCAN
-#define BWD_SCAN 1          // 1: scan-based backward (lane = splat), 0: lane = pixel backward
-#endif
-
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
                             const float* grad_color, float* partials, bool want_abs, hipStream_t st)
 {
@@ -865,7 +416,6 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     const int T = gx * gy;
     if (T == 0) return hipSuccess;
     const int grid = ((T + 7) / 8) * 8;
-#if BWD_SCAN
     if (want_abs)
         hipLaunchKernelGGL(blend_bwd_scan_kernel<true>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
                            b.ranges, b.point_list, g.xy, g.conic_opacity, g.rgbz, g.rect, g.inst_offset, s.bg,
@@ -874,29 +424,18 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
         hipLaunchKernelGGL(blend_bwd_scan_kernel<false>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
                            b.ranges, b.point_list, g.xy, g.conic_opacity, g.rgbz, g.rect, g.inst_offset, s.bg,
                            im.final_T, im.n_contrib, grad_color, partials);
-#else
-    if (want_abs)
-        hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(grid), dim3(64), 0, st, s.image_width, s.image_height, gx, T,
-                           b.ranges, b.point_list, g.xy, g.conic_opacity, g.rgbz, g.rect, g.inst_offset, s.bg,
-                           im.final_T, im.n_contrib, grad_color, partials);
-    else
-        hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(grid), dim3(64), 0, st, s.image_width, s.image_height, gx, T,
-                           b.ranges, b.point_list, g.xy, g.conic_opacity, g.rgbz, g.rect, g.inst_offset, s.bg,
-                           im.final_T, im.n_contrib, grad_color, partials);
-#endif
     return hipGetLastError();
 }
 
-
 // ================================================================================================================
-// Forward, "one DPP row per 4x4 block".  The quadrant forward above is latency-bound: one wave per tile leaves ~3.7
-// busy waves per SIMD on a scene whose splats cluster in half of the tiles, and each of them serialises on
-// LDS-read -> exp -> compare -> scalar-branch chains.  Here a 256-thread workgroup owns the tile:
+// Forward, "one DPP row per 4x4 block".  (The first forward -- one wave per tile, 4 pixels per lane, 8x8 quadrant
+// culling -- was latency-bound: ~3.7 busy waves per SIMD on a scene whose splats cluster in half of the tiles, each
+// serialising on LDS-read -> exp -> compare -> scalar-branch chains.)  Here a 256-thread workgroup owns the tile:
 //   * the list is staged 256 splats at a time with the same 16-bit reach mask of 4x4 blocks as the backward;
 //   * wave w owns quadrant w; each of its four 16-lane rows owns one 4x4 block and walks ITS OWN ballot-compacted list
 //     of the chunk (one splat per row per step, 16 pixels each): ~1.8x fewer (pixel, splat) evaluations than 8x8
 //     quadrants, four times as many waves to hide latency, no scalar branch inside the walk.
-// Compositing arithmetic is unchanged (same pair_power2 / exp2 / thresholds), so images match the quadrant kernel.
+// Compositing arithmetic per (pixel, splat) pair is pair_power2 / exp2 / the reference thresholds, shared with backward.
 // ================================================================================================================
 template <int DUMMY>
 __global__ void __launch_bounds__(256)
@@ -1007,13 +546,9 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
     }
 }
 
-#ifndef FWD_ROWS
-#define FWD_ROWS 1          // 1: row-per-block forward, 0: quadrant forward
-#endif
 hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
                             const BagsForwardOut& out, hipStream_t st)
 {
-#if FWD_ROWS
     const int gx = cdiv(s.image_width, BAGS_TILE), gy = cdiv(s.image_height, BAGS_TILE);
     const int T = gx * gy;
     if (T == 0) return hipSuccess;
@@ -1022,7 +557,4 @@ hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinV
                        b.ranges, b.point_list, g.xy, g.conic_opacity, g.rgbz, s.bg, out.color, out.depth, out.weights,
                        im.final_T, im.n_contrib);
     return hipGetLastError();
-#else
-    return launch_blend_fwd_quadrants(s, g, b, im, out, st);
-#endif
 }
