@@ -222,6 +222,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.shapes = dict(sh=None if sh is None else sh.shape, opac=opacities.shape, campos=campos.shape)
         color, radii, depth, weights, mean2D = outs
         ctx.mark_non_differentiable(radii, depth, weights, mean2D)
+        ctx.set_materialize_grads(False)     # no zero-fill kernels for the four outputs nobody differentiates
         return color, radii, depth, weights, mean2D
 
     @staticmethod
@@ -230,6 +231,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         fw: _Forwarded = ctx.fw
         pk, dev, P = fw.packed, fw.packed.device, fw.packed.P
         need = ctx.needs_input_grad
+        if grad_color is None:
+            return (None,) * 15
         with torch.cuda.device(dev):
             gc = grad_color.detach()
             if gc.dtype != torch.float32 or not gc.is_contiguous():
