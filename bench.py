@@ -222,9 +222,19 @@ def main():
             dom = max(stages, key=lambda k: stages[k])
             if dom in alg:
                 ach = alg[dom] / (stages[dom] * 1e-3)
+                traffic = None      # PMC bytes of this kernel, measured in a separate rocprofv3 --pmc pass (profiles/)
+                try:
+                    tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))
+                    if tj["key"] == {"P": P, "width": W, "height": H, "sm": args.sm} and dom in tj:
+                        traffic = tj[dom]["fetch_bytes"] + tj[dom]["write_bytes"]
+                except (OSError, KeyError, ValueError):
+                    pass
                 out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
-                                   "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": None,
-                                   "alg_bytes_per_launch": alg[dom], "mean_launch_ms": stages[dom]}
+                                   "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic,
+                                   "alg_bytes_per_launch": alg[dom], "mean_launch_ms": stages[dom],
+                                   "note": "kernel is VALU-issue bound (59 % of SIMD issue cycles busy, PMC in "
+                                           "profiles/r01/pmc_blend_v2.txt), not HBM bound; traffic = FETCH_SIZE + "
+                                           "WRITE_SIZE of a separate --pmc pass, fetch side uncorrected (gathers)"}
             dev_ms = sum(stages.values())
             out["op_roofline"] = {"bound": "hbm", "alg_bytes_per_step": b_alg, "device_ms_per_step": dev_ms,
                                   "achieved": b_alg / (dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

@@ -32,13 +32,13 @@ static inline int bit_length(u32 v) { int b = 0; while (v) { ++b; v >>= 1; } ret
 // ---- carved views of the three caller-owned state buffers -------------------------------------------------
 struct GeomView {            // per Gaussian, indexed by Gaussian id unless stated
     u32*    depth_key;       // float bits of the sort depth, KEY_CULLED when not rendered
-    float2* xy;              // pixel centre
-    float4* conic_opacity;   // conic a,b,c + opacity
-    float4* rgbz;            // colour after clamp + view depth z
-    uint2*  rect;            // (minx | miny<<16, maxx | maxy<<16), max exclusive
-    u32*    tiles_touched;
-    u32*    inst_offset;     // first emission index of the Gaussian's instances
-    u32*    clamped;         // bit c set: SH colour channel c was clamped at 0
+    // One 64-byte line per Gaussian with everything the blend kernels gather per (tile, Gaussian) instance, so an
+    // instance costs ONE line fetch instead of five partial ones from id-ordered (spatially random) SoA arrays:
+    //   q0 = conic a, b, c, opacity      q1 = pixel x, y, colour r, g
+    //   q2 = colour b, view depth z, rect.x, rect.y (bits)      q3 = inst_offset, tiles_touched, clamped mask, 0 (bits)
+    float4* g2d;             // [4 * P]
+    uint2*  rect;            // (minx | miny<<16, maxx | maxy<<16), max exclusive   (compact copy for emit)
+    u32*    tiles_touched;   // compact copy for the offsets scan / emit
     // scratch (dead after forward)
     u32 *keys_a, *keys_b, *vals_a, *vals_b;   // depth ordering of Gaussians (ping-pong)
     u32*    rank_offset;     // exclusive instance offset per depth rank

@@ -147,9 +147,7 @@ __device__ unsigned long long g_phase_cycles[8];
 template <bool ABS>
 __global__ void __launch_bounds__(256, SCAN_WG_PER_CU)
 blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ ranges, const u32* __restrict__ point_list,
-                      const float2* __restrict__ xy, const float4* __restrict__ conic_opacity,
-                      const float4* __restrict__ rgbz, const uint2* __restrict__ rect, const u32* __restrict__ inst_offset,
-                      const float* __restrict__ bg, const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
+                      const float4* __restrict__ g2d, const float* __restrict__ bg, const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
                       const float* __restrict__ grad_color, float* __restrict__ partials)
 {
     const int tile = tile_of_block(blockIdx.x, T);
@@ -198,8 +196,9 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
     // instances behind the last contributor of every pixel are never visited: their records are zero
     for (u32 p = maxc + tid; p < n; p += 256) {
         const u32 g = point_list[range.x + p];
-        const uint2 rc = rect[g];
-        const u32 e = inst_offset[g] + (u32)(tile_y - (int)(rc.x >> 16)) * ((rc.y & 0xFFFF) - (rc.x & 0xFFFF)) +
+        const float4 t2 = g2d[4 * (size_t)g + 2];
+        const uint2 rc = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w));
+        const u32 e = __float_as_uint(g2d[4 * (size_t)g + 3].x) + (u32)(tile_y - (int)(rc.x >> 16)) * ((rc.y & 0xFFFF) - (rc.x & 0xFFFF)) +
                       (u32)(tile_x - (int)(rc.x & 0xFFFF));
         float4* dst = reinterpret_cast<float4*>(partials + (size_t)e * PART_FLOATS);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -209,14 +208,17 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
 
     // Software pipeline over chunks: Gaussian ids are fetched TWO chunks ahead and the per-splat gathers ONE chunk
     // ahead, so neither the id load nor the dependent gathers sit on the critical path of a chunk.
-    struct Raw { float2 c2; float4 co; float4 cz; uint2 rc; u32 io; };
+    struct Raw { float4 q0, q1, q2; u32 io; };      // conic+opacity | x y r g | b z rect | inst_offset
     auto fetch_id = [&](u32 hi_) -> u32 {            // id of this thread's slot in the chunk that ends at hi_
         const u32 c_ = min(hi_, (u32)CHUNK);
         return ((u32)tid < c_) ? point_list[range.x + (hi_ - c_) + tid] : 0xFFFFFFFFu;
     };
     auto fetch = [&](u32 g) {
-        Raw r; r.c2 = make_float2(0.f, 0.f); r.co = make_float4(0.f, 0.f, 0.f, 0.f); r.cz = r.co; r.rc = make_uint2(0u, 0u); r.io = 0u;
-        if (g != 0xFFFFFFFFu) { r.c2 = xy[g]; r.co = conic_opacity[g]; r.cz = rgbz[g]; r.rc = rect[g]; r.io = inst_offset[g]; }
+        Raw r; r.q0 = make_float4(0.f, 0.f, 0.f, 0.f); r.q1 = r.q0; r.q2 = r.q0; r.io = 0u;
+        if (g != 0xFFFFFFFFu) {                       // one 64-byte line
+            const float4* rec = g2d + 4 * (size_t)g;
+            r.q0 = rec[0]; r.q1 = rec[1]; r.q2 = rec[2]; r.io = __float_as_uint(rec[3].x);
+        }
         return r;
     };
     if (tid < CHUNK) {
@@ -232,7 +234,9 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
         ChunkRec rec; rec.mask = 0; rec.e = 0;
         rec.x = rec.y = rec.ap = rec.bp = rec.cp = rec.o = rec.r = rec.g = rec.b = 0.f; rec.pos = 0;
         if ((u32)tid < cnt_) {
-            const float2 c2 = rw.c2; const float4 co = rw.co, cz = rw.cz; const uint2 rc = rw.rc;
+            const float2 c2 = make_float2(rw.q1.x, rw.q1.y); const float4 co = rw.q0;
+            const float4 cz = make_float4(rw.q1.z, rw.q1.w, rw.q2.x, rw.q2.y);
+            const uint2 rc = make_uint2(__float_as_uint(rw.q2.z), __float_as_uint(rw.q2.w));
             rec.e = rw.io + (u32)(tile_y - (int)(rc.x >> 16)) * ((rc.y & 0xFFFF) - (rc.x & 0xFFFF)) +
                     (u32)(tile_x - (int)(rc.x & 0xFFFF));
             rec.x = c2.x; rec.y = c2.y;
@@ -418,11 +422,11 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     const int grid = ((T + 7) / 8) * 8;
     if (want_abs)
         hipLaunchKernelGGL(blend_bwd_scan_kernel<true>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
-                           b.ranges, b.point_list, g.xy, g.conic_opacity, g.rgbz, g.rect, g.inst_offset, s.bg,
+                           b.ranges, b.point_list, g.g2d, s.bg,
                            im.final_T, im.n_contrib, grad_color, partials);
     else
         hipLaunchKernelGGL(blend_bwd_scan_kernel<false>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
-                           b.ranges, b.point_list, g.xy, g.conic_opacity, g.rgbz, g.rect, g.inst_offset, s.bg,
+                           b.ranges, b.point_list, g.g2d, s.bg,
                            im.final_T, im.n_contrib, grad_color, partials);
     return hipGetLastError();
 }
@@ -440,8 +444,7 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
 template <int DUMMY>
 __global__ void __launch_bounds__(256)
 blend_fwd_rows_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ ranges, const u32* __restrict__ point_list,
-                      const float2* __restrict__ xy, const float4* __restrict__ conic_opacity,
-                      const float4* __restrict__ rgbz, const float* __restrict__ bg, float* __restrict__ out_color,
+                      const float4* __restrict__ g2d, const float* __restrict__ bg, float* __restrict__ out_color,
                       float* __restrict__ out_depth, float* __restrict__ out_weights, float* __restrict__ final_T,
                       u32* __restrict__ n_contrib)
 {
@@ -477,9 +480,10 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
         SplatRec rec; rec.mask = 0; rec.x = rec.y = rec.ap = rec.bp = rec.cp = rec.o = rec.r = rec.g = rec.b = rec.z = 0.f; rec.pos = 0;
         if ((u32)tid < cnt) {
             const u32 g = point_list[range.x + base + tid];
-            const float2 c2 = xy[g];
-            const float4 co = conic_opacity[g];
-            const float4 cz = rgbz[g];
+            const float4* grec = g2d + 4 * (size_t)g;             // one 64-byte line per instance
+            const float4 co = grec[0], g1 = grec[1], g2v = grec[2];
+            const float2 c2 = make_float2(g1.x, g1.y);
+            const float4 cz = make_float4(g1.z, g1.w, g2v.x, g2v.y);
             rec.x = c2.x; rec.y = c2.y;
             rec.ap = -0.5f * LOG2E * co.x; rec.bp = -LOG2E * co.y; rec.cp = -0.5f * LOG2E * co.z; rec.o = co.w;
             rec.r = cz.x; rec.g = cz.y; rec.b = cz.z; rec.z = cz.w;
@@ -554,7 +558,7 @@ hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinV
     if (T == 0) return hipSuccess;
     const int grid = ((T + 7) / 8) * 8;
     hipLaunchKernelGGL(blend_fwd_rows_kernel<0>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
-                       b.ranges, b.point_list, g.xy, g.conic_opacity, g.rgbz, s.bg, out.color, out.depth, out.weights,
+                       b.ranges, b.point_list, g.g2d, s.bg, out.color, out.depth, out.weights,
                        im.final_T, im.n_contrib);
     return hipGetLastError();
 }

@@ -29,15 +29,15 @@ __device__ __forceinline__ float wave_sum(float x)
 // K8a: each Gaussian's consecutive partial records (written by blend_bwd at its emission slots) summed in list order.
 // Light kernel (high occupancy, two records in flight per lane): the record stream is the only traffic.
 __global__ void __launch_bounds__(256)
-sum_partials_kernel(int P, const u32* __restrict__ tiles_touched, const u32* __restrict__ inst_offset,
-                    const float* __restrict__ partials, float4* __restrict__ sums)
+sum_partials_kernel(int P, const float4* __restrict__ g2d, const float* __restrict__ partials, float4* __restrict__ sums)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
-    const u32 nrec = tiles_touched[i];
+    const float4 q3 = g2d[4 * (size_t)i + 3];
+    const u32 nrec = __float_as_uint(q3.y);
     if (nrec) {
-        const float4* rec = reinterpret_cast<const float4*>(partials + (size_t)inst_offset[i] * PART_FLOATS);
+        const float4* rec = reinterpret_cast<const float4*>(partials + (size_t)__float_as_uint(q3.x) * PART_FLOATS);
         u32 r = 0;
         for (; r + 1 < nrec; r += 2) {
             const float4 a0 = rec[4 * r], b0 = rec[4 * r + 1], c0 = rec[4 * r + 2];
@@ -67,8 +67,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                       const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
                       const float* __restrict__ projmatrix, const float* __restrict__ intrinsic,
                       const float* __restrict__ campos_p,
-                      const float4* __restrict__ conic_opacity, const u32* __restrict__ tiles_touched,
-                      const u32* __restrict__ inst_offset, const u32* __restrict__ clamped,
+                      const float4* __restrict__ g2d,
                       const float* __restrict__ partials, float* __restrict__ pose_slab,
                       float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_densify,
                       float* __restrict__ g_shs, float* __restrict__ g_colors, float* __restrict__ g_opac,
@@ -97,7 +96,8 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     float gs0 = 0.f, gs1 = 0.f, gs2 = 0.f, gqr = 0.f, gqx = 0.f, gqy = 0.f, gqz = 0.f;
     float gc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float drgb[3] = {0.f, 0.f, 0.f};
-    const bool live = (i < P) && (tiles_touched[i] > 0);
+    const float4 q3 = (i < P) ? g2d[4 * (size_t)i + 3] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool live = (i < P) && (__float_as_uint(q3.y) > 0);
 
     if (live) {
         // ---- 1. sum the per-instance records
@@ -111,7 +111,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         drgb[0] = s[0]; drgb[1] = s[1]; drgb[2] = s[2];
         gop = s[3];
         const float Mx = s[4], My = s[5], Mxx = s[6], Mxy = s[7], Myy = s[8];
-        const float4 co = conic_opacity[i];
+        const float4 co = g2d[4 * (size_t)i];
         // ---- 2. moments -> screen-space gradients
         const float dpx = -(co.x * Mx + co.y * My);         // dL/d centre (pixel units)
         const float dpy = -(co.z * My + co.y * Mx);
@@ -259,7 +259,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
 
         // ---- colour
         if (!colors_precomp) {
-            const u32 cl = clamped[i];
+            const u32 cl = __float_as_uint(q3.z);
             if (cl & 1u) drgb[0] = 0.f;
             if (cl & 2u) drgb[1] = 0.f;
             if (cl & 4u) drgb[2] = 0.f;
@@ -412,13 +412,13 @@ hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, co
     const int nb = cdiv(P, 256);
     *nblocks_out = nb;
     if (P == 0) return hipSuccess;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(nb), dim3(256), 0, st, P, g.tiles_touched, g.inst_offset,
-                       partials_records, reinterpret_cast<float4*>(sums));
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(nb), dim3(256), 0, st, P, g.g2d, partials_records,
+                       reinterpret_cast<float4*>(sums));
     const float* partials = sums;
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nb), dim3(256), 0, st, P, s.sh_coeffs, s.sh_degree, s.image_width,
                        s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, in.means3D, in.shift_factors, in.shs,
                        in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, s.viewmatrix, s.projmatrix,
-                       s.intrinsic, s.campos, g.conic_opacity, g.tiles_touched, g.inst_offset, g.clamped, partials,
+                       s.intrinsic, s.campos, g.g2d, partials,
                        pose_slab, a.grad_means3D, a.grad_means2D, a.grad_means2D_densify, a.grad_shs,
                        a.grad_colors_precomp, a.grad_opacities, a.grad_scales, a.grad_rotations, a.grad_cov3D_precomp);
     return hipGetLastError();

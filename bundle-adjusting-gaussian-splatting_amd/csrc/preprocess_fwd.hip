@@ -23,9 +23,8 @@ preprocess_fwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                       const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
                       const float* __restrict__ projmatrix, const float* __restrict__ intrinsic,
                       const float* __restrict__ campos_p,
-                      u32* __restrict__ depth_key, float2* __restrict__ xy_out, float4* __restrict__ conic_opacity,
-                      float4* __restrict__ rgbz, uint2* __restrict__ rect_out, u32* __restrict__ tiles_touched,
-                      u32* __restrict__ clamped_out, int32_t* __restrict__ radii, float* __restrict__ mean2D_out)
+                      u32* __restrict__ depth_key, float4* __restrict__ g2d, uint2* __restrict__ rect_out,
+                      u32* __restrict__ tiles_touched, int32_t* __restrict__ radii, float* __restrict__ mean2D_out)
 {
     __shared__ CamConst cam;
     if (threadIdx.x < 16) {
@@ -46,6 +45,8 @@ preprocess_fwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     u32 key = KEY_CULLED; u32 tiles = 0; int radius = 0;
     uint2 rect = make_uint2(0u, 0u);
     float2 pxy = make_float2(0.f, 0.f);
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), rgbz_v = q0;
+    u32 clamp_bits = 0;
 
     const float x = means3D[3 * i + 0], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
     const float tx = x * v[0] + y * v[4] + z * v[8] + v[12];
@@ -181,9 +182,9 @@ preprocess_fwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                         if (g < 0.f) { cl |= 2u; g = 0.f; }
                         if (b < 0.f) { cl |= 4u; b = 0.f; }
                     }
-                    conic_opacity[i] = make_float4(con_a, con_b, con_c, opacities[i]);
-                    rgbz[i] = make_float4(r, g, b, tzs);
-                    clamped_out[i] = cl;
+                    q0 = make_float4(con_a, con_b, con_c, opacities[i]);
+                    rgbz_v = make_float4(r, g, b, tzs);
+                    clamp_bits = cl;
                 }
             }
         }
@@ -191,7 +192,11 @@ preprocess_fwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     depth_key[i] = key;
     tiles_touched[i] = tiles;
     rect_out[i] = rect;
-    xy_out[i] = pxy;
+    float4* rec = g2d + 4 * (size_t)i;            // one full 64-byte line per thread
+    rec[0] = q0;
+    rec[1] = make_float4(pxy.x, pxy.y, rgbz_v.x, rgbz_v.y);
+    rec[2] = make_float4(rgbz_v.z, rgbz_v.w, __uint_as_float(rect.x), __uint_as_float(rect.y));
+    rec[3] = make_float4(__uint_as_float(0u), __uint_as_float(tiles), __uint_as_float(clamp_bits), 0.f);
     radii[i] = radius;
     if (mean2D_out) { mean2D_out[2 * i] = pxy.x; mean2D_out[2 * i + 1] = pxy.y; }
 }
@@ -205,6 +210,6 @@ hipError_t launch_preprocess_fwd(const BagsSettings& s, const BagsInputs& in, co
                        s.image_width, s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, s.depth_key,
                        in.means3D, in.means2D, in.shift_factors, in.shs, in.colors_precomp, in.opacities, in.scales,
                        in.rotations, in.cov3D_precomp, s.viewmatrix, s.projmatrix, s.intrinsic, s.campos,
-                       g.depth_key, g.xy, g.conic_opacity, g.rgbz, g.rect, g.tiles_touched, g.clamped, radii, mean2D);
+                       g.depth_key, g.g2d, g.rect, g.tiles_touched, radii, mean2D);
     return hipGetLastError();
 }

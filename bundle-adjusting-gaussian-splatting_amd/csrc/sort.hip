@@ -274,7 +274,7 @@ offsets_top_kernel(u32* __restrict__ partials, int nparts, u32* __restrict__ tot
 // item order inside a workgroup here is (thread, item) with SCAN_ITEMS consecutive ranks per thread
 __global__ void __launch_bounds__(SCAN_BLOCK)
 offsets_final_kernel(const u32* __restrict__ sorted_ids, const u32* __restrict__ tiles_touched, int P,
-                     const u32* __restrict__ partials, u32* __restrict__ rank_offset, u32* __restrict__ inst_offset)
+                     const u32* __restrict__ partials, u32* __restrict__ rank_offset, float4* __restrict__ g2d)
 {
     __shared__ u32 wsum[SCAN_BLOCK / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -301,7 +301,7 @@ offsets_final_kernel(const u32* __restrict__ sorted_ids, const u32* __restrict__
 #pragma unroll
     for (int r = 0; r < SCAN_ITEMS; ++r) {
         const int j = j0 + r;
-        if (j < P) { rank_offset[j] = run; inst_offset[id[r]] = run; }
+        if (j < P) { rank_offset[j] = run; reinterpret_cast<u32*>(g2d)[16 * (size_t)id[r] + 12] = run; }   // q3.x
         run += t[r];
     }
 }
@@ -313,7 +313,7 @@ hipError_t launch_offsets_scan(const GeomView& g, const u32* sorted_ids, int P, 
     hipLaunchKernelGGL(offsets_partial_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, st, sorted_ids, g.tiles_touched, P, g.scan_partials);
     hipLaunchKernelGGL(offsets_top_kernel, dim3(1), dim3(256), 0, st, g.scan_partials, nb, g.num_rendered);
     hipLaunchKernelGGL(offsets_final_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, st, sorted_ids, g.tiles_touched, P,
-                       g.scan_partials, g.rank_offset, g.inst_offset);
+                       g.scan_partials, g.rank_offset, g.g2d);
     return hipGetLastError();
 }
 
