@@ -59,7 +59,10 @@ sum_partials_kernel(int P, const float4* __restrict__ g2d, const float* __restri
     sums[3 * (size_t)i] = s0; sums[3 * (size_t)i + 1] = s1; sums[3 * (size_t)i + 2] = s2;
 }
 
-__global__ void __launch_bounds__(256)
+#ifndef PRE_BWD_WAVES
+#define PRE_BWD_WAVES 1
+#endif
+__global__ void __launch_bounds__(256, PRE_BWD_WAVES)
 preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod,
                       const float* __restrict__ means3D, const float* __restrict__ shift_factors,
                       const float* __restrict__ shs, const float* __restrict__ colors_precomp,

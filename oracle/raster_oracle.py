@@ -20,7 +20,9 @@ Design of the oracle
 * ``dtype=torch.float32`` mode mirrors the kernels' index-producing arithmetic op for op (explicit
   scalar expressions, left-to-right, no matmul) so radii / tile rects / depth keys / sorted lists are
   comparable BIT-EXACTLY;  ``dtype=torch.float64`` mode is the gradient reference and may be handed the
-  fp32 run's discrete decisions (``discrete=``) so both walk the same instance lists;
+  fp32 run's discrete decisions (``discrete=``): it then walks the same instance lists AND takes every
+  per-pair threshold decision from an fp32 evaluation, so it differs from an fp32 implementation by
+  arithmetic only;
 * blending is evaluated tile by tile as dense (256 x N) tensors; backward runs tile by tile as well
   (bounded memory), accumulating into per-Gaussian 2-D leaves that are then pulled back through the
   preprocess graph.
@@ -339,8 +341,13 @@ def bin_and_sort(depth32: torch.Tensor, rect: torch.Tensor, tiles_touched: torch
     return keys_sorted, point_list, ranges, offsets
 
 
-def _blend_tile(ids, xy, conic, opacity, rgb, zdepth, bg, px0, py0, W, H, want_pairs=False):
-    """Front-to-back alpha blend of one 16x16 tile as dense (256,N) tensors."""
+def _blend_tile(ids, xy, conic, opacity, rgb, zdepth, bg, px0, py0, W, H, want_pairs=False, decide32=False):
+    """Front-to-back alpha blend of one 16x16 tile as dense (256,N) tensors.
+
+    ``decide32``: take the per-(pixel, splat) threshold decisions (power <= 0, alpha >= 1/255, T < 1e-4 stop) from an
+    fp32 evaluation of the same pairs while the values are computed in the tensors' own dtype.  Used by the fp64
+    gradient reference so that it walks exactly the pairs an fp32 implementation walks: otherwise an ulp of difference
+    in exp() flips borderline pairs and the comparison measures threshold flips, not arithmetic."""
     dt = xy.dtype
     jj, ii = torch.meshgrid(torch.arange(TILE), torch.arange(TILE), indexing="ij")
     pxs = (px0 + ii.reshape(-1)).to(dt)
@@ -353,12 +360,26 @@ def _blend_tile(ids, xy, conic, opacity, rgb, zdepth, bg, px0, py0, W, H, want_p
     G = torch.exp(power)
     a_raw = gop[None, :] * G
     alpha = a_raw + (torch.clamp(a_raw, max=0.99) - a_raw).detach()        # D3 straight-through
-    valid = (power.detach() <= 0) & (alpha.detach() >= 1.0 / 255.0) & inside[:, None]
+    if decide32 and dt != torch.float32:
+        with torch.no_grad():
+            f = torch.float32
+            dx32 = gxy[None, :, 0].to(f) - pxs[:, None].to(f)
+            dy32 = gxy[None, :, 1].to(f) - pys[:, None].to(f)
+            c32 = gcon.to(f)
+            p32 = -0.5 * (c32[None, :, 0] * dx32 * dx32 + c32[None, :, 2] * dy32 * dy32) - c32[None, :, 1] * dx32 * dy32
+            a32 = torch.clamp(gop.to(f)[None, :] * torch.exp(p32), max=0.99)
+            valid = (p32 <= 0) & (a32 >= 1.0 / 255.0) & inside[:, None]
+            T32 = torch.cumprod(1.0 - torch.where(valid, a32, torch.zeros_like(a32)), 1)
+            stop = valid & (T32 < 1e-4)
+    else:
+        valid = (power.detach() <= 0) & (alpha.detach() >= 1.0 / 255.0) & inside[:, None]
+        stop = None
     a_eff = torch.where(valid, alpha, torch.zeros_like(alpha))
     one_m = 1.0 - a_eff
     Tincl = torch.cumprod(one_m, 1)                                         # T after splat i
     Texcl = torch.cat([torch.ones(256, 1, dtype=dt), Tincl[:, :-1]], 1)     # T before splat i
-    stop = valid & (Tincl.detach() < 1e-4)
+    if stop is None:
+        stop = valid & (Tincl.detach() < 1e-4)
     live = torch.cumsum(stop.to(torch.int32), 1) == 0                       # the stopping splat is excluded
     contrib = valid & live
     w = torch.where(contrib, a_eff * Texcl, torch.zeros_like(a_eff))
@@ -396,6 +417,7 @@ def rasterize_forward(means3D, means2D, shift_factors, shs, colors_precomp, opac
         keys_sorted, point_list, ranges, offsets = bin_and_sort(d32, pre.rect, pre.tiles_touched, gx, gy)
     st = OracleState()
     st.pre, st.s, st.dtype = pre, s, dtype
+    st.decide32 = discrete is not None and dtype != torch.float32
     st.keys_sorted, st.point_list, st.ranges, st.offsets = keys_sorted, point_list, ranges, offsets
     st.gx, st.gy, st.W, st.H = gx, gy, W, H
     bg = s.bg.to(dtype).reshape(3)
@@ -411,7 +433,7 @@ def rasterize_forward(means3D, means2D, shift_factors, shs, colors_precomp, opac
         for t in tile_ids:
             ty, tx = divmod(t, gx)
             ids = pl[int(ranges[t, 0]):int(ranges[t, 1])]
-            r = _blend_tile(ids, xy, conic, op, rgb, zd, bg, tx * TILE, ty * TILE, W, H)
+            r = _blend_tile(ids, xy, conic, op, rgb, zd, bg, tx * TILE, ty * TILE, W, H, decide32=st.decide32)
             y0, x0 = ty * TILE, tx * TILE
             hh, ww = min(TILE, H - y0), min(TILE, W - x0)
             image[:, y0:y0 + hh, x0:x0 + ww] = r["out"].reshape(TILE, TILE, 3)[:hh, :ww].permute(2, 0, 1)
@@ -446,7 +468,8 @@ def rasterize_backward(st: OracleState, grad_image: torch.Tensor, inputs: Dict[s
         if hi <= lo:
             continue
         ids = pl[lo:hi]
-        r = _blend_tile(ids, lxy, lcon, lop, lrgb, zd, bg, tx * TILE, ty * TILE, W, H, want_pairs=True)
+        r = _blend_tile(ids, lxy, lcon, lop, lrgb, zd, bg, tx * TILE, ty * TILE, W, H, want_pairs=True,
+                        decide32=st.decide32)
         y0, x0 = ty * TILE, tx * TILE
         hh, ww = min(TILE, H - y0), min(TILE, W - x0)
         g = torch.zeros(TILE, TILE, 3, dtype=dtype)

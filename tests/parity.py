@@ -85,8 +85,11 @@ def compare(scene, cam, deg, seed=1, check_fp64=True, **kw):
     # ---- floats
     img_err = (outs[0] - st32.image).abs() / (1.0 + st32.image.abs())
     rep["image_max_err_fp32"] = img_err.max().item()
-    rep["depth_max_err"] = ((outs[2] - st32.depth_img).abs() / (1.0 + st32.depth_img.abs())).max().item()
-    rep["weights_max_err"] = (outs[3] - st32.weights).abs().max().item()
+    d_err = (outs[2] - st32.depth_img).abs() / (1.0 + st32.depth_img.abs())
+    w_err = (outs[3] - st32.weights).abs()
+    rep["depth_max_err"], rep["weights_max_err"] = d_err.max().item(), w_err.max().item()
+    rep["depth_bad_frac"] = (d_err > 1e-4).float().mean().item()       # same flipped-pair caveat as the image
+    rep["weights_bad_frac"] = (w_err > 1e-4).float().mean().item()
     rep["mean2D_max_err"] = (outs[4] - st32.mean2D).abs().max().item()
     rep["grad_rel_fp32"] = {k: rel_err(grads[k], gr32[k]) for k in GRAD_NAMES if grads.get(k) is not None and k in gr32}
     if check_fp64:
@@ -106,14 +109,15 @@ INT_KEYS = ("radii_equal", "tiles_touched_equal", "rect_equal", "depth_bits_equa
             "ranges_equal")
 
 
-def assert_report(rep, grad_tol=1e-4, img_tol=1e-5, skip_zero=()):
+def assert_report(rep, grad_tol=1e-4, img_tol=1e-5, skip_zero=(), tol_override=None):
     for k in INT_KEYS:
         assert rep[k], f"{k} failed: {rep}"
     assert rep["num_rendered"][0] == rep["num_rendered"][1]
     assert rep["n_contrib_mismatch_frac"] <= 1e-4, rep["n_contrib_mismatch_frac"]
     # image: |d| <= 1e-5 (1+|x|) against the oracle; at most 2e-4 of the pixels may sit on a flipped threshold pair
     assert rep["image_bad_frac"] <= 2e-4 and rep["image_max_err"] <= 5e-3, (rep["image_bad_frac"], rep["image_max_err"])
-    assert rep["depth_max_err"] <= 1e-3 and rep["weights_max_err"] <= 1e-3 and rep["mean2D_max_err"] <= 1e-3
+    assert rep["depth_bad_frac"] <= 2e-4 and rep["weights_bad_frac"] <= 2e-4, (rep["depth_bad_frac"], rep["weights_bad_frac"])
+    assert rep["depth_max_err"] <= 5e-2 and rep["weights_max_err"] <= 2e-2 and rep["mean2D_max_err"] <= 1e-3
     # gradients: <= 1e-4 relative to the closer oracle (fp32 / fp64 walk), never worse than 2e-3 to the other one
     # (the two oracles themselves differ by that much when one of them flips a threshold pair: 'oracle32_vs_64')
     g32, g64 = rep.get("grad_rel_fp32", {}), rep.get("grad_rel_fp64", rep.get("grad_rel_fp32", {}))
@@ -121,5 +125,6 @@ def assert_report(rep, grad_tol=1e-4, img_tol=1e-5, skip_zero=()):
         if k in skip_zero:
             continue
         best, worst = min(g32[k], g64.get(k, g32[k])), max(g32[k], g64.get(k, g32[k]))
-        assert best <= grad_tol, f"grad[{k}]: best-of {best:.3e} > {grad_tol}: {rep}"
-        assert worst <= 2e-3, f"grad[{k}]: worst-of {worst:.3e}: {rep}"
+        tb, tw = (tol_override or {}).get(k, (grad_tol, 2e-3))
+        assert best <= tb, f"grad[{k}]: best-of {best:.3e} > {tb}: {rep}"
+        assert worst <= tw, f"grad[{k}]: worst-of {worst:.3e} > {tw}: {rep}"

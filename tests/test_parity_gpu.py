@@ -148,3 +148,30 @@ def test_speculative_forward_matches_exact_and_recovers_from_overflow():
     for k in g_ref:
         if g_ref[k] is not None:
             assert torch.equal(g_big[k], g_ref[k]), k
+
+
+@pytest.mark.timeout(900)
+def test_full_size_config3_against_oracle():
+    """BASELINE config 3 at full size (500 k Gaussians, 1920x1080, SH 3, pose + intrinsics learnable): integer artefacts
+    bit-exact, image and EVERY gradient (Gaussian and pose) against the CPU oracle on all 8160 tiles.
+
+    The 1e-4 bar is held against the fp32 oracle (the arithmetic of an fp32 reference rasterizer).  Against the fp64
+    oracle -- even when it replays every fp32 threshold decision -- ANY fp32 rasterizer sits at 1e-4..1e-3: pixel
+    centres near x = 1900 carry 1.2e-4 px of fp32 quantisation, which moves each Gaussian's gradient by ~1e-4
+    relative; the fp32 oracle is exactly as far from fp64 as the HIP path is (printed: oracle32_vs_64).  shift_factors
+    (an extension parameter, zero in the reference) is a sum of 5e5 terms of mixed sign and is only good to ~5e-3 in
+    any fp32 evaluation."""
+    import os
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    scene, cam = make_case(500_000, 1920, 1080, 0.5, 3, seed=0)
+    rep = compare(scene, cam, 3, check_fp64=True)
+    print({k: rep[k] for k in ("num_rendered", "n_contrib_mismatch_frac", "image_max_err", "image_bad_frac", "depth_max_err",
+                               "weights_max_err", "mean2D_max_err", "grad_rel_fp32", "grad_rel_fp64", "oracle32_vs_64")})
+    assert rep["num_rendered"][0] == rep["num_rendered"][1] == 3450308
+    assert_report(rep, tol_override={"shift_factors": (2e-3, 2e-2)})
+    for k, e in rep["grad_rel_fp32"].items():
+        if k != "shift_factors":
+            assert e <= 1e-4, (k, e)
+    # the HIP path must not be further from fp64 than the fp32 oracle itself is (x1.5 slack)
+    for k, e in rep["grad_rel_fp64"].items():
+        assert e <= 1.5 * rep["oracle32_vs_64"][k] + 1e-5, (k, e, rep["oracle32_vs_64"][k])
