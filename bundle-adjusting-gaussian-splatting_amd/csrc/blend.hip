@@ -104,15 +104,17 @@ struct __attribute__((aligned(16))) ChunkRec {
 //   [g0A g0B g1A g1B] [g2A g2B TfA TfB] [bgtA bgtB ncA ncB] [BcA BcB ScA ScB]
 struct __attribute__((aligned(16))) PixPair { float4 q0, q1, q2, q3; };
 
-// blocks of the tile a splat can reach with alpha >= 1/255 (conservative; exactness comes from the per-pixel test)
+// blocks of the tile a splat can reach with alpha >= 1/255 (conservative; exactness comes from the per-pixel test).
+// Branch-free: one thread evaluates all 16 blocks (the lanes of a wave hold unrelated splats, so early-outs would only
+// serialise).  Block (bx,by) is reachable iff the splat's bounding box overlaps it AND the Q-norm distance from the
+// splat centre to the block centre is within sqrt(2 ln(255 o)) + r_block (triangle inequality in the Q-norm).
 __device__ __forceinline__ u32 block_mask16(float x, float y, float a, float b, float c, float o, float X0, float Y0)
 {
     const float vis = 255.0f * o;
-    if (!(vis >= 0.99f)) return 0u;
     const float det = a * c - b * b;
-    if (!(det > 0.f) || !(a > 0.f) || !(c > 0.f)) return 0xFFFFu;
-    const float tau2 = 2.0f * (fmaxf(__logf(vis), 0.f) + 1e-3f);
-    const float idet = 1.0f / det;
+    const bool degenerate = !(det > 0.f) || !(a > 0.f) || !(c > 0.f);
+    const float tau2 = 2.0f * (fmaxf(__logf(fmaxf(vis, 1e-30f)), 0.f) + 1e-3f);
+    const float idet = __builtin_amdgcn_rcpf(det);
     const float hx = sqrtf(tau2 * c * idet) * 1.001f + 0.05f;
     const float hy = sqrtf(tau2 * a * idet) * 1.001f + 0.05f;
     // Q-norm radius of a 4x4 block around its centre: corners at (+-1.5, +-1.5)
@@ -120,21 +122,25 @@ __device__ __forceinline__ u32 block_mask16(float x, float y, float a, float b, 
     const float rb = sqrtf(fmaxf(qd + qo, qd - qo));
     const float lim = sqrtf(tau2) * 1.001f + rb + 1e-3f;
     const float lim2 = lim * lim;
+    const float xl = x - hx - X0, xh = x + hx - X0, yl = y - hy - Y0, yh = y + hy - Y0;   // box relative to the tile
+    const float ex = (X0 + 1.5f) - x, ey = (Y0 + 1.5f) - y;                               // centre of block (0,0) - splat
+    const float b2 = 2.f * b;
     u32 m = 0;
 #pragma unroll
     for (int by = 0; by < 4; ++by) {
-        const float y0 = Y0 + 4.f * by;
-        if (!((y + hy >= y0) && (y - hy <= y0 + 3.f))) continue;
-        const float dy = (y0 + 1.5f) - y;
+        const float dy = ey + 4.f * by;
+        const float cdy = c * dy * dy, bdy = b2 * dy;
+        const bool rowok = (yh >= 4.f * by) && (yl <= 4.f * by + 3.f);
 #pragma unroll
         for (int bx = 0; bx < 4; ++bx) {
-            const float x0 = X0 + 4.f * bx;
-            if (!((x + hx >= x0) && (x - hx <= x0 + 3.f))) continue;
-            const float dx = (x0 + 1.5f) - x;
-            const float Q = a * dx * dx + 2.f * b * dx * dy + c * dy * dy;      // squared Q-norm of centre offset
-            if (Q <= lim2) m |= 1u << (by * 4 + bx);
+            const float dx = ex + 4.f * bx;
+            const float Q = __fmaf_rn(dx, __fmaf_rn(a, dx, bdy), cdy);                    // squared Q-norm of centre offset
+            const bool ok = rowok && (xh >= 4.f * bx) && (xl <= 4.f * bx + 3.f) && (Q <= lim2);
+            m |= ok ? (1u << (by * 4 + bx)) : 0u;
         }
     }
+    if (degenerate) m = 0xFFFFu;
+    if (!(vis >= 0.99f)) m = 0u;
     return m;
 }
 
@@ -441,8 +447,11 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
 //     quadrants, four times as many waves to hide latency, no scalar branch inside the walk.
 // Compositing arithmetic per (pixel, splat) pair is pair_power2 / exp2 / the reference thresholds, shared with backward.
 // ================================================================================================================
+#ifndef FWD_WG_PER_CU
+#define FWD_WG_PER_CU 8       // forward workgroups per CU (= waves per SIMD): caps VGPRs at 64 (measured best of 5,6,8)
+#endif
 template <int DUMMY>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, FWD_WG_PER_CU)
 blend_fwd_rows_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ ranges, const u32* __restrict__ point_list,
                       const float4* __restrict__ g2d, const float* __restrict__ bg, float* __restrict__ out_color,
                       float* __restrict__ out_depth, float* __restrict__ out_weights, float* __restrict__ final_T,
