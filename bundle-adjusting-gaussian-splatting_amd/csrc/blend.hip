@@ -170,6 +170,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
     __shared__ unsigned char lists[16][CHUNK];       //  4 KB
     __shared__ float acc[4][CHUNK][12];              // 48 KB, one copy per wave (LDS float atomics on a shared copy were 1.6x slower)
     __shared__ u32 wmax[4];
+    __shared__ u32 blk_maxc[16];                     // last contributor over the 16 pixels of each block
 
 #ifdef DIAG_PHASES
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -193,7 +194,10 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
         pp[8 + h] = bgt; pp[10 + h] = __uint_as_float(nc); pp[12 + h] = 1.f; pp[14 + h] = 0.f;
         u32 m = nc;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) m = max(m, (u32)__shfl_xor((int)m, d));
+        for (int d = 8; d >= 1; d >>= 1) m = max(m, (u32)__shfl_xor((int)m, d));   // 16 consecutive threads = one block
+        if ((tid & 15) == 0) blk_maxc[b] = m;
+#pragma unroll
+        for (int d = 32; d >= 16; d >>= 1) m = max(m, (u32)__shfl_xor((int)m, d));
         if (lane == 0) wmax[wave] = m;
         __syncthreads();
         maxc = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
@@ -279,10 +283,11 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
             const int blk = j * 4 + wave;
             // ballot-compact the chunk's slots that reach this block (list order = depth order)
             int L = 0;
+            const u32 bmax = blk_maxc[blk];              // splats behind every pixel's last contributor cannot matter here
 #pragma unroll
             for (int r = 0; r < CHUNK / 64; ++r) {
                 const int slot = r * 64 + lane;
-                const bool hit = (recs[slot].mask >> blk) & 1u;
+                const bool hit = ((recs[slot].mask >> blk) & 1u) && (lo + (u32)slot < bmax);   // pos = lo + slot + 1
                 const u64 bal = __ballot(hit);
                 if (hit) lists[blk][L + __popcll(bal & lt_mask)] = (unsigned char)slot;
                 L += __popcll(bal);
