@@ -27,17 +27,23 @@ __device__ __forceinline__ float wave_sum(float x)
 }
 
 // K8a: each Gaussian's consecutive partial records (written by blend_bwd at its emission slots) summed in list order.
-// Light kernel (high occupancy, two records in flight per lane): the record stream is the only traffic.
+// Light kernel (high occupancy, two records in flight per lane): the record stream is the only traffic.  Gaussians with
+// more than SUM_COOP records are summed by the whole wave (lane k takes records k, k+64, ...; fixed-order shuffle
+// tree), so a splat covering thousands of tiles does not serialise one lane.
+#define SUM_COOP 64
 __global__ void __launch_bounds__(256)
 sum_partials_kernel(int P, const float4* __restrict__ g2d, const float* __restrict__ partials, float4* __restrict__ sums)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+    const int lane = threadIdx.x & 63;
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
-    const float4 q3 = g2d[4 * (size_t)i + 3];
-    const u32 nrec = __float_as_uint(q3.y);
-    if (nrec) {
-        const float4* rec = reinterpret_cast<const float4*>(partials + (size_t)__float_as_uint(q3.x) * PART_FLOATS);
+    u32 nrec = 0, first = 0;
+    if (i < P) {
+        const float4 q3 = g2d[4 * (size_t)i + 3];
+        nrec = __float_as_uint(q3.y); first = __float_as_uint(q3.x);
+    }
+    if (nrec > 0 && nrec <= SUM_COOP) {
+        const float4* rec = reinterpret_cast<const float4*>(partials + (size_t)first * PART_FLOATS);
         u32 r = 0;
         for (; r + 1 < nrec; r += 2) {
             const float4 a0 = rec[4 * r], b0 = rec[4 * r + 1], c0 = rec[4 * r + 2];
@@ -56,7 +62,31 @@ sum_partials_kernel(int P, const float4* __restrict__ g2d, const float* __restri
             s2.x += c0.x; s2.y += c0.y; s2.z += c0.z;
         }
     }
-    sums[3 * (size_t)i] = s0; sums[3 * (size_t)i + 1] = s1; sums[3 * (size_t)i + 2] = s2;
+    u64 big = __ballot(nrec > SUM_COOP);
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const u32 bn = __shfl(nrec, src), bf = __shfl(first, src);
+        const float4* rec = reinterpret_cast<const float4*>(partials + (size_t)bf * PART_FLOATS);
+        float v[11];
+#pragma unroll
+        for (int t = 0; t < 11; ++t) v[t] = 0.f;
+        for (u32 r = lane; r < bn; r += 64) {
+            const float4 a0 = rec[4 * r], b0 = rec[4 * r + 1], c0 = rec[4 * r + 2];
+            v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += b0.x; v[5] += b0.y; v[6] += b0.z; v[7] += b0.w;
+            v[8] += c0.x; v[9] += c0.y; v[10] += c0.z;
+        }
+#pragma unroll
+        for (int t = 0; t < 11; ++t) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v[t] += __shfl_xor(v[t], d);
+        }
+        if (lane == src) {
+            s0 = make_float4(v[0], v[1], v[2], v[3]); s1 = make_float4(v[4], v[5], v[6], v[7]);
+            s2 = make_float4(v[8], v[9], v[10], 0.f);
+        }
+    }
+    if (i < P) { sums[3 * (size_t)i] = s0; sums[3 * (size_t)i + 1] = s1; sums[3 * (size_t)i + 2] = s2; }
 }
 
 #ifndef PRE_BWD_WAVES

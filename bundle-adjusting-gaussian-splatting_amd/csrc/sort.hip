@@ -318,27 +318,49 @@ hipError_t launch_offsets_scan(const GeomView& g, const u32* sorted_ids, int P, 
 }
 
 // ------------------------------------------------------------------------------------------------ emission
-// One thread per depth rank: writes the Gaussian's rectangle of tiles (y outer, x inner) at its offset.
+// One thread per depth rank writes the Gaussian's rectangle of tiles (y outer, x inner) at its offset.  Rectangles of
+// more than EMIT_COOP tiles (a few huge splats can cover the whole image) are written by the whole wave instead, 64
+// consecutive instances per step, so no lane serialises thousands of stores.
+#define EMIT_COOP 32
 __global__ void __launch_bounds__(256)
 emit_kernel(const u32* __restrict__ sorted_ids, const u32* __restrict__ rank_offset, const uint2* __restrict__ rect,
             const u32* __restrict__ tiles_touched, int P, int grid_x, u32* __restrict__ keys, u32* __restrict__ vals,
             u32 capacity, const u32* __restrict__ n_dev)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= P) return;
-    const u32 g = sorted_ids[j];
-    if (tiles_touched[g] == 0) return;
-    const uint2 rc = rect[g];
-    const int minx = rc.x & 0xFFFF, miny = rc.x >> 16, maxx = rc.y & 0xFFFF, maxy = rc.y >> 16;
-    u32 off = rank_offset[j];
     if (n_dev && *n_dev > capacity) return;                 // speculative capacity exceeded: nothing is emitted, the caller reruns
-    if ((unsigned long long)off + tiles_touched[g] > (unsigned long long)capacity) return;
-    for (int y = miny; y < maxy; ++y)
-        for (int x = minx; x < maxx; ++x) {
-            keys[off] = (u32)(y * grid_x + x);
-            vals[off] = g;
-            ++off;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    u32 g = 0, nt = 0, off = 0;
+    uint2 rc = make_uint2(0u, 0u);
+    if (j < P) {
+        g = sorted_ids[j];
+        nt = tiles_touched[g];
+        if (nt) { rc = rect[g]; off = rank_offset[j]; }
+        if ((unsigned long long)off + nt > (unsigned long long)capacity) nt = 0;
+    }
+    if (nt > 0 && nt <= EMIT_COOP) {
+        const int minx = rc.x & 0xFFFF, miny = rc.x >> 16, maxx = rc.y & 0xFFFF, maxy = rc.y >> 16;
+        u32 o = off;
+        for (int y = miny; y < maxy; ++y)
+            for (int x = minx; x < maxx; ++x) {
+                keys[o] = (u32)(y * grid_x + x);
+                vals[o] = g;
+                ++o;
+            }
+    }
+    u64 big = __ballot(nt > EMIT_COOP);
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const u32 bg_ = __shfl(g, src), bn = __shfl(nt, src), bo = __shfl(off, src);
+        const u32 bx = __shfl(rc.x, src), by = __shfl(rc.y, src);
+        const int minx = bx & 0xFFFF, miny = bx >> 16, w = (int)(by & 0xFFFF) - minx;
+        for (u32 k = lane; k < bn; k += 64) {
+            const int y = miny + (int)(k / (u32)w), x = minx + (int)(k % (u32)w);
+            keys[bo + k] = (u32)(y * grid_x + x);
+            vals[bo + k] = bg_;
         }
+    }
 }
 
 hipError_t launch_emit(const GeomView& g, const u32* sorted_ids, int P, int grid_x, u32* keys, u32* vals, u32 capacity,

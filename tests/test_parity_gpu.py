@@ -175,3 +175,14 @@ def test_full_size_config3_against_oracle():
     # the HIP path must not be further from fp64 than the fp32 oracle itself is (x1.5 slack)
     for k, e in rep["grad_rel_fp64"].items():
         assert e <= 1.5 * rep["oracle32_vs_64"][k] + 1e-5, (k, e, rep["oracle32_vs_64"][k])
+
+
+def test_huge_splats_take_the_wave_cooperative_paths():
+    """A few splats that cover most of the image (hundreds of tiles each): emission and per-Gaussian record summation
+    switch to their wave-cooperative branches (> 32 / > 64 instances per Gaussian)."""
+    scene, cam = make_case(150, 256, 192, 25.0, 1, seed=17)
+    scene["opacities"] = scene["opacities"] * 0.5
+    rep = compare(scene, cam, 1)
+    _report({k: rep[k] for k in ("num_rendered", "image_max_err", "grad_rel_fp32", "grad_rel_fp64")})
+    assert rep["num_rendered"][0] > 150 * 64, rep["num_rendered"]        # well past both thresholds on average
+    assert_report(rep, grad_tol=2e-4)
