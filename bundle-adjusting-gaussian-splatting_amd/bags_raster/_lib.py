@@ -103,8 +103,9 @@ def check(rc: int, what: str) -> None:
         raise RuntimeError(f"{what}: {msg} (code {rc})")
 
 
-def profile_enable(on: bool) -> None:
-    load().bags_profile_enable(1 if on else 0)
+def profile_enable(mode) -> None:
+    """0/False off, 1 dominant kernel only, 2/True every stage."""
+    load().bags_profile_enable(2 if mode is True else int(mode))
 
 
 def profile_read():

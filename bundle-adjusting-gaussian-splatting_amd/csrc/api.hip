@@ -33,7 +33,7 @@ enum Stage { ST_PRE_FWD, ST_DEPTH_SORT, ST_OFFSETS, ST_EMIT, ST_TILE_SORT, ST_RA
 static const char* kStageNames[ST_COUNT] = {"preprocess_fwd", "depth_sort", "offsets_scan", "emit", "tile_sort",
                                             "tile_ranges", "blend_fwd", "blend_bwd", "preprocess_bwd", "pose_reduce"};
 struct ProfInterval { int stage; hipEvent_t a, b; };
-static bool g_prof_on = false;
+static int g_prof_mode = 0;          // 0 off, 1 dominant kernel only (blend_bwd), 2 every stage
 static std::vector<ProfInterval> g_prof_pending;
 static std::vector<hipEvent_t> g_prof_free;
 static double g_prof_ms[ST_COUNT];
@@ -46,7 +46,9 @@ static hipEvent_t prof_event()
 }
 struct ProfScope {
     hipStream_t st; int stage; hipEvent_t a = nullptr;
-    ProfScope(int stage_, hipStream_t st_) : st(st_), stage(stage_) { if (g_prof_on) { a = prof_event(); (void)hipEventRecord(a, st); } }
+    ProfScope(int stage_, hipStream_t st_) : st(st_), stage(stage_) {
+        if (g_prof_mode == 2 || (g_prof_mode == 1 && stage_ == ST_BLEND_BWD)) { a = prof_event(); (void)hipEventRecord(a, st); }
+    }
     ~ProfScope() { if (a) { hipEvent_t b = prof_event(); (void)hipEventRecord(b, st); g_prof_pending.push_back({stage, a, b}); } }
 };
 
@@ -318,9 +320,9 @@ int bags_debug_views(const BagsSettings* s, const BagsInputs* in, const BagsStat
     return BAGS_OK;
 }
 
-int bags_profile_enable(int on)
+int bags_profile_enable(int mode)
 {
-    g_prof_on = on != 0;
+    g_prof_mode = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
     return BAGS_OK;
 }
 

@@ -154,11 +154,12 @@ int bags_debug_views(const BagsSettings*, const BagsInputs*, const BagsState*, i
                      const BagsDebugViews*, void* stream);
 
 /* Opt-in per-stage device timing (hipEvents recorded on the caller's stream around each kernel group):
- * bench.py's roofline leg.  Off by default; the hot path records nothing unless enabled.
+ * bench.py's roofline leg.  mode 0 = off (default; the hot path records nothing), 1 = only the dominant kernel
+ * (blend_bwd: two events per step), 2 = every stage (each event pair costs a few microseconds of stream bubble).
  * bags_profile_read synchronises on the recorded events, returns the number of stages, fills up to `max_stages`
  * entries (stage name, summed milliseconds, number of timed intervals) and clears the accumulators. */
 #define BAGS_PROFILE_MAX_STAGES 16
-int bags_profile_enable(int on);
+int bags_profile_enable(int mode);
 int bags_profile_read(int max_stages, const char** names, double* total_ms, int64_t* calls);
 
 /* compute_relocation of the fork's MCMC path (utils/reloc_utils.py:11-13): its only caller is commented out in
