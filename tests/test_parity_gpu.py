@@ -186,3 +186,54 @@ def test_huge_splats_take_the_wave_cooperative_paths():
     _report({k: rep[k] for k in ("num_rendered", "image_max_err", "grad_rel_fp32", "grad_rel_fp64")})
     assert rep["num_rendered"][0] > 150 * 64, rep["num_rendered"]        # well past both thresholds on average
     assert_report(rep, grad_tol=2e-4)
+
+
+def test_bundle_adjustment_recovers_a_perturbed_pose():
+    """End-to-end use as in train.py (--opt_cam --opt_intrinsic): the four pose leaves of a camera (scene/cameras.py:99-110)
+    are optimised with Adam (scene/__init__.py:164-193) through the op's viewmatrix / projmatrix / intrinsic / campos
+    gradients and the photometric loss (train.py:311-325), Gaussians fixed.  The pose must move back towards the truth."""
+    import math
+    from bags_raster import GaussianRasterizationSettings, GaussianRasterizer
+    from bags_raster.loss import photometric_loss
+    from bags_raster.synth import look_at_origin_camera, synth_scene
+    dev = torch.device("cuda")
+    W, H = 160, 120
+    scene = {k: v.to(dev) for k, v in synth_scene(4000, 3, 2.0, 2).items()}
+    P = scene["means3D"].shape[0]
+
+    def render(cam):
+        st = GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+            bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=cam.get_world_view_transform(),
+            projmatrix=cam.get_full_proj_transform(), intrinsic=cam.get_intrinsic(), sh_degree=2,
+            campos=cam.get_camera_center(), prefiltered=False, debug=False, debug_iter=0)
+        img, radii, depth, weights, mean2D = GaussianRasterizer(st)(
+            means3D=scene["means3D"], means2D=torch.zeros(P, 3, device=dev), means2D_densify=torch.zeros(P, 3, device=dev),
+            shift_factors=torch.zeros(3, device=dev), shs=scene["shs"], colors_precomp=None, opacities=scene["opacities"],
+            scales=scene["scales"], rotations=scene["rotations"], cov3D_precomp=None)
+        return img
+
+    true_cam = look_at_origin_camera(W, H, device=dev)
+    with torch.no_grad():
+        target = render(true_cam)
+    cam = look_at_origin_camera(W, H, device=dev)
+    with torch.no_grad():
+        cam.delta_translation += torch.tensor([[0.06], [-0.04], [0.08]], device=dev)
+        cam.delta_quaternion += torch.tensor([0.0, 0.01, -0.012, 0.008], device=dev)
+        cam.learnable_fovx += 0.02
+    opt = torch.optim.Adam([{"params": [cam.delta_quaternion], "lr": 2e-3}, {"params": [cam.delta_translation], "lr": 5e-3},
+                            {"params": [cam.learnable_fovx, cam.learnable_fovy], "lr": 2e-3}])
+
+    def pose_err():
+        return (cam.delta_translation.norm() + cam.delta_quaternion[1:].norm() + (cam.learnable_fovx - true_cam.FoVx).abs()).item()
+    e0 = pose_err()
+    losses = []
+    for it in range(150):
+        opt.zero_grad(set_to_none=True)
+        loss = photometric_loss(render(cam), target)
+        loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in cam.pose_leaves())
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < 0.35 * losses[0], (losses[0], losses[-1])
+    assert pose_err() < 0.5 * e0, (e0, pose_err())
