@@ -168,6 +168,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
     __shared__ ChunkRec recs[CHUNK];                 // 12 KB
     __shared__ PixPair pix[128];                     //  8 KB
     __shared__ unsigned char lists[16][CHUNK];       //  4 KB
+    __shared__ u32 masks[CHUNK];                     //  1 KB: block reach masks, compact (the 48-B record stride bank-conflicts)
     __shared__ float acc[4][CHUNK][12];              // 48 KB, one copy per wave (LDS float atomics on a shared copy were 1.6x slower)
     __shared__ u32 wmax[4];
     __shared__ u32 blk_maxc[16];                     // last contributor over the 16 pixels of each block
@@ -270,7 +271,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
         const u32 cnt = min(hi, (u32)CHUNK);
         const u32 lo = hi - cnt;
         // ---- publish the staged chunk [lo, hi): slot s <-> list position lo + s (front to back)
-        if (tid < CHUNK) recs[tid] = rec;        // safe without a barrier: after the previous chunk's second barrier nobody reads recs
+        if (tid < CHUNK) { recs[tid] = rec; masks[tid] = rec.mask; }   // safe without a barrier: after the previous chunk's second barrier nobody reads them
         lds_barrier();
         PH_MARK(2);    // barrier 1
         __builtin_amdgcn_s_setprio(0);
@@ -278,6 +279,9 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
         const u32 gid2 = (lo > CHUNK) ? fetch_id(lo - CHUNK) : 0xFFFFFFFFu;          // ids of chunk k+2
 
         // ---- this wave's four blocks: one per block row, column = wave
+        u32 mreg[CHUNK / 64];
+#pragma unroll
+        for (int r = 0; r < CHUNK / 64; ++r) mreg[r] = masks[r * 64 + lane];
 #pragma unroll 1
         for (int j = 0; j < 4; ++j) {
             const int blk = j * 4 + wave;
@@ -287,7 +291,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
 #pragma unroll
             for (int r = 0; r < CHUNK / 64; ++r) {
                 const int slot = r * 64 + lane;
-                const bool hit = ((recs[slot].mask >> blk) & 1u) && (lo + (u32)slot < bmax);   // pos = lo + slot + 1
+                const bool hit = ((mreg[r] >> blk) & 1u) && (lo + (u32)slot < bmax);   // pos = lo + slot + 1
                 const u64 bal = __ballot(hit);
                 if (hit) lists[blk][L + __popcll(bal & lt_mask)] = (unsigned char)slot;
                 L += __popcll(bal);
@@ -472,6 +476,7 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
 
     __shared__ SplatRec recs[CHUNK];                 // x y ap bp | cp o r g | b z mask pos
     __shared__ unsigned char lists[16][CHUNK];
+    __shared__ u32 masks[CHUNK];
     __shared__ int s_live[4];
 
     const int bx = (wave & 1) * 2 + (row & 1), by = (wave >> 1) * 2 + (row >> 1), blk = by * 4 + bx;
@@ -504,7 +509,7 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
             rec.pos = base + tid + 1;
             rec.mask = block_mask16(c2.x, c2.y, co.x, co.y, co.z, co.w, X0, Y0);
         }
-        if (tid < CHUNK) recs[tid] = rec;
+        if (tid < CHUNK) { recs[tid] = rec; masks[tid] = rec.mask; }
         __syncthreads();
         if (live_b == 0ull) continue;                        // this quadrant is finished; keep pace at the barriers
         // ---- per-row lists (rows whose 16 pixels are all done take nothing)
@@ -514,7 +519,7 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
 #pragma unroll
         for (int rnd = 0; rnd < CHUNK / 64; ++rnd) {
             const int slot = rnd * 64 + lane;
-            const u32 m = recs[slot].mask >> qb;             // bits 0,1,4,5 = this wave's rows 0..3
+            const u32 m = masks[slot] >> qb;                 // bits 0,1,4,5 = this wave's rows 0..3
             const bool h0 = r0 && (m & 1u), h1 = r1 && (m & 2u), h2 = r2 && (m & 16u), h3 = r3 && (m & 32u);
             const u64 b0 = __ballot(h0), b1 = __ballot(h1), b2 = __ballot(h2), b3 = __ballot(h3);
             if (h0) lists[qb][L0 + __popcll(b0 & lt_mask)] = (unsigned char)slot;

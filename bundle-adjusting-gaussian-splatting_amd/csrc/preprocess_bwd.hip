@@ -149,6 +149,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         const float dpx = -(co.x * Mx + co.y * My);         // dL/d centre (pixel units)
         const float dpy = -(co.z * My + co.y * Mx);
         const float gA = -0.5f * Mxx, gB = -Mxy, gC = -0.5f * Myy;   // dL/dconic
+
         gm2x = dpx * (0.5f * (float)W); gm2y = dpy * (0.5f * (float)H);
         gdx = s[9] * (0.5f * (float)W); gdy = s[10] * (0.5f * (float)H);
 
@@ -190,10 +191,11 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         const float fx = k[0] * (0.5f * (float)W), fy = k[5] * (0.5f * (float)H);
         const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
         const float itz = 1.0f / tzs;
-        const float txtz = tx * itz, tytz = ty * itz;
+        const float txtz = tx / tzs, tytz = ty / tzs;                 // same expressions as preprocess_fwd
         const bool clx = (txtz < -limx) || (txtz > limx), cly = (tytz < -limy) || (tytz > limy);
         const float ux = fminf(limx, fmaxf(-limx, txtz)), uy = fminf(limy, fmaxf(-limy, tytz));
-        const float j00 = fx * itz, j02 = -fx * ux * itz, j11 = fy * itz, j12 = -fy * uy * itz;
+        const float itz2 = itz * itz;
+        const float j00 = fx * itz, j02 = -(fx * (ux * tzs)) * itz2, j11 = fy * itz, j12 = -(fy * (uy * tzs)) * itz2;
         const float a00 = j00 * v[0] + j02 * v[2], a01 = j00 * v[4] + j02 * v[6], a02 = j00 * v[8] + j02 * v[10];
         const float a10 = j11 * v[1] + j12 * v[2], a11 = j11 * v[5] + j12 * v[6], a12 = j11 * v[9] + j12 * v[10];
         const float b00 = a00 * c0 + a01 * c1 + a02 * c2, b01 = a00 * c1 + a01 * c3 + a02 * c4, b02 = a00 * c2 + a01 * c4 + a02 * c5;
@@ -201,13 +203,19 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         const float cxx = b00 * a00 + b01 * a01 + b02 * a02 + 0.3f;
         const float cxy = b00 * a10 + b01 * a11 + b02 * a12;
         const float cyy = b10 * a10 + b11 * a11 + b12 * a12 + 0.3f;
+        // ---- 3. conic -> cov2D.  For needle-shaped splats (lambda1 >> lambda2) dL/dcov2D is ~ g n n^T (n = thin axis) and
+        // the next step multiplies it by B = A Sigma, whose component along the long axis is lambda1/lambda2 times larger
+        // than the one that matters: the long-axis component of dL/dcov2D must be accurate to ~1e-7 of the WHOLE matrix.
+        // The expanded polynomial -Q G Q (three products of size |G|/lambda2^2 per entry) is not, and gave O(1) errors at
+        // 1500:1 anisotropy; the two-step form below (trace term first, then one two-term difference per entry) keeps
+        // that component at rounding level.  It is the order reverse-mode differentiation of the forward lines produces.
+        // The file is compiled with -ffp-contract=off so cov2D and det are bit-identical to what preprocess_fwd used.
         const float det = cxx * cyy - cxy * cxy;
         const float di = 1.0f / det, di2 = di * di;
-
-        // ---- 3. conic -> cov2D
-        const float dcxx = di2 * (-gA * cyy * cyy + gB * cxy * cyy - gC * cxy * cxy);
-        const float dcyy = di2 * (-gA * cxy * cxy + gB * cxy * cxx - gC * cxx * cxx);
-        const float dcxy = di2 * (2.f * gA * cyy * cxy + 2.f * gC * cxx * cxy) - gB * (di + 2.f * cxy * cxy * di2);
+        const float ddet = -((gA * cyy - gB * cxy + gC * cxx) * di2);
+        const float dcxx = gC * di + ddet * cyy;
+        const float dcyy = gA * di + ddet * cxx;
+        const float dcxy = -(gB * di) - 2.f * (ddet * cxy);
         // cov2D -> Sigma (unique entries)
         gc[0] = dcxx * a00 * a00 + dcxy * a00 * a10 + dcyy * a10 * a10;
         gc[3] = dcxx * a01 * a01 + dcxy * a01 * a11 + dcyy * a11 * a11;

@@ -307,7 +307,9 @@ def preprocess(means3D, means2D, shift_factors, shs, colors_precomp, opacities, 
     return Preprocessed(xy=full(torch.stack([px, py], 1)), conic=full(torch.stack([con_a, con_b, con_c], 1)),
                         opacity=full(op_s.reshape(n)), rgb=full(rgb), depth=full(depth), radii=radii, rect=rect,
                         tiles_touched=tiles_touched, clamped=full(clamped_s, False), visible=visible,
-                        extras={"cov2d": full(torch.stack([cxx, cxy, cyy], 1)), "tz": full(tzs)})
+                        extras={"cov2d": full(torch.stack([cxx, cxy, cyy], 1)), "tz": full(tzs),
+                                "_graph": {"idx": idx, "cov": (cxx, cxy, cyy), "A": (a00, a01, a02, a10, a11, a12),
+                                           "sigma": (c0, c1, c2, c3, c4, c5)}})
 
 
 def bin_and_sort(depth32: torch.Tensor, rect: torch.Tensor, tiles_touched: torch.Tensor, gx: int, gy: int):

@@ -97,7 +97,10 @@ def compare(scene, cam, deg, seed=1, check_fp64=True, **kw):
         rep["grad_rel_fp64"] = {k: rel_err(grads[k], gr64[k]) for k in GRAD_NAMES if grads.get(k) is not None and k in gr64}
         rep["oracle32_vs_64"] = {k: rel_err(gr32[k], gr64[k]) for k in GRAD_NAMES if k in gr32 and k in gr64}
         img64 = st64.image.float()
-        img_err = torch.minimum(img_err, (outs[0] - img64).abs() / (1.0 + img64.abs()))
+        err64 = (outs[0] - img64).abs() / (1.0 + img64.abs())
+        rep["image_max_err_fp64"] = err64.max().item()
+        rep["oracle32_vs_64_image_max"] = ((st32.image - img64).abs() / (1.0 + img64.abs())).max().item()
+        img_err = torch.minimum(img_err, err64)
     # A pixel counts as wrong only if it disagrees with BOTH oracles: alpha>=1/255, power<=0 and T<1e-4 are hard
     # thresholds, so an ulp of difference in exp() flips a (pixel, splat) pair in any one implementation.
     rep["image_max_err"] = img_err.max().item()
@@ -107,6 +110,21 @@ def compare(scene, cam, deg, seed=1, check_fp64=True, **kw):
 
 INT_KEYS = ("radii_equal", "tiles_touched_equal", "rect_equal", "depth_bits_equal", "point_list_equal", "keys_equal",
             "ranges_equal")
+
+
+def assert_ill_conditioned(rep, slack=3.0, floor=1e-4):
+    """Cases whose fp32 evaluation is itself ill-conditioned (needle-shaped splats: the conic quadratic form and
+    det(cov2D) cancel by ~1e5).  Integers stay bit-exact; floats are held to the accuracy the fp32 ORACLE achieves
+    against the fp64 oracle on the same input: HIP may be at most `slack` x as far from fp64 as the fp32 oracle is."""
+    for k in INT_KEYS:
+        assert rep[k], f"{k} failed: {rep}"
+    assert rep["num_rendered"][0] == rep["num_rendered"][1]
+    assert rep["n_contrib_mismatch_frac"] <= 1e-3, rep["n_contrib_mismatch_frac"]
+    assert rep["image_max_err_fp64"] <= slack * rep["oracle32_vs_64_image_max"] + 1e-5, \
+        (rep["image_max_err_fp64"], rep["oracle32_vs_64_image_max"])
+    for k, ref in rep["oracle32_vs_64"].items():
+        if k in rep["grad_rel_fp64"]:
+            assert rep["grad_rel_fp64"][k] <= slack * ref + floor, f"grad[{k}]: {rep['grad_rel_fp64'][k]:.3e} vs oracle32 {ref:.3e}"
 
 
 def assert_report(rep, grad_tol=1e-4, img_tol=1e-5, skip_zero=(), tol_override=None):
