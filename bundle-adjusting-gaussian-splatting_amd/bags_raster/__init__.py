@@ -6,5 +6,8 @@ Mirrors the operator API of the reference's ``diff_gaussian_rasterization`` pack
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians, debug_views,
                          compute_relocation)
 
+from .render import render, PipelineParams
+from .gaussians import GaussianBag, eval_sh
+
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "debug_views",
-           "compute_relocation"]
+           "compute_relocation", "render", "PipelineParams", "GaussianBag", "eval_sh"]

@@ -6,6 +6,9 @@ inputs and expected outputs are stored).
   camera_chain.npz  utils/graphics_utils.py:83-107 getProjectionMatrix (values + d/dfov),
                     scene/cameras.py:399-416 quaternion_to_rotation_matrix (values + Jacobian)
   loss.npz          utils/loss_utils.py l1_loss / ssim on seeded images (the loss that produces dL/dimage)
+  gaussian_activations.npz  utils/general_utils.py:114-163 build_rotation / build_scaling_rotation / strip_lowerdiag and
+                    scene/gaussian_model.py:27-31 covariance activation (values + d/d{scaling, rotation}),
+                    gaussian_renderer/__init__.py:19-28 quaternion_multiply, utils/general_utils.py inverse_sigmoid
 
 Functions whose modules cannot be imported off-GPU (default arguments call .cuda()) are extracted by name from the
 module AST and exec'd in isolation.
@@ -19,10 +22,22 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REF)
 
 
-def extract(path, names):
+class _CpuTorch:
+    """`torch` as seen by extracted functions that allocate with a hard-coded device="cuda": the allocation lands on
+    the CPU instead.  Nothing else is changed."""
+    def __getattr__(self, name):
+        return getattr(torch, name)
+
+    @staticmethod
+    def zeros(*a, **k):
+        k.pop("device", None)
+        return torch.zeros(*a, **k)
+
+
+def extract(path, names, cpu_alloc=False):
     src = open(os.path.join(REF, path)).read()
     tree = ast.parse(src)
-    ns = {"torch": torch, "math": math, "np": np}
+    ns = {"torch": _CpuTorch() if cpu_alloc else torch, "math": math, "np": np}
     for node in tree.body:
         if isinstance(node, ast.FunctionDef) and node.name in names:
             exec(compile(ast.Module([node], []), path, "exec"), ns)
@@ -75,6 +90,32 @@ def main():
     (ga,) = torch.autograd.grad(loss, a)
     np.savez(os.path.join(OUT, "loss.npz"), a=a.detach().numpy(), b=b.numpy(), l1=l1.item(), ssim=s.item(),
              loss=loss.item(), dloss_da=ga.numpy())
+
+    # ---- Gaussian activations feeding the op
+    names = ["strip_lowerdiag", "strip_symmetric", "build_rotation", "build_scaling_rotation", "inverse_sigmoid"]
+    strip_lowerdiag, strip_symmetric, build_rotation, build_scaling_rotation, inverse_sigmoid = \
+        extract("utils/general_utils.py", names, cpu_alloc=True)
+    build_scaling_rotation.__globals__["build_rotation"] = build_rotation
+    strip_symmetric.__globals__["strip_lowerdiag"] = strip_lowerdiag
+    (quaternion_multiply,) = extract("gaussian_renderer/__init__.py", ["quaternion_multiply"])
+    N = 12
+    s_ = torch.exp(0.5 * torch.randn(N, 3, generator=g)); r_ = torch.randn(N, 4, generator=g)
+
+    def covariance(scaling, modifier, rotation):          # scene/gaussian_model.py:27-31, line for line
+        Lm = build_scaling_rotation(modifier * scaling, rotation)
+        return strip_symmetric(Lm @ Lm.transpose(1, 2))
+    act = {"scaling": s_.numpy(), "rotation": r_.numpy(), "R": build_rotation(r_).numpy(),
+           "L": build_scaling_rotation(s_, r_).numpy(), "cov_mod1": covariance(s_, 1.0, r_).numpy(),
+           "cov_mod07": covariance(s_, 0.7, r_).numpy()}
+    sg = s_.clone().requires_grad_(True); rg = r_.clone().requires_grad_(True)
+    wts = torch.randn(N, 6, generator=g)
+    (covariance(sg, 0.7, rg) * wts).sum().backward()
+    act["cov_weights"] = wts.numpy(); act["dcov_dscaling"] = sg.grad.numpy(); act["dcov_drotation"] = rg.grad.numpy()
+    qa = torch.randn(5, 4, generator=g); qb = torch.randn(5, 4, generator=g)
+    act["qa"] = qa.numpy(); act["qb"] = qb.numpy(); act["qa_qb"] = quaternion_multiply(qa, qb).numpy()
+    pr = torch.rand(9, generator=g) * 0.98 + 0.01
+    act["p"] = pr.numpy(); act["inverse_sigmoid_p"] = inverse_sigmoid(pr).numpy()
+    np.savez(os.path.join(OUT, "gaussian_activations.npz"), **act)
     print("golden vectors written to", OUT)
 
 

@@ -73,3 +73,63 @@ def test_pose_camera_chain_consistency():
     s = c.get_full_proj_transform().sum() + c.get_camera_center().sum()
     grads = torch.autograd.grad(s, c.pose_leaves())
     assert all(torch.isfinite(g).all() and g.abs().sum() > 0 for g in grads)
+
+
+def test_product_eval_sh_matches_reference(golden_dir):
+    """bags_raster.gaussians.eval_sh is the colour path render() takes for hybrid / convert_SHs_python
+    (gaussian_renderer/__init__.py:90-95): same (…, C, K) layout as utils/sh_utils.py:57."""
+    from bags_raster import gaussians as G
+    g = np.load(os.path.join(golden_dir, "sh_basis.npz"))
+    sh, d = torch.from_numpy(g["sh"]), torch.from_numpy(g["dirs"])
+    for deg in range(4):
+        np.testing.assert_allclose(G.eval_sh(deg, sh, d).numpy(), g[f"rgb_deg{deg}"], rtol=1e-5, atol=1e-6)
+    rgb = torch.from_numpy(g["rgb_in"])
+    np.testing.assert_allclose(G.RGB2SH(rgb).numpy(), g["rgb2sh"], rtol=1e-6)
+    np.testing.assert_allclose(G.SH2RGB(G.RGB2SH(rgb)).numpy(), g["sh2rgb"], rtol=1e-6)
+
+
+def test_gaussian_activations_match_reference(golden_dir):
+    """build_rotation / build_scaling_rotation / strip_lowerdiag / covariance activation / quaternion_multiply /
+    inverse_sigmoid against the reference's own functions (utils/general_utils.py:114-163,
+    scene/gaussian_model.py:27-31, gaussian_renderer/__init__.py:19-28)."""
+    from bags_raster import gaussians as G
+    from bags_raster.render import quaternion_multiply
+    g = np.load(os.path.join(golden_dir, "gaussian_activations.npz"))
+    s, r = torch.from_numpy(g["scaling"]), torch.from_numpy(g["rotation"])
+    np.testing.assert_allclose(G.build_rotation(r).numpy(), g["R"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(G.build_scaling_rotation(s, r).numpy(), g["L"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(G.covariance_from_scaling_rotation(s, 1.0, r).numpy(), g["cov_mod1"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(G.covariance_from_scaling_rotation(s, 0.7, r).numpy(), g["cov_mod07"], rtol=1e-5, atol=1e-7)
+    sg, rg = s.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    (G.covariance_from_scaling_rotation(sg, 0.7, rg) * torch.from_numpy(g["cov_weights"])).sum().backward()
+    np.testing.assert_allclose(sg.grad.numpy(), g["dcov_dscaling"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(rg.grad.numpy(), g["dcov_drotation"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(quaternion_multiply(torch.from_numpy(g["qa"]), torch.from_numpy(g["qb"])).numpy(), g["qa_qb"],
+                               rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(G.inverse_sigmoid(torch.from_numpy(g["p"])).numpy(), g["inverse_sigmoid_p"], rtol=1e-6)
+
+
+def test_gaussian_bag_round_trips_activations():
+    """from_activated inverts exp / sigmoid / keeps unit quaternions: the activated values come back, get_features has the
+    (P,K,3) layout the op takes, and the densification accumulators consume .grad[:, :2] norms
+    (scene/gaussian_model.py:449-455)."""
+    from bags_raster import gaussians as G
+    from bags_raster.synth import synth_scene
+    sc = synth_scene(50, 3, 0.5, 3)
+    pc = G.GaussianBag.from_activated(sc, 3)
+    assert pc.active_sh_degree == 3 and pc.max_sh_degree == 3
+    np.testing.assert_allclose(pc.get_scaling.detach().numpy(), sc["scales"].numpy(), rtol=1e-6)
+    np.testing.assert_allclose(pc.get_opacity.detach().numpy(), sc["opacities"].numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(pc.get_rotation.detach().numpy(), sc["rotations"].numpy(), rtol=1e-6, atol=1e-7)
+    assert pc.get_features.shape == (50, 16, 3) and torch.equal(pc.get_features.detach(), sc["shs"])
+    cov = pc.get_covariance(1.0)
+    L = G.build_scaling_rotation(sc["scales"], sc["rotations"])
+    np.testing.assert_allclose(cov.detach().numpy(), G.strip_symmetric(L @ L.transpose(1, 2)).numpy(), rtol=1e-5, atol=1e-9)
+    vp = torch.zeros(50, 3, requires_grad=True); vpd = torch.zeros(50, 3, requires_grad=True)
+    vp.grad = torch.ones(50, 3) * 3.0; vpd.grad = torch.ones(50, 3) * 4.0
+    flt = torch.arange(50) % 2 == 0
+    pc.add_densification_stats(vp, vpd, flt, abs_grad=False)
+    pc.add_densification_stats(vp, vpd, flt, abs_grad=True)
+    want = (3.0 + 4.0) * (2.0 ** 0.5)
+    assert torch.allclose(pc.xyz_gradient_accum[flt], torch.full((25, 1), want)) and (pc.xyz_gradient_accum[~flt] == 0).all()
+    assert (pc.denom[flt] == 2).all()

@@ -267,3 +267,55 @@ def test_extreme_inputs_match_oracle(case):
         assert_ill_conditioned(rep)
     else:
         assert_report(rep, grad_tol=3e-4, tol_override={"shift_factors": (1e-3, 1e-2)})
+
+
+@pytest.mark.gpu
+def test_render_caller_paths_agree_and_match_oracle():
+    """render() (mirror of gaussian_renderer/__init__.py:30-133) assembles the op's arguments three ways -- rasterizer-side
+    SH + scales/rotations, convert_SHs_python (eval_sh + 0.5, clamp), compute_cov3D_python (strip(L L^T)).  All three must
+    render the same image and send the same gradients to the RAW leaves (pre-activation parameters and the four pose
+    leaves of the camera), and the default path must match the oracle fed with the activated values."""
+    from bags_raster.gaussians import GaussianBag
+    from bags_raster.render import render, PipelineParams
+    from bags_raster.synth import sphere_views
+    dev = "cuda"
+    P, W, H = 1500, 160, 128
+    scene, _ = make_case(P, W, H, 1.5, 3, seed=17)
+    cam = sphere_views(3, W, H, noise=0.05, device=dev)[2]
+    cam0 = sphere_views(3, W, H, noise=0.05)[2]
+    gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(3)).to(dev)
+    bgc = torch.tensor([0.2, 0.1, 0.3], device=dev)
+    results = {}
+    for name, pipe in (("default", PipelineParams()), ("sh_python", PipelineParams(convert_SHs_python=True)),
+                       ("cov_python", PipelineParams(compute_cov3D_python=True))):
+        pc = GaussianBag.from_activated(scene, 3, device=dev)
+        for p_ in cam.pose_leaves():
+            p_.grad = None
+        out = render(cam, pc, pipe, bgc, scaling_modifier=0.9)
+        assert set(out) == {"render", "viewspace_points", "viewspace_points_densify", "visibility_filter", "radii", "depth",
+                            "weights", "means2D"}
+        out["render"].backward(gimg)
+        assert out["viewspace_points"].grad is not None and out["viewspace_points_densify"].grad is not None
+        assert torch.equal(out["visibility_filter"], out["radii"] > 0)
+        results[name] = dict(img=out["render"].detach().cpu(), radii=out["radii"].cpu(),
+                             leaves=[t.grad.detach().cpu().clone() for t in pc.leaves()],
+                             pose=[t.grad.detach().cpu().clone() for t in cam.pose_leaves()],
+                             vp=out["viewspace_points"].grad.detach().cpu(), vpd=out["viewspace_points_densify"].grad.detach().cpu())
+    ref = results["default"]
+    for name in ("sh_python", "cov_python"):
+        r = results[name]
+        assert torch.equal(r["radii"], ref["radii"])
+        assert (r["img"] - ref["img"]).abs().max().item() < 2e-5, name
+        for a, b in zip(r["leaves"] + r["pose"] + [r["vp"], r["vpd"]], ref["leaves"] + ref["pose"] + [ref["vp"], ref["vpd"]]):
+            assert rel_err(a, b) < 2e-4, (name, rel_err(a, b))
+    # default path against the oracle on activated values (same camera on the CPU)
+    st32, gr32 = run_oracle(scene, cam0, 3, gimg.cpu(), torch.float32, bg=bgc.cpu(), scale_modifier=0.9)
+    assert torch.equal(ref["radii"], st32.radii)
+    assert ((ref["img"] - st32.image).abs() / (1 + st32.image.abs())).max().item() < 5e-5
+    # chain the oracle's gradients w.r.t. activated values to the raw leaves with autograd on the CPU
+    pc = GaussianBag.from_activated(scene, 3)
+    acts = [pc.get_xyz, pc.get_features, pc.get_opacity, pc.get_scaling, pc.get_rotation]
+    cots = [gr32["means3D"], gr32["shs"], gr32["opacities"], gr32["scales"], gr32["rotations"]]
+    want = torch.autograd.grad(acts, pc.leaves(), cots)
+    for a, b in zip(ref["leaves"], want):
+        assert rel_err(a, b) < 3e-4, rel_err(a, b)
