@@ -72,6 +72,11 @@ SYMBOLS = {
                                    C.POINTER(BagsDebugViews), C.c_void_p]),
     "bags_profile_enable": (C.c_int, [C.c_int]),
     "bags_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "bags_loss_workspace_size": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "bags_loss_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
+                                    C.c_void_p, C.c_void_p]),
+    "bags_loss_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "bags_compute_relocation": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int32, C.c_int32, c_fp, c_fp, C.c_void_p]),
 }
 

@@ -1,6 +1,13 @@
 """Photometric loss that produces dL/dimage for the op: 0.8*L1 + 0.2*(1-SSIM)  (train.py:311-313,325;
-utils/loss_utils.py:18-76).  Plain PyTorch (host-side plumbing); the 11x11 Gaussian window is applied as two 1-D
-passes, which is the same linear filter as the reference's dense 11x11 conv.  Pinned by tests/golden/loss.npz."""
+utils/loss_utils.py:18-76).
+
+Two implementations with the reference's names and semantics:
+  * ``l1_loss / ssim / photometric_loss``        plain PyTorch (any device); the 11x11 Gaussian window is applied as two
+    1-D passes, which is the same linear filter as the reference's dense 11x11 conv.
+  * ``fused_l1_ssim / fused_photometric_loss``   the HIP kernels of csrc/loss.hip behind ``bags_loss_forward`` /
+    ``bags_loss_backward`` (include/bags_raster.h): one forward and one backward kernel instead of ~50 launches.
+    GPU tensors only; there is no fallback.
+Both are pinned by tests/golden/loss.npz (values and dL/dimage from the reference's own functions)."""
 from __future__ import annotations
 
 import math
@@ -39,3 +46,60 @@ def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11) -> torch
 
 def photometric_loss(image: torch.Tensor, gt: torch.Tensor, lambda_dssim: float = 0.2) -> torch.Tensor:
     return (1.0 - lambda_dssim) * l1_loss(image, gt) + lambda_dssim * (1.0 - ssim(image, gt))
+
+
+# ------------------------------------------------------------------------------------------------ fused HIP path
+class _FusedL1SSIM(torch.autograd.Function):
+    """(image, gt) -> (mean |image - gt|, mean SSIM), differentiable w.r.t. ``image``."""
+
+    @staticmethod
+    def forward(ctx, image: torch.Tensor, gt: torch.Tensor):
+        from . import _lib as L
+        for name, t in (("image", image), ("gt", gt)):
+            if not t.is_cuda:
+                raise RuntimeError(f"fused_l1_ssim: {name} must be a GPU tensor (the fused loss has no CPU path; "
+                                   f"use bags_raster.loss.l1_loss / ssim on the host)")
+            if t.dtype != torch.float32:
+                raise RuntimeError(f"fused_l1_ssim: {name} must be float32, got {t.dtype}")
+        if image.shape != gt.shape or image.dim() != 3:
+            raise RuntimeError(f"fused_l1_ssim: expected two (C,H,W) tensors of one shape, got {tuple(image.shape)} and {tuple(gt.shape)}")
+        lib = L.load()
+        image, gt = image.contiguous(), gt.contiguous()
+        Cn, H, W = image.shape
+        with torch.cuda.device(image.device):
+            nbytes = lib.bags_loss_workspace_size(Cn, H, W)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=image.device)
+            terms = torch.empty(2, dtype=torch.float32, device=image.device)
+            stream = torch.cuda.current_stream().cuda_stream
+            L.check(lib.bags_loss_forward(image.data_ptr(), gt.data_ptr(), Cn, H, W, ws.data_ptr(), nbytes,
+                                          terms.data_ptr(), stream), "bags_loss_forward")
+        ctx.save_for_backward(image, gt, ws)
+        return terms[0], terms[1]
+
+    @staticmethod
+    def backward(ctx, g_l1, g_ssim):
+        from . import _lib as L
+        image, gt, ws = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None
+        lib = L.load()
+        Cn, H, W = image.shape
+        z = torch.zeros((), dtype=torch.float32, device=image.device)
+        gt_terms = torch.stack([z if g_l1 is None else g_l1.to(torch.float32), z if g_ssim is None else g_ssim.to(torch.float32)]).contiguous()
+        grad = torch.empty_like(image)
+        with torch.cuda.device(image.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            L.check(lib.bags_loss_backward(image.data_ptr(), gt.data_ptr(), Cn, H, W, ws.data_ptr(), ws.numel(),
+                                           gt_terms.data_ptr(), grad.data_ptr(), stream), "bags_loss_backward")
+        return grad, None
+
+
+def fused_l1_ssim(image: torch.Tensor, gt: torch.Tensor):
+    """(l1_loss(image, gt), ssim(image, gt)) of utils/loss_utils.py in one HIP kernel; both scalars carry gradient."""
+    return _FusedL1SSIM.apply(image, gt)
+
+
+def fused_photometric_loss(image: torch.Tensor, gt: torch.Tensor, lambda_dssim: float = 0.2) -> torch.Tensor:
+    """train.py:325: (1 - lambda) L1 + lambda (1 - SSIM)."""
+    l1, s = fused_l1_ssim(image, gt)
+    return (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - s)

@@ -346,6 +346,35 @@ int bags_profile_read(int max_stages, const char** names, double* total_ms, int6
     return (int)ST_COUNT;
 }
 
+// ---------------------------------------------------------------------------------------------- photometric loss
+size_t bags_loss_workspace_size(int32_t C, int32_t H, int32_t W)
+{
+    if (C <= 0 || H <= 0 || W <= 0) return 256;
+    return loss_workspace_bytes(C, H, W);
+}
+
+int bags_loss_forward(const float* image, const float* gt, int32_t C, int32_t H, int32_t W, void* workspace,
+                      size_t workspace_bytes, float* out_terms, void* stream)
+{
+    if (C <= 0 || H <= 0 || W <= 0) return fail(BAGS_ERR_ARG, "loss_forward: C, H, W must be positive (got %d, %d, %d)", C, H, W);
+    if (!image || !gt || !workspace || !out_terms) return fail(BAGS_ERR_ARG, "loss_forward: null pointer");
+    if (workspace_bytes < loss_workspace_bytes(C, H, W))
+        return fail(BAGS_ERR_SIZE, "loss_forward: workspace %zu bytes < %zu", workspace_bytes, loss_workspace_bytes(C, H, W));
+    HIP_TRY(launch_loss_fwd(image, gt, C, H, W, workspace, out_terms, (hipStream_t)stream));
+    return BAGS_OK;
+}
+
+int bags_loss_backward(const float* image, const float* gt, int32_t C, int32_t H, int32_t W, const void* workspace,
+                       size_t workspace_bytes, const float* grad_terms, float* grad_image, void* stream)
+{
+    if (C <= 0 || H <= 0 || W <= 0) return fail(BAGS_ERR_ARG, "loss_backward: C, H, W must be positive (got %d, %d, %d)", C, H, W);
+    if (!image || !gt || !workspace || !grad_terms || !grad_image) return fail(BAGS_ERR_ARG, "loss_backward: null pointer");
+    if (workspace_bytes < loss_workspace_bytes(C, H, W))
+        return fail(BAGS_ERR_SIZE, "loss_backward: workspace %zu bytes < %zu", workspace_bytes, loss_workspace_bytes(C, H, W));
+    HIP_TRY(launch_loss_bwd(image, gt, C, H, W, workspace, grad_terms, grad_image, (hipStream_t)stream));
+    return BAGS_OK;
+}
+
 int bags_compute_relocation(const float*, const float*, const int32_t*, const float*, int32_t, int32_t, float*, float*, void*)
 {
     return fail(BAGS_ERR_ARG, "compute_relocation: the reference's only caller is commented out (scene/gaussian_model.py:23,494-504); not implemented");

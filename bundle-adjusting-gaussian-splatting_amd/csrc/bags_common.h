@@ -88,5 +88,10 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
 hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, const int32_t* radii_or_null,
                                  const float* partials, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a, hipStream_t st, float* sums);
 hipError_t launch_pose_reduce(const float* pose_slab, int nblocks, const BagsBackwardArgs& a, hipStream_t st);
+// loss.hip: fused L1 + SSIM terms and their image gradient
+size_t loss_workspace_bytes(int C, int H, int W);
+hipError_t launch_loss_fwd(const float* img, const float* gt, int C, int H, int W, void* ws, float* out_terms, hipStream_t st);
+hipError_t launch_loss_bwd(const float* img, const float* gt, int C, int H, int W, const void* ws, const float* grad_terms,
+                           float* grad_img, hipStream_t st);
 hipError_t launch_debug_keys(const u32* tile_sorted, const u32* point_list, const u32* depth_key, long long I, u64* out, hipStream_t st);
 hipError_t launch_unpack_rect(const uint2* rect, int P, u32* out, hipStream_t st);

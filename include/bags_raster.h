@@ -162,6 +162,21 @@ int bags_debug_views(const BagsSettings*, const BagsInputs*, const BagsState*, i
 int bags_profile_enable(int mode);
 int bags_profile_read(int max_stages, const char** names, double* total_ms, int64_t* calls);
 
+/* Fused photometric loss terms.  Replaces the reference's l1_loss + ssim pair
+ * (utils/loss_utils.py:18-19 and :48-76: five dense 11x11 depthwise conv2d calls and their autograd backward; call
+ * site train.py:311-313, combined at train.py:325 as (1-lambda) L1 + lambda (1-SSIM)).
+ *   image, gt     device, fp32, contiguous (C,H,W)
+ *   workspace     caller-owned, bags_loss_workspace_size(C,H,W) bytes, kept from forward to backward
+ *   out_terms     device float[2]: { mean |image-gt| , mean SSIM }
+ *   grad_terms    device float[2]: upstream dL/d{L1 mean, SSIM mean} (read on the device: no host round trip)
+ *   grad_image    device (C,H,W): dL/dimage
+ * Stream-ordered on `stream`; sums are taken in a fixed order (bitwise reproducible). */
+size_t bags_loss_workspace_size(int32_t C, int32_t H, int32_t W);
+int bags_loss_forward(const float* image, const float* gt, int32_t C, int32_t H, int32_t W, void* workspace,
+                      size_t workspace_bytes, float* out_terms, void* stream);
+int bags_loss_backward(const float* image, const float* gt, int32_t C, int32_t H, int32_t W, const void* workspace,
+                       size_t workspace_bytes, const float* grad_terms, float* grad_image, void* stream);
+
 /* compute_relocation of the fork's MCMC path (utils/reloc_utils.py:11-13): its only caller is commented out in
  * the reference (scene/gaussian_model.py:23,494-504); exported so the symbol exists, returns BAGS_ERR_ARG. */
 int bags_compute_relocation(const float* opacity_old, const float* scale_old, const int32_t* N, const float* binoms,

@@ -6,6 +6,8 @@ inputs and expected outputs are stored).
   camera_chain.npz  utils/graphics_utils.py:83-107 getProjectionMatrix (values + d/dfov),
                     scene/cameras.py:399-416 quaternion_to_rotation_matrix (values + Jacobian)
   loss.npz          utils/loss_utils.py l1_loss / ssim on seeded images (the loss that produces dL/dimage)
+  loss_odd.npz      the same on a (3,37,53) pair (sizes that are not multiples of the kernels' 32x32 tile), with the
+                    gradients of the two terms stored separately
   gaussian_activations.npz  utils/general_utils.py:114-163 build_rotation / build_scaling_rotation / strip_lowerdiag and
                     scene/gaussian_model.py:27-31 covariance activation (values + d/d{scaling, rotation}),
                     gaussian_renderer/__init__.py:19-28 quaternion_multiply, utils/general_utils.py inverse_sigmoid
@@ -116,6 +118,14 @@ def main():
     pr = torch.rand(9, generator=g) * 0.98 + 0.01
     act["p"] = pr.numpy(); act["inverse_sigmoid_p"] = inverse_sigmoid(pr).numpy()
     np.savez(os.path.join(OUT, "gaussian_activations.npz"), **act)
+
+    # ---- photometric loss, odd size, separate terms (drawn last so that the earlier files stay byte-identical)
+    a = torch.rand(3, 37, 53, generator=g); b = (a + 0.1 * torch.randn(3, 37, 53, generator=g)).clamp(0, 1)
+    a.requires_grad_(True)
+    l1 = l1_loss(a, b); s = ssim(a, b)
+    (d1,) = torch.autograd.grad(l1, a, retain_graph=True); (d2,) = torch.autograd.grad(s, a)
+    np.savez(os.path.join(OUT, "loss_odd.npz"), a=a.detach().numpy(), b=b.numpy(), l1=l1.item(), ssim=s.item(),
+             dl1_da=d1.numpy(), dssim_da=d2.numpy())
     print("golden vectors written to", OUT)
 
 

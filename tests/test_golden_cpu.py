@@ -133,3 +133,21 @@ def test_gaussian_bag_round_trips_activations():
     want = (3.0 + 4.0) * (2.0 ** 0.5)
     assert torch.allclose(pc.xyz_gradient_accum[flt], torch.full((25, 1), want)) and (pc.xyz_gradient_accum[~flt] == 0).all()
     assert (pc.denom[flt] == 2).all()
+
+
+def test_loss_oracle_matches_reference(golden_dir):
+    """oracle/loss_oracle.py (numpy, dense 121-tap window, analytic adjoint) against the reference's l1_loss / ssim values
+    and autograd gradients (utils/loss_utils.py:18-19,48-76)."""
+    from oracle import loss_oracle as LO
+    g = np.load(os.path.join(golden_dir, "loss.npz"))
+    l1, s, grad = LO.loss_and_grad(g["a"], g["b"], 0.8, -0.2)          # d/da of 0.8 L1 + 0.2 (1 - SSIM)
+    assert abs(l1 - float(g["l1"])) < 1e-6 and abs(s - float(g["ssim"])) < 1e-5
+    assert abs(0.8 * l1 + 0.2 * (1 - s) - float(g["loss"])) < 1e-5
+    np.testing.assert_allclose(grad, g["dloss_da"], rtol=1e-3, atol=2e-8)
+    g = np.load(os.path.join(golden_dir, "loss_odd.npz"))
+    l1, s, g1 = LO.loss_and_grad(g["a"], g["b"], 1.0, 0.0)
+    _, _, g2 = LO.loss_and_grad(g["a"], g["b"], 0.0, 1.0)
+    assert abs(l1 - float(g["l1"])) < 1e-6 and abs(s - float(g["ssim"])) < 1e-5
+    np.testing.assert_allclose(g1, g["dl1_da"], rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(g2, g["dssim_da"], rtol=2e-3, atol=3e-8)
+    np.testing.assert_allclose(LO.window_2d().sum(), 1.0, rtol=1e-6)
