@@ -77,6 +77,18 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
         : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 __device__ __forceinline__ void scan_mul64x4(float& a, float& b, float& c, float& d) { SCAN4("v_mul_f32_dpp"); }
 __device__ __forceinline__ void scan_add64x4(float& a, float& b, float& c, float& d) { SCAN4("v_add_f32_dpp"); }
+// the same inclusive scans confined to each 16-lane DPP row (four independent segments per wave)
+#define SCAN4R(OP)                                                                                       \
+    asm volatile(                                                                                        \
+        "s_nop 1\n\t"                                                                                    \
+        SCAN4_STEP(OP, "row_shr:1 row_mask:0xf bank_mask:0xf")                                           \
+        SCAN4_STEP(OP, "row_shr:2 row_mask:0xf bank_mask:0xf")                                           \
+        SCAN4_STEP(OP, "row_shr:4 row_mask:0xf bank_mask:0xf")                                           \
+        SCAN4_STEP(OP, "row_shr:8 row_mask:0xf bank_mask:0xf")                                           \
+        "s_nop 1"                                                                                        \
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+__device__ __forceinline__ void scan_mul16x4(float& a, float& b, float& c, float& d) { SCAN4R("v_mul_f32_dpp"); }
+__device__ __forceinline__ void scan_add16x4(float& a, float& b, float& c, float& d) { SCAN4R("v_add_f32_dpp"); }
 
 // ================================================================================================================
 // backward
@@ -150,7 +162,10 @@ __device__ unsigned long long g_phase_cycles[8];
 #else
 #define PH_MARK(i) do {} while (0)
 #endif
-template <bool ABS>
+#ifndef BWD_ROWS
+#define BWD_ROWS 1          // 1: each 16-lane DPP row of a wave walks its own block list (16 splats per step); 0: one block, 64 splats
+#endif
+template <bool ABS, bool ROWS>
 __global__ void __launch_bounds__(256, SCAN_WG_PER_CU)
 blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ ranges, const u32* __restrict__ point_list,
                       const float4* __restrict__ g2d, const float* __restrict__ bg, const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
@@ -166,7 +181,9 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
     if (n == 0) return;
 
     __shared__ ChunkRec recs[CHUNK];                 // 12 KB
-    __shared__ PixPair pix[128];                     //  8 KB
+    // 8 pixel pairs (PixPair = 4 x float4) per block + one float4 of padding: the four rows of a wave read four different
+    // blocks in one ds_read_b128, and a 512-B block stride would put all four on the same banks
+    __shared__ float4 pixq[16][33];                  //  8.25 KB
     __shared__ unsigned char lists[16][CHUNK];       //  4 KB
     __shared__ u32 masks[CHUNK];                     //  1 KB: block reach masks, compact (the 48-B record stride bank-conflicts)
     __shared__ float acc[4][CHUNK][12];              // 48 KB, one copy per wave (LDS float atomics on a shared copy were 1.6x slower)
@@ -189,7 +206,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
         const float Tf = in ? final_T[pixi] : 1.f;
         const u32 nc = in ? n_contrib[pixi] : 0u;
         const float bgt = Tf * (bg[0] * g0 + bg[1] * g1 + bg[2] * g2);
-        float* pp = reinterpret_cast<float*>(&pix[tid >> 1]);
+        float* pp = reinterpret_cast<float*>(&pixq[tid >> 4][((tid >> 1) & 7) * 4]);
         const int h = tid & 1;                        // A or B of the pair
         pp[0 + h] = g0; pp[2 + h] = g1; pp[4 + h] = g2; pp[6 + h] = Tf;
         pp[8 + h] = bgt; pp[10 + h] = __uint_as_float(nc); pp[12 + h] = 1.f; pp[14 + h] = 0.f;
@@ -278,14 +295,93 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
         Raw raw_n = fetch(lo > 0 ? gid1 : 0xFFFFFFFFu);                             // gathers of chunk k+1
         const u32 gid2 = (lo > CHUNK) ? fetch_id(lo - CHUNK) : 0xFFFFFFFFu;          // ids of chunk k+2
 
-        // ---- this wave's four blocks: one per block row, column = wave
+        // The per-(splat, block) work: one block row (4 pixels = two packed pairs) per step; four independent scan chains
+        // interleave without pipeline bubbles.  `s` is the lane's splat, (bx0, by0) its block origin, pixb its block's
+        // pixel pairs, `carry` marks the lane that holds the scan totals (the shallowest of its segment).
+        f2 a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10;
+        auto block_rows = [&](const ChunkRec& s, const bool live, const float bx0, const float by0, float4* pixb, const bool carry) {
+            a0 = (f2){0.f, 0.f}; a1 = a0; a2 = a0; a3 = a0; a4 = a0; a5 = a0; a6 = a0; a7 = a0; a8 = a0; a9 = a0; a10 = a0;
+#pragma unroll SCAN_UNROLL
+            for (int iy = 0; iy < 4; ++iy) {
+                float4* P0 = pixb + iy * 8;
+                float4* P1 = P0 + 4;
+                const float4 q00 = P0[0], q01 = P0[1], q02 = P0[2], q03 = P0[3];
+                const float4 q10 = P1[0], q11 = P1[1], q12 = P1[2], q13 = P1[3];
+                const float dy = s.y - (by0 + (float)iy);
+                const float u = __fmul_rn(__fmul_rn(s.cp, dy), dy);
+                const f2 dyy = {dy, dy};
+                // ---- part 1: alpha of the four pixels (same arithmetic as pair_power2 on d = centre - pixel)
+                const f2 dxa = {s.x - bx0, s.x - (bx0 + 1.f)}, dxb = {s.x - (bx0 + 2.f), s.x - (bx0 + 3.f)};
+                const f2 ta = __builtin_elementwise_fma((f2){s.bp, s.bp}, dyy, s.ap * dxa);
+                const f2 tb = __builtin_elementwise_fma((f2){s.bp, s.bp}, dyy, s.ap * dxb);
+                const f2 pa = __builtin_elementwise_fma(dxa, ta, (f2){u, u});
+                const f2 pb = __builtin_elementwise_fma(dxb, tb, (f2){u, u});
+                f2 Ga = {__builtin_amdgcn_exp2f(pa.x), __builtin_amdgcn_exp2f(pa.y)};
+                f2 Gb = {__builtin_amdgcn_exp2f(pb.x), __builtin_amdgcn_exp2f(pb.y)};
+                f2 ala = s.o * Ga, alb = s.o * Gb;
+                ala.x = fminf(0.99f, ala.x); ala.y = fminf(0.99f, ala.y); alb.x = fminf(0.99f, alb.x); alb.y = fminf(0.99f, alb.y);
+                const bool v0 = live && (pa.x <= 0.f) && (ala.x >= ALPHA_MIN) && (s.pos <= __float_as_uint(q02.z));
+                const bool v1 = live && (pa.y <= 0.f) && (ala.y >= ALPHA_MIN) && (s.pos <= __float_as_uint(q02.w));
+                const bool v2 = live && (pb.x <= 0.f) && (alb.x >= ALPHA_MIN) && (s.pos <= __float_as_uint(q12.z));
+                const bool v3 = live && (pb.y <= 0.f) && (alb.y >= ALPHA_MIN) && (s.pos <= __float_as_uint(q12.w));
+                ala.x = v0 ? ala.x : 0.f; ala.y = v1 ? ala.y : 0.f; alb.x = v2 ? alb.x : 0.f; alb.y = v3 ? alb.y : 0.f;
+                Ga.x = v0 ? Ga.x : 0.f; Ga.y = v1 ? Ga.y : 0.f; Gb.x = v2 ? Gb.x : 0.f; Gb.y = v3 ? Gb.y : 0.f;
+                const f2 oma = 1.f - ala, omb = 1.f - alb;
+                // ---- B_i: product over this and deeper splats (x what lies behind the group, carried in q*3.xy)
+                float B0 = oma.x, B1 = oma.y, B2 = omb.x, B3 = omb.y;
+                if (ROWS) scan_mul16x4(B0, B1, B2, B3); else scan_mul64x4(B0, B1, B2, B3);
+                const f2 Ba = (f2){B0, B1} * (f2){q03.x, q03.y}, Bb = (f2){B2, B3} * (f2){q13.x, q13.y};
+                const f2 Tna = {q01.z * __builtin_amdgcn_rcpf(Ba.x), q01.w * __builtin_amdgcn_rcpf(Ba.y)};   // T in front of i
+                const f2 Tnb = {q11.z * __builtin_amdgcn_rcpf(Bb.x), q11.w * __builtin_amdgcn_rcpf(Bb.y)};
+                const f2 wa = ala * Tna, wb = alb * Tnb;
+                const f2 g0a = {q00.x, q00.y}, g1a = {q00.z, q00.w}, g2a = {q01.x, q01.y};
+                const f2 g0b = {q10.x, q10.y}, g1b = {q10.z, q10.w}, g2b = {q11.x, q11.y};
+                const f2 sda = __builtin_elementwise_fma((f2){s.b, s.b}, g2a, __builtin_elementwise_fma((f2){s.g, s.g}, g1a, s.r * g0a));
+                const f2 sdb = __builtin_elementwise_fma((f2){s.b, s.b}, g2b, __builtin_elementwise_fma((f2){s.g, s.g}, g1b, s.r * g0b));
+                const f2 wsa = wa * sda, wsb = wb * sdb;
+                float S0 = wsa.x, S1 = wsa.y, S2 = wsb.x, S3 = wsb.y;
+                if (ROWS) scan_add16x4(S0, S1, S2, S3); else scan_add64x4(S0, S1, S2, S3);
+                const f2 Sia = (f2){S0, S1} + (f2){q03.z, q03.w}, Sib = (f2){S2, S3} + (f2){q13.z, q13.w};
+                if (carry) {                                            // carries for the next (shallower) group
+                    P0[3] = make_float4(Ba.x, Ba.y, Sia.x, Sia.y);
+                    P1[3] = make_float4(Bb.x, Bb.y, Sib.x, Sib.y);
+                }
+                const f2 ioma = {__builtin_amdgcn_rcpf(oma.x), __builtin_amdgcn_rcpf(oma.y)};
+                const f2 iomb = {__builtin_amdgcn_rcpf(omb.x), __builtin_amdgcn_rcpf(omb.y)};
+                const f2 dLa = __builtin_elementwise_fma(Tna, sda, -(((Sia - wsa) + (f2){q02.x, q02.y}) * ioma));
+                const f2 dLb = __builtin_elementwise_fma(Tnb, sdb, -(((Sib - wsb) + (f2){q12.x, q12.y}) * iomb));
+                a0 = __builtin_elementwise_fma(wa, g0a, a0); a1 = __builtin_elementwise_fma(wa, g1a, a1); a2 = __builtin_elementwise_fma(wa, g2a, a2);
+                a0 = __builtin_elementwise_fma(wb, g0b, a0); a1 = __builtin_elementwise_fma(wb, g1b, a1); a2 = __builtin_elementwise_fma(wb, g2b, a2);
+                const f2 gda = Ga * dLa, gdb = Gb * dLb;                // G == 0 for non-contributing pairs
+                a3 = a3 + gda; a3 = a3 + gdb;
+                const f2 qva = s.o * gda, qvb = s.o * gdb;
+                const f2 qdxa = qva * dxa, qdxb = qvb * dxb, qdya = qva * dy, qdyb = qvb * dy;
+                a4 = a4 + qdxa; a4 = a4 + qdxb; a5 = a5 + qdya; a5 = a5 + qdyb;
+                a6 = __builtin_elementwise_fma(qdxa, dxa, a6); a6 = __builtin_elementwise_fma(qdxb, dxb, a6);
+                a7 = __builtin_elementwise_fma(qdxa, dyy, a7); a7 = __builtin_elementwise_fma(qdxb, dyy, a7);
+                a8 = __builtin_elementwise_fma(qdya, dyy, a8); a8 = __builtin_elementwise_fma(qdyb, dyy, a8);
+                if (ABS) {
+                    const f2 ap2 = {2.f * s.ap, 2.f * s.ap}, cp2 = {2.f * s.cp, 2.f * s.cp};
+                    a9 = a9 + __builtin_elementwise_abs(__builtin_elementwise_fma(ap2, qdxa, s.bp * qdya));
+                    a9 = a9 + __builtin_elementwise_abs(__builtin_elementwise_fma(ap2, qdxb, s.bp * qdyb));
+                    a10 = a10 + __builtin_elementwise_abs(__builtin_elementwise_fma(cp2, qdya, s.bp * qdxa));
+                    a10 = a10 + __builtin_elementwise_abs(__builtin_elementwise_fma(cp2, qdyb, s.bp * qdxb));
+                }
+            }
+        };
+        auto add_to_copy = [&](const int slot) {      // plain read-modify-write of the wave's own copy
+            float4* d4 = reinterpret_cast<float4*>(&acc[wave][slot][0]);
+            float4 r0 = d4[0], r1 = d4[1], r2 = d4[2];
+            r0.x += a0.x + a0.y; r0.y += a1.x + a1.y; r0.z += a2.x + a2.y; r0.w += a3.x + a3.y;
+            r1.x += a4.x + a4.y; r1.y += a5.x + a5.y; r1.z += a6.x + a6.y; r1.w += a7.x + a7.y;
+            r2.x += a8.x + a8.y; r2.y += a9.x + a9.y; r2.z += a10.x + a10.y;
+            d4[0] = r0; d4[1] = r1; d4[2] = r2;
+        };
         u32 mreg[CHUNK / 64];
 #pragma unroll
         for (int r = 0; r < CHUNK / 64; ++r) mreg[r] = masks[r * 64 + lane];
-#pragma unroll 1
-        for (int j = 0; j < 4; ++j) {
-            const int blk = j * 4 + wave;
-            // ballot-compact the chunk's slots that reach this block (list order = depth order)
+        // ballot-compact the chunk's slots that reach block `blk` (list order = depth order); returns the list length
+        auto build_list = [&](const int blk) -> int {
             int L = 0;
             const u32 bmax = blk_maxc[blk];              // splats behind every pixel's last contributor cannot matter here
 #pragma unroll
@@ -296,94 +392,53 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
                 if (hit) lists[blk][L + __popcll(bal & lt_mask)] = (unsigned char)slot;
                 L += __popcll(bal);
             }
+            return L;
+        };
+        if (ROWS) {
+            // ---- the wave owns quadrant `wave`; DPP row r of the wave owns one 4x4 block of it and walks that block's
+            // list 16 splats per step (deepest in the row's lane 0).  Against "64 lanes = 64 splats of one block" this
+            // quantises the lists at 16 instead of 64 entries and shortens the scans from six DPP steps to four.
+            const int row = lane >> 4, li = lane & 15;
+            const int qx = (wave & 1) * 2, qy = (wave >> 1) * 2;
+            const int myblk = (qy + (row >> 1)) * 4 + qx + (row & 1);
+            int Lr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Lr[j] = build_list((qy + (j >> 1)) * 4 + qx + (j & 1));
             PH_MARK(3);    // list building
-            if (L == 0) continue;
-            const float bx0 = X0 + 4.f * (float)(blk & 3), by0 = Y0 + 4.f * (float)(blk >> 2);
-            // groups of 64 list entries, deepest group first; inside a group lane 0 holds the deepest entry
-            for (int gend = L; gend > 0; gend -= 64) {
-                const int gcnt = min(gend, 64);
-                const bool live = lane < gcnt;
-                const int slot = live ? (int)lists[blk][gend - 1 - lane] : 0;
+            const int myL = (row == 0) ? Lr[0] : (row == 1) ? Lr[1] : (row == 2) ? Lr[2] : Lr[3];
+            const int nIter = (max(max(Lr[0], Lr[1]), max(Lr[2], Lr[3])) + 15) >> 4;
+            const float bx0 = X0 + 4.f * (float)(myblk & 3), by0 = Y0 + 4.f * (float)(myblk >> 2);
+            float4* pixb = &pixq[myblk][0];
+            for (int it = 0; it < nIter; ++it) {
+                const int gend = myL - 16 * it;                 // <= 0: this row's list is exhausted
+                const bool live = li < gend;
+                const int slot = live ? (int)lists[myblk][gend - 1 - li] : 0;
                 const ChunkRec s = recs[slot];
-                f2 a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0, a4 = a0, a5 = a0, a6 = a0, a7 = a0, a8 = a0, a9 = a0, a10 = a0;
-                // one block row (4 pixels = two packed pairs) per step: four independent scan chains interleave
-                // without pipeline bubbles
-#pragma unroll SCAN_UNROLL
-                for (int iy = 0; iy < 4; ++iy) {
-                    PixPair& P0 = pix[blk * 8 + iy * 2];
-                    PixPair& P1 = pix[blk * 8 + iy * 2 + 1];
-                    const float4 q00 = P0.q0, q01 = P0.q1, q02 = P0.q2, q03 = P0.q3;
-                    const float4 q10 = P1.q0, q11 = P1.q1, q12 = P1.q2, q13 = P1.q3;
-                    const float dy = s.y - (by0 + (float)iy);
-                    const float u = __fmul_rn(__fmul_rn(s.cp, dy), dy);
-                    const f2 dyy = {dy, dy};
-                    // ---- part 1: alpha of the four pixels (same arithmetic as pair_power2 on d = centre - pixel)
-                    const f2 dxa = {s.x - bx0, s.x - (bx0 + 1.f)}, dxb = {s.x - (bx0 + 2.f), s.x - (bx0 + 3.f)};
-                    const f2 ta = __builtin_elementwise_fma((f2){s.bp, s.bp}, dyy, s.ap * dxa);
-                    const f2 tb = __builtin_elementwise_fma((f2){s.bp, s.bp}, dyy, s.ap * dxb);
-                    const f2 pa = __builtin_elementwise_fma(dxa, ta, (f2){u, u});
-                    const f2 pb = __builtin_elementwise_fma(dxb, tb, (f2){u, u});
-                    f2 Ga = {__builtin_amdgcn_exp2f(pa.x), __builtin_amdgcn_exp2f(pa.y)};
-                    f2 Gb = {__builtin_amdgcn_exp2f(pb.x), __builtin_amdgcn_exp2f(pb.y)};
-                    f2 ala = s.o * Ga, alb = s.o * Gb;
-                    ala.x = fminf(0.99f, ala.x); ala.y = fminf(0.99f, ala.y); alb.x = fminf(0.99f, alb.x); alb.y = fminf(0.99f, alb.y);
-                    const bool v0 = live && (pa.x <= 0.f) && (ala.x >= ALPHA_MIN) && (s.pos <= __float_as_uint(q02.z));
-                    const bool v1 = live && (pa.y <= 0.f) && (ala.y >= ALPHA_MIN) && (s.pos <= __float_as_uint(q02.w));
-                    const bool v2 = live && (pb.x <= 0.f) && (alb.x >= ALPHA_MIN) && (s.pos <= __float_as_uint(q12.z));
-                    const bool v3 = live && (pb.y <= 0.f) && (alb.y >= ALPHA_MIN) && (s.pos <= __float_as_uint(q12.w));
-                    ala.x = v0 ? ala.x : 0.f; ala.y = v1 ? ala.y : 0.f; alb.x = v2 ? alb.x : 0.f; alb.y = v3 ? alb.y : 0.f;
-                    Ga.x = v0 ? Ga.x : 0.f; Ga.y = v1 ? Ga.y : 0.f; Gb.x = v2 ? Gb.x : 0.f; Gb.y = v3 ? Gb.y : 0.f;
-                    const f2 oma = 1.f - ala, omb = 1.f - alb;
-                    // ---- B_i: product over this and deeper splats (x what lies behind the group, carried in q*3.xy)
-                    float B0 = oma.x, B1 = oma.y, B2 = omb.x, B3 = omb.y;
-                    scan_mul64x4(B0, B1, B2, B3);
-                    const f2 Ba = (f2){B0, B1} * (f2){q03.x, q03.y}, Bb = (f2){B2, B3} * (f2){q13.x, q13.y};
-                    const f2 Tna = {q01.z * __builtin_amdgcn_rcpf(Ba.x), q01.w * __builtin_amdgcn_rcpf(Ba.y)};   // T in front of i
-                    const f2 Tnb = {q11.z * __builtin_amdgcn_rcpf(Bb.x), q11.w * __builtin_amdgcn_rcpf(Bb.y)};
-                    const f2 wa = ala * Tna, wb = alb * Tnb;
-                    const f2 g0a = {q00.x, q00.y}, g1a = {q00.z, q00.w}, g2a = {q01.x, q01.y};
-                    const f2 g0b = {q10.x, q10.y}, g1b = {q10.z, q10.w}, g2b = {q11.x, q11.y};
-                    const f2 sda = __builtin_elementwise_fma((f2){s.b, s.b}, g2a, __builtin_elementwise_fma((f2){s.g, s.g}, g1a, s.r * g0a));
-                    const f2 sdb = __builtin_elementwise_fma((f2){s.b, s.b}, g2b, __builtin_elementwise_fma((f2){s.g, s.g}, g1b, s.r * g0b));
-                    const f2 wsa = wa * sda, wsb = wb * sdb;
-                    float S0 = wsa.x, S1 = wsa.y, S2 = wsb.x, S3 = wsb.y;
-                    scan_add64x4(S0, S1, S2, S3);
-                    const f2 Sia = (f2){S0, S1} + (f2){q03.z, q03.w}, Sib = (f2){S2, S3} + (f2){q13.z, q13.w};
-                    if (lane == 63) {                                       // carries for the next (shallower) group
-                        P0.q3 = make_float4(Ba.x, Ba.y, Sia.x, Sia.y);
-                        P1.q3 = make_float4(Bb.x, Bb.y, Sib.x, Sib.y);
-                    }
-                    const f2 ioma = {__builtin_amdgcn_rcpf(oma.x), __builtin_amdgcn_rcpf(oma.y)};
-                    const f2 iomb = {__builtin_amdgcn_rcpf(omb.x), __builtin_amdgcn_rcpf(omb.y)};
-                    const f2 dLa = __builtin_elementwise_fma(Tna, sda, -(((Sia - wsa) + (f2){q02.x, q02.y}) * ioma));
-                    const f2 dLb = __builtin_elementwise_fma(Tnb, sdb, -(((Sib - wsb) + (f2){q12.x, q12.y}) * iomb));
-                    a0 = __builtin_elementwise_fma(wa, g0a, a0); a1 = __builtin_elementwise_fma(wa, g1a, a1); a2 = __builtin_elementwise_fma(wa, g2a, a2);
-                    a0 = __builtin_elementwise_fma(wb, g0b, a0); a1 = __builtin_elementwise_fma(wb, g1b, a1); a2 = __builtin_elementwise_fma(wb, g2b, a2);
-                    const f2 gda = Ga * dLa, gdb = Gb * dLb;                // G == 0 for non-contributing pairs
-                    a3 = a3 + gda; a3 = a3 + gdb;
-                    const f2 qva = s.o * gda, qvb = s.o * gdb;
-                    const f2 qdxa = qva * dxa, qdxb = qvb * dxb, qdya = qva * dy, qdyb = qvb * dy;
-                    a4 = a4 + qdxa; a4 = a4 + qdxb; a5 = a5 + qdya; a5 = a5 + qdyb;
-                    a6 = __builtin_elementwise_fma(qdxa, dxa, a6); a6 = __builtin_elementwise_fma(qdxb, dxb, a6);
-                    a7 = __builtin_elementwise_fma(qdxa, dyy, a7); a7 = __builtin_elementwise_fma(qdxb, dyy, a7);
-                    a8 = __builtin_elementwise_fma(qdya, dyy, a8); a8 = __builtin_elementwise_fma(qdyb, dyy, a8);
-                    if (ABS) {
-                        const f2 ap2 = {2.f * s.ap, 2.f * s.ap}, cp2 = {2.f * s.cp, 2.f * s.cp};
-                        a9 = a9 + __builtin_elementwise_abs(__builtin_elementwise_fma(ap2, qdxa, s.bp * qdya));
-                        a9 = a9 + __builtin_elementwise_abs(__builtin_elementwise_fma(ap2, qdxb, s.bp * qdyb));
-                        a10 = a10 + __builtin_elementwise_abs(__builtin_elementwise_fma(cp2, qdya, s.bp * qdxa));
-                        a10 = a10 + __builtin_elementwise_abs(__builtin_elementwise_fma(cp2, qdyb, s.bp * qdxb));
-                    }
-                }
-                if (live) {      // distinct lanes hold distinct slots: plain read-modify-write of the wave's own copy
-                    float4* d4 = reinterpret_cast<float4*>(&acc[wave][slot][0]);
-                    float4 r0 = d4[0], r1 = d4[1], r2 = d4[2];
-                    r0.x += a0.x + a0.y; r0.y += a1.x + a1.y; r0.z += a2.x + a2.y; r0.w += a3.x + a3.y;
-                    r1.x += a4.x + a4.y; r1.y += a5.x + a5.y; r1.z += a6.x + a6.y; r1.w += a7.x + a7.y;
-                    r2.x += a8.x + a8.y; r2.y += a9.x + a9.y; r2.z += a10.x + a10.y;
-                    d4[0] = r0; d4[1] = r1; d4[2] = r2;
-                }
+                block_rows(s, live, bx0, by0, pixb, (li == 15) && (gend > 0));
+                // the same splat can sit in several rows (it reaches several blocks of the quadrant): one row at a time
+#pragma unroll
+                for (int ph = 0; ph < 4; ++ph)
+                    if (row == ph && live) add_to_copy(slot);
                 PH_MARK(4);    // groups
+            }
+        } else {
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                const int blk = j * 4 + wave;                    // one block per block row, column = wave
+                const int L = build_list(blk);
+                PH_MARK(3);    // list building
+                if (L == 0) continue;
+                const float bx0 = X0 + 4.f * (float)(blk & 3), by0 = Y0 + 4.f * (float)(blk >> 2);
+                // groups of 64 list entries, deepest group first; inside a group lane 0 holds the deepest entry
+                for (int gend = L; gend > 0; gend -= 64) {
+                    const int gcnt = min(gend, 64);
+                    const bool live = lane < gcnt;
+                    const int slot = live ? (int)lists[blk][gend - 1 - lane] : 0;
+                    const ChunkRec s = recs[slot];
+                    block_rows(s, live, bx0, by0, &pixq[blk][0], lane == 63);
+                    if (live) add_to_copy(slot);                 // distinct lanes hold distinct slots
+                    PH_MARK(4);    // groups
+                }
             }
         }
         PH_MARK(3);
@@ -436,11 +491,11 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     if (T == 0) return hipSuccess;
     const int grid = ((T + 7) / 8) * 8;
     if (want_abs)
-        hipLaunchKernelGGL(blend_bwd_scan_kernel<true>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
+        hipLaunchKernelGGL((blend_bwd_scan_kernel<true, BWD_ROWS != 0>), dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
                            b.ranges, b.point_list, g.g2d, s.bg,
                            im.final_T, im.n_contrib, grad_color, partials);
     else
-        hipLaunchKernelGGL(blend_bwd_scan_kernel<false>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
+        hipLaunchKernelGGL((blend_bwd_scan_kernel<false, BWD_ROWS != 0>), dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
                            b.ranges, b.point_list, g.g2d, s.bg,
                            im.final_T, im.n_contrib, grad_color, partials);
     return hipGetLastError();
