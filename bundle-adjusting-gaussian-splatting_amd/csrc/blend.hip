@@ -25,6 +25,9 @@
 #ifndef CHUNK
 #define CHUNK 256           // splats staged per step (LDS: 48 B record + 4 x 48 B accumulator copies + 16 list bytes each)
 #endif
+#ifndef BCHUNK
+#define BCHUNK CHUNK        // the backward's chunk (its LDS footprint is dominated by 4 x 48 B x BCHUNK of accumulator copies)
+#endif
 #ifndef SCAN_WG_PER_CU
 #define SCAN_WG_PER_CU 2    // backward workgroups per CU (LDS-limited: 72 KB each)
 #endif
@@ -180,13 +183,13 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
     const u32 n = range.y - range.x;
     if (n == 0) return;
 
-    __shared__ ChunkRec recs[CHUNK];                 // 12 KB
+    __shared__ ChunkRec recs[BCHUNK];                 // 12 KB
     // 8 pixel pairs (PixPair = 4 x float4) per block + one float4 of padding: the four rows of a wave read four different
     // blocks in one ds_read_b128, and a 512-B block stride would put all four on the same banks
     __shared__ float4 pixq[16][33];                  //  8.25 KB
-    __shared__ unsigned char lists[16][CHUNK];       //  4 KB
-    __shared__ u32 masks[CHUNK];                     //  1 KB: block reach masks, compact (the 48-B record stride bank-conflicts)
-    __shared__ float acc[4][CHUNK][12];              // 48 KB, one copy per wave (LDS float atomics on a shared copy were 1.6x slower)
+    __shared__ unsigned char lists[16][BCHUNK];       //  4 KB
+    __shared__ u32 masks[BCHUNK];                     //  1 KB: block reach masks, compact (the 48-B record stride bank-conflicts)
+    __shared__ float acc[4][BCHUNK][12];              // 48 KB, one copy per wave (LDS float atomics on a shared copy were 1.6x slower)
     __shared__ u32 wmax[4];
     __shared__ u32 blk_maxc[16];                     // last contributor over the 16 pixels of each block
 
@@ -238,7 +241,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
     // ahead, so neither the id load nor the dependent gathers sit on the critical path of a chunk.
     struct Raw { float4 q0, q1, q2; u32 io; };      // conic+opacity | x y r g | b z rect | inst_offset
     auto fetch_id = [&](u32 hi_) -> u32 {            // id of this thread's slot in the chunk that ends at hi_
-        const u32 c_ = min(hi_, (u32)CHUNK);
+        const u32 c_ = min(hi_, (u32)BCHUNK);
         return ((u32)tid < c_) ? point_list[range.x + (hi_ - c_) + tid] : 0xFFFFFFFFu;
     };
     auto fetch = [&](u32 g) {
@@ -249,7 +252,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
         }
         return r;
     };
-    if (tid < CHUNK) {
+    if (tid < BCHUNK) {
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -281,19 +284,21 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
     //   then     issue the gathers of chunk k+1 (ids known) and the id load of chunk k+2
     //   ...      lists + groups of chunk k            <- the loads land underneath
     //   barrier  consume gathers -> rec(k+1), ids(k+2); only then store the records of chunk k
-    ChunkRec rec = make_rec(fetch(fetch_id(maxc)), maxc - min(maxc, (u32)CHUNK), min(maxc, (u32)CHUNK));
-    u32 gid1 = (maxc > CHUNK) ? fetch_id(maxc - CHUNK) : 0xFFFFFFFFu;       // ids of chunk 1
+    const u32 gid0 = fetch_id(maxc);
+    u32 gid1 = (maxc > BCHUNK) ? fetch_id(maxc - BCHUNK) : 0xFFFFFFFFu;       // ids of chunk 1, in flight with chunk 0's
+    ChunkRec rec = make_rec(fetch(gid0), maxc - min(maxc, (u32)BCHUNK), min(maxc, (u32)BCHUNK));
+    asm volatile("" :: "v"(gid1));    // complete before the loop: a pending load on the entry edge costs a vmcnt(0) at every loop top
 
     for (u32 hi = maxc; hi > 0;) {
-        const u32 cnt = min(hi, (u32)CHUNK);
+        const u32 cnt = min(hi, (u32)BCHUNK);
         const u32 lo = hi - cnt;
         // ---- publish the staged chunk [lo, hi): slot s <-> list position lo + s (front to back)
-        if (tid < CHUNK) { recs[tid] = rec; masks[tid] = rec.mask; }   // safe without a barrier: after the previous chunk's second barrier nobody reads them
+        if (tid < BCHUNK) { recs[tid] = rec; masks[tid] = rec.mask; }   // safe without a barrier: after the previous chunk's second barrier nobody reads them
         lds_barrier();
         PH_MARK(2);    // barrier 1
         __builtin_amdgcn_s_setprio(0);
         Raw raw_n = fetch(lo > 0 ? gid1 : 0xFFFFFFFFu);                             // gathers of chunk k+1
-        const u32 gid2 = (lo > CHUNK) ? fetch_id(lo - CHUNK) : 0xFFFFFFFFu;          // ids of chunk k+2
+        const u32 gid2 = (lo > BCHUNK) ? fetch_id(lo - BCHUNK) : 0xFFFFFFFFu;          // ids of chunk k+2
 
         // The per-(splat, block) work: one block row (4 pixels = two packed pairs) per step; four independent scan chains
         // interleave without pipeline bubbles.  `s` is the lane's splat, (bx0, by0) its block origin, pixb its block's
@@ -377,15 +382,15 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
             r2.x += a8.x + a8.y; r2.y += a9.x + a9.y; r2.z += a10.x + a10.y;
             d4[0] = r0; d4[1] = r1; d4[2] = r2;
         };
-        u32 mreg[CHUNK / 64];
+        u32 mreg[BCHUNK / 64];
 #pragma unroll
-        for (int r = 0; r < CHUNK / 64; ++r) mreg[r] = masks[r * 64 + lane];
+        for (int r = 0; r < BCHUNK / 64; ++r) mreg[r] = masks[r * 64 + lane];
         // ballot-compact the chunk's slots that reach block `blk` (list order = depth order); returns the list length
         auto build_list = [&](const int blk) -> int {
             int L = 0;
             const u32 bmax = blk_maxc[blk];              // splats behind every pixel's last contributor cannot matter here
 #pragma unroll
-            for (int r = 0; r < CHUNK / 64; ++r) {
+            for (int r = 0; r < BCHUNK / 64; ++r) {
                 const int slot = r * 64 + lane;
                 const bool hit = ((mreg[r] >> blk) & 1u) && (lo + (u32)slot < bmax);   // pos = lo + slot + 1
                 const u64 bal = __ballot(hit);
@@ -450,7 +455,14 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
         __builtin_amdgcn_s_setprio(3);
         // ---- next chunk: its gathers were issued before the groups; turn them into the staged record
         const ChunkRec cur = rec;
-        if (lo > 0) { const u32 ncnt = min(lo, (u32)CHUNK); rec = make_rec(raw_n, lo - ncnt, ncnt); }
+        // Keep every loaded register -- also the components nobody reads (q1 z, q3 yzw are not loaded; q2.y, the view
+        // depth, is) -- and the id word "in use" up to this point.  Otherwise the register allocator recycles a dead
+        // component of an in-flight load as scratch, which needs s_waitcnt vmcnt(0) right after the loads were issued
+        // and exposes the whole gather latency once per chunk (seen in the ISA; 20 % of the wave time).  Touching gid2
+        // here also retires the id load before this chunk's record stores are issued, so the top of the next chunk
+        // does not have to drain the stores to be sure the id has arrived.
+        asm volatile("" :: "v"(raw_n.q2.y), "v"(gid2));
+        if (lo > 0) { const u32 ncnt = min(lo, (u32)BCHUNK); rec = make_rec(raw_n, lo - ncnt, ncnt); }
         gid1 = gid2;
         PH_MARK(1);
         // ---- one record per staged instance: the four wave copies added in fixed order
