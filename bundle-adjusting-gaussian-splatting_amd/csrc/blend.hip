@@ -26,10 +26,10 @@
 #define CHUNK 256           // splats staged per step (LDS: 48 B record + 4 x 48 B accumulator copies + 16 list bytes each)
 #endif
 #ifndef BCHUNK
-#define BCHUNK CHUNK        // the backward's chunk (its LDS footprint is dominated by 4 x 48 B x BCHUNK of accumulator copies)
+#define BCHUNK 128          // the backward's chunk: 4 x 48 B x BCHUNK of accumulator copies dominate its LDS (41 KB at 128)
 #endif
 #ifndef SCAN_WG_PER_CU
-#define SCAN_WG_PER_CU 2    // backward workgroups per CU (LDS-limited: 72 KB each)
+#define SCAN_WG_PER_CU 3    // backward workgroups per CU: 3 x 41 KB of LDS, 168 VGPRs (measured: 128/3 beats 256/2 by 3 %)
 #endif
 #ifndef SCAN_UNROLL
 #define SCAN_UNROLL 1
@@ -65,50 +65,58 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // global memory, so lgkmcnt(0) + s_barrier is sufficient.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-#define SCAN4_STEP(OP, PAT)                                                                              \
-        OP " %0, %0, %0 " PAT "\n\t" OP " %1, %1, %1 " PAT "\n\t" OP " %2, %2, %2 " PAT "\n\t" OP " %3, %3, %3 " PAT "\n\t"
-#define SCAN4(OP)                                                                                        \
-    asm volatile(                                                                                        \
-        "s_nop 1\n\t"                                                                                    \
-        SCAN4_STEP(OP, "row_shr:1 row_mask:0xf bank_mask:0xf")                                           \
-        SCAN4_STEP(OP, "row_shr:2 row_mask:0xf bank_mask:0xf")                                           \
-        SCAN4_STEP(OP, "row_shr:4 row_mask:0xf bank_mask:0xf")                                           \
-        SCAN4_STEP(OP, "row_shr:8 row_mask:0xf bank_mask:0xf")                                           \
-        SCAN4_STEP(OP, "row_bcast:15 row_mask:0xa bank_mask:0xf")                                        \
-        SCAN4_STEP(OP, "row_bcast:31 row_mask:0xc bank_mask:0xf")                                        \
-        "s_nop 1"                                                                                        \
-        : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
-__device__ __forceinline__ void scan_mul64x4(float& a, float& b, float& c, float& d) { SCAN4("v_mul_f32_dpp"); }
-__device__ __forceinline__ void scan_add64x4(float& a, float& b, float& c, float& d) { SCAN4("v_add_f32_dpp"); }
-// the same inclusive scans confined to each 16-lane DPP row (four independent segments per wave)
-#define SCAN4R(OP)                                                                                       \
-    asm volatile(                                                                                        \
-        "s_nop 1\n\t"                                                                                    \
-        SCAN4_STEP(OP, "row_shr:1 row_mask:0xf bank_mask:0xf")                                           \
-        SCAN4_STEP(OP, "row_shr:2 row_mask:0xf bank_mask:0xf")                                           \
-        SCAN4_STEP(OP, "row_shr:4 row_mask:0xf bank_mask:0xf")                                           \
-        SCAN4_STEP(OP, "row_shr:8 row_mask:0xf bank_mask:0xf")                                           \
-        "s_nop 1"                                                                                        \
-        : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
-__device__ __forceinline__ void scan_mul16x4(float& a, float& b, float& c, float& d) { SCAN4R("v_mul_f32_dpp"); }
-__device__ __forceinline__ void scan_add16x4(float& a, float& b, float& c, float& d) { SCAN4R("v_add_f32_dpp"); }
+// Inclusive prefix composition of affine maps x -> a x + b over each 16-lane DPP row, four independent chains
+// interleaved (a dependent DPP op needs two wait states after the VALU write it reads; seven other instructions sit
+// between here).  Lane l ends with (A_l, b_l) such that F_l(F_{l-1}(...F_0(x))) = A_l x + b_l, lane 0 innermost.
+// A step with shift d combines lane l with lane l-d:  b_l += a_l * b_{l-d};  a_l *= a_{l-d}  (b first: it needs the old a_l).
+// Lanes whose source falls outside the row are not written (bound_ctrl off), which is the identity they need.
+#define AFF4_STEP(PAT)                                                                                   \
+        "v_fmac_f32_dpp %4, %4, %0 " PAT "\n\t" "v_fmac_f32_dpp %5, %5, %1 " PAT "\n\t"                   \
+        "v_fmac_f32_dpp %6, %6, %2 " PAT "\n\t" "v_fmac_f32_dpp %7, %7, %3 " PAT "\n\t"                   \
+        "v_mul_f32_dpp %0, %0, %0 " PAT "\n\t"  "v_mul_f32_dpp %1, %1, %1 " PAT "\n\t"                    \
+        "v_mul_f32_dpp %2, %2, %2 " PAT "\n\t"  "v_mul_f32_dpp %3, %3, %3 " PAT "\n\t"
+__device__ __forceinline__ void scan_affine16x4(float& a0, float& a1, float& a2, float& a3, float& b0, float& b1, float& b2, float& b3)
+{
+    asm volatile(
+        "s_nop 1\n\t"
+        AFF4_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
+        AFF4_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+        AFF4_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
+        AFF4_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+        "s_nop 1"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+}
+// r_k <- v_k of the next lower lane of the row; the row's lane 0 keeps the value r_k came in with (the carry)
+__device__ __forceinline__ void shift_up16x4(float& r0, float& r1, float& r2, float& r3, float v0, float v1, float v2, float v3)
+{
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mov_b32_dpp %0, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %1, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %2, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %3, %7 row_shr:1 row_mask:0xf bank_mask:0xf"
+        : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(v0), "v"(v1), "v"(v2), "v"(v3));
+}
 
 // ================================================================================================================
 // backward
 // Scan-based backward ("lane = splat").  PMC showed a lane = pixel backward saturates VALU issue (96 % of SIMD cycles)
 // and spends most of it on 64-wide work where a third of the lanes contribute, plus an 11-value cross-lane reduction
 // per (tile, splat).  Here the roles are swapped:
-//   * a 256-thread workgroup owns a tile; the tile list is consumed back to front in chunks of 256 splats, staged once
-//     in LDS together with a 16-bit mask of the 4x4-pixel blocks each splat's alpha >= 1/255 ellipse can reach
+//   * a 256-thread workgroup owns a tile; the tile list is consumed back to front in chunks of BCHUNK splats, staged
+//     once in LDS together with a 16-bit mask of the 4x4-pixel blocks each splat's alpha >= 1/255 ellipse can reach
 //     (Mahalanobis triangle-inequality test, conservative);
-//   * each wave owns four of the sixteen blocks and ballot-compacts, per block, the chunk's splats that reach it;
-//   * 64 lanes = 64 splats of one block list (deepest in lane 0); the block's pixels are visited two at a time with
-//     packed fp32 math.  The per-pixel recurrences of alpha compositing become wave64 DPP scans:
-//         B_i = prod_{j at or behind i} (1 - alpha_j)          T_i = T_final / B_i        (transmittance in front of i)
-//         S_i = sum_{j behind i} alpha_j T_j (c_j . dL/dC)                                  (colour behind i)
-//     carried across groups / chunks through one (B, S) pair per pixel in LDS;
+//   * wave w owns quadrant w and ballot-compacts, per block, the chunk's splats that reach it;
+//   * each 16-lane DPP row of the wave owns one block and takes 16 entries of its list per step (deepest in the row's
+//     lane 0); the block's pixels are visited two at a time with packed fp32 math.  With x_i = c_i . dL/dC, the per-pixel
+//     recurrences of alpha compositing are ONE prefix scan of affine maps over the row's lanes:
+//         F_i(x) = alpha_i x_i + (1 - alpha_i) x          (what is seen at the front face of splat i, given x behind it)
+//         A_i = prod_{j at or behind i} (1 - alpha_j)      T_i = T_final / (A_i * carry)   (transmittance in front of i)
+//         R_i = (F_{i+1} o F_{i+2} o ...)(bg . dL/dC)      dL/dalpha_i = T_i (x_i - R_i)
+//     so no division by (1 - alpha) is needed.  (A, R) behind the group is carried through one pair per pixel in LDS;
 //   * every lane then owns its splat's 11 sums outright: no cross-lane reduction, no atomics.  Each wave adds into its
-//     own LDS copy of the chunk's records; the four copies are added in fixed order => bitwise reproducible.
+//     own LDS copy of the chunk's records, one row after the other (a splat can sit in several rows); the four copies
+//     are added in fixed order => bitwise reproducible.
 // ================================================================================================================
 struct __attribute__((aligned(16))) ChunkRec {
     float x, y, ap, bp;
@@ -116,7 +124,7 @@ struct __attribute__((aligned(16))) ChunkRec {
     float b; u32 pos; u32 mask; u32 e;         // mask: 4x4 blocks reachable (bit by*4+bx); e: emission slot
 };
 // per pixel PAIR (two horizontally adjacent pixels A,B of one block row), 16 floats:
-//   [g0A g0B g1A g1B] [g2A g2B TfA TfB] [bgtA bgtB ncA ncB] [BcA BcB ScA ScB]
+//   [g0A g0B g1A g1B] [g2A g2B TfA TfB] [ -    -   ncA ncB] [AcA AcB RcA RcB]     (Ac, Rc: carries behind the group)
 struct __attribute__((aligned(16))) PixPair { float4 q0, q1, q2, q3; };
 
 // blocks of the tile a splat can reach with alpha >= 1/255 (conservative; exactness comes from the per-pixel test).
@@ -165,10 +173,7 @@ __device__ unsigned long long g_phase_cycles[8];
 #else
 #define PH_MARK(i) do {} while (0)
 #endif
-#ifndef BWD_ROWS
-#define BWD_ROWS 1          // 1: each 16-lane DPP row of a wave walks its own block list (16 splats per step); 0: one block, 64 splats
-#endif
-template <bool ABS, bool ROWS>
+template <bool ABS>
 __global__ void __launch_bounds__(256, SCAN_WG_PER_CU)
 blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ ranges, const u32* __restrict__ point_list,
                       const float4* __restrict__ g2d, const float* __restrict__ bg, const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
@@ -208,11 +213,11 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
         const float g0 = in ? grad_color[pixi] : 0.f, g1 = in ? grad_color[HW + pixi] : 0.f, g2 = in ? grad_color[2 * HW + pixi] : 0.f;
         const float Tf = in ? final_T[pixi] : 1.f;
         const u32 nc = in ? n_contrib[pixi] : 0u;
-        const float bgt = Tf * (bg[0] * g0 + bg[1] * g1 + bg[2] * g2);
+        const float bgg = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;          // what lies behind the deepest splat
         float* pp = reinterpret_cast<float*>(&pixq[tid >> 4][((tid >> 1) & 7) * 4]);
         const int h = tid & 1;                        // A or B of the pair
         pp[0 + h] = g0; pp[2 + h] = g1; pp[4 + h] = g2; pp[6 + h] = Tf;
-        pp[8 + h] = bgt; pp[10 + h] = __uint_as_float(nc); pp[12 + h] = 1.f; pp[14 + h] = 0.f;
+        pp[8 + h] = 0.f; pp[10 + h] = __uint_as_float(nc); pp[12 + h] = 1.f; pp[14 + h] = bgg;
         u32 m = nc;
 #pragma unroll
         for (int d = 8; d >= 1; d >>= 1) m = max(m, (u32)__shfl_xor((int)m, d));   // 16 consecutive threads = one block
@@ -332,29 +337,31 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
                 ala.x = v0 ? ala.x : 0.f; ala.y = v1 ? ala.y : 0.f; alb.x = v2 ? alb.x : 0.f; alb.y = v3 ? alb.y : 0.f;
                 Ga.x = v0 ? Ga.x : 0.f; Ga.y = v1 ? Ga.y : 0.f; Gb.x = v2 ? Gb.x : 0.f; Gb.y = v3 ? Gb.y : 0.f;
                 const f2 oma = 1.f - ala, omb = 1.f - alb;
-                // ---- B_i: product over this and deeper splats (x what lies behind the group, carried in q*3.xy)
-                float B0 = oma.x, B1 = oma.y, B2 = omb.x, B3 = omb.y;
-                if (ROWS) scan_mul16x4(B0, B1, B2, B3); else scan_mul64x4(B0, B1, B2, B3);
-                const f2 Ba = (f2){B0, B1} * (f2){q03.x, q03.y}, Bb = (f2){B2, B3} * (f2){q13.x, q13.y};
-                const f2 Tna = {q01.z * __builtin_amdgcn_rcpf(Ba.x), q01.w * __builtin_amdgcn_rcpf(Ba.y)};   // T in front of i
-                const f2 Tnb = {q11.z * __builtin_amdgcn_rcpf(Bb.x), q11.w * __builtin_amdgcn_rcpf(Bb.y)};
-                const f2 wa = ala * Tna, wb = alb * Tnb;
                 const f2 g0a = {q00.x, q00.y}, g1a = {q00.z, q00.w}, g2a = {q01.x, q01.y};
                 const f2 g0b = {q10.x, q10.y}, g1b = {q10.z, q10.w}, g2b = {q11.x, q11.y};
                 const f2 sda = __builtin_elementwise_fma((f2){s.b, s.b}, g2a, __builtin_elementwise_fma((f2){s.g, s.g}, g1a, s.r * g0a));
                 const f2 sdb = __builtin_elementwise_fma((f2){s.b, s.b}, g2b, __builtin_elementwise_fma((f2){s.g, s.g}, g1b, s.r * g0b));
-                const f2 wsa = wa * sda, wsb = wb * sdb;
-                float S0 = wsa.x, S1 = wsa.y, S2 = wsb.x, S3 = wsb.y;
-                if (ROWS) scan_add16x4(S0, S1, S2, S3); else scan_add64x4(S0, S1, S2, S3);
-                const f2 Sia = (f2){S0, S1} + (f2){q03.z, q03.w}, Sib = (f2){S2, S3} + (f2){q13.z, q13.w};
+                // ---- one affine scan per pixel: F_i(x) = alpha_i (c_i . g) + (1 - alpha_i) x, lane 0 (deepest) innermost
+                const f2 ofa = ala * sda, ofb = alb * sdb;
+                float A0 = oma.x, A1 = oma.y, A2 = omb.x, A3 = omb.y;
+                float o0 = ofa.x, o1 = ofa.y, o2 = ofb.x, o3 = ofb.y;
+                scan_affine16x4(A0, A1, A2, A3, o0, o1, o2, o3);
+                // carries in q*3: .xy = prod (1 - alpha) behind the group, .zw = colour . g seen behind the group
+                const f2 Ba = (f2){A0, A1} * (f2){q03.x, q03.y}, Bb = (f2){A2, A3} * (f2){q13.x, q13.y};
+                const f2 Tna = {q01.z * __builtin_amdgcn_rcpf(Ba.x), q01.w * __builtin_amdgcn_rcpf(Ba.y)};   // T in front of i
+                const f2 Tnb = {q11.z * __builtin_amdgcn_rcpf(Bb.x), q11.w * __builtin_amdgcn_rcpf(Bb.y)};
+                const f2 wa = ala * Tna, wb = alb * Tnb;
+                // what is seen at the FRONT face of i; the next deeper lane's value is what lies BEHIND i
+                const f2 Va = __builtin_elementwise_fma((f2){A0, A1}, (f2){q03.z, q03.w}, (f2){o0, o1});
+                const f2 Vb = __builtin_elementwise_fma((f2){A2, A3}, (f2){q13.z, q13.w}, (f2){o2, o3});
+                float R0 = q03.z, R1 = q03.w, R2 = q13.z, R3 = q13.w;
+                shift_up16x4(R0, R1, R2, R3, Va.x, Va.y, Vb.x, Vb.y);
                 if (carry) {                                            // carries for the next (shallower) group
-                    P0[3] = make_float4(Ba.x, Ba.y, Sia.x, Sia.y);
-                    P1[3] = make_float4(Bb.x, Bb.y, Sib.x, Sib.y);
+                    P0[3] = make_float4(Ba.x, Ba.y, Va.x, Va.y);
+                    P1[3] = make_float4(Bb.x, Bb.y, Vb.x, Vb.y);
                 }
-                const f2 ioma = {__builtin_amdgcn_rcpf(oma.x), __builtin_amdgcn_rcpf(oma.y)};
-                const f2 iomb = {__builtin_amdgcn_rcpf(omb.x), __builtin_amdgcn_rcpf(omb.y)};
-                const f2 dLa = __builtin_elementwise_fma(Tna, sda, -(((Sia - wsa) + (f2){q02.x, q02.y}) * ioma));
-                const f2 dLb = __builtin_elementwise_fma(Tnb, sdb, -(((Sib - wsb) + (f2){q12.x, q12.y}) * iomb));
+                const f2 dLa = Tna * (sda - (f2){R0, R1});
+                const f2 dLb = Tnb * (sdb - (f2){R2, R3});
                 a0 = __builtin_elementwise_fma(wa, g0a, a0); a1 = __builtin_elementwise_fma(wa, g1a, a1); a2 = __builtin_elementwise_fma(wa, g2a, a2);
                 a0 = __builtin_elementwise_fma(wb, g0b, a0); a1 = __builtin_elementwise_fma(wb, g1b, a1); a2 = __builtin_elementwise_fma(wb, g2b, a2);
                 const f2 gda = Ga * dLa, gdb = Gb * dLb;                // G == 0 for non-contributing pairs
@@ -399,52 +406,31 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
             }
             return L;
         };
-        if (ROWS) {
-            // ---- the wave owns quadrant `wave`; DPP row r of the wave owns one 4x4 block of it and walks that block's
-            // list 16 splats per step (deepest in the row's lane 0).  Against "64 lanes = 64 splats of one block" this
-            // quantises the lists at 16 instead of 64 entries and shortens the scans from six DPP steps to four.
-            const int row = lane >> 4, li = lane & 15;
-            const int qx = (wave & 1) * 2, qy = (wave >> 1) * 2;
-            const int myblk = (qy + (row >> 1)) * 4 + qx + (row & 1);
-            int Lr[4];
+        // ---- the wave owns quadrant `wave`; DPP row r of the wave owns one 4x4 block of it and walks that block's
+        // list 16 splats per step (deepest in the row's lane 0).  Against "64 lanes = 64 splats of one block" (in the git
+        // history) this quantises the lists at 16 instead of 64 entries and shortens the scans from six DPP steps to four.
+        const int row = lane >> 4, li = lane & 15;
+        const int qx = (wave & 1) * 2, qy = (wave >> 1) * 2;
+        const int myblk = (qy + (row >> 1)) * 4 + qx + (row & 1);
+        int Lr[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) Lr[j] = build_list((qy + (j >> 1)) * 4 + qx + (j & 1));
-            PH_MARK(3);    // list building
-            const int myL = (row == 0) ? Lr[0] : (row == 1) ? Lr[1] : (row == 2) ? Lr[2] : Lr[3];
-            const int nIter = (max(max(Lr[0], Lr[1]), max(Lr[2], Lr[3])) + 15) >> 4;
-            const float bx0 = X0 + 4.f * (float)(myblk & 3), by0 = Y0 + 4.f * (float)(myblk >> 2);
-            float4* pixb = &pixq[myblk][0];
-            for (int it = 0; it < nIter; ++it) {
-                const int gend = myL - 16 * it;                 // <= 0: this row's list is exhausted
-                const bool live = li < gend;
-                const int slot = live ? (int)lists[myblk][gend - 1 - li] : 0;
-                const ChunkRec s = recs[slot];
-                block_rows(s, live, bx0, by0, pixb, (li == 15) && (gend > 0));
-                // the same splat can sit in several rows (it reaches several blocks of the quadrant): one row at a time
+        for (int j = 0; j < 4; ++j) Lr[j] = build_list((qy + (j >> 1)) * 4 + qx + (j & 1));
+        PH_MARK(3);    // list building
+        const int myL = (row == 0) ? Lr[0] : (row == 1) ? Lr[1] : (row == 2) ? Lr[2] : Lr[3];
+        const int nIter = (max(max(Lr[0], Lr[1]), max(Lr[2], Lr[3])) + 15) >> 4;
+        const float bx0 = X0 + 4.f * (float)(myblk & 3), by0 = Y0 + 4.f * (float)(myblk >> 2);
+        float4* pixb = &pixq[myblk][0];
+        for (int it = 0; it < nIter; ++it) {
+            const int gend = myL - 16 * it;                 // <= 0: this row's list is exhausted
+            const bool live = li < gend;
+            const int slot = live ? (int)lists[myblk][gend - 1 - li] : 0;
+            const ChunkRec s = recs[slot];
+            block_rows(s, live, bx0, by0, pixb, (li == 15) && (gend > 0));
+            // the same splat can sit in several rows (it reaches several blocks of the quadrant): one row at a time
 #pragma unroll
-                for (int ph = 0; ph < 4; ++ph)
-                    if (row == ph && live) add_to_copy(slot);
-                PH_MARK(4);    // groups
-            }
-        } else {
-#pragma unroll 1
-            for (int j = 0; j < 4; ++j) {
-                const int blk = j * 4 + wave;                    // one block per block row, column = wave
-                const int L = build_list(blk);
-                PH_MARK(3);    // list building
-                if (L == 0) continue;
-                const float bx0 = X0 + 4.f * (float)(blk & 3), by0 = Y0 + 4.f * (float)(blk >> 2);
-                // groups of 64 list entries, deepest group first; inside a group lane 0 holds the deepest entry
-                for (int gend = L; gend > 0; gend -= 64) {
-                    const int gcnt = min(gend, 64);
-                    const bool live = lane < gcnt;
-                    const int slot = live ? (int)lists[blk][gend - 1 - lane] : 0;
-                    const ChunkRec s = recs[slot];
-                    block_rows(s, live, bx0, by0, &pixq[blk][0], lane == 63);
-                    if (live) add_to_copy(slot);                 // distinct lanes hold distinct slots
-                    PH_MARK(4);    // groups
-                }
-            }
+            for (int ph = 0; ph < 4; ++ph)
+                if (row == ph && live) add_to_copy(slot);
+            PH_MARK(4);    // groups
         }
         PH_MARK(3);
         lds_barrier();
@@ -503,11 +489,11 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     if (T == 0) return hipSuccess;
     const int grid = ((T + 7) / 8) * 8;
     if (want_abs)
-        hipLaunchKernelGGL((blend_bwd_scan_kernel<true, BWD_ROWS != 0>), dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
+        hipLaunchKernelGGL(blend_bwd_scan_kernel<true>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
                            b.ranges, b.point_list, g.g2d, s.bg,
                            im.final_T, im.n_contrib, grad_color, partials);
     else
-        hipLaunchKernelGGL((blend_bwd_scan_kernel<false, BWD_ROWS != 0>), dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
+        hipLaunchKernelGGL(blend_bwd_scan_kernel<false>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
                            b.ranges, b.point_list, g.g2d, s.bg,
                            im.final_T, im.n_contrib, grad_color, partials);
     return hipGetLastError();
