@@ -105,6 +105,7 @@ size_t carve_image(void* base, int W, int H, ImgView* v)
     ImgView im;
     const size_t n = (size_t)W * H > 0 ? (size_t)W * H : 1;
     take(p, im.final_T, n); take(p, im.n_contrib, n);
+    take(p, im.tile_maxc, (size_t)cdiv(W > 0 ? W : 1, BAGS_TILE) * cdiv(H > 0 ? H : 1, BAGS_TILE));
     if (v) *v = im;
     return (size_t)(p - reinterpret_cast<char*>(base));
 }

@@ -62,6 +62,7 @@ struct BinView {
 struct ImgView {
     float* final_T;          // [H*W]
     u32*   n_contrib;        // [H*W]
+    u32*   tile_maxc;        // [tiles] max n_contrib over the tile's pixels (written by blend_fwd, read by blend_bwd)
 };
 
 int radix_items_for(long long n);

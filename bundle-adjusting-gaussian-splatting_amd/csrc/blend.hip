@@ -177,7 +177,7 @@ template <bool ABS>
 __global__ void __launch_bounds__(256, SCAN_WG_PER_CU)
 blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ ranges, const u32* __restrict__ point_list,
                       const float4* __restrict__ g2d, const float* __restrict__ bg, const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
-                      const float* __restrict__ grad_color, float* __restrict__ partials)
+                      const u32* __restrict__ tile_maxc, const float* __restrict__ grad_color, float* __restrict__ partials)
 {
     const int tile = tile_of_block(blockIdx.x, T);
     if (tile >= T) return;
@@ -195,24 +195,38 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
     __shared__ unsigned char lists[16][BCHUNK];       //  4 KB
     __shared__ u32 masks[BCHUNK];                     //  1 KB: block reach masks, compact (the 48-B record stride bank-conflicts)
     __shared__ float acc[4][BCHUNK][12];              // 48 KB, one copy per wave (LDS float atomics on a shared copy were 1.6x slower)
-    __shared__ u32 wmax[4];
     __shared__ u32 blk_maxc[16];                     // last contributor over the 16 pixels of each block
 
 #ifdef DIAG_PHASES
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
 #endif
+    // The tile's deepest contributor comes from the forward (one scalar load), so the ids of the first two chunks are
+    // requested before anything else and the pixel loads below overlap them: the per-tile dependent chain is
+    // range -> ids -> gathers instead of range -> pixels -> workgroup max -> ids -> gathers.
+    const u32 maxc = min(tile_maxc[tile], n);
+    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    struct Raw { float4 q0, q1, q2; u32 io; };      // conic+opacity | x y r g | b z rect | inst_offset
+    auto fetch_id = [&](u32 hi_) -> u32 {            // id of this thread's slot in the chunk that ends at hi_
+        const u32 c_ = min(hi_, (u32)BCHUNK);
+        return ((u32)tid < c_) ? point_list[range.x + (hi_ - c_) + tid] : 0xFFFFFFFFu;
+    };
+    const u32 gid0 = fetch_id(maxc);
+    u32 gid1 = (maxc > BCHUNK) ? fetch_id(maxc - BCHUNK) : 0xFFFFFFFFu;       // ids of chunk 1, in flight with chunk 0's
+
     // ---- per-pixel constants: thread tid <-> block tid>>4, pixel tid&15 (ix = &3, iy = >>2)
-    u32 maxc;
     {
         const int b = tid >> 4, i = tid & 15;
         const int px = tile_x * BAGS_TILE + (b & 3) * 4 + (i & 3);
         const int py = tile_y * BAGS_TILE + (b >> 2) * 4 + (i >> 2);
         const bool in = (px < W) && (py < H);
-        const size_t HW = (size_t)W * H, pixi = (size_t)py * W + px;
-        const float g0 = in ? grad_color[pixi] : 0.f, g1 = in ? grad_color[HW + pixi] : 0.f, g2 = in ? grad_color[2 * HW + pixi] : 0.f;
-        const float Tf = in ? final_T[pixi] : 1.f;
-        const u32 nc = in ? n_contrib[pixi] : 0u;
+        const size_t HW = (size_t)W * H, pixi = (size_t)min(py, H - 1) * W + min(px, W - 1);   // always a valid address
+        const float l0 = grad_color[pixi], l1 = grad_color[HW + pixi], l2 = grad_color[2 * HW + pixi];
+        const float lT = final_T[pixi];
+        const u32 lnc = n_contrib[pixi];
+        const float g0 = in ? l0 : 0.f, g1 = in ? l1 : 0.f, g2 = in ? l2 : 0.f;
+        const float Tf = in ? lT : 1.f;
+        const u32 nc = in ? lnc : 0u;
         const float bgg = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;          // what lies behind the deepest splat
         float* pp = reinterpret_cast<float*>(&pixq[tid >> 4][((tid >> 1) & 7) * 4]);
         const int h = tid & 1;                        // A or B of the pair
@@ -221,12 +235,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
         u32 m = nc;
 #pragma unroll
         for (int d = 8; d >= 1; d >>= 1) m = max(m, (u32)__shfl_xor((int)m, d));   // 16 consecutive threads = one block
-        if ((tid & 15) == 0) blk_maxc[b] = m;
-#pragma unroll
-        for (int d = 32; d >= 16; d >>= 1) m = max(m, (u32)__shfl_xor((int)m, d));
-        if (lane == 0) wmax[wave] = m;
-        __syncthreads();
-        maxc = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        if ((tid & 15) == 0) blk_maxc[b] = m;        // read after the first chunk barrier
     }
 
     // instances behind the last contributor of every pixel are never visited: their records are zero
@@ -240,15 +249,9 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         dst[0] = z4; dst[1] = z4; dst[2] = z4;
     }
-    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
     // Software pipeline over chunks: Gaussian ids are fetched TWO chunks ahead and the per-splat gathers ONE chunk
     // ahead, so neither the id load nor the dependent gathers sit on the critical path of a chunk.
-    struct Raw { float4 q0, q1, q2; u32 io; };      // conic+opacity | x y r g | b z rect | inst_offset
-    auto fetch_id = [&](u32 hi_) -> u32 {            // id of this thread's slot in the chunk that ends at hi_
-        const u32 c_ = min(hi_, (u32)BCHUNK);
-        return ((u32)tid < c_) ? point_list[range.x + (hi_ - c_) + tid] : 0xFFFFFFFFu;
-    };
     auto fetch = [&](u32 g) {
         Raw r; r.q0 = make_float4(0.f, 0.f, 0.f, 0.f); r.q1 = r.q0; r.q2 = r.q0; r.io = 0u;
         if (g != 0xFFFFFFFFu) {                       // one 64-byte line
@@ -289,8 +292,6 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
     //   then     issue the gathers of chunk k+1 (ids known) and the id load of chunk k+2
     //   ...      lists + groups of chunk k            <- the loads land underneath
     //   barrier  consume gathers -> rec(k+1), ids(k+2); only then store the records of chunk k
-    const u32 gid0 = fetch_id(maxc);
-    u32 gid1 = (maxc > BCHUNK) ? fetch_id(maxc - BCHUNK) : 0xFFFFFFFFu;       // ids of chunk 1, in flight with chunk 0's
     ChunkRec rec = make_rec(fetch(gid0), maxc - min(maxc, (u32)BCHUNK), min(maxc, (u32)BCHUNK));
     asm volatile("" :: "v"(gid1));    // complete before the loop: a pending load on the entry edge costs a vmcnt(0) at every loop top
 
@@ -491,11 +492,11 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     if (want_abs)
         hipLaunchKernelGGL(blend_bwd_scan_kernel<true>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
                            b.ranges, b.point_list, g.g2d, s.bg,
-                           im.final_T, im.n_contrib, grad_color, partials);
+                           im.final_T, im.n_contrib, im.tile_maxc, grad_color, partials);
     else
         hipLaunchKernelGGL(blend_bwd_scan_kernel<false>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
                            b.ranges, b.point_list, g.g2d, s.bg,
-                           im.final_T, im.n_contrib, grad_color, partials);
+                           im.final_T, im.n_contrib, im.tile_maxc, grad_color, partials);
     return hipGetLastError();
 }
 
@@ -517,7 +518,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU)
 blend_fwd_rows_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ ranges, const u32* __restrict__ point_list,
                       const float4* __restrict__ g2d, const float* __restrict__ bg, float* __restrict__ out_color,
                       float* __restrict__ out_depth, float* __restrict__ out_weights, float* __restrict__ final_T,
-                      u32* __restrict__ n_contrib)
+                      u32* __restrict__ n_contrib, u32* __restrict__ tile_maxc)
 {
     const int tile = tile_of_block(blockIdx.x, T);
     if (tile >= T) return;
@@ -620,6 +621,14 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
         final_T[pix] = Tq;
         n_contrib[pix] = last;
     }
+    // the tile's deepest contributor: with it the backward can fetch its first chunk of ids before it has seen a pixel
+    u32 m = last;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (u32)__shfl_xor((int)m, d));
+    __syncthreads();                                         // s_live is free again
+    if (lane == 0) s_live[wave] = (int)m;
+    __syncthreads();
+    if (tid == 0) tile_maxc[tile] = (u32)max(max(s_live[0], s_live[1]), max(s_live[2], s_live[3]));
 }
 
 hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
@@ -631,6 +640,6 @@ hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinV
     const int grid = ((T + 7) / 8) * 8;
     hipLaunchKernelGGL(blend_fwd_rows_kernel<0>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
                        b.ranges, b.point_list, g.g2d, s.bg, out.color, out.depth, out.weights,
-                       im.final_T, im.n_contrib);
+                       im.final_T, im.n_contrib, im.tile_maxc);
     return hipGetLastError();
 }
