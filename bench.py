@@ -45,7 +45,7 @@ def build_case(P, W, H, sm, rank, dev):
     return scene, cam
 
 
-def make_step(scene, cam, dev, pose_grads=True):
+def make_step(scene, cam, dev, pose_grads=True, tile_bounds="opacity"):
     from bags_raster import GaussianRasterizationSettings, GaussianRasterizer
     from scenes import camera_tensors
     P = scene["means3D"].shape[0]
@@ -58,7 +58,8 @@ def make_step(scene, cam, dev, pose_grads=True):
                                        tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
                                        bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=ct["viewmatrix"],
                                        projmatrix=ct["projmatrix"], intrinsic=ct["intrinsic"], sh_degree=DEG,
-                                       campos=ct["campos"], prefiltered=False, debug=False, debug_iter=0)
+                                       campos=ct["campos"], prefiltered=False, debug=False, debug_iter=0,
+                                       tile_bounds=tile_bounds)
     rast = GaussianRasterizer(st)
     cot = torch.randn(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(1)).to(dev)
     params = list(leaves.values())
@@ -128,6 +129,9 @@ def main():
     ap.add_argument("--sm", type=float, default=SM_DEFAULT)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage hipEvents in the timed region")
+    ap.add_argument("--tile-bounds", default="opacity", choices=("opacity", "aabb"),
+                    help="opacity: bin a Gaussian into the tiles its alpha >= 1/255 ellipse can reach (default; same image and "
+                         "gradients); aabb: the stock 3-sigma square (upstream's instance list)")
     ap.add_argument("--fixed-pose", action="store_true", help="config 2 exactly: no pose/intrinsic gradients requested")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for self-tests "
                                                       "of the multi-rank path on a single GPU)")
@@ -157,7 +161,7 @@ def main():
     from bags_raster.sharding import GradAllReducer
     P, W, H = args.P, args.width, args.height
     scene, cam = build_case(P, W, H, args.sm, rank, dev)
-    step, params, ct = make_step(scene, cam, dev, pose_grads=not args.fixed_pose)
+    step, params, ct = make_step(scene, cam, dev, pose_grads=not args.fixed_pose, tile_bounds=args.tile_bounds)
     reducer = GradAllReducer(params) if world > 1 else None
 
     def full_step():
@@ -226,7 +230,7 @@ def main():
             "config": {"workload": f"BASELINE config {'2' if args.fixed_pose else '3'}: synth({P}, seed 0, sm {args.sm}), "
                                    f"1 camera/rank @{W}x{H}, SH deg 3, fwd+bwd"
                                    f"{'' if args.fixed_pose else ' incl. pose/intrinsic gradients'}",
-                       "P": P, "visible_G": G, "instances_I": I, "width": W, "height": H,
+                       "P": P, "visible_G": G, "instances_I": I, "tile_bounds": args.tile_bounds, "width": W, "height": H,
                        "parallelism": f"view-sharded x{world}" + (", RCCL all-reduce of Gaussian grads" if world > 1 else "")},
             "instances_per_s": world * I * args.steps / elapsed,
         }
@@ -237,7 +241,7 @@ def main():
                 traffic = None      # PMC bytes of this kernel, measured in a separate rocprofv3 --pmc pass (profiles/)
                 try:
                     tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))
-                    if tj["key"] == {"P": P, "width": W, "height": H, "sm": args.sm} and dom in tj:
+                    if tj["key"] == {"P": P, "width": W, "height": H, "sm": args.sm, "tile_bounds": args.tile_bounds} and dom in tj:
                         traffic = tj[dom]["fetch_bytes"] + tj[dom]["write_bytes"]
                 except (OSError, KeyError, ValueError):
                     pass

@@ -15,7 +15,7 @@ struct CamConst {
 };
 
 __global__ void __launch_bounds__(256)
-preprocess_fwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod, int depth_mode,
+preprocess_fwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod, int depth_mode, int tile_bounds,
                       const float* __restrict__ means3D, const float* __restrict__ means2D,
                       const float* __restrict__ shift_factors, const float* __restrict__ shs,
                       const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
@@ -142,10 +142,34 @@ preprocess_fwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                 const int maxx = min(gx, max(0, (int)fminf(big, fmaxf(-big, (px + rad_f + 15.0f) / 16.0f))));
                 const int maxy = min(gy, max(0, (int)fminf(big, fmaxf(-big, (py + rad_f + 15.0f) / 16.0f))));
                 const int nt = (maxx - minx) * (maxy - miny);
-                if (nt > 0) {
-                    tiles = (u32)nt;
+                if (nt > 0) {                                // "visible" (radii > 0) is decided by the stock rectangle
+                    int ex0 = minx, ey0 = miny, ex1 = maxx, ey1 = maxy;      // rectangle the instances are emitted for
+                    if (tile_bounds == BAGS_TILES_OPACITY) {
+                        // alpha = o exp(-d^T Q d / 2) >= 1/255 only inside d^T Q d <= 2 ln(255 o), whose axis-aligned half
+                        // extents are sqrt(2 ln(255 o) cov_xx), sqrt(.. cov_yy).  ln is bounded from above with operations
+                        // every IEEE implementation rounds identically (the oracle repeats them in torch): 255 o = m 2^e,
+                        // ln(m) <= t - t^2/2 + t^3/3 - t^4/4 for t = m - 1 in [-1/2, 0) (all dropped terms are negative).
+                        // Margins: 1e-3 + 0.02 on 2 ln, 2 % + 0.1 px on the extents (the conic the pixel test uses is the
+                        // inverse of cov2D only up to det's rounding, ~1e-7 x anisotropy, a common scale on the ellipse).
+                        const float visv = 255.0f * opacities[i];
+                        if (!(visv >= 1.0f)) { ex1 = ex0; ey1 = ey0; }
+                        else {
+                            int e2; const float mant = frexpf(visv, &e2);
+                            const float t = mant - 1.0f;
+                            const float poly = t * (1.0f + t * (-0.5f + t * (0.33333334f + t * -0.25f)));
+                            const float lnu = (float)e2 * 0.6931472f + poly + 1.0e-3f;
+                            const float tau2 = 2.0f * lnu + 0.02f;
+                            const float rx = sqrtf(tau2 * cxx) * 1.02f + 0.1f, ry = sqrtf(tau2 * cyy) * 1.02f + 0.1f;
+                            ex0 = max(ex0, min(gx, max(0, (int)fminf(big, fmaxf(-big, (px - rx) / 16.0f)))));
+                            ey0 = max(ey0, min(gy, max(0, (int)fminf(big, fmaxf(-big, (py - ry) / 16.0f)))));
+                            ex1 = min(ex1, min(gx, max(0, (int)fminf(big, fmaxf(-big, (px + rx) / 16.0f)) + 1)));
+                            ey1 = min(ey1, min(gy, max(0, (int)fminf(big, fmaxf(-big, (py + ry) / 16.0f)) + 1)));
+                            if (ex1 <= ex0 || ey1 <= ey0) { ex1 = ex0; ey1 = ey0; }
+                        }
+                    }
+                    tiles = (u32)((ex1 - ex0) * (ey1 - ey0));
                     radius = (int)rad_f;
-                    rect = make_uint2((u32)minx | ((u32)miny << 16), (u32)maxx | ((u32)maxy << 16));
+                    rect = make_uint2((u32)ex0 | ((u32)ey0 << 16), (u32)ex1 | ((u32)ey1 << 16));
                     pxy = make_float2(px, py);
                     const float dsort = (depth_mode == BAGS_DEPTH_DISTANCE) ? sqrtf(tx * tx + ty * ty + tzs * tzs) : tzs;
                     key = __float_as_uint(dsort);
@@ -207,7 +231,7 @@ hipError_t launch_preprocess_fwd(const BagsSettings& s, const BagsInputs& in, co
     const int P = in.P;
     if (P == 0) return hipSuccess;
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, P, s.sh_coeffs, s.sh_degree,
-                       s.image_width, s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, s.depth_key,
+                       s.image_width, s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, s.depth_key, s.tile_bounds,
                        in.means3D, in.means2D, in.shift_factors, in.shs, in.colors_precomp, in.opacities, in.scales,
                        in.rotations, in.cov3D_precomp, s.viewmatrix, s.projmatrix, s.intrinsic, s.campos,
                        g.depth_key, g.g2d, g.rect, g.tiles_touched, radii, mean2D);

@@ -31,11 +31,18 @@
 extern "C" {
 #endif
 
-#define BAGS_ABI_VERSION 1
+#define BAGS_ABI_VERSION 2
 #define BAGS_TILE 16
 
 enum { BAGS_OK = 0, BAGS_ERR_ARG = -1, BAGS_ERR_HIP = -2, BAGS_ERR_SIZE = -3, BAGS_ERR_DEVICE = -4 };
 enum { BAGS_DEPTH_Z = 0, BAGS_DEPTH_DISTANCE = 1 };   /* README.md:126: sort key is view z, or distance for cubemaps */
+/* Which tiles a Gaussian is binned into.  BAGS_TILES_AABB is the stock rule: every tile overlapping the square
+ * [p - r, p + r + 15] with r = ceil(3 sqrt(lambda_max)).  BAGS_TILES_OPACITY intersects that rectangle with the
+ * axis-aligned bounds of the ellipse alpha >= 1/255 (half extents sqrt(2 ln(255 o) cov_xx), sqrt(.. cov_yy), with a
+ * 2 % + 0.1 px safety margin): every (tile, Gaussian) pair it drops has alpha < 1/255 on all 256 pixels, i.e. is skipped
+ * by the compositing loop anyway, so image, radii and every gradient are unchanged while the sorted instance list
+ * shrinks (27 % on BASELINE config 3). */
+enum { BAGS_TILES_AABB = 0, BAGS_TILES_OPACITY = 1 };
 
 /* GaussianRasterizationSettings (gaussian_renderer/__init__.py:50-65) */
 typedef struct BagsSettings {
@@ -47,6 +54,8 @@ typedef struct BagsSettings {
     int32_t depth_key;               /* BAGS_DEPTH_Z | BAGS_DEPTH_DISTANCE */
     int32_t debug;                   /* !=0: synchronise + check after every kernel */
     int32_t debug_iter;              /* carried for error messages only */
+    int32_t tile_bounds;             /* BAGS_TILES_AABB | BAGS_TILES_OPACITY */
+    int32_t reserved0;               /* keeps the pointers 8-byte aligned; must be 0 */
     const float* bg;                 /* (3)   */
     const float* viewmatrix;         /* (4,4) world->view, transposed (W2C^T) */
     const float* projmatrix;         /* (4,4) viewmatrix * intrinsic */

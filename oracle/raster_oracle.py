@@ -100,6 +100,7 @@ class OracleSettings:
     debug: bool = False
     debug_iter: Optional[int] = None
     depth_key: str = "z"
+    tile_bounds: str = "opacity"      # "aabb": stock 3-sigma square; "opacity": intersected with the alpha >= 1/255 bounds
 
 
 @dataclass
@@ -293,7 +294,34 @@ def preprocess(means3D, means2D, shift_factors, shs, colors_precomp, opacities, 
         minx, maxx = tile_lo(pxd, rd, gx), tile_hi(pxd, rd, gx)
         miny, maxy = tile_lo(pyd, rd, gy), tile_hi(pyd, rd, gy)
         tiles = (maxx - minx) * (maxy - miny)
-        vis_s = ok & (tiles > 0)
+        vis_s = ok & (tiles > 0)                       # "visible" (radii > 0) is decided by the stock rectangle
+        if s.tile_bounds == "opacity":
+            # Decision D7 (include/bags_raster.h: BAGS_TILES_OPACITY): emit instances only for tiles inside the axis-aligned
+            # bounds of the ellipse alpha >= 1/255.  Same operations, same order as preprocess_fwd.hip (every one of
+            # them is correctly rounded in both implementations, so the rectangles are bit-identical).
+            f = lambda v: _f(v, pxd)
+            visv = f(255.0) * op_s.reshape(n).detach()
+            has = ok & (visv >= 1.0)
+            visv = torch.where(has, visv, torch.ones_like(visv))
+            mant, e2 = torch.frexp(visv)
+            t = mant - 1.0
+            poly = t * (1.0 + t * (-0.5 + t * (f(0.33333334) + t * -0.25)))
+            lnu = e2.to(pxd.dtype) * f(0.6931472) + poly + f(1.0e-3)
+            tau2 = 2.0 * lnu + f(0.02)
+            rx = _sqrt(tau2 * cxx.detach()) * f(1.02) + f(0.1)
+            ry = _sqrt(tau2 * cyy.detach()) * f(1.02) + f(0.1)
+            rx = torch.where(has, rx, torch.zeros_like(rx)); ry = torch.where(has, ry, torch.zeros_like(ry))
+            def t_lo(p, r, g):
+                return torch.clamp(torch.trunc(torch.clamp((p - r) / TILE, -big, big)).to(torch.int64), 0, g)
+            def t_hi(p, r, g):
+                return torch.clamp(torch.trunc(torch.clamp((p + r) / TILE, -big, big)).to(torch.int64) + 1, 0, g)
+            ex0, ex1 = torch.maximum(minx, t_lo(pxd, rx, gx)), torch.minimum(maxx, t_hi(pxd, rx, gx))
+            ey0, ey1 = torch.maximum(miny, t_lo(pyd, ry, gy)), torch.minimum(maxy, t_hi(pyd, ry, gy))
+            ex0 = torch.where(has, ex0, minx); ey0 = torch.where(has, ey0, miny)      # 255 o < 1: nothing can contribute
+            empty = (~has) | (ex1 <= ex0) | (ey1 <= ey0)
+            ex1 = torch.where(empty, ex0, ex1); ey1 = torch.where(empty, ey0, ey1)
+            minx, maxx, miny, maxy = ex0, ex1, ey0, ey1
+            tiles = (maxx - minx) * (maxy - miny)
         tiles = torch.where(vis_s, tiles, torch.zeros_like(tiles))
         radii_s = torch.where(vis_s, rd, torch.zeros_like(rd)).to(torch.int32)
         rect_s = torch.stack([minx, miny, maxx, maxy], 1).to(torch.int32)

@@ -9,7 +9,7 @@ GRAD_NAMES = ("means3D", "means2D", "means2D_densify", "shift_factors", "shs", "
 
 
 def run_hip(scene, cam, deg, grad_image=None, device="cuda", bg=None, shift=None, colors=None, cov3D=None,
-            scale_modifier=1.0, depth_key="z", debug=False, means2D=None):
+            scale_modifier=1.0, depth_key="z", debug=False, means2D=None, tile_bounds="opacity"):
     """Forward (+ backward) through the product op.  Returns (outputs, grads dict, views dict)."""
     from bags_raster import GaussianRasterizer, debug_views
     dev = torch.device(device)
@@ -22,7 +22,8 @@ def run_hip(scene, cam, deg, grad_image=None, device="cuda", bg=None, shift=None
     sf = (torch.zeros(3) if shift is None else shift).to(dev).requires_grad_(want)
     col = None if colors is None else colors.to(dev).clone().requires_grad_(want)
     cov = None if cov3D is None else cov3D.to(dev).clone().requires_grad_(want)
-    st = hip_settings(cam, deg, dev, bg=bg, scale_modifier=scale_modifier, depth_key=depth_key, tensors=ct, debug=debug)
+    st = hip_settings(cam, deg, dev, bg=bg, scale_modifier=scale_modifier, depth_key=depth_key, tensors=ct, debug=debug,
+                      tile_bounds=tile_bounds)
     rast = GaussianRasterizer(st)
     kw = dict(means3D=t["means3D"], means2D=m2, means2D_densify=m2d, shift_factors=sf,
               shs=None if col is not None else t["shs"], colors_precomp=col, opacities=t["opacities"],
@@ -45,8 +46,8 @@ def run_hip(scene, cam, deg, grad_image=None, device="cuda", bg=None, shift=None
 
 
 def run_oracle(scene, cam, deg, grad_image=None, dtype=torch.float32, bg=None, shift=None, colors=None, cov3D=None,
-               scale_modifier=1.0, depth_key="z", discrete=None, means2D=None):
-    s = oracle_settings(cam, deg, bg=bg, scale_modifier=scale_modifier, depth_key=depth_key)
+               scale_modifier=1.0, depth_key="z", discrete=None, means2D=None, tile_bounds="opacity"):
+    s = oracle_settings(cam, deg, bg=bg, scale_modifier=scale_modifier, depth_key=depth_key, tile_bounds=tile_bounds)
     inp = dict(scene)
     inp["shift_factors"] = torch.zeros(3) if shift is None else shift
     if means2D is not None:

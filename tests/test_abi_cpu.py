@@ -41,7 +41,7 @@ def test_buffer_sizes_grow_with_problem(lib):
 
 def test_struct_layout_matches_header(lib):
     # field counts and pointer-size packing of the POD structs (a mismatch would corrupt every call)
-    assert C.sizeof(_lib.BagsSettings) == 10 * 4 + 5 * 8
+    assert C.sizeof(_lib.BagsSettings) == 12 * 4 + 5 * 8
     assert C.sizeof(_lib.BagsInputs) == 8 + 9 * 8
     assert C.sizeof(_lib.BagsState) == 6 * 8
     assert C.sizeof(_lib.BagsForwardOut) == 5 * 8

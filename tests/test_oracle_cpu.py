@@ -12,12 +12,20 @@ from scenes import make_case, oracle_settings, rel_err
 
 
 def test_config1_counts_match_survey():
-    """BASELINE config 1 (10k Gaussians, 400x400): SURVEY.md 8d measured G = 9 936 visible, I = 270 130 instances."""
+    """BASELINE config 1 (10k Gaussians, 400x400): SURVEY.md 8d measured G = 9 936 visible, I = 270 130 instances with the
+    stock 3-sigma tile rule; the opacity-aware bounds keep the visible set and emit a subset of those instances."""
     scene, cam = make_case(10000, 400, 400, 1.0, 0, seed=0)
-    pre = O.preprocess(scene["means3D"], torch.zeros(10000, 3), torch.zeros(3), scene["shs"], None, scene["opacities"],
-                       scene["scales"], scene["rotations"], None, oracle_settings(cam, 0))
+    args = (scene["means3D"], torch.zeros(10000, 3), torch.zeros(3), scene["shs"], None, scene["opacities"],
+            scene["scales"], scene["rotations"], None)
+    pre = O.preprocess(*args, oracle_settings(cam, 0, tile_bounds="aabb"))
     assert int(pre.visible.sum()) == 9936
     assert int(pre.tiles_touched.sum()) == 270130
+    tight = O.preprocess(*args, oracle_settings(cam, 0, tile_bounds="opacity"))
+    assert torch.equal(tight.visible, pre.visible) and torch.equal(tight.radii, pre.radii)
+    r0, r1 = pre.rect, tight.rect                      # (minx, miny, maxx, maxy): the tight rectangle lies inside the stock one
+    nz = tight.tiles_touched > 0
+    assert bool(((r1[nz, 0] >= r0[nz, 0]) & (r1[nz, 1] >= r0[nz, 1]) & (r1[nz, 2] <= r0[nz, 2]) & (r1[nz, 3] <= r0[nz, 3])).all())
+    assert 0.5 * 270130 < int(tight.tiles_touched.sum()) < 0.85 * 270130
 
 
 def test_binning_is_sorted_stable_and_ranges_partition():
