@@ -376,6 +376,20 @@ int bags_loss_backward(const float* image, const float* gt, int32_t C, int32_t H
     return BAGS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- kNN scale initialiser
+size_t bags_knn_workspace_size(int32_t P) { return knn_workspace_bytes(P > 0 ? P : 1); }
+
+int bags_knn_mean_dist2(const float* points, int32_t P, void* workspace, size_t workspace_bytes, float* out, void* stream)
+{
+    if (P < 0) return fail(BAGS_ERR_ARG, "knn: P < 0");
+    if (P == 0) return BAGS_OK;
+    if (!points || !workspace || !out) return fail(BAGS_ERR_ARG, "knn: null pointer");
+    if (workspace_bytes < knn_workspace_bytes(P))
+        return fail(BAGS_ERR_SIZE, "knn: workspace %zu bytes < %zu", workspace_bytes, knn_workspace_bytes(P));
+    HIP_TRY(launch_knn(points, P, align256(workspace), out, (hipStream_t)stream));
+    return BAGS_OK;
+}
+
 int bags_compute_relocation(const float*, const float*, const int32_t*, const float*, int32_t, int32_t, float*, float*, void*)
 {
     return fail(BAGS_ERR_ARG, "compute_relocation: the reference's only caller is commented out (scene/gaussian_model.py:23,494-504); not implemented");

@@ -94,5 +94,8 @@ size_t loss_workspace_bytes(int C, int H, int W);
 hipError_t launch_loss_fwd(const float* img, const float* gt, int C, int H, int W, void* ws, float* out_terms, hipStream_t st);
 hipError_t launch_loss_bwd(const float* img, const float* gt, int C, int H, int W, const void* ws, const float* grad_terms,
                            float* grad_img, hipStream_t st);
+// knn.hip: mean squared distance to the three nearest neighbours (distCUDA2)
+size_t knn_workspace_bytes(int P);
+hipError_t launch_knn(const float* pts, int P, void* ws, float* out, hipStream_t st);
 hipError_t launch_debug_keys(const u32* tile_sorted, const u32* point_list, const u32* depth_key, long long I, u64* out, hipStream_t st);
 hipError_t launch_unpack_rect(const uint2* rect, int P, u32* out, hipStream_t st);

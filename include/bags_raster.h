@@ -186,6 +186,14 @@ int bags_loss_forward(const float* image, const float* gt, int32_t C, int32_t H,
 int bags_loss_backward(const float* image, const float* gt, int32_t C, int32_t H, int32_t W, const void* workspace,
                        size_t workspace_bytes, const float* grad_terms, float* grad_image, void* stream);
 
+/* distCUDA2 of the reference's second native dependency (simple_knn._C, imported at scene/gaussian_model.py:20, called at
+ * scene/gaussian_model.py:177 to initialise the scales): out[i] = mean of the squared distances from point i to its three
+ * nearest neighbours (self excluded by index; coincident points count with distance 0; with fewer than four points the
+ * missing neighbours contribute FLT_MAX).  points: device (P,3) fp32; out: device (P); workspace: caller-owned,
+ * bags_knn_workspace_size(P) bytes.  Exact (uniform grid + shell walk), no host round trip, stream-ordered. */
+size_t bags_knn_workspace_size(int32_t P);
+int bags_knn_mean_dist2(const float* points, int32_t P, void* workspace, size_t workspace_bytes, float* out, void* stream);
+
 /* compute_relocation of the fork's MCMC path (utils/reloc_utils.py:11-13): its only caller is commented out in
  * the reference (scene/gaussian_model.py:23,494-504); exported so the symbol exists, returns BAGS_ERR_ARG. */
 int bags_compute_relocation(const float* opacity_old, const float* scale_old, const int32_t* N, const float* binoms,
