@@ -248,8 +248,8 @@ def main():
                 out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
                                    "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic,
                                    "alg_bytes_per_launch": alg[dom], "mean_launch_ms": stages[dom],
-                                   "note": "kernel is VALU-issue bound (59 % of SIMD issue cycles busy, PMC in "
-                                           "profiles/r01/pmc_blend_v2.txt), not HBM bound; traffic = FETCH_SIZE + "
+                                   "note": "kernel is VALU-issue / latency bound (63 % of SIMD issue cycles busy, PMC in "
+                                           "profiles/r01/pmc_blend_v7.txt), not HBM bound; traffic = FETCH_SIZE + "
                                            "WRITE_SIZE of a separate --pmc pass, fetch side uncorrected (gathers)"}
             dev_ms = sum(stages.values())
             out["op_roofline"] = {"bound": "hbm", "alg_bytes_per_step": b_alg, "device_ms_per_step": dev_ms,
