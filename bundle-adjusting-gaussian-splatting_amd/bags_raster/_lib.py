@@ -53,6 +53,13 @@ class BagsDebugViews(C.Structure):
 
 
 # every symbol include/bags_raster.h declares: (restype, argtypes)
+class BagsCamera(C.Structure):
+    _fields_ = [("init_quaternion", C.c_void_p), ("delta_quaternion", C.c_void_p), ("init_translation", C.c_void_p),
+                ("delta_translation", C.c_void_p), ("fovx", C.c_void_p), ("fovy", C.c_void_p),
+                ("global_rotation", C.c_void_p), ("global_translation_scale", C.c_void_p),
+                ("znear", C.c_float), ("zfar", C.c_float)]
+
+
 SYMBOLS = {
     "bags_abi_version": (C.c_int, []),
     "bags_last_error": (C.c_char_p, []),
@@ -79,6 +86,8 @@ SYMBOLS = {
                                     C.c_void_p, C.c_void_p]),
     "bags_loss_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bags_camera_forward": (C.c_int, [C.POINTER(BagsCamera), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bags_camera_backward": (C.c_int, [C.POINTER(BagsCamera)] + [C.c_void_p] * 11),
     "bags_knn_workspace_size": (C.c_size_t, [C.c_int32]),
     "bags_knn_mean_dist2": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "bags_compute_relocation": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int32, C.c_int32, c_fp, c_fp, C.c_void_p]),

@@ -131,3 +131,80 @@ class PoseCamera(torch.nn.Module):
 
     def pose_leaves(self):
         return [self.delta_quaternion, self.delta_translation, self.learnable_fovx, self.learnable_fovy]
+
+    def get_matrices(self, global_rotation: Optional[torch.Tensor] = None,
+                     global_translation_scale: Optional[torch.Tensor] = None):
+        """(viewmatrix, projmatrix, intrinsic, campos) for GaussianRasterizationSettings.  On a GPU this is ONE HIP launch
+        (and one for the backward) instead of the ~40 PyTorch kernels of the four getters above; on the CPU it is those
+        getters (each evaluated once)."""
+        if self.delta_quaternion.is_cuda:
+            return fused_camera_chain(self.delta_quaternion, self.delta_translation, self.learnable_fovx, self.learnable_fovy,
+                                      self.init_quaternion, self.init_translation, self.znear, self.zfar,
+                                      global_rotation, global_translation_scale)
+        v = self.get_world_view_transform(global_rotation, global_translation_scale)
+        k = self.get_intrinsic()
+        return v, (v.unsqueeze(0).bmm(k.unsqueeze(0))).squeeze(0), k, v.inverse()[3, :3]
+
+
+class _FusedCameraChain(torch.autograd.Function):
+    """Pose leaves -> the four camera tensors through bags_camera_forward / bags_camera_backward (csrc/camera.hip)."""
+
+    @staticmethod
+    def forward(ctx, dq, dt, fovx, fovy, q0, t0, znear, zfar, grot, gscale):
+        from . import _lib as L
+        dev = dq.device
+        if not dq.is_cuda:
+            raise RuntimeError("fused_camera_chain: tensors must live on a GPU (use PoseCamera's getters on the host)")
+
+        def f32(t, n):
+            if t is None:
+                return None
+            t = t.detach().to(dev, torch.float32).contiguous().reshape(-1)
+            if t.numel() != n:
+                raise RuntimeError(f"fused_camera_chain: expected {n} values, got {t.numel()}")
+            return t
+        keep = dict(q0=f32(q0, 4), dq=f32(dq, 4), t0=f32(t0, 3), dt=f32(dt, 3), fovx=f32(fovx, 1), fovy=f32(fovy, 1),
+                    grot=f32(grot, 9), gscale=f32(gscale, 1))
+        p = lambda t: None if t is None else t.data_ptr()
+        cam = L.BagsCamera(p(keep["q0"]), p(keep["dq"]), p(keep["t0"]), p(keep["dt"]), p(keep["fovx"]), p(keep["fovy"]),
+                           p(keep["grot"]), p(keep["gscale"]), float(znear), float(zfar))
+        out = torch.empty(51, dtype=torch.float32, device=dev)
+        V, M, K, Cc = out[0:16].view(4, 4), out[16:32].view(4, 4), out[32:48].view(4, 4), out[48:51]
+        lib = L.load()
+        with torch.cuda.device(dev):
+            L.check(lib.bags_camera_forward(cam, V.data_ptr(), M.data_ptr(), K.data_ptr(), Cc.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream), "bags_camera_forward")
+        ctx.keep, ctx.cam = keep, cam
+        ctx.shapes = (dq.shape, dt.shape, fovx.shape, fovy.shape, None if grot is None else grot.shape,
+                      None if gscale is None else gscale.shape)
+        return V, M, K, Cc
+
+    @staticmethod
+    def backward(ctx, gV, gM, gK, gC):
+        from . import _lib as L
+        keep, cam = ctx.keep, ctx.cam
+        dev = keep["dq"].device
+        c = lambda t: None if t is None else t.to(torch.float32).contiguous()
+        gV, gM, gK, gC = c(gV), c(gM), c(gK), c(gC)
+        need = ctx.needs_input_grad
+        out = torch.zeros(19, dtype=torch.float32, device=dev)                  # dq 4 | dt 3 | fovx | fovy | grot 9 | gscale
+        g_dq, g_dt, g_fx, g_fy, g_gr, g_gs = out[0:4], out[4:7], out[7:8], out[8:9], out[9:18], out[18:19]
+        p = lambda t, on=True: None if (t is None or not on) else t.data_ptr()
+        lib = L.load()
+        with torch.cuda.device(dev):
+            L.check(lib.bags_camera_backward(cam, p(gV), p(gM), p(gK), p(gC), p(g_dq, need[0]), p(g_dt, need[1]),
+                                             p(g_fx, need[2]), p(g_fy, need[3]), p(g_gr, need[8] and keep["grot"] is not None),
+                                             p(g_gs, need[9] and keep["gscale"] is not None),
+                                             torch.cuda.current_stream().cuda_stream), "bags_camera_backward")
+        sh = ctx.shapes
+        r = lambda g, on, shape: g.reshape(shape) if (on and shape is not None) else None
+        return (r(g_dq, need[0], sh[0]), r(g_dt, need[1], sh[1]), r(g_fx, need[2], sh[2]), r(g_fy, need[3], sh[3]), None, None,
+                None, None, r(g_gr, need[8], sh[4]), r(g_gs, need[9], sh[5]))
+
+
+def fused_camera_chain(delta_quaternion, delta_translation, fovx, fovy, init_quaternion, init_translation,
+                       znear: float = 0.01, zfar: float = 100.0, global_rotation=None, global_translation_scale=None):
+    """(viewmatrix, projmatrix, intrinsic, campos), differentiable w.r.t. the four pose leaves (and the global alignment
+    when given).  Mirrors scene/cameras.py:356-381."""
+    return _FusedCameraChain.apply(delta_quaternion, delta_translation, fovx, fovy, init_quaternion, init_translation,
+                                   znear, zfar, global_rotation, global_translation_scale)

@@ -59,10 +59,13 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, mlp_color=0.0, sh
         screenspace_points_densify.retain_grad()
 
     ga = global_alignment if global_alignment is not None else (None, None)
-    viewmatrix = viewpoint_camera.get_world_view_transform(ga[0], ga[1])
-    intrinsic = viewpoint_camera.get_intrinsic()
-    projmatrix = (viewmatrix.unsqueeze(0).bmm(intrinsic.unsqueeze(0))).squeeze(0)
-    campos = viewmatrix.inverse()[3, :3]
+    if hasattr(viewpoint_camera, "get_matrices"):              # one HIP launch (bags_raster.camera.PoseCamera)
+        viewmatrix, projmatrix, intrinsic, campos = viewpoint_camera.get_matrices(ga[0], ga[1])
+    else:                                                      # any camera object with the reference's four getters
+        viewmatrix = viewpoint_camera.get_world_view_transform(ga[0], ga[1])
+        intrinsic = viewpoint_camera.get_intrinsic()
+        projmatrix = (viewmatrix.unsqueeze(0).bmm(intrinsic.unsqueeze(0))).squeeze(0)
+        campos = viewmatrix.inverse()[3, :3]
 
     raster_settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height),

@@ -376,6 +376,37 @@ int bags_loss_backward(const float* image, const float* gt, int32_t C, int32_t H
     return BAGS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- camera chain
+static int check_camera(const BagsCamera* c)
+{
+    if (!c) return fail(BAGS_ERR_ARG, "camera: null struct");
+    if (!c->init_quaternion || !c->delta_quaternion || !c->init_translation || !c->delta_translation || !c->fovx || !c->fovy)
+        return fail(BAGS_ERR_ARG, "camera: quaternion / translation / fov pointers must be given");
+    if (!(c->zfar > c->znear) || !(c->znear > 0.f)) return fail(BAGS_ERR_ARG, "camera: need 0 < znear < zfar (got %g, %g)", c->znear, c->zfar);
+    return BAGS_OK;
+}
+
+int bags_camera_forward(const BagsCamera* c, float* V, float* M, float* K, float* C, void* stream)
+{
+    int rc = check_camera(c);
+    if (rc) return rc;
+    if (!V || !M || !K || !C) return fail(BAGS_ERR_ARG, "camera_forward: null output");
+    HIP_TRY(launch_camera_fwd(c->init_quaternion, c->delta_quaternion, c->init_translation, c->delta_translation, c->fovx, c->fovy,
+                              c->global_rotation, c->global_translation_scale, c->znear, c->zfar, V, M, K, C, (hipStream_t)stream));
+    return BAGS_OK;
+}
+
+int bags_camera_backward(const BagsCamera* c, const float* gV, const float* gM, const float* gK, const float* gC,
+                         float* g_dq, float* g_dt, float* g_fovx, float* g_fovy, float* g_grot, float* g_gscale, void* stream)
+{
+    int rc = check_camera(c);
+    if (rc) return rc;
+    HIP_TRY(launch_camera_bwd(c->init_quaternion, c->delta_quaternion, c->init_translation, c->delta_translation, c->fovx, c->fovy,
+                              c->global_rotation, c->global_translation_scale, c->znear, c->zfar, gV, gM, gK, gC,
+                              g_dq, g_dt, g_fovx, g_fovy, g_grot, g_gscale, (hipStream_t)stream));
+    return BAGS_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- kNN scale initialiser
 size_t bags_knn_workspace_size(int32_t P) { return knn_workspace_bytes(P > 0 ? P : 1); }
 

@@ -94,6 +94,14 @@ size_t loss_workspace_bytes(int C, int H, int W);
 hipError_t launch_loss_fwd(const float* img, const float* gt, int C, int H, int W, void* ws, float* out_terms, hipStream_t st);
 hipError_t launch_loss_bwd(const float* img, const float* gt, int C, int H, int W, const void* ws, const float* grad_terms,
                            float* grad_img, hipStream_t st);
+// camera.hip: pose leaves -> viewmatrix / projmatrix / intrinsic / campos, and the adjoint
+hipError_t launch_camera_fwd(const float* q0, const float* dq, const float* t0, const float* dt, const float* fovx, const float* fovy,
+                             const float* grot, const float* gscale, float znear, float zfar,
+                             float* V, float* M, float* K, float* C, hipStream_t st);
+hipError_t launch_camera_bwd(const float* q0, const float* dq, const float* t0, const float* dt, const float* fovx, const float* fovy,
+                             const float* grot, const float* gscale, float znear, float zfar,
+                             const float* gV, const float* gM, const float* gK, const float* gC,
+                             float* g_dq, float* g_dt, float* g_fovx, float* g_fovy, float* g_grot, float* g_gscale, hipStream_t st);
 // knn.hip: mean squared distance to the three nearest neighbours (distCUDA2)
 size_t knn_workspace_bytes(int P);
 hipError_t launch_knn(const float* pts, int P, void* ws, float* out, hipStream_t st);

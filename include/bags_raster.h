@@ -186,6 +186,28 @@ int bags_loss_forward(const float* image, const float* gt, int32_t C, int32_t H,
 int bags_loss_backward(const float* image, const float* gt, int32_t C, int32_t H, int32_t W, const void* workspace,
                        size_t workspace_bytes, const float* grad_terms, float* grad_image, void* stream);
 
+/* The pose -> matrix chain of scene/cameras.py:356-381 in one launch each way: replaces
+ * get_world_view_transform / get_full_proj_transform / get_intrinsic / get_camera_center (~40 PyTorch kernels and six 4x4
+ * inversions per render() call, gaussian_renderer/__init__.py:57,58,61) and their autograd backward.  All pointers are
+ * device pointers; optional ones may be NULL. */
+typedef struct BagsCamera {
+    const float* init_quaternion;    /* (4) w,x,y,z of the world-to-camera rotation (scene/cameras.py:98) */
+    const float* delta_quaternion;   /* (4) learnable, added before normalisation (scene/cameras.py:360) */
+    const float* init_translation;   /* (3) */
+    const float* delta_translation;  /* (3) learnable */
+    const float* fovx;               /* scalar, learnable (scene/cameras.py:109-110) */
+    const float* fovy;
+    const float* global_rotation;    /* (3,3) row-major or NULL: R <- G R (scene/cameras.py:361) */
+    const float* global_translation_scale;   /* scalar or NULL: t <- s t (scene/cameras.py:367-370) */
+    float znear, zfar;
+} BagsCamera;
+/* viewmatrix, projmatrix, intrinsic: (4,4); campos: (3) */
+int bags_camera_forward(const BagsCamera* cam, float* viewmatrix, float* projmatrix, float* intrinsic, float* campos, void* stream);
+/* upstream gradients may be NULL (= zero); gradient outputs may be NULL (= not wanted) */
+int bags_camera_backward(const BagsCamera* cam, const float* g_viewmatrix, const float* g_projmatrix, const float* g_intrinsic,
+                         const float* g_campos, float* g_delta_quaternion, float* g_delta_translation, float* g_fovx,
+                         float* g_fovy, float* g_global_rotation, float* g_global_translation_scale, void* stream);
+
 /* distCUDA2 of the reference's second native dependency (simple_knn._C, imported at scene/gaussian_model.py:20, called at
  * scene/gaussian_model.py:177 to initialise the scales): out[i] = mean of the squared distances from point i to its three
  * nearest neighbours (self excluded by index; coincident points count with distance 0; with fewer than four points the
