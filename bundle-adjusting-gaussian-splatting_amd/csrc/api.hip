@@ -407,6 +407,40 @@ int bags_camera_backward(const BagsCamera* c, const float* gV, const float* gM, 
     return BAGS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- distortion resampling
+static int check_resample(int C, int H, int W, int h, int w, int Hf, int Wf, int Hc, int Wc)
+{
+    if (C <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0 || Hf <= 0 || Wf <= 0 || Hc <= 0 || Wc <= 0)
+        return fail(BAGS_ERR_ARG, "resample: every extent must be positive");
+    if (Hc > Hf || Wc > Wf) return fail(BAGS_ERR_ARG, "resample: crop %dx%d exceeds the flow size %dx%d", Wc, Hc, Wf, Hf);
+    return BAGS_OK;
+}
+
+int bags_resample_forward(const float* image, int32_t C, int32_t H, int32_t W, const float* ctrl, int32_t h, int32_t w,
+                          int32_t Hf, int32_t Wf, int32_t Hc, int32_t Wc, float* out, float* mask, float* flow_out, void* stream)
+{
+    int rc = check_resample(C, H, W, h, w, Hf, Wf, Hc, Wc);
+    if (rc) return rc;
+    if (!image || !ctrl || !out) return fail(BAGS_ERR_ARG, "resample_forward: null pointer");
+    HIP_TRY(launch_resample_fwd(image, C, H, W, ctrl, h, w, Hf, Wf, Hc, Wc, out, mask, flow_out, (hipStream_t)stream));
+    return BAGS_OK;
+}
+
+size_t bags_resample_workspace_size(int32_t Hc, int32_t Wc) { return resample_workspace_bytes(Hc > 0 ? Hc : 1, Wc > 0 ? Wc : 1); }
+
+int bags_resample_backward(const float* image, int32_t C, int32_t H, int32_t W, const float* ctrl, int32_t h, int32_t w,
+                           int32_t Hf, int32_t Wf, int32_t Hc, int32_t Wc, const float* grad_out, void* workspace,
+                           size_t workspace_bytes, float* grad_image, float* grad_ctrl, void* stream)
+{
+    int rc = check_resample(C, H, W, h, w, Hf, Wf, Hc, Wc);
+    if (rc) return rc;
+    if (!image || !ctrl || !grad_out) return fail(BAGS_ERR_ARG, "resample_backward: null pointer");
+    if (grad_ctrl && (!workspace || workspace_bytes < resample_workspace_bytes(Hc, Wc)))
+        return fail(BAGS_ERR_SIZE, "resample_backward: grad_ctrl needs a workspace of %zu bytes", resample_workspace_bytes(Hc, Wc));
+    HIP_TRY(launch_resample_bwd(image, C, H, W, ctrl, h, w, Hf, Wf, Hc, Wc, grad_out, workspace, grad_image, grad_ctrl, (hipStream_t)stream));
+    return BAGS_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- kNN scale initialiser
 size_t bags_knn_workspace_size(int32_t P) { return knn_workspace_bytes(P > 0 ? P : 1); }
 

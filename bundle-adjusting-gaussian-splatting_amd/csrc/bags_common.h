@@ -102,6 +102,12 @@ hipError_t launch_camera_bwd(const float* q0, const float* dq, const float* t0, 
                              const float* grot, const float* gscale, float znear, float zfar,
                              const float* gV, const float* gM, const float* gK, const float* gC,
                              float* g_dq, float* g_dt, float* g_fovx, float* g_fovy, float* g_grot, float* g_gscale, hipStream_t st);
+// resample.hip: flow upsample + grid_sample + centre crop + mask in one pass, and the adjoint
+hipError_t launch_resample_fwd(const float* image, int C, int H, int W, const float* ctrl, int h, int w, int Hf, int Wf, int Hc, int Wc,
+                               float* out, float* mask, float* flow_out, hipStream_t st);
+hipError_t launch_resample_bwd(const float* image, int C, int H, int W, const float* ctrl, int h, int w, int Hf, int Wf, int Hc, int Wc,
+                               const float* grad_out, void* workspace, float* grad_image, float* grad_ctrl, hipStream_t st);
+size_t resample_workspace_bytes(int Hc, int Wc);
 // knn.hip: mean squared distance to the three nearest neighbours (distCUDA2)
 size_t knn_workspace_bytes(int P);
 hipError_t launch_knn(const float* pts, int P, void* ws, float* out, hipStream_t st);

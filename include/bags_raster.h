@@ -208,6 +208,24 @@ int bags_camera_backward(const BagsCamera* cam, const float* g_viewmatrix, const
                          const float* g_campos, float* g_delta_quaternion, float* g_delta_translation, float* g_fovx,
                          float* g_fovy, float* g_global_rotation, float* g_global_translation_scale, void* stream);
 
+/* Image-space distortion resampling: the apply2gt == False branch of apply_distortion
+ * (utils/util_distortion.py:271-311, call site train.py:255-263) in one pass each way:
+ *   flow  = interpolate(control flow (h,w,2) -> (flow_H, flow_W), bilinear, align_corners=False)
+ *   out   = center_crop(grid_sample(image (C,H,W), flow, bilinear, zeros, align_corners=True), crop_H, crop_W)
+ *   mask  = !(out[0] == 0 && out[1] == 0)                                    (may be NULL)
+ *   flow_out (crop_H, crop_W, 2): the upsampled flow at the cropped pixels     (may be NULL)
+ * Pass h == flow_H, w == flow_W to resample with an already dense flow (the cached flow_apply2_gt_or_img path).
+ * Backward: grad_image (C,H,W) is zero-filled and accumulated with float atomics (summation order is not fixed, as in
+ * PyTorch's grid_sample backward); grad_ctrl (h,w,2) is gathered per control node in a fixed order and needs a caller-owned
+ * workspace of bags_resample_workspace_size(crop_H, crop_W) bytes.  Either gradient may be NULL. */
+size_t bags_resample_workspace_size(int32_t crop_H, int32_t crop_W);
+int bags_resample_forward(const float* image, int32_t C, int32_t H, int32_t W, const float* ctrl_flow, int32_t h, int32_t w,
+                          int32_t flow_H, int32_t flow_W, int32_t crop_H, int32_t crop_W, float* out, float* mask,
+                          float* flow_out, void* stream);
+int bags_resample_backward(const float* image, int32_t C, int32_t H, int32_t W, const float* ctrl_flow, int32_t h, int32_t w,
+                           int32_t flow_H, int32_t flow_W, int32_t crop_H, int32_t crop_W, const float* grad_out,
+                           void* workspace, size_t workspace_bytes, float* grad_image, float* grad_ctrl, void* stream);
+
 /* distCUDA2 of the reference's second native dependency (simple_knn._C, imported at scene/gaussian_model.py:20, called at
  * scene/gaussian_model.py:177 to initialise the scales): out[i] = mean of the squared distances from point i to its three
  * nearest neighbours (self excluded by index; coincident points count with distance 0; with fewer than four points the

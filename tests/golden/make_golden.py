@@ -8,6 +8,8 @@ inputs and expected outputs are stored).
   loss.npz          utils/loss_utils.py l1_loss / ssim on seeded images (the loss that produces dL/dimage)
   loss_odd.npz      the same on a (3,37,53) pair (sizes that are not multiples of the kernels' 32x32 tile), with the
                     gradients of the two terms stored separately
+  resample.npz      utils/util_distortion.py:58-77 center_crop and :271-311 apply_distortion (apply2gt=False, flow given):
+                    warped image, mask and d/d{image, flow} on a seeded image and a coarse control flow
   gaussian_activations.npz  utils/general_utils.py:114-163 build_rotation / build_scaling_rotation / strip_lowerdiag and
                     scene/gaussian_model.py:27-31 covariance activation (values + d/d{scaling, rotation}),
                     gaussian_renderer/__init__.py:19-28 quaternion_multiply, utils/general_utils.py inverse_sigmoid
@@ -126,6 +128,38 @@ def main():
     (d1,) = torch.autograd.grad(l1, a, retain_graph=True); (d2,) = torch.autograd.grad(s, a)
     np.savez(os.path.join(OUT, "loss_odd.npz"), a=a.detach().numpy(), b=b.numpy(), l1=l1.item(), ssim=s.item(),
              dl1_da=d1.numpy(), dssim_da=d2.numpy())
+
+    # ---- distortion resampling: the reference's own apply_distortion on a dense flow (its cached-flow path) and the
+    # upsample it applies to a coarse control flow.  .cuda() inside center_crop is redirected to the CPU for this call only.
+    import types
+    import torch.nn.functional as F
+    src = open(os.path.join(REF, "utils/util_distortion.py")).read()
+    ns = {"torch": torch, "F": F, "nn": torch.nn, "np": np, "math": math}
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("center_crop", "apply_distortion"):
+            exec(compile(ast.Module([node], []), "utils/util_distortion.py", "exec"), ns)
+    C_, H_, W_ = 3, 40, 56
+    img = torch.rand(C_, H_, W_, generator=g)
+    img[:, :, :6] = 0.0                                             # a black border: exercises the mask
+    hc, wc = 7, 9
+    gy, gx = torch.meshgrid(torch.linspace(-1.15, 1.15, hc), torch.linspace(-1.2, 1.2, wc), indexing="ij")
+    ctrl = torch.stack((gx, gy), -1) + 0.08 * torch.randn(hc, wc, 2, generator=g)       # mildly warped identity
+    Hf, Wf, Hc, Wc = 48, 64, 36, 50
+    cam = types.SimpleNamespace(fish_gt_image_resolution=(3, Hc, Wc))
+    saved_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        ctrl_g = ctrl.clone().requires_grad_(True); img_g = img.clone().requires_grad_(True)
+        flow = F.interpolate(ctrl_g.permute(2, 0, 1).unsqueeze(0), size=(Hf, Wf), mode="bilinear",
+                             align_corners=False).permute(0, 2, 3, 1).squeeze(0)          # util_distortion.py:301
+        out, mask, _ = ns["apply_distortion"](flow, None, None, None, cam, img_g, apply2gt=False, flow_scale=None)
+        cot = torch.randn(C_, Hc, Wc, generator=g)
+        (out * cot).sum().backward()
+    finally:
+        torch.Tensor.cuda = saved_cuda
+    np.savez(os.path.join(OUT, "resample.npz"), image=img.numpy(), ctrl=ctrl.numpy(), flow_hw=np.array([Hf, Wf]),
+             crop_hw=np.array([Hc, Wc]), out=out.detach().numpy(), mask=mask.numpy(), cot=cot.numpy(),
+             d_image=img_g.grad.numpy(), d_ctrl=ctrl_g.grad.numpy())
     print("golden vectors written to", OUT)
 
 

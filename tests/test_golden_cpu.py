@@ -151,3 +151,26 @@ def test_loss_oracle_matches_reference(golden_dir):
     np.testing.assert_allclose(g1, g["dl1_da"], rtol=1e-6, atol=1e-10)
     np.testing.assert_allclose(g2, g["dssim_da"], rtol=2e-3, atol=3e-8)
     np.testing.assert_allclose(LO.window_2d().sum(), 1.0, rtol=1e-6)
+
+
+def test_resample_oracle_and_torch_pipeline_match_reference(golden_dir):
+    """oracle/resample_oracle.py (numpy, explicit taps and adjoint) and bags_raster.distortion.resample_image_torch against the
+    reference's own apply_distortion / center_crop (utils/util_distortion.py:58-77,271-311).  The reference crops with a
+    second grid_sample whose integer grid is only reproduced to ~1e-4 px, hence the 2e-4 absolute bar."""
+    from oracle import resample_oracle as RO
+    from bags_raster.distortion import resample_image_torch
+    g = np.load(os.path.join(golden_dir, "resample.npz"))
+    fhw, chw = tuple(int(v) for v in g["flow_hw"]), tuple(int(v) for v in g["crop_hw"])
+    out, mask = RO.forward(g["image"], g["ctrl"], fhw, chw)
+    np.testing.assert_allclose(out, g["out"], atol=2e-4)
+    assert (mask != g["mask"]).mean() < 0.002                          # pixels that are exactly 0 in one and 1e-7 in the other
+    gi, gc = RO.backward(g["image"], g["ctrl"], fhw, chw, g["cot"])
+    np.testing.assert_allclose(gi, g["d_image"], atol=3e-4)
+    np.testing.assert_allclose(gc, g["d_ctrl"], rtol=2e-3, atol=2e-3 * np.abs(g["d_ctrl"]).max())
+    img = torch.from_numpy(g["image"]).requires_grad_(True); ctl = torch.from_numpy(g["ctrl"]).requires_grad_(True)
+    o2, m2 = resample_image_torch(img, ctl, fhw, chw)
+    np.testing.assert_allclose(o2.detach().numpy(), g["out"], atol=1e-6)
+    assert np.array_equal(m2.numpy(), g["mask"])
+    (o2 * torch.from_numpy(g["cot"])).sum().backward()
+    np.testing.assert_allclose(img.grad.numpy(), g["d_image"], atol=1e-6)
+    np.testing.assert_allclose(ctl.grad.numpy(), g["d_ctrl"], rtol=1e-4, atol=1e-4)
