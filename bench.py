@@ -251,6 +251,18 @@ def main():
                                    "note": "kernel is VALU-issue / latency bound (63 % of SIMD issue cycles busy, PMC in "
                                            "profiles/r01/pmc_blend_v7.txt), not HBM bound; traffic = FETCH_SIZE + "
                                            "WRITE_SIZE of a separate --pmc pass, fetch side uncorrected (gathers)"}
+                # the blend kernels are VALU-issue bound, so the fraction of SIMD issue cycles they keep busy is
+                # reported next to the HBM figure (cycles from a separate rocprofv3 --pmc pass; 1024 SIMDs at 2.4 GHz), and the
+                # atomic roofline is moot: the rasterizer issues no global atomics at all.
+                try:
+                    va = tj[dom]["valu_active_cycles"] if traffic is not None else None
+                except (KeyError, NameError):
+                    va = None
+                out["roofline_valu"] = {"kernel": dom, "busy_frac": None if va is None else va / (1024 * 2.4e9 * stages[dom] * 1e-3),
+                                        "valu_active_cycles": va, "simds": 1024, "clock_ghz": 2.4,
+                                        "source": "profiles/r01/pmc_blend_v7.txt (SQ_ACTIVE_INST_VALU x 4)"}
+                out["roofline_atomic"] = {"global_float_atomics_per_step": 0,
+                                          "note": "gradients are reduced through per-wave LDS copies and one 64-B record per instance"}
             dev_ms = sum(stages.values())
             out["op_roofline"] = {"bound": "hbm", "alg_bytes_per_step": b_alg, "device_ms_per_step": dev_ms,
                                   "achieved": b_alg / (dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
