@@ -356,3 +356,65 @@ def test_tile_bound_modes_render_the_same():
             # ulps; behind the conic -> cov2D -> Sigma chain the strongly anisotropic splats of this scene amplify that.
             tol = 2e-6 if k in ("shs", "opacities", "means2D", "means2D_densify") else 1e-4
             assert rel_err(g_t[k], g_a[k]) < tol, (k, rel_err(g_t[k], g_a[k]))
+
+
+@pytest.mark.gpu
+def test_means2D_offsets_and_debug_mode_match_oracle():
+    """Non-zero additive NDC offsets in means2D (decision D4) move the splats and receive gradient; debug=True (a sync and an
+    error check after every kernel, pipe.debug in the reference) must not change any result."""
+    scene, cam = make_case(1500, 144, 112, 2.0, 1, seed=21)
+    off = torch.zeros(1500, 3)
+    off[:, :2] = 0.02 * torch.randn(1500, 2, generator=torch.Generator().manual_seed(5))
+    rep = compare(scene, cam, 1, means2D=off)
+    _report({k: rep[k] for k in ("num_rendered", "image_max_err", "grad_rel_fp32")})
+    assert_report(rep)
+    g = torch.randn(3, 112, 144, generator=torch.Generator().manual_seed(6))
+    o0, g0, _ = run_hip(scene, cam, 1, g, means2D=off)
+    o1, g1, _ = run_hip(scene, cam, 1, g, means2D=off, debug=True)
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)
+    for k in g0:
+        if g0[k] is not None:
+            assert torch.equal(g0[k], g1[k]), k
+
+
+@pytest.mark.gpu
+def test_side_stream_and_non_contiguous_inputs():
+    """The library enqueues on torch's CURRENT stream, and the shim accepts non-contiguous views (gradients flow back to
+    the original tensors): results are bitwise those of the default-stream, contiguous call."""
+    from bags_raster import GaussianRasterizer
+    from scenes import hip_settings
+    dev = torch.device("cuda")
+    scene, cam = make_case(1200, 128, 96, 2.0, 3, seed=23)
+    cot = torch.randn(3, 96, 128, generator=torch.Generator().manual_seed(7)).to(dev)
+
+    def run(stream, strided):
+        t = {k: v.to(dev).clone() for k, v in scene.items()}
+        if strided:       # scales as every second column of a wider tensor, rotations as a transposed-back view
+            wide = torch.zeros(1200, 6, device=dev); wide[:, ::2] = t["scales"]; wide.requires_grad_(True)
+            rot_src = t["rotations"].t().contiguous().requires_grad_(True)
+            scales, rots = wide[:, ::2], rot_src.t()
+            leaves = dict(scales=wide, rotations=rot_src)
+        else:
+            scales, rots = t["scales"].requires_grad_(True), t["rotations"].requires_grad_(True)
+            leaves = dict(scales=scales, rotations=rots)
+        m3 = t["means3D"].requires_grad_(True)
+        ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream())
+        with ctx:
+            st = hip_settings(cam, 3, dev)
+            out = GaussianRasterizer(st)(means3D=m3, means2D=torch.zeros(1200, 3, device=dev), means2D_densify=torch.zeros(1200, 3, device=dev),
+                                         shift_factors=torch.zeros(3, device=dev), shs=t["shs"], colors_precomp=None,
+                                         opacities=t["opacities"], scales=scales, rotations=rots, cov3D_precomp=None)
+            out[0].backward(cot)
+        torch.cuda.synchronize()
+        gs = leaves["scales"].grad
+        gr = leaves["rotations"].grad
+        if strided:
+            assert (gs[:, 1::2] == 0).all()
+            gs, gr = gs[:, ::2].contiguous(), gr.t().contiguous()
+        return out[0].detach().clone(), m3.grad.clone(), gs.clone(), gr.clone()
+    base = run(None, False)
+    side = run(torch.cuda.Stream(), False)
+    strided = run(None, True)
+    for a, b, c in zip(base, side, strided):
+        assert torch.equal(a, b) and torch.equal(a, c)
