@@ -18,6 +18,9 @@
 #define LT 32                 // tile edge
 #define LHALO 5
 #define LEXT (LT + 2 * LHALO) // 42
+#define LROW 48               // staged row: [x0 - 8, x0 + 40): twelve 16-byte groups, so rows load as aligned dwordx4 when W % 4 == 0
+#define LOFF 3                // column of x0 - 5 (first tap of output 0) inside the staged row
+#define LSTR 49               // LDS row stride (floats): odd, so the row pass (8 rows x 8 column groups per wave) is conflict-free
 #define SSIM_C1 0.0001f       // 0.01^2
 #define SSIM_C2 0.0009f       // 0.03^2
 
@@ -36,10 +39,10 @@ __device__ __forceinline__ float block_sum_256(float v, float* red)
 }
 
 __global__ void __launch_bounds__(256)
-loss_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, int H, int W, LossWindow win,
+loss_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, int H, int W, int vec, LossWindow win,
                 float* __restrict__ dmu, float* __restrict__ de11, float* __restrict__ de12, float* __restrict__ partials)
 {
-    __shared__ float sa[LEXT][LEXT + 1], sb[LEXT][LEXT + 1];
+    __shared__ float sa[LEXT][LSTR], sb[LEXT][LSTR];
     __shared__ float h[5][LEXT][LT + 1];            // row-filtered a, b, aa, bb, ab
     __shared__ float red[4];
     const int tid = threadIdx.x;
@@ -48,12 +51,26 @@ loss_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, int
     const float* A = img + c * plane;
     const float* B = gt + c * plane;
 
-    for (int i = tid; i < LEXT * LEXT; i += 256) {
-        const int ly = i / LEXT, lx = i - ly * LEXT;
-        const int gx = x0 + lx - LHALO, gy = y0 + ly - LHALO;
-        const bool in = (gx >= 0) && (gx < W) && (gy >= 0) && (gy < H);
-        sa[ly][lx] = in ? A[(size_t)gy * W + gx] : 0.f;
-        sb[ly][lx] = in ? B[(size_t)gy * W + gx] : 0.f;
+    if (vec) {                     // W % 4 == 0 and 16-byte aligned planes: a 16-byte group is entirely inside or outside the image
+        for (int i = tid; i < LEXT * (LROW / 4); i += 256) {
+            const int ly = i / (LROW / 4), q = i - ly * (LROW / 4);
+            const int gx = x0 - 8 + 4 * q, gy = y0 + ly - LHALO;
+            const bool in = (gx >= 0) && (gx < W) && (gy >= 0) && (gy < H);
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 va = in ? *reinterpret_cast<const float4*>(A + (size_t)gy * W + gx) : z4;
+            const float4 vb = in ? *reinterpret_cast<const float4*>(B + (size_t)gy * W + gx) : z4;
+            float* da = &sa[ly][4 * q]; float* db = &sb[ly][4 * q];
+            da[0] = va.x; da[1] = va.y; da[2] = va.z; da[3] = va.w;
+            db[0] = vb.x; db[1] = vb.y; db[2] = vb.z; db[3] = vb.w;
+        }
+    } else {
+        for (int i = tid; i < LEXT * LEXT; i += 256) {
+            const int ly = i / LEXT, lx = i - ly * LEXT;
+            const int gx = x0 + lx - LHALO, gy = y0 + ly - LHALO;
+            const bool in = (gx >= 0) && (gx < W) && (gy >= 0) && (gy < H);
+            sa[ly][lx + LOFF] = in ? A[(size_t)gy * W + gx] : 0.f;
+            sb[ly][lx + LOFF] = in ? B[(size_t)gy * W + gx] : 0.f;
+        }
     }
     __syncthreads();
     // rows: LEXT x LT outputs, four consecutive columns per work item (14 LDS reads per image feed 4 x 11 taps)
@@ -63,7 +80,7 @@ loss_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, int
               s4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 14; ++k) {
-            const float a = sa[ly][lx + k], b = sb[ly][lx + k];
+            const float a = sa[ly][lx + k + LOFF], b = sb[ly][lx + k + LOFF];
             const float aa = a * a, bb = b * b, ab = a * b;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -123,7 +140,7 @@ loss_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, int
             const size_t o = c * plane + (size_t)gy * W + gx;
             dmu[o] = d_mu; de11[o] = d_e11; de12[o] = d_e12;
             sum_ssim += m;
-            sum_l1 += fabsf(sa[ly + LHALO][lx + LHALO] - sb[ly + LHALO][lx + LHALO]);
+            sum_l1 += fabsf(sa[ly + LHALO][lx + LHALO + LOFF] - sb[ly + LHALO][lx + LHALO + LOFF]);
         }
     }
     const float t_l1 = block_sum_256(sum_l1, red);
@@ -151,16 +168,19 @@ loss_reduce_kernel(const float* __restrict__ partials, int nslots, double inv_co
 }
 
 __global__ void __launch_bounds__(256)
-loss_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, int H, int W, LossWindow win,
+loss_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, int H, int W, int vec, LossWindow win,
                 const float* __restrict__ dmu, const float* __restrict__ de11, const float* __restrict__ de12,
                 const float* __restrict__ grad_terms, float inv_count, float* __restrict__ grad_img)
 {
+    // 42-wide rows, scalar staging: the 48-wide aligned rows of the forward would cost this kernel its fourth resident
+    // workgroup per CU (38 KB -> 41 KB of LDS) and measured 11 % slower
     __shared__ float sm[3][LEXT][LEXT + 1];
     __shared__ float h[3][LEXT][LT + 1];
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT, c = blockIdx.z;
     const size_t plane = (size_t)H * W;
     const float* M0 = dmu + c * plane; const float* M1 = de11 + c * plane; const float* M2 = de12 + c * plane;
+    (void)vec;
     for (int i = tid; i < LEXT * LEXT; i += 256) {
         const int ly = i / LEXT, lx = i - ly * LEXT;
         const int gx = x0 + lx - LHALO, gy = y0 + ly - LHALO;
@@ -251,7 +271,8 @@ hipError_t launch_loss_fwd(const float* img, const float* gt, int C, int H, int 
     carve_loss(ws, C, H, W, &dmu, &de11, &de12, &partials);
     const dim3 grid(cdiv(W, LT), cdiv(H, LT), C);
     const LossWindow win = make_window();
-    hipLaunchKernelGGL(loss_fwd_kernel, grid, dim3(256), 0, st, img, gt, H, W, win, dmu, de11, de12, partials);
+    const int vec = ((W & 3) == 0) && (((size_t)img | (size_t)gt) & 15) == 0;
+    hipLaunchKernelGGL(loss_fwd_kernel, grid, dim3(256), 0, st, img, gt, H, W, vec, win, dmu, de11, de12, partials);
     const int nslots = (int)(grid.x * grid.y * grid.z);
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)partials, nslots,
                        1.0 / ((double)C * H * W), out_terms);
@@ -265,7 +286,8 @@ hipError_t launch_loss_bwd(const float* img, const float* gt, int C, int H, int 
     carve_loss(const_cast<void*>(ws), C, H, W, &dmu, &de11, &de12, &partials);
     const dim3 grid(cdiv(W, LT), cdiv(H, LT), C);
     const LossWindow win = make_window();
-    hipLaunchKernelGGL(loss_bwd_kernel, grid, dim3(256), 0, st, img, gt, H, W, win, (const float*)dmu, (const float*)de11,
+    const int vec = ((W & 3) == 0) && (((size_t)dmu | (size_t)de11 | (size_t)de12) & 15) == 0;
+    hipLaunchKernelGGL(loss_bwd_kernel, grid, dim3(256), 0, st, img, gt, H, W, vec, win, (const float*)dmu, (const float*)de11,
                        (const float*)de12, grad_terms, (float)(1.0 / ((double)C * H * W)), grad_img);
     return hipGetLastError();
 }
