@@ -1,7 +1,7 @@
 """CPU-only: replicate preprocess_bwd's conic -> cov2D -> Sigma -> (scales, rotations) chain in torch fp32 and compare each
 stage with autograd through the oracle graph (fp32 and fp64) on needle-shaped splats."""
 import sys, torch
-sys.path[:0] = ['.', 'bundle-adjusting-gaussian-splatting_amd', 'tests']
+sys.path[:0] = ['.', 'bundle-adjusting-gaussian-splatting_amd', 'tests']      # run from the repo root: python tests/analysis_needle_chain.py
 from parity import run_oracle
 from oracle import raster_oracle as O
 from scenes import make_case, rel_err, oracle_settings

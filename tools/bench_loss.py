@@ -1,6 +1,6 @@
 """Times the fused photometric loss (csrc/loss.hip) fwd+bwd at 1080p against (a) the separable PyTorch implementation in
 bags_raster/loss.py and (b) a dense 11x11 depthwise-conv formulation (what utils/loss_utils.py:58-76 launches), and prints
-one JSON line with the HBM roofline of the fused kernels.  Usage: python tools/bench_loss.py [--steps 50] [--cpu]"""
+one JSON line with the HBM roofline of the fused kernels.  Usage: python tools/bench_loss.py [--steps 50]"""
 import argparse, json, os, sys, time
 
 import torch
@@ -39,7 +39,6 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--cpu", action="store_true", help="also time oracle/loss_oracle.py (numpy) on the host")
     args = ap.parse_args()
     g = torch.Generator().manual_seed(0)
     a = torch.rand(3, args.height, args.width, generator=g).cuda()
@@ -54,10 +53,6 @@ def main():
                roofline=dict(bound="hbm", alg_bytes=alg, achieved=alg / (t_fused * 1e-3) / 1e9, peak=8000.0, unit="GB/s",
                              frac=alg / (t_fused * 1e-3) / 8e12,
                              note="wall time per fwd+bwd incl. the autograd glue (clone, two scalar ops, stack); kernel-only times are in the rocprof summary"))
-    if args.cpu:
-        from oracle import loss_oracle as LO
-        an, bn = a.cpu().numpy(), b.cpu().numpy()
-        t0 = time.perf_counter(); LO.loss_and_grad(an, bn, 0.8, -0.2); out["cpu_oracle_s"] = time.perf_counter() - t0
     print(json.dumps(out))
 
 
