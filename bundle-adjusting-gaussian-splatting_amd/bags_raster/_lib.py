@@ -60,6 +60,11 @@ class BagsCamera(C.Structure):
                 ("znear", C.c_float), ("zfar", C.c_float)]
 
 
+class BagsRawGaussians(C.Structure):
+    _fields_ = [("P", C.c_int32), ("K", C.c_int32), ("features_dc", C.c_void_p), ("features_rest", C.c_void_p),
+                ("opacity", C.c_void_p), ("scaling", C.c_void_p), ("rotation", C.c_void_p)]
+
+
 SYMBOLS = {
     "bags_abi_version": (C.c_int, []),
     "bags_last_error": (C.c_char_p, []),
@@ -92,6 +97,8 @@ SYMBOLS = {
     "bags_resample_workspace_size": (C.c_size_t, [C.c_int32, C.c_int32]),
     "bags_resample_backward": (C.c_int, [C.c_void_p] + [C.c_int32] * 3 + [C.c_void_p] + [C.c_int32] * 6 +
                                [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bags_activations_forward": (C.c_int, [C.POINTER(BagsRawGaussians)] + [C.c_void_p] * 5),
+    "bags_activations_backward": (C.c_int, [C.POINTER(BagsRawGaussians)] + [C.c_void_p] * 10),
     "bags_knn_workspace_size": (C.c_size_t, [C.c_int32]),
     "bags_knn_mean_dist2": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "bags_compute_relocation": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int32, C.c_int32, c_fp, c_fp, C.c_void_p]),

@@ -161,6 +161,14 @@ class GaussianBag:
     def get_covariance(self, scaling_modifier: float = 1.0):
         return covariance_from_scaling_rotation(self.get_scaling, scaling_modifier, self._rotation)
 
+    def activated(self):
+        """(get_xyz, get_features, get_opacity, get_scaling, get_rotation) in one HIP launch each way on a GPU
+        (bags_activations_forward / _backward, csrc/activations.hip); the same properties evaluated one by one on the host."""
+        if self._xyz.is_cuda:
+            shs, op, sc, rot = fused_activations(self._features_dc, self._features_rest, self._opacity, self._scaling, self._rotation)
+            return self._xyz, shs, op, sc, rot
+        return self.get_xyz, self.get_features, self.get_opacity, self.get_scaling, self.get_rotation
+
     def oneupSHdegree(self):
         if self.active_sh_degree < self.max_sh_degree:
             self.active_sh_degree += 1
@@ -174,3 +182,54 @@ class GaussianBag:
             g = viewspace_point_tensor.grad
         self.xyz_gradient_accum[update_filter] += torch.norm(g[update_filter, :2], dim=-1, keepdim=True)
         self.denom[update_filter] += 1
+
+
+class _FusedActivations(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dc, rest, opacity, scaling, rotation):
+        from . import _lib as L
+        ts = [t.detach().to(torch.float32).contiguous() for t in (dc, rest, opacity, scaling, rotation)]
+        if not all(t.is_cuda for t in ts):
+            raise RuntimeError("fused_activations: tensors must live on a GPU (use the GaussianBag properties on the host)")
+        P, K = ts[0].shape[0], 1 + ts[1].shape[1]
+        if ts[0].shape != (P, 1, 3) or ts[1].shape != (P, K - 1, 3) or ts[2].numel() != P or ts[3].shape != (P, 3) or ts[4].shape != (P, 4):
+            raise RuntimeError("fused_activations: expected features_dc (P,1,3), features_rest (P,K-1,3), opacity (P,1), scaling (P,3), rotation (P,4)")
+        dev = ts[0].device
+        shs = torch.empty(P, K, 3, dtype=torch.float32, device=dev)
+        op = torch.empty(P, 1, dtype=torch.float32, device=dev)
+        sc = torch.empty(P, 3, dtype=torch.float32, device=dev)
+        rot = torch.empty(P, 4, dtype=torch.float32, device=dev)
+        raw = L.BagsRawGaussians(P, K, *[t.data_ptr() for t in ts])
+        lib = L.load()
+        with torch.cuda.device(dev):
+            L.check(lib.bags_activations_forward(raw, shs.data_ptr(), op.data_ptr(), sc.data_ptr(), rot.data_ptr(),
+                                                 torch.cuda.current_stream().cuda_stream), "bags_activations_forward")
+        ctx.save_for_backward(*ts)
+        ctx.set_materialize_grads(False)          # an unused output arrives as None, not as 96 MB of zeros
+        return shs, op, sc, rot
+
+    @staticmethod
+    def backward(ctx, g_shs, g_op, g_sc, g_rot):
+        from . import _lib as L
+        ts = ctx.saved_tensors
+        P, K = ts[0].shape[0], 1 + ts[1].shape[1]
+        need = ctx.needs_input_grad
+        c = lambda g: None if g is None else g.to(torch.float32).contiguous()
+        g_shs, g_op, g_sc, g_rot = c(g_shs), c(g_op), c(g_sc), c(g_rot)
+        out = [torch.empty_like(ts[0]) if (need[0] and g_shs is not None) else None,
+               torch.empty_like(ts[1]) if (need[1] and g_shs is not None) else None,
+               torch.empty_like(ts[2]) if (need[2] and g_op is not None) else None,
+               torch.empty_like(ts[3]) if (need[3] and g_sc is not None) else None,
+               torch.empty_like(ts[4]) if (need[4] and g_rot is not None) else None]
+        p = lambda t: None if t is None else t.data_ptr()
+        raw = L.BagsRawGaussians(P, K, *[t.data_ptr() for t in ts])
+        lib = L.load()
+        with torch.cuda.device(ts[0].device):
+            L.check(lib.bags_activations_backward(raw, p(g_shs), p(g_op), p(g_sc), p(g_rot), *[p(o) for o in out],
+                                                  torch.cuda.current_stream().cuda_stream), "bags_activations_backward")
+        return tuple(out)
+
+
+def fused_activations(features_dc, features_rest, opacity, scaling, rotation):
+    """(get_features, get_opacity, get_scaling, get_rotation) of scene/gaussian_model.py:118-141 in one HIP launch."""
+    return _FusedActivations.apply(features_dc, features_rest, opacity, scaling, rotation)

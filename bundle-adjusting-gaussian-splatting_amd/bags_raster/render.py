@@ -37,11 +37,10 @@ def quaternion_multiply(q1: torch.Tensor, q2: torch.Tensor) -> torch.Tensor:
                         w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2), dim=-1)
 
 
-def _python_colors(pc, campos: torch.Tensor, mlp_color) -> torch.Tensor:
+def _python_colors(pc, xyz, feats, campos: torch.Tensor, mlp_color) -> torch.Tensor:
     """SH -> RGB in Python: eval_sh on unit view directions, +0.5, clamp at 0  (gaussian_renderer/__init__.py:90-95)."""
-    feats = pc.get_features
     shs_view = feats.transpose(1, 2).reshape(-1, 3, (pc.max_sh_degree + 1) ** 2)
-    dir_pp = pc.get_xyz - campos.unsqueeze(0)
+    dir_pp = xyz - campos.unsqueeze(0)
     dir_pp = dir_pp / dir_pp.norm(dim=1, keepdim=True)
     rgb = torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dir_pp) + 0.5, 0.0)
     return rgb + mlp_color
@@ -50,7 +49,11 @@ def _python_colors(pc, campos: torch.Tensor, mlp_color) -> torch.Tensor:
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, mlp_color=0.0, shift_factors: Optional[torch.Tensor] = None,
            hybrid: bool = False, scaling_modifier: float = 1.0, override_color: Optional[torch.Tensor] = None,
            iteration: Optional[int] = None, global_alignment=None, depth_key: str = "z"):
-    xyz = pc.get_xyz
+    # activations: one fused launch when the container offers it (GaussianBag on a GPU), else the reference's properties
+    if hasattr(pc, "activated"):
+        xyz, features, opacity, scaling, rotation = pc.activated()
+    else:
+        xyz, features, opacity, scaling, rotation = pc.get_xyz, pc.get_features, pc.get_opacity, pc.get_scaling, pc.get_rotation
     # zero tensors whose .grad receives the screen-space gradients (:37-44)
     screenspace_points = torch.zeros_like(xyz, requires_grad=True) + 0
     screenspace_points_densify = torch.zeros_like(xyz, requires_grad=True) + 0
@@ -90,22 +93,22 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, mlp_color=0.0, sh
     if pipe.compute_cov3D_python:
         cov3D_precomp = pc.get_covariance(scaling_modifier)
     else:
-        scales, rotations = pc.get_scaling, pc.get_rotation
+        scales, rotations = scaling, rotation
 
     shs = colors_precomp = None
     if override_color is not None:
         colors_precomp = override_color
     elif hybrid or pipe.convert_SHs_python:
-        colors_precomp = _python_colors(pc, campos, mlp_color)
+        colors_precomp = _python_colors(pc, xyz, features, campos, mlp_color)
     else:
-        shs = pc.get_features
+        shs = features
 
     if shift_factors is None:
         shift_factors = torch.zeros(3, device=xyz.device)
 
     rendered_image, radii, depth, weights, mean2D = rasterizer(
         means3D=xyz, means2D=screenspace_points, means2D_densify=screenspace_points_densify,
-        shift_factors=shift_factors, shs=shs, colors_precomp=colors_precomp, opacities=pc.get_opacity,
+        shift_factors=shift_factors, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
         scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
 
     return {"render": rendered_image,

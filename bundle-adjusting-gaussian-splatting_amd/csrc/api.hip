@@ -441,6 +441,36 @@ int bags_resample_backward(const float* image, int32_t C, int32_t H, int32_t W, 
     return BAGS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- activations
+static int check_raw(const BagsRawGaussians* r)
+{
+    if (!r) return fail(BAGS_ERR_ARG, "activations: null struct");
+    if (r->P < 0 || r->K < 1) return fail(BAGS_ERR_ARG, "activations: need P >= 0 and K >= 1 (got %d, %d)", r->P, r->K);
+    if (r->P > 0 && (!r->features_dc || (r->K > 1 && !r->features_rest) || !r->opacity || !r->scaling || !r->rotation))
+        return fail(BAGS_ERR_ARG, "activations: null parameter pointer");
+    return BAGS_OK;
+}
+
+int bags_activations_forward(const BagsRawGaussians* r, float* shs, float* opacity, float* scales, float* rotations, void* stream)
+{
+    int rc = check_raw(r);
+    if (rc) return rc;
+    HIP_TRY(launch_activations_fwd(r->P, r->K, r->features_dc, r->features_rest, r->opacity, r->scaling, r->rotation, shs, opacity,
+                                   scales, rotations, (hipStream_t)stream));
+    return BAGS_OK;
+}
+
+int bags_activations_backward(const BagsRawGaussians* r, const float* g_shs, const float* g_opacity, const float* g_scales,
+                              const float* g_rotations, float* g_dc, float* g_rest, float* g_opacity_raw, float* g_scaling,
+                              float* g_rotation, void* stream)
+{
+    int rc = check_raw(r);
+    if (rc) return rc;
+    HIP_TRY(launch_activations_bwd(r->P, r->K, r->features_dc, r->features_rest, r->opacity, r->scaling, r->rotation, g_shs, g_opacity,
+                                   g_scales, g_rotations, g_dc, g_rest, g_opacity_raw, g_scaling, g_rotation, (hipStream_t)stream));
+    return BAGS_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- kNN scale initialiser
 size_t bags_knn_workspace_size(int32_t P) { return knn_workspace_bytes(P > 0 ? P : 1); }
 

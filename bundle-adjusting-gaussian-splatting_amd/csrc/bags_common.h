@@ -108,6 +108,13 @@ hipError_t launch_resample_fwd(const float* image, int C, int H, int W, const fl
 hipError_t launch_resample_bwd(const float* image, int C, int H, int W, const float* ctrl, int h, int w, int Hf, int Wf, int Hc, int Wc,
                                const float* grad_out, void* workspace, float* grad_image, float* grad_ctrl, hipStream_t st);
 size_t resample_workspace_bytes(int Hc, int Wc);
+// activations.hip: cat / sigmoid / exp / normalize of the raw Gaussian parameters, and the adjoint
+hipError_t launch_activations_fwd(int P, int K, const float* dc, const float* rest, const float* opacity, const float* scaling,
+                                  const float* rotation, float* shs, float* o_opacity, float* o_scales, float* o_rot, hipStream_t st);
+hipError_t launch_activations_bwd(int P, int K, const float* dc, const float* rest, const float* opacity, const float* scaling,
+                                  const float* rotation, const float* g_shs, const float* g_opacity, const float* g_scales,
+                                  const float* g_rot, float* g_dc, float* g_rest, float* g_opacity_raw, float* g_scaling,
+                                  float* g_rotation, hipStream_t st);
 // knn.hip: mean squared distance to the three nearest neighbours (distCUDA2)
 size_t knn_workspace_bytes(int P);
 hipError_t launch_knn(const float* pts, int P, void* ws, float* out, hipStream_t st);

@@ -226,6 +226,22 @@ int bags_resample_backward(const float* image, int32_t C, int32_t H, int32_t W, 
                            int32_t flow_H, int32_t flow_W, int32_t crop_H, int32_t crop_W, const float* grad_out,
                            void* workspace, size_t workspace_bytes, float* grad_image, float* grad_ctrl, void* stream);
 
+/* The parameter activations that feed the op, one launch each way: GaussianModel.get_features
+ * (cat of features_dc and features_rest), get_opacity (sigmoid), get_scaling (exp), get_rotation (normalize) --
+ * scene/gaussian_model.py:118-141.  K = SH coefficients per Gaussian (1 + rest).  Outputs / gradients may be NULL. */
+typedef struct BagsRawGaussians {
+    int32_t P, K;
+    const float* features_dc;        /* (P,1,3)   */
+    const float* features_rest;      /* (P,K-1,3) */
+    const float* opacity;            /* (P,1) pre-sigmoid */
+    const float* scaling;            /* (P,3) log-scale   */
+    const float* rotation;           /* (P,4) unnormalised quaternion */
+} BagsRawGaussians;
+int bags_activations_forward(const BagsRawGaussians* raw, float* shs, float* opacity, float* scales, float* rotations, void* stream);
+int bags_activations_backward(const BagsRawGaussians* raw, const float* g_shs, const float* g_opacity, const float* g_scales,
+                              const float* g_rotations, float* g_features_dc, float* g_features_rest, float* g_opacity_raw,
+                              float* g_scaling, float* g_rotation, void* stream);
+
 /* distCUDA2 of the reference's second native dependency (simple_knn._C, imported at scene/gaussian_model.py:20, called at
  * scene/gaussian_model.py:177 to initialise the scales): out[i] = mean of the squared distances from point i to its three
  * nearest neighbours (self excluded by index; coincident points count with distance 0; with fewer than four points the
