@@ -101,6 +101,8 @@ def compare(scene, cam, deg, seed=1, check_fp64=True, **kw):
         err64 = (outs[0] - img64).abs() / (1.0 + img64.abs())
         rep["image_max_err_fp64"] = err64.max().item()
         rep["oracle32_vs_64_image_max"] = ((st32.image - img64).abs() / (1.0 + img64.abs())).max().item()
+        # pixels further from fp64 than 3x the fp32 oracle's worst pixel: flipped threshold pairs (alpha >= 1/255, T < 1e-4)
+        rep["image_outlier_frac_fp64"] = (err64 > 3.0 * rep["oracle32_vs_64_image_max"] + 1e-5).float().mean().item()
         img_err = torch.minimum(img_err, err64)
     # A pixel counts as wrong only if it disagrees with BOTH oracles: alpha>=1/255, power<=0 and T<1e-4 are hard
     # thresholds, so an ulp of difference in exp() flips a (pixel, splat) pair in any one implementation.
@@ -121,8 +123,10 @@ def assert_ill_conditioned(rep, slack=3.0, floor=1e-4):
         assert rep[k], f"{k} failed: {rep}"
     assert rep["num_rendered"][0] == rep["num_rendered"][1]
     assert rep["n_contrib_mismatch_frac"] <= 1e-3, rep["n_contrib_mismatch_frac"]
-    assert rep["image_max_err_fp64"] <= slack * rep["oracle32_vs_64_image_max"] + 1e-5, \
-        (rep["image_max_err_fp64"], rep["oracle32_vs_64_image_max"])
+    # at most 2e-4 of the pixels may sit on a flipped threshold pair (same allowance as assert_report), none beyond 5e-3
+    assert rep["image_outlier_frac_fp64"] <= 2e-4 and \
+        rep["image_max_err_fp64"] <= max(5e-3, slack * rep["oracle32_vs_64_image_max"] + 1e-5), \
+        (rep["image_outlier_frac_fp64"], rep["image_max_err_fp64"], rep["oracle32_vs_64_image_max"])
     for k, ref in rep["oracle32_vs_64"].items():
         if k in rep["grad_rel_fp64"]:
             assert rep["grad_rel_fp64"][k] <= slack * ref + floor, f"grad[{k}]: {rep['grad_rel_fp64'][k]:.3e} vs oracle32 {ref:.3e}"
