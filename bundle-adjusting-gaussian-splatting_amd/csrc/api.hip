@@ -105,7 +105,8 @@ size_t carve_image(void* base, int W, int H, ImgView* v)
     ImgView im;
     const size_t n = (size_t)W * H > 0 ? (size_t)W * H : 1;
     take(p, im.final_T, n); take(p, im.n_contrib, n);
-    take(p, im.tile_maxc, (size_t)cdiv(W > 0 ? W : 1, BAGS_TILE) * cdiv(H > 0 ? H : 1, BAGS_TILE));
+    const size_t T = (size_t)cdiv(W > 0 ? W : 1, BAGS_TILE) * cdiv(H > 0 ? H : 1, BAGS_TILE);
+    take(p, im.tile_maxc, T); take(p, im.tile_order, T);
     if (v) *v = im;
     return (size_t)(p - reinterpret_cast<char*>(base));
 }
@@ -188,7 +189,9 @@ static int enqueue_finish(const BagsSettings* s, const BagsInputs* in, const Geo
                                     false, b.radix_hist, b.digit_totals, b.nblocks_sort, st, n_dev)); }
         DEBUG_SYNC(s, st, "tile sort");
     }
-    { ProfScope ps(ST_RANGES, st); HIP_TRY(launch_tile_ranges(b.tile_sorted, I, b.ranges, gx * gy, st, n_dev)); }
+    { ProfScope ps(ST_RANGES, st);
+      HIP_TRY(launch_tile_ranges(b.tile_sorted, I, b.ranges, gx * gy, st, n_dev));
+      HIP_TRY(launch_tile_order(b.ranges, gx * gy, im.tile_order, st)); }
     DEBUG_SYNC(s, st, "tile ranges");
     { ProfScope ps(ST_BLEND_FWD, st); HIP_TRY(launch_blend_fwd(*s, g, b, im, *out, st)); }
     DEBUG_SYNC(s, st, "blend_fwd");

@@ -34,6 +34,9 @@
 #ifndef SCAN_UNROLL
 #define SCAN_UNROLL 1
 #endif
+#ifndef BWD_LEAN
+#define BWD_LEAN 1
+#endif
 
 struct __attribute__((aligned(16))) SplatRec {
     float x, y, ap, bp;       // centre, pre-scaled conic: exp2(ap dx^2 + bp dx dy + cp dy^2) == exp(power)
@@ -41,11 +44,42 @@ struct __attribute__((aligned(16))) SplatRec {
     float b, z; u32 mask; u32 pos;   // mask: 4x4 blocks reachable (bit by*4+bx); pos: 1-based position in the tile list
 };
 
-__device__ __forceinline__ int tile_of_block(int b, int T)
-{   // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous band of tiles so that
-    // neighbouring tiles, which share splats, hit the same L2.  Placement only affects speed.
+// Workgroup -> tile.  Workgroups are dispatched in blockIdx order, round-robin over the 8 XCDs (b and b+8 share one), and
+// a launch ends when its busiest XCD ends.  Placement only affects speed (every tile is computed independently).
+//   0: one contiguous band of tiles per XCD (neighbouring tiles share splats => same L2).  On the bench scene the top and
+//      bottom bands hold 0.62-0.67x the mean number of instances and the six middle ones 1.12x: the launch runs 12-20 %
+//      longer than a balanced one (tests/analysis_lane_fill.py, tools/sim_tile_schedule.py).
+//   1: runs of TILE_ILV consecutive tiles, round-robin over the XCDs (balance within 1 %, row neighbours still share an L2).
+//   2: the same over `order` = tiles sorted heavy-first by instance count (tile_order_kernel, sort.hip): balanced AND the
+//      long tiles start first, so the launch does not end on a few late heavy tiles (longest-processing-time-first).
+#ifndef TILE_MAP
+#define TILE_MAP 2
+#endif
+#ifndef TILE_ILV
+#define TILE_ILV 16         // must not share a large factor with the tile-row length in mode 1 (15 or 30 against 120 tiles/row resonate)
+#endif
+__device__ __forceinline__ int tile_of_block(int b, int T, const u32* __restrict__ order)
+{
+#if TILE_MAP == 0
     const int chunk = (T + 7) / 8;
     return (b & 7) * chunk + (b >> 3);
+#else
+    const int k = b >> 3;
+    const int slot = ((k / TILE_ILV) * 8 + (b & 7)) * TILE_ILV + (k % TILE_ILV);
+#if TILE_MAP == 1
+    return slot;
+#else
+    return slot < T ? (int)order[slot] : T;
+#endif
+#endif
+}
+static inline int blend_grid(int T)
+{
+#if TILE_MAP == 0
+    return ((T + 7) / 8) * 8;
+#else
+    return cdiv(T, 8 * TILE_ILV) * 8 * TILE_ILV;
+#endif
 }
 
 // exp(power) for one (pixel, splat) pair: the SAME instruction sequence in forward and backward so both make the
@@ -177,9 +211,10 @@ template <bool ABS>
 __global__ void __launch_bounds__(256, SCAN_WG_PER_CU)
 blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ ranges, const u32* __restrict__ point_list,
                       const float4* __restrict__ g2d, const float* __restrict__ bg, const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
-                      const u32* __restrict__ tile_maxc, const float* __restrict__ grad_color, float* __restrict__ partials)
+                      const u32* __restrict__ tile_maxc, const u32* __restrict__ tile_order, const float* __restrict__ grad_color,
+                      float* __restrict__ partials)
 {
-    const int tile = tile_of_block(blockIdx.x, T);
+    const int tile = tile_of_block(blockIdx.x, T, tile_order);
     if (tile >= T) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
@@ -323,12 +358,24 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
                 const f2 dyy = {dy, dy};
                 // ---- part 1: alpha of the four pixels (same arithmetic as pair_power2 on d = centre - pixel)
                 const f2 dxa = {s.x - bx0, s.x - (bx0 + 1.f)}, dxb = {s.x - (bx0 + 2.f), s.x - (bx0 + 3.f)};
-                const f2 ta = __builtin_elementwise_fma((f2){s.bp, s.bp}, dyy, s.ap * dxa);
-                const f2 tb = __builtin_elementwise_fma((f2){s.bp, s.bp}, dyy, s.ap * dxb);
+                const f2 apdxa = s.ap * dxa, apdxb = s.ap * dxb;
+                const f2 ta = __builtin_elementwise_fma((f2){s.bp, s.bp}, dyy, apdxa);
+                const f2 tb = __builtin_elementwise_fma((f2){s.bp, s.bp}, dyy, apdxb);
                 const f2 pa = __builtin_elementwise_fma(dxa, ta, (f2){u, u});
                 const f2 pb = __builtin_elementwise_fma(dxb, tb, (f2){u, u});
                 f2 Ga = {__builtin_amdgcn_exp2f(pa.x), __builtin_amdgcn_exp2f(pa.y)};
                 f2 Gb = {__builtin_amdgcn_exp2f(pb.x), __builtin_amdgcn_exp2f(pb.y)};
+#if BWD_LEAN
+                // unclamped o G, zeroed for non-contributing pairs; min(0.99, x) >= 1/255 <=> x >= 1/255, so the contribute /
+                // skip decision is the forward's.  The clamp is applied after the select (0 stays 0).
+                f2 aua = s.o * Ga, aub = s.o * Gb;
+                const bool v0 = live && (pa.x <= 0.f) && (aua.x >= ALPHA_MIN) && (s.pos <= __float_as_uint(q02.z));
+                const bool v1 = live && (pa.y <= 0.f) && (aua.y >= ALPHA_MIN) && (s.pos <= __float_as_uint(q02.w));
+                const bool v2 = live && (pb.x <= 0.f) && (aub.x >= ALPHA_MIN) && (s.pos <= __float_as_uint(q12.z));
+                const bool v3 = live && (pb.y <= 0.f) && (aub.y >= ALPHA_MIN) && (s.pos <= __float_as_uint(q12.w));
+                aua.x = v0 ? aua.x : 0.f; aua.y = v1 ? aua.y : 0.f; aub.x = v2 ? aub.x : 0.f; aub.y = v3 ? aub.y : 0.f;
+                const f2 ala = {fminf(0.99f, aua.x), fminf(0.99f, aua.y)}, alb = {fminf(0.99f, aub.x), fminf(0.99f, aub.y)};
+#else
                 f2 ala = s.o * Ga, alb = s.o * Gb;
                 ala.x = fminf(0.99f, ala.x); ala.y = fminf(0.99f, ala.y); alb.x = fminf(0.99f, alb.x); alb.y = fminf(0.99f, alb.y);
                 const bool v0 = live && (pa.x <= 0.f) && (ala.x >= ALPHA_MIN) && (s.pos <= __float_as_uint(q02.z));
@@ -337,6 +384,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
                 const bool v3 = live && (pb.y <= 0.f) && (alb.y >= ALPHA_MIN) && (s.pos <= __float_as_uint(q12.w));
                 ala.x = v0 ? ala.x : 0.f; ala.y = v1 ? ala.y : 0.f; alb.x = v2 ? alb.x : 0.f; alb.y = v3 ? alb.y : 0.f;
                 Ga.x = v0 ? Ga.x : 0.f; Ga.y = v1 ? Ga.y : 0.f; Gb.x = v2 ? Gb.x : 0.f; Gb.y = v3 ? Gb.y : 0.f;
+#endif
                 const f2 oma = 1.f - ala, omb = 1.f - alb;
                 const f2 g0a = {q00.x, q00.y}, g1a = {q00.z, q00.w}, g2a = {q01.x, q01.y};
                 const f2 g0b = {q10.x, q10.y}, g1b = {q10.z, q10.w}, g2b = {q11.x, q11.y};
@@ -365,6 +413,34 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
                 const f2 dLb = Tnb * (sdb - (f2){R2, R3});
                 a0 = __builtin_elementwise_fma(wa, g0a, a0); a1 = __builtin_elementwise_fma(wa, g1a, a1); a2 = __builtin_elementwise_fma(wa, g2a, a2);
                 a0 = __builtin_elementwise_fma(wb, g0b, a0); a1 = __builtin_elementwise_fma(wb, g1b, a1); a2 = __builtin_elementwise_fma(wb, g2b, a2);
+#if BWD_LEAN
+                // q = dL/dpower = (o G) dL/dalpha (straight through the clamp, decision D3); 0 for non-contributing pairs.
+                // dy is common to the row: the moments in dy are taken on the row sums.  a3 collects sum q = o * sum G dL/dalpha;
+                // the division by o happens once per record.
+                const f2 qva = aua * dLa, qvb = aub * dLb;
+                const f2 qdxa = qva * dxa, qdxb = qvb * dxb;
+                const f2 rq = qva + qvb, rqdx = qdxa + qdxb;
+                a3 = a3 + rq; a4 = a4 + rqdx;
+                a6 = __builtin_elementwise_fma(qdxa, dxa, a6); a6 = __builtin_elementwise_fma(qdxb, dxb, a6);
+                const f2 rqdy = rq * dyy;
+                a5 = a5 + rqdy;
+                a7 = __builtin_elementwise_fma(rqdx, dyy, a7);
+                a8 = __builtin_elementwise_fma(rqdy, dyy, a8);
+                if (ABS) {                                              // sum |q d power / d centre| per pixel
+                    const f2 bp2 = {s.bp, s.bp};
+                    const f2 hxa = ta + apdxa, hxb = tb + apdxb;                              // 2 ap dx + bp dy
+                    const float cdy2 = 2.f * s.cp * dy;
+                    const f2 hya = __builtin_elementwise_fma(bp2, dxa, (f2){cdy2, cdy2});       // 2 cp dy + bp dx
+                    const f2 hyb = __builtin_elementwise_fma(bp2, dxb, (f2){cdy2, cdy2});
+                    const f2 mxa = qva * hxa, mxb = qvb * hxb, mya = qva * hya, myb = qvb * hyb;
+                    // acc += |v| as ONE v_add_f32 with the abs source modifier (packed fp32 has none: the compiler's
+                    // version is two v_and + one v_pk_add per pair)
+#define ACC_ABS(acc, v) asm("v_add_f32 %0, %0, |%1|" : "+v"(acc) : "v"(v))
+                    ACC_ABS(a9.x, mxa.x); ACC_ABS(a9.y, mxa.y); ACC_ABS(a9.x, mxb.x); ACC_ABS(a9.y, mxb.y);
+                    ACC_ABS(a10.x, mya.x); ACC_ABS(a10.y, mya.y); ACC_ABS(a10.x, myb.x); ACC_ABS(a10.y, myb.y);
+#undef ACC_ABS
+                }
+#else
                 const f2 gda = Ga * dLa, gdb = Gb * dLb;                // G == 0 for non-contributing pairs
                 a3 = a3 + gda; a3 = a3 + gdb;
                 const f2 qva = s.o * gda, qvb = s.o * gdb;
@@ -380,6 +456,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
                     a10 = a10 + __builtin_elementwise_abs(__builtin_elementwise_fma(cp2, qdya, s.bp * qdxa));
                     a10 = a10 + __builtin_elementwise_abs(__builtin_elementwise_fma(cp2, qdyb, s.bp * qdxb));
                 }
+#endif
             }
         };
         auto add_to_copy = [&](const int slot) {      // plain read-modify-write of the wave's own copy
@@ -467,6 +544,9 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
                     r2.x += x2.x; r2.y += x2.y; r2.z += x2.z;
                 }
                 r2.y *= (1.0f / LOG2E); r2.z *= (1.0f / LOG2E);      // abs sums were taken on the scaled conic
+#if BWD_LEAN
+                r0.w = (cur.o > 0.f) ? r0.w / cur.o : 0.f;           // sum q -> sum G dL/dalpha (a contributing splat has o >= 1/255)
+#endif
             }
             float4* dst = reinterpret_cast<float4*>(partials + (size_t)cur.e * PART_FLOATS);
             dst[0] = r0; dst[1] = r1; dst[2] = r2;
@@ -488,15 +568,15 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     const int gx = cdiv(s.image_width, BAGS_TILE), gy = cdiv(s.image_height, BAGS_TILE);
     const int T = gx * gy;
     if (T == 0) return hipSuccess;
-    const int grid = ((T + 7) / 8) * 8;
+    const int grid = blend_grid(T);
     if (want_abs)
         hipLaunchKernelGGL(blend_bwd_scan_kernel<true>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
                            b.ranges, b.point_list, g.g2d, s.bg,
-                           im.final_T, im.n_contrib, im.tile_maxc, grad_color, partials);
+                           im.final_T, im.n_contrib, im.tile_maxc, im.tile_order, grad_color, partials);
     else
         hipLaunchKernelGGL(blend_bwd_scan_kernel<false>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
                            b.ranges, b.point_list, g.g2d, s.bg,
-                           im.final_T, im.n_contrib, im.tile_maxc, grad_color, partials);
+                           im.final_T, im.n_contrib, im.tile_maxc, im.tile_order, grad_color, partials);
     return hipGetLastError();
 }
 
@@ -518,9 +598,9 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU)
 blend_fwd_rows_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ ranges, const u32* __restrict__ point_list,
                       const float4* __restrict__ g2d, const float* __restrict__ bg, float* __restrict__ out_color,
                       float* __restrict__ out_depth, float* __restrict__ out_weights, float* __restrict__ final_T,
-                      u32* __restrict__ n_contrib, u32* __restrict__ tile_maxc)
+                      u32* __restrict__ n_contrib, u32* __restrict__ tile_maxc, const u32* __restrict__ tile_order)
 {
-    const int tile = tile_of_block(blockIdx.x, T);
+    const int tile = tile_of_block(blockIdx.x, T, tile_order);
     if (tile >= T) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4, li = lane & 15;
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
@@ -637,9 +717,9 @@ hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinV
     const int gx = cdiv(s.image_width, BAGS_TILE), gy = cdiv(s.image_height, BAGS_TILE);
     const int T = gx * gy;
     if (T == 0) return hipSuccess;
-    const int grid = ((T + 7) / 8) * 8;
+    const int grid = blend_grid(T);
     hipLaunchKernelGGL(blend_fwd_rows_kernel<0>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
                        b.ranges, b.point_list, g.g2d, s.bg, out.color, out.depth, out.weights,
-                       im.final_T, im.n_contrib, im.tile_maxc);
+                       im.final_T, im.n_contrib, im.tile_maxc, im.tile_order);
     return hipGetLastError();
 }

@@ -396,6 +396,50 @@ hipError_t launch_tile_ranges(const u32* tile_sorted, long long I, uint2* ranges
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ tile order
+// Heavy-first order of the tiles for the blend launches (blend.hip, TILE_MAP 2): a counting sort of the tiles by
+// instance count into ORDER_LEVELS levels relative to the fullest tile, fullest level first.  One workgroup (T is a few
+// thousand to a few ten thousand).  The position of a tile inside its level depends on the order the LDS atomics land
+// in, which is harmless: the order only decides which workgroup computes which tile, never what is computed.
+#define ORDER_LEVELS 64
+__global__ void __launch_bounds__(1024)
+tile_order_kernel(const uint2* __restrict__ ranges, int T, u32* __restrict__ order)
+{
+    __shared__ u32 s_max[16];
+    __shared__ u32 s_cur[ORDER_LEVELS];
+    const int tid = threadIdx.x;
+    u32 m = 0;
+    for (int t = tid; t < T; t += 1024) { const uint2 r = ranges[t]; m = max(m, r.y - r.x); }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (u32)__shfl_xor((int)m, d));
+    if ((tid & 63) == 0) s_max[tid >> 6] = m;
+    if (tid < ORDER_LEVELS) s_cur[tid] = 0;
+    __syncthreads();
+    m = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) m = max(m, s_max[w]);
+    const u64 span = (u64)m + 1;
+    auto level_of = [&](int t) -> int {
+        const uint2 r = ranges[t];
+        return ORDER_LEVELS - 1 - (int)(((u64)(r.y - r.x) * ORDER_LEVELS) / span);     // n == m -> level 0
+    };
+    for (int t = tid; t < T; t += 1024) atomicAdd(&s_cur[level_of(t)], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        u32 run = 0;
+        for (int l = 0; l < ORDER_LEVELS; ++l) { const u32 c = s_cur[l]; s_cur[l] = run; run += c; }
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += 1024) order[atomicAdd(&s_cur[level_of(t)], 1u)] = (u32)t;
+}
+
+hipError_t launch_tile_order(const uint2* ranges, int T, u32* order, hipStream_t st)
+{
+    if (T <= 0) return hipSuccess;
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, ranges, T, order);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ debug views
 __global__ void debug_keys_kernel(const u32* tile_sorted, const u32* point_list, const u32* depth_key, long long I, u64* out)
 {
