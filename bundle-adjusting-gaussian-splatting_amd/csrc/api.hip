@@ -106,7 +106,7 @@ size_t carve_image(void* base, int W, int H, ImgView* v)
     const size_t n = (size_t)W * H > 0 ? (size_t)W * H : 1;
     take(p, im.final_T, n); take(p, im.n_contrib, n);
     const size_t T = (size_t)cdiv(W > 0 ? W : 1, BAGS_TILE) * cdiv(H > 0 ? H : 1, BAGS_TILE);
-    take(p, im.tile_maxc, T); take(p, im.tile_order, T);
+    take(p, im.tile_desc, T); take(p, im.n_active, 64);
     if (v) *v = im;
     return (size_t)(p - reinterpret_cast<char*>(base));
 }
@@ -191,7 +191,7 @@ static int enqueue_finish(const BagsSettings* s, const BagsInputs* in, const Geo
     }
     { ProfScope ps(ST_RANGES, st);
       HIP_TRY(launch_tile_ranges(b.tile_sorted, I, b.ranges, gx * gy, st, n_dev));
-      HIP_TRY(launch_tile_order(b.ranges, gx * gy, im.tile_order, st)); }
+      HIP_TRY(launch_tile_order(b.ranges, gx * gy, im.tile_desc, im.n_active, st)); }
     DEBUG_SYNC(s, st, "tile ranges");
     { ProfScope ps(ST_BLEND_FWD, st); HIP_TRY(launch_blend_fwd(*s, g, b, im, *out, st)); }
     DEBUG_SYNC(s, st, "blend_fwd");

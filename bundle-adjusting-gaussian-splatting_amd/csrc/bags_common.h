@@ -62,8 +62,10 @@ struct BinView {
 struct ImgView {
     float* final_T;          // [H*W]
     u32*   n_contrib;        // [H*W]
-    u32*   tile_maxc;        // [tiles] max n_contrib over the tile's pixels (written by blend_fwd, read by blend_bwd)
-    u32*   tile_order;       // [tiles] tiles heavy-first by instance count: which workgroup of a blend launch takes which tile
+    // [tiles] the tiles heavy-first by instance count: {tile, first instance, instance count, deepest contributor}.
+    // x,y,z by tile_order_kernel, w by blend_fwd; decides which workgroup of a blend launch takes which tile.
+    uint4* tile_desc;
+    u32*   n_active;         // [1] tiles that hold at least one instance (they come first in tile_desc)
 };
 
 int radix_items_for(long long n);
@@ -83,7 +85,7 @@ hipError_t launch_emit(const GeomView& g, const u32* sorted_ids, int P, int grid
                        hipStream_t st, const u32* n_dev = nullptr);
 hipError_t launch_tile_ranges(const u32* tile_sorted, long long I, uint2* ranges, int T, hipStream_t st,
                               const u32* n_dev = nullptr);
-hipError_t launch_tile_order(const uint2* ranges, int T, u32* order, hipStream_t st);
+hipError_t launch_tile_order(const uint2* ranges, int T, uint4* tile_desc, u32* n_active, hipStream_t st);
 hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
                             const BagsForwardOut& out, hipStream_t st);
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,

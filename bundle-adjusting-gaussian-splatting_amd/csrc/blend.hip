@@ -34,9 +34,6 @@
 #ifndef SCAN_UNROLL
 #define SCAN_UNROLL 1
 #endif
-#ifndef BWD_LEAN
-#define BWD_LEAN 1
-#endif
 
 struct __attribute__((aligned(16))) SplatRec {
     float x, y, ap, bp;       // centre, pre-scaled conic: exp2(ap dx^2 + bp dx dy + cp dy^2) == exp(power)
@@ -45,41 +42,23 @@ struct __attribute__((aligned(16))) SplatRec {
 };
 
 // Workgroup -> tile.  Workgroups are dispatched in blockIdx order, round-robin over the 8 XCDs (b and b+8 share one), and
-// a launch ends when its busiest XCD ends.  Placement only affects speed (every tile is computed independently).
-//   0: one contiguous band of tiles per XCD (neighbouring tiles share splats => same L2).  On the bench scene the top and
-//      bottom bands hold 0.62-0.67x the mean number of instances and the six middle ones 1.12x: the launch runs 12-20 %
-//      longer than a balanced one (tests/analysis_lane_fill.py, tools/sim_tile_schedule.py).
-//   1: runs of TILE_ILV consecutive tiles, round-robin over the XCDs (balance within 1 %, row neighbours still share an L2).
-//   2: the same over `order` = tiles sorted heavy-first by instance count (tile_order_kernel, sort.hip): balanced AND the
-//      long tiles start first, so the launch does not end on a few late heavy tiles (longest-processing-time-first).
-#ifndef TILE_MAP
-#define TILE_MAP 2
-#endif
+// a launch ends when its busiest XCD ends.  tile_order_kernel (sort.hip) lists the tiles heavy-first by instance count
+// as descriptors {tile, first instance, instance count, deepest contributor (written by the forward)}; virtual block v
+// takes descriptor slot_of_vblock(v): runs of TILE_ILV consecutive descriptors go round-robin over the XCDs, so
+//   * every XCD gets the same mix of heavy and light tiles (one contiguous band of tiles per XCD, the first layout, left
+//     the two XCDs holding the top and bottom of the bench image with 0.62-0.67x the mean load and the other six with
+//     1.12x: the launch ran 12-20 % longer than a balanced one, tests/analysis_lane_fill.py),
+//   * the long tiles start first and the launch does not end on a few late heavy ones,
+//   * descriptors of a run are mostly neighbouring tiles, which share splats, and stay on one L2.
+// Placement only affects speed: every tile is computed independently of where and when it runs.
 #ifndef TILE_ILV
-#define TILE_ILV 16         // must not share a large factor with the tile-row length in mode 1 (15 or 30 against 120 tiles/row resonate)
+#define TILE_ILV 16
 #endif
-__device__ __forceinline__ int tile_of_block(int b, int T, const u32* __restrict__ order)
+#define TILE_RUN (8 * TILE_ILV)        // virtual blocks [k TILE_RUN, (k+1) TILE_RUN) permute descriptors of the same interval
+__device__ __forceinline__ int slot_of_vblock(int v)
 {
-#if TILE_MAP == 0
-    const int chunk = (T + 7) / 8;
-    return (b & 7) * chunk + (b >> 3);
-#else
-    const int k = b >> 3;
-    const int slot = ((k / TILE_ILV) * 8 + (b & 7)) * TILE_ILV + (k % TILE_ILV);
-#if TILE_MAP == 1
-    return slot;
-#else
-    return slot < T ? (int)order[slot] : T;
-#endif
-#endif
-}
-static inline int blend_grid(int T)
-{
-#if TILE_MAP == 0
-    return ((T + 7) / 8) * 8;
-#else
-    return cdiv(T, 8 * TILE_ILV) * 8 * TILE_ILV;
-#endif
+    const int k = v >> 3;
+    return ((k / TILE_ILV) * 8 + (v & 7)) * TILE_ILV + (k % TILE_ILV);
 }
 
 // exp(power) for one (pixel, splat) pair: the SAME instruction sequence in forward and backward so both make the
@@ -207,86 +186,48 @@ __device__ unsigned long long g_phase_cycles[8];
 #else
 #define PH_MARK(i) do {} while (0)
 #endif
+struct TileRef { int tx, ty; u32 rx, n, maxc; };   // wave-uniform: tile coordinates, first instance, instances, deepest contributor
+
 template <bool ABS>
 __global__ void __launch_bounds__(256, SCAN_WG_PER_CU)
-blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ ranges, const u32* __restrict__ point_list,
-                      const float4* __restrict__ g2d, const float* __restrict__ bg, const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
-                      const u32* __restrict__ tile_maxc, const u32* __restrict__ tile_order, const float* __restrict__ grad_color,
+blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__ tile_desc,
+                      const u32* __restrict__ point_list, const float4* __restrict__ g2d, const float* __restrict__ bg,
+                      const float* __restrict__ final_T, const u32* __restrict__ n_contrib, const float* __restrict__ grad_color,
                       float* __restrict__ partials)
 {
-    const int tile = tile_of_block(blockIdx.x, T, tile_order);
-    if (tile >= T) return;
+    // One workgroup per tile that holds at least one instance, heavy tiles first (slot_of_vblock).  Tried and dropped:
+    // persistent workgroups that run the chunk pipeline over the flattened (tile, chunk) sequence, with the next tile's
+    // ids and gathers in flight during the current tile's last chunk (static b, b+G, ... walk or per-XCD ticket counters).
+    // Every variant was 2-8 % SLOWER than one workgroup per tile although the per-tile dependent chain disappears from
+    // the wave timeline: the hardware dispatcher refills a CU as soon as any workgroup leaves, while a persistent
+    // workgroup keeps its four waves coupled at two barriers per chunk for the whole launch.
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile_x = tile % grid_x, tile_y = tile / grid_x;
-    const float X0 = (float)(tile_x * BAGS_TILE), Y0 = (float)(tile_y * BAGS_TILE);
-    const uint2 range = ranges[tile];
-    const u32 n = range.y - range.x;
-    if (n == 0) return;
+    const int dslot = slot_of_vblock((int)blockIdx.x);
+    if (dslot >= T) return;
+    const uint4 desc = tile_desc[dslot];                     // {tile, first instance, instances, deepest contributor}
+    if (desc.z == 0) return;                                 // empty tile: no records to write
+    TileRef A;
+    A.tx = (int)(desc.x % (u32)grid_x); A.ty = (int)(desc.x / (u32)grid_x); A.rx = desc.y; A.n = desc.z; A.maxc = min(desc.w, desc.z);
 
-    __shared__ ChunkRec recs[BCHUNK];                 // 12 KB
+    __shared__ ChunkRec recs[BCHUNK];                 // 6 KB
     // 8 pixel pairs (PixPair = 4 x float4) per block + one float4 of padding: the four rows of a wave read four different
     // blocks in one ds_read_b128, and a 512-B block stride would put all four on the same banks
     __shared__ float4 pixq[16][33];                  //  8.25 KB
-    __shared__ unsigned char lists[16][BCHUNK];       //  4 KB
-    __shared__ u32 masks[BCHUNK];                     //  1 KB: block reach masks, compact (the 48-B record stride bank-conflicts)
-    __shared__ float acc[4][BCHUNK][12];              // 48 KB, one copy per wave (LDS float atomics on a shared copy were 1.6x slower)
+    __shared__ unsigned char lists[16][BCHUNK];       //  2 KB
+    __shared__ u32 masks[BCHUNK];                     //  0.5 KB: block reach masks, compact (the 48-B record stride bank-conflicts)
+    __shared__ float acc[4][BCHUNK][12];              // 24 KB, one copy per wave (LDS float atomics on a shared copy were 1.6x slower)
     __shared__ u32 blk_maxc[16];                     // last contributor over the 16 pixels of each block
 
 #ifdef DIAG_PHASES
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
 #endif
-    // The tile's deepest contributor comes from the forward (one scalar load), so the ids of the first two chunks are
-    // requested before anything else and the pixel loads below overlap them: the per-tile dependent chain is
-    // range -> ids -> gathers instead of range -> pixels -> workgroup max -> ids -> gathers.
-    const u32 maxc = min(tile_maxc[tile], n);
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     struct Raw { float4 q0, q1, q2; u32 io; };      // conic+opacity | x y r g | b z rect | inst_offset
-    auto fetch_id = [&](u32 hi_) -> u32 {            // id of this thread's slot in the chunk that ends at hi_
+    auto fetch_id = [&](u32 rx_, u32 hi_) -> u32 {   // id of this thread's slot in the chunk of a tile's list that ends at hi_
         const u32 c_ = min(hi_, (u32)BCHUNK);
-        return ((u32)tid < c_) ? point_list[range.x + (hi_ - c_) + tid] : 0xFFFFFFFFu;
+        return ((u32)tid < c_) ? point_list[rx_ + (hi_ - c_) + tid] : 0xFFFFFFFFu;
     };
-    const u32 gid0 = fetch_id(maxc);
-    u32 gid1 = (maxc > BCHUNK) ? fetch_id(maxc - BCHUNK) : 0xFFFFFFFFu;       // ids of chunk 1, in flight with chunk 0's
-
-    // ---- per-pixel constants: thread tid <-> block tid>>4, pixel tid&15 (ix = &3, iy = >>2)
-    {
-        const int b = tid >> 4, i = tid & 15;
-        const int px = tile_x * BAGS_TILE + (b & 3) * 4 + (i & 3);
-        const int py = tile_y * BAGS_TILE + (b >> 2) * 4 + (i >> 2);
-        const bool in = (px < W) && (py < H);
-        const size_t HW = (size_t)W * H, pixi = (size_t)min(py, H - 1) * W + min(px, W - 1);   // always a valid address
-        const float l0 = grad_color[pixi], l1 = grad_color[HW + pixi], l2 = grad_color[2 * HW + pixi];
-        const float lT = final_T[pixi];
-        const u32 lnc = n_contrib[pixi];
-        const float g0 = in ? l0 : 0.f, g1 = in ? l1 : 0.f, g2 = in ? l2 : 0.f;
-        const float Tf = in ? lT : 1.f;
-        const u32 nc = in ? lnc : 0u;
-        const float bgg = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;          // what lies behind the deepest splat
-        float* pp = reinterpret_cast<float*>(&pixq[tid >> 4][((tid >> 1) & 7) * 4]);
-        const int h = tid & 1;                        // A or B of the pair
-        pp[0 + h] = g0; pp[2 + h] = g1; pp[4 + h] = g2; pp[6 + h] = Tf;
-        pp[8 + h] = 0.f; pp[10 + h] = __uint_as_float(nc); pp[12 + h] = 1.f; pp[14 + h] = bgg;
-        u32 m = nc;
-#pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) m = max(m, (u32)__shfl_xor((int)m, d));   // 16 consecutive threads = one block
-        if ((tid & 15) == 0) blk_maxc[b] = m;        // read after the first chunk barrier
-    }
-
-    // instances behind the last contributor of every pixel are never visited: their records are zero
-    for (u32 p = maxc + tid; p < n; p += 256) {
-        const u32 g = point_list[range.x + p];
-        const float4 t2 = g2d[4 * (size_t)g + 2];
-        const uint2 rc = make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w));
-        const u32 e = __float_as_uint(g2d[4 * (size_t)g + 3].x) + (u32)(tile_y - (int)(rc.x >> 16)) * ((rc.y & 0xFFFF) - (rc.x & 0xFFFF)) +
-                      (u32)(tile_x - (int)(rc.x & 0xFFFF));
-        float4* dst = reinterpret_cast<float4*>(partials + (size_t)e * PART_FLOATS);
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        dst[0] = z4; dst[1] = z4; dst[2] = z4;
-    }
-
-    // Software pipeline over chunks: Gaussian ids are fetched TWO chunks ahead and the per-splat gathers ONE chunk
-    // ahead, so neither the id load nor the dependent gathers sit on the critical path of a chunk.
     auto fetch = [&](u32 g) {
         Raw r; r.q0 = make_float4(0.f, 0.f, 0.f, 0.f); r.q1 = r.q0; r.q2 = r.q0; r.io = 0u;
         if (g != 0xFFFFFFFFu) {                       // one 64-byte line
@@ -295,6 +236,67 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
         }
         return r;
     };
+    // emission slot of a Gaussian's record for tile (tx, ty): its rectangle is walked y outer, x inner
+    auto emission_slot = [&](u32 io, uint2 rc, int tx, int ty) -> u32 {
+        return io + (u32)(ty - (int)(rc.x >> 16)) * ((rc.y & 0xFFFF) - (rc.x & 0xFFFF)) + (u32)(tx - (int)(rc.x & 0xFFFF));
+    };
+    auto make_rec = [&](const Raw& rw, const TileRef& t, u32 lo_, u32 cnt_) {
+        ChunkRec rec; rec.mask = 0; rec.e = 0;
+        rec.x = rec.y = rec.ap = rec.bp = rec.cp = rec.o = rec.r = rec.g = rec.b = 0.f; rec.pos = 0;
+        if ((u32)tid < cnt_) {
+            const float2 c2 = make_float2(rw.q1.x, rw.q1.y); const float4 co = rw.q0;
+            const float4 cz = make_float4(rw.q1.z, rw.q1.w, rw.q2.x, rw.q2.y);
+            rec.e = emission_slot(rw.io, make_uint2(__float_as_uint(rw.q2.z), __float_as_uint(rw.q2.w)), t.tx, t.ty);
+            rec.x = c2.x; rec.y = c2.y;
+            rec.ap = -0.5f * LOG2E * co.x; rec.bp = -LOG2E * co.y; rec.cp = -0.5f * LOG2E * co.z; rec.o = co.w;
+            rec.r = cz.x; rec.g = cz.y; rec.b = cz.z;
+            rec.pos = lo_ + tid + 1;
+            rec.mask = block_mask16(c2.x, c2.y, co.x, co.y, co.z, co.w, (float)(t.tx * BAGS_TILE), (float)(t.ty * BAGS_TILE));
+        }
+        return rec;
+    };
+    // Per-pixel constants and scan carries into LDS, per-block deepest contributor, and zero records for the instances
+    // behind every pixel's last contributor (they are never visited).  The first chunk's first barrier publishes it.
+    auto tile_begin = [&](const TileRef& t) {
+        {   // thread tid <-> block tid>>4, pixel tid&15 (ix = &3, iy = >>2)
+            const int b = tid >> 4, i = tid & 15;
+            const int px = t.tx * BAGS_TILE + (b & 3) * 4 + (i & 3);
+            const int py = t.ty * BAGS_TILE + (b >> 2) * 4 + (i >> 2);
+            const bool in = (px < W) && (py < H);
+            const size_t HW = (size_t)W * H, pixi = (size_t)min(py, H - 1) * W + min(px, W - 1);   // always a valid address
+            const float l0 = grad_color[pixi], l1 = grad_color[HW + pixi], l2 = grad_color[2 * HW + pixi];
+            const float lT = final_T[pixi];
+            const u32 lnc = n_contrib[pixi];
+            const float g0 = in ? l0 : 0.f, g1 = in ? l1 : 0.f, g2 = in ? l2 : 0.f;
+            const float Tf = in ? lT : 1.f;
+            const u32 nc = in ? lnc : 0u;
+            const float bgg = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;          // what lies behind the deepest splat
+            float* pp = reinterpret_cast<float*>(&pixq[tid >> 4][((tid >> 1) & 7) * 4]);
+            const int h = tid & 1;                        // A or B of the pair
+            pp[0 + h] = g0; pp[2 + h] = g1; pp[4 + h] = g2; pp[6 + h] = Tf;
+            pp[8 + h] = 0.f; pp[10 + h] = __uint_as_float(nc); pp[12 + h] = 1.f; pp[14 + h] = bgg;
+            u32 m = nc;
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) m = max(m, (u32)__shfl_xor((int)m, d));   // 16 consecutive threads = one block
+            if ((tid & 15) == 0) blk_maxc[b] = m;
+        }
+        for (u32 p = t.maxc + tid; p < t.n; p += 256) {
+            const u32 g = point_list[t.rx + p];
+            const float4 t2 = g2d[4 * (size_t)g + 2];
+            const u32 e = emission_slot(__float_as_uint(g2d[4 * (size_t)g + 3].x), make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)), t.tx, t.ty);
+            float4* dst = reinterpret_cast<float4*>(partials + (size_t)e * PART_FLOATS);
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            dst[0] = z4; dst[1] = z4; dst[2] = z4;
+        }
+    };
+
+    // The tile's descriptor carries its deepest contributor (from the forward), so the ids of the first two chunks are
+    // requested before anything else and the pixel loads of tile_begin overlap them: the per-tile dependent chain is
+    // descriptor -> ids -> gathers.
+    const u32 gid0 = fetch_id(A.rx, A.maxc);
+    u32 gid1 = (A.maxc > BCHUNK) ? fetch_id(A.rx, A.maxc - BCHUNK) : 0xFFFFFFFFu;      // ids of chunk 1, in flight with chunk 0's
+    tile_begin(A);
+    if (A.maxc == 0) return;                                 // nothing contributed anywhere in the tile: all records are zero
     if (tid < BCHUNK) {
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -304,42 +306,31 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
         }
     }
     PH_MARK(0);        // prologue
-    auto make_rec = [&](const Raw& rw, u32 lo_, u32 cnt_) {
-        ChunkRec rec; rec.mask = 0; rec.e = 0;
-        rec.x = rec.y = rec.ap = rec.bp = rec.cp = rec.o = rec.r = rec.g = rec.b = 0.f; rec.pos = 0;
-        if ((u32)tid < cnt_) {
-            const float2 c2 = make_float2(rw.q1.x, rw.q1.y); const float4 co = rw.q0;
-            const float4 cz = make_float4(rw.q1.z, rw.q1.w, rw.q2.x, rw.q2.y);
-            const uint2 rc = make_uint2(__float_as_uint(rw.q2.z), __float_as_uint(rw.q2.w));
-            rec.e = rw.io + (u32)(tile_y - (int)(rc.x >> 16)) * ((rc.y & 0xFFFF) - (rc.x & 0xFFFF)) +
-                    (u32)(tile_x - (int)(rc.x & 0xFFFF));
-            rec.x = c2.x; rec.y = c2.y;
-            rec.ap = -0.5f * LOG2E * co.x; rec.bp = -LOG2E * co.y; rec.cp = -0.5f * LOG2E * co.z; rec.o = co.w;
-            rec.r = cz.x; rec.g = cz.y; rec.b = cz.z;
-            rec.pos = lo_ + tid + 1;
-            rec.mask = block_mask16(c2.x, c2.y, co.x, co.y, co.z, co.w, X0, Y0);
-        }
-        return rec;
-    };
     // Chunk pipeline.  Every value carried around the loop is COMPLETE (the compiler copies loop-carried registers at
     // the loop head, and copying the destination of an in-flight load stalls on it -- measured: 23 % of the wave time):
     //   top      publish rec(k) to LDS, barrier
     //   then     issue the gathers of chunk k+1 (ids known) and the id load of chunk k+2
     //   ...      lists + groups of chunk k            <- the loads land underneath
     //   barrier  consume gathers -> rec(k+1), ids(k+2); only then store the records of chunk k
-    ChunkRec rec = make_rec(fetch(gid0), maxc - min(maxc, (u32)BCHUNK), min(maxc, (u32)BCHUNK));
+    ChunkRec rec = make_rec(fetch(gid0), A, A.maxc - min(A.maxc, (u32)BCHUNK), min(A.maxc, (u32)BCHUNK));
     asm volatile("" :: "v"(gid1));    // complete before the loop: a pending load on the entry edge costs a vmcnt(0) at every loop top
 
-    for (u32 hi = maxc; hi > 0;) {
+    const int row = lane >> 4, li = lane & 15;
+    const int qx = (wave & 1) * 2, qy = (wave >> 1) * 2;
+    const int myblk = (qy + (row >> 1)) * 4 + qx + (row & 1);
+    float4* const pixb = &pixq[myblk][0];
+
+    for (u32 hi = A.maxc;;) {
         const u32 cnt = min(hi, (u32)BCHUNK);
         const u32 lo = hi - cnt;
-        // ---- publish the staged chunk [lo, hi): slot s <-> list position lo + s (front to back)
+        // ---- publish the staged chunk [lo, hi) of tile A: slot s <-> list position lo + s (front to back)
         if (tid < BCHUNK) { recs[tid] = rec; masks[tid] = rec.mask; }   // safe without a barrier: after the previous chunk's second barrier nobody reads them
         lds_barrier();
         PH_MARK(2);    // barrier 1
         __builtin_amdgcn_s_setprio(0);
+        const u32 nx_cnt = min(lo, (u32)BCHUNK), nx_lo = lo - nx_cnt;                  // chunk k+1 = [nx_lo, lo)
         Raw raw_n = fetch(lo > 0 ? gid1 : 0xFFFFFFFFu);                             // gathers of chunk k+1
-        const u32 gid2 = (lo > BCHUNK) ? fetch_id(lo - BCHUNK) : 0xFFFFFFFFu;          // ids of chunk k+2
+        const u32 gid2 = (nx_lo > 0) ? fetch_id(A.rx, nx_lo) : 0xFFFFFFFFu;          // ids of chunk k+2
 
         // The per-(splat, block) work: one block row (4 pixels = two packed pairs) per step; four independent scan chains
         // interleave without pipeline bubbles.  `s` is the lane's splat, (bx0, by0) its block origin, pixb its block's
@@ -365,26 +356,17 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
                 const f2 pb = __builtin_elementwise_fma(dxb, tb, (f2){u, u});
                 f2 Ga = {__builtin_amdgcn_exp2f(pa.x), __builtin_amdgcn_exp2f(pa.y)};
                 f2 Gb = {__builtin_amdgcn_exp2f(pb.x), __builtin_amdgcn_exp2f(pb.y)};
-#if BWD_LEAN
                 // unclamped o G, zeroed for non-contributing pairs; min(0.99, x) >= 1/255 <=> x >= 1/255, so the contribute /
                 // skip decision is the forward's.  The clamp is applied after the select (0 stays 0).
                 f2 aua = s.o * Ga, aub = s.o * Gb;
-                const bool v0 = live && (pa.x <= 0.f) && (aua.x >= ALPHA_MIN) && (s.pos <= __float_as_uint(q02.z));
-                const bool v1 = live && (pa.y <= 0.f) && (aua.y >= ALPHA_MIN) && (s.pos <= __float_as_uint(q02.w));
-                const bool v2 = live && (pb.x <= 0.f) && (aub.x >= ALPHA_MIN) && (s.pos <= __float_as_uint(q12.z));
-                const bool v3 = live && (pb.y <= 0.f) && (aub.y >= ALPHA_MIN) && (s.pos <= __float_as_uint(q12.w));
+                // bitwise &, not &&: a short-circuit makes the compiler branch around one pixel's n_contrib read and wait for
+                // every outstanding LDS read (lgkmcnt(0)) in the middle of the row
+                const bool v0 = live & (pa.x <= 0.f) & (aua.x >= ALPHA_MIN) & (s.pos <= __float_as_uint(q02.z));
+                const bool v1 = live & (pa.y <= 0.f) & (aua.y >= ALPHA_MIN) & (s.pos <= __float_as_uint(q02.w));
+                const bool v2 = live & (pb.x <= 0.f) & (aub.x >= ALPHA_MIN) & (s.pos <= __float_as_uint(q12.z));
+                const bool v3 = live & (pb.y <= 0.f) & (aub.y >= ALPHA_MIN) & (s.pos <= __float_as_uint(q12.w));
                 aua.x = v0 ? aua.x : 0.f; aua.y = v1 ? aua.y : 0.f; aub.x = v2 ? aub.x : 0.f; aub.y = v3 ? aub.y : 0.f;
                 const f2 ala = {fminf(0.99f, aua.x), fminf(0.99f, aua.y)}, alb = {fminf(0.99f, aub.x), fminf(0.99f, aub.y)};
-#else
-                f2 ala = s.o * Ga, alb = s.o * Gb;
-                ala.x = fminf(0.99f, ala.x); ala.y = fminf(0.99f, ala.y); alb.x = fminf(0.99f, alb.x); alb.y = fminf(0.99f, alb.y);
-                const bool v0 = live && (pa.x <= 0.f) && (ala.x >= ALPHA_MIN) && (s.pos <= __float_as_uint(q02.z));
-                const bool v1 = live && (pa.y <= 0.f) && (ala.y >= ALPHA_MIN) && (s.pos <= __float_as_uint(q02.w));
-                const bool v2 = live && (pb.x <= 0.f) && (alb.x >= ALPHA_MIN) && (s.pos <= __float_as_uint(q12.z));
-                const bool v3 = live && (pb.y <= 0.f) && (alb.y >= ALPHA_MIN) && (s.pos <= __float_as_uint(q12.w));
-                ala.x = v0 ? ala.x : 0.f; ala.y = v1 ? ala.y : 0.f; alb.x = v2 ? alb.x : 0.f; alb.y = v3 ? alb.y : 0.f;
-                Ga.x = v0 ? Ga.x : 0.f; Ga.y = v1 ? Ga.y : 0.f; Gb.x = v2 ? Gb.x : 0.f; Gb.y = v3 ? Gb.y : 0.f;
-#endif
                 const f2 oma = 1.f - ala, omb = 1.f - alb;
                 const f2 g0a = {q00.x, q00.y}, g1a = {q00.z, q00.w}, g2a = {q01.x, q01.y};
                 const f2 g0b = {q10.x, q10.y}, g1b = {q10.z, q10.w}, g2b = {q11.x, q11.y};
@@ -413,7 +395,6 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
                 const f2 dLb = Tnb * (sdb - (f2){R2, R3});
                 a0 = __builtin_elementwise_fma(wa, g0a, a0); a1 = __builtin_elementwise_fma(wa, g1a, a1); a2 = __builtin_elementwise_fma(wa, g2a, a2);
                 a0 = __builtin_elementwise_fma(wb, g0b, a0); a1 = __builtin_elementwise_fma(wb, g1b, a1); a2 = __builtin_elementwise_fma(wb, g2b, a2);
-#if BWD_LEAN
                 // q = dL/dpower = (o G) dL/dalpha (straight through the clamp, decision D3); 0 for non-contributing pairs.
                 // dy is common to the row: the moments in dy are taken on the row sums.  a3 collects sum q = o * sum G dL/dalpha;
                 // the division by o happens once per record.
@@ -440,23 +421,6 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
                     ACC_ABS(a10.x, mya.x); ACC_ABS(a10.y, mya.y); ACC_ABS(a10.x, myb.x); ACC_ABS(a10.y, myb.y);
 #undef ACC_ABS
                 }
-#else
-                const f2 gda = Ga * dLa, gdb = Gb * dLb;                // G == 0 for non-contributing pairs
-                a3 = a3 + gda; a3 = a3 + gdb;
-                const f2 qva = s.o * gda, qvb = s.o * gdb;
-                const f2 qdxa = qva * dxa, qdxb = qvb * dxb, qdya = qva * dy, qdyb = qvb * dy;
-                a4 = a4 + qdxa; a4 = a4 + qdxb; a5 = a5 + qdya; a5 = a5 + qdyb;
-                a6 = __builtin_elementwise_fma(qdxa, dxa, a6); a6 = __builtin_elementwise_fma(qdxb, dxb, a6);
-                a7 = __builtin_elementwise_fma(qdxa, dyy, a7); a7 = __builtin_elementwise_fma(qdxb, dyy, a7);
-                a8 = __builtin_elementwise_fma(qdya, dyy, a8); a8 = __builtin_elementwise_fma(qdyb, dyy, a8);
-                if (ABS) {
-                    const f2 ap2 = {2.f * s.ap, 2.f * s.ap}, cp2 = {2.f * s.cp, 2.f * s.cp};
-                    a9 = a9 + __builtin_elementwise_abs(__builtin_elementwise_fma(ap2, qdxa, s.bp * qdya));
-                    a9 = a9 + __builtin_elementwise_abs(__builtin_elementwise_fma(ap2, qdxb, s.bp * qdyb));
-                    a10 = a10 + __builtin_elementwise_abs(__builtin_elementwise_fma(cp2, qdya, s.bp * qdxa));
-                    a10 = a10 + __builtin_elementwise_abs(__builtin_elementwise_fma(cp2, qdyb, s.bp * qdxb));
-                }
-#endif
             }
         };
         auto add_to_copy = [&](const int slot) {      // plain read-modify-write of the wave's own copy
@@ -467,15 +431,15 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
             r2.x += a8.x + a8.y; r2.y += a9.x + a9.y; r2.z += a10.x + a10.y;
             d4[0] = r0; d4[1] = r1; d4[2] = r2;
         };
-        u32 mreg[BCHUNK / 64];
+        u32 mreg[(BCHUNK + 63) / 64];
 #pragma unroll
-        for (int r = 0; r < BCHUNK / 64; ++r) mreg[r] = masks[r * 64 + lane];
+        for (int r = 0; r < (BCHUNK + 63) / 64; ++r) mreg[r] = (r * 64 + lane < BCHUNK) ? masks[r * 64 + lane] : 0u;
         // ballot-compact the chunk's slots that reach block `blk` (list order = depth order); returns the list length
         auto build_list = [&](const int blk) -> int {
             int L = 0;
             const u32 bmax = blk_maxc[blk];              // splats behind every pixel's last contributor cannot matter here
 #pragma unroll
-            for (int r = 0; r < BCHUNK / 64; ++r) {
+            for (int r = 0; r < (BCHUNK + 63) / 64; ++r) {
                 const int slot = r * 64 + lane;
                 const bool hit = ((mreg[r] >> blk) & 1u) && (lo + (u32)slot < bmax);   // pos = lo + slot + 1
                 const u64 bal = __ballot(hit);
@@ -487,22 +451,21 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
         // ---- the wave owns quadrant `wave`; DPP row r of the wave owns one 4x4 block of it and walks that block's
         // list 16 splats per step (deepest in the row's lane 0).  Against "64 lanes = 64 splats of one block" (in the git
         // history) this quantises the lists at 16 instead of 64 entries and shortens the scans from six DPP steps to four.
-        const int row = lane >> 4, li = lane & 15;
-        const int qx = (wave & 1) * 2, qy = (wave >> 1) * 2;
-        const int myblk = (qy + (row >> 1)) * 4 + qx + (row & 1);
         int Lr[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) Lr[j] = build_list((qy + (j >> 1)) * 4 + qx + (j & 1));
         PH_MARK(3);    // list building
         const int myL = (row == 0) ? Lr[0] : (row == 1) ? Lr[1] : (row == 2) ? Lr[2] : Lr[3];
         const int nIter = (max(max(Lr[0], Lr[1]), max(Lr[2], Lr[3])) + 15) >> 4;
-        const float bx0 = X0 + 4.f * (float)(myblk & 3), by0 = Y0 + 4.f * (float)(myblk >> 2);
-        float4* pixb = &pixq[myblk][0];
+        const float bx0 = (float)(A.tx * BAGS_TILE) + 4.f * (float)(myblk & 3), by0 = (float)(A.ty * BAGS_TILE) + 4.f * (float)(myblk >> 2);
+        int slot_next = (li < myL) ? (int)lists[myblk][myL - 1 - li] : 0;
         for (int it = 0; it < nIter; ++it) {
             const int gend = myL - 16 * it;                 // <= 0: this row's list is exhausted
             const bool live = li < gend;
-            const int slot = live ? (int)lists[myblk][gend - 1 - li] : 0;
+            const int slot = slot_next;
             const ChunkRec s = recs[slot];
+            // the next step's list entry is read now: list byte -> record is a chain of two LDS latencies otherwise
+            slot_next = (li < gend - 16) ? (int)lists[myblk][gend - 17 - li] : 0;
             block_rows(s, live, bx0, by0, pixb, (li == 15) && (gend > 0));
             // the same splat can sit in several rows (it reaches several blocks of the quadrant): one row at a time
 #pragma unroll
@@ -526,7 +489,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
         // here also retires the id load before this chunk's record stores are issued, so the top of the next chunk
         // does not have to drain the stores to be sure the id has arrived.
         asm volatile("" :: "v"(raw_n.q2.y), "v"(gid2));
-        if (lo > 0) { const u32 ncnt = min(lo, (u32)BCHUNK); rec = make_rec(raw_n, lo - ncnt, ncnt); }
+        if (lo > 0) rec = make_rec(raw_n, A, nx_lo, nx_cnt);
         gid1 = gid2;
         PH_MARK(1);
         // ---- one record per staged instance: the four wave copies added in fixed order
@@ -544,15 +507,15 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
                     r2.x += x2.x; r2.y += x2.y; r2.z += x2.z;
                 }
                 r2.y *= (1.0f / LOG2E); r2.z *= (1.0f / LOG2E);      // abs sums were taken on the scaled conic
-#if BWD_LEAN
                 r0.w = (cur.o > 0.f) ? r0.w / cur.o : 0.f;           // sum q -> sum G dL/dalpha (a contributing splat has o >= 1/255)
-#endif
             }
             float4* dst = reinterpret_cast<float4*>(partials + (size_t)cur.e * PART_FLOATS);
             dst[0] = r0; dst[1] = r1; dst[2] = r2;
         }
         PH_MARK(6);    // record sums + stores
-        hi = lo;          // no barrier here: the next chunk's first barrier orders these LDS accesses before any reuse
+        // no barrier here: the next chunk's first barrier orders these LDS accesses before any reuse
+        if (lo == 0) break;
+        hi = lo;
     }
 #ifdef DIAG_PHASES
     if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_cycles[i], ph[i]);
@@ -568,15 +531,15 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     const int gx = cdiv(s.image_width, BAGS_TILE), gy = cdiv(s.image_height, BAGS_TILE);
     const int T = gx * gy;
     if (T == 0) return hipSuccess;
-    const int grid = blend_grid(T);
+    const int grid = cdiv(T, TILE_RUN) * TILE_RUN;
     if (want_abs)
         hipLaunchKernelGGL(blend_bwd_scan_kernel<true>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
-                           b.ranges, b.point_list, g.g2d, s.bg,
-                           im.final_T, im.n_contrib, im.tile_maxc, im.tile_order, grad_color, partials);
+                           im.tile_desc, b.point_list, g.g2d, s.bg,
+                           im.final_T, im.n_contrib, grad_color, partials);
     else
         hipLaunchKernelGGL(blend_bwd_scan_kernel<false>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
-                           b.ranges, b.point_list, g.g2d, s.bg,
-                           im.final_T, im.n_contrib, im.tile_maxc, im.tile_order, grad_color, partials);
+                           im.tile_desc, b.point_list, g.g2d, s.bg,
+                           im.final_T, im.n_contrib, grad_color, partials);
     return hipGetLastError();
 }
 
@@ -595,18 +558,20 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
 #endif
 template <int DUMMY>
 __global__ void __launch_bounds__(256, FWD_WG_PER_CU)
-blend_fwd_rows_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__ ranges, const u32* __restrict__ point_list,
+blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_desc, const u32* __restrict__ point_list,
                       const float4* __restrict__ g2d, const float* __restrict__ bg, float* __restrict__ out_color,
                       float* __restrict__ out_depth, float* __restrict__ out_weights, float* __restrict__ final_T,
-                      u32* __restrict__ n_contrib, u32* __restrict__ tile_maxc, const u32* __restrict__ tile_order)
+                      u32* __restrict__ n_contrib)
 {
-    const int tile = tile_of_block(blockIdx.x, T, tile_order);
-    if (tile >= T) return;
+    const int dslot = slot_of_vblock(blockIdx.x);            // heavy tiles first, balanced over the XCDs
+    if (dslot >= T) return;
+    const uint4 desc = tile_desc[dslot];                     // {tile, first instance, instances, -}
+    const int tile = (int)desc.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4, li = lane & 15;
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
     const float X0 = (float)(tile_x * BAGS_TILE), Y0 = (float)(tile_y * BAGS_TILE);
-    const uint2 range = ranges[tile];
-    const u32 n = range.y - range.x;
+    const uint2 range = make_uint2(desc.y, desc.y + desc.z);
+    const u32 n = desc.z;
 
     __shared__ SplatRec recs[CHUNK];                 // x y ap bp | cp o r g | b z mask pos
     __shared__ unsigned char lists[16][CHUNK];
@@ -701,14 +666,15 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, const uint2* __restrict__
         final_T[pix] = Tq;
         n_contrib[pix] = last;
     }
-    // the tile's deepest contributor: with it the backward can fetch its first chunk of ids before it has seen a pixel
+    // the tile's deepest contributor goes into the tile's descriptor: with it the backward can fetch a tile's first chunk of
+    // ids before it has seen a pixel of it
     u32 m = last;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (u32)__shfl_xor((int)m, d));
     __syncthreads();                                         // s_live is free again
     if (lane == 0) s_live[wave] = (int)m;
     __syncthreads();
-    if (tid == 0) tile_maxc[tile] = (u32)max(max(s_live[0], s_live[1]), max(s_live[2], s_live[3]));
+    if (tid == 0) tile_desc[dslot].w = (u32)max(max(s_live[0], s_live[1]), max(s_live[2], s_live[3]));
 }
 
 hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
@@ -717,9 +683,9 @@ hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinV
     const int gx = cdiv(s.image_width, BAGS_TILE), gy = cdiv(s.image_height, BAGS_TILE);
     const int T = gx * gy;
     if (T == 0) return hipSuccess;
-    const int grid = blend_grid(T);
+    const int grid = cdiv(T, TILE_RUN) * TILE_RUN;
     hipLaunchKernelGGL(blend_fwd_rows_kernel<0>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
-                       b.ranges, b.point_list, g.g2d, s.bg, out.color, out.depth, out.weights,
-                       im.final_T, im.n_contrib, im.tile_maxc, im.tile_order);
+                       im.tile_desc, b.point_list, g.g2d, s.bg, out.color, out.depth, out.weights,
+                       im.final_T, im.n_contrib);
     return hipGetLastError();
 }

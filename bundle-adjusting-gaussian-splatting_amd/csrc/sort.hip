@@ -397,46 +397,52 @@ hipError_t launch_tile_ranges(const u32* tile_sorted, long long I, uint2* ranges
 }
 
 // ------------------------------------------------------------------------------------------------ tile order
-// Heavy-first order of the tiles for the blend launches (blend.hip, TILE_MAP 2): a counting sort of the tiles by
-// instance count into ORDER_LEVELS levels relative to the fullest tile, fullest level first.  One workgroup (T is a few
-// thousand to a few ten thousand).  The position of a tile inside its level depends on the order the LDS atomics land
-// in, which is harmless: the order only decides which workgroup computes which tile, never what is computed.
+// Heavy-first list of the tiles for the blend launches (blend.hip): a counting sort of the tiles by instance count into
+// ORDER_LEVELS levels, four per octave of the count (scale-free: no pass for the maximum), fullest level first, empty
+// tiles last.  Output: one descriptor {tile, first instance, instance count, 0} per tile in that order, and the number of
+// non-empty tiles.  One workgroup (T is a few thousand to a few ten thousand).  The position of a tile inside its level
+// depends on the order the LDS atomics land in, which is harmless: the list only decides which workgroup computes
+// which tile and when, never what is computed.
 #define ORDER_LEVELS 64
-__global__ void __launch_bounds__(1024)
-tile_order_kernel(const uint2* __restrict__ ranges, int T, u32* __restrict__ order)
+__device__ __forceinline__ int order_level(u32 n)
 {
-    __shared__ u32 s_max[16];
+    if (n == 0) return ORDER_LEVELS - 1;
+    const int e = 31 - __clz((int)n);                                    // floor(log2 n)
+    const int frac = (e >= 2) ? (int)((n >> (e - 2)) & 3u) : (int)((n << (2 - e)) & 3u);
+    const int q = e * 4 + frac;                                          // 4 levels per octave
+    return ORDER_LEVELS - 2 - min(ORDER_LEVELS - 2, q);                  // n >= 2^15.5 share level 0
+}
+__global__ void __launch_bounds__(1024)
+tile_order_kernel(const uint2* __restrict__ ranges, int T, uint4* __restrict__ tile_desc, u32* __restrict__ n_active)
+{
     __shared__ u32 s_cur[ORDER_LEVELS];
     const int tid = threadIdx.x;
-    u32 m = 0;
-    for (int t = tid; t < T; t += 1024) { const uint2 r = ranges[t]; m = max(m, r.y - r.x); }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = max(m, (u32)__shfl_xor((int)m, d));
-    if ((tid & 63) == 0) s_max[tid >> 6] = m;
     if (tid < ORDER_LEVELS) s_cur[tid] = 0;
     __syncthreads();
-    m = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) m = max(m, s_max[w]);
-    const u64 span = (u64)m + 1;
-    auto level_of = [&](int t) -> int {
-        const uint2 r = ranges[t];
-        return ORDER_LEVELS - 1 - (int)(((u64)(r.y - r.x) * ORDER_LEVELS) / span);     // n == m -> level 0
-    };
-    for (int t = tid; t < T; t += 1024) atomicAdd(&s_cur[level_of(t)], 1u);
+#pragma unroll 4
+    for (int t = tid; t < T; t += 1024) { const uint2 r = ranges[t]; atomicAdd(&s_cur[order_level(r.y - r.x)], 1u); }
     __syncthreads();
-    if (tid == 0) {
-        u32 run = 0;
-        for (int l = 0; l < ORDER_LEVELS; ++l) { const u32 c = s_cur[l]; s_cur[l] = run; run += c; }
+    if (tid < 64) {                                                      // exclusive scan of the level counts (one wave)
+        const u32 c = s_cur[tid];
+        u32 inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)inc, d); if (tid >= d) inc += o; }
+        s_cur[tid] = inc - c;
+        if (tid == ORDER_LEVELS - 1) *n_active = inc - c;                // everything in front of the empty tiles
     }
     __syncthreads();
-    for (int t = tid; t < T; t += 1024) order[atomicAdd(&s_cur[level_of(t)], 1u)] = (u32)t;
+#pragma unroll 4
+    for (int t = tid; t < T; t += 1024) {
+        const uint2 r = ranges[t];
+        const u32 n = r.y - r.x;
+        tile_desc[atomicAdd(&s_cur[order_level(n)], 1u)] = make_uint4((u32)t, r.x, n, 0u);
+    }
 }
 
-hipError_t launch_tile_order(const uint2* ranges, int T, u32* order, hipStream_t st)
+hipError_t launch_tile_order(const uint2* ranges, int T, uint4* tile_desc, u32* n_active, hipStream_t st)
 {
     if (T <= 0) return hipSuccess;
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, ranges, T, order);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, ranges, T, tile_desc, n_active);
     return hipGetLastError();
 }
 
