@@ -400,9 +400,9 @@ hipError_t launch_tile_ranges(const u32* tile_sorted, long long I, uint2* ranges
 // Heavy-first list of the tiles for the blend launches (blend.hip): a counting sort of the tiles by instance count into
 // ORDER_LEVELS levels, four per octave of the count (scale-free: no pass for the maximum), fullest level first, empty
 // tiles last.  Output: one descriptor {tile, first instance, instance count, 0} per tile in that order, and the number of
-// non-empty tiles.  One workgroup (T is a few thousand to a few ten thousand).  The position of a tile inside its level
-// depends on the order the LDS atomics land in, which is harmless: the list only decides which workgroup computes
-// which tile and when, never what is computed.
+// non-empty tiles.  One workgroup (T is a few thousand to a few ten thousand).  Where a wave's tiles land inside their
+// level depends on the order the waves' LDS atomics arrive in, which is harmless: the list only decides which workgroup
+// computes which tile and when, never what is computed.
 #define ORDER_LEVELS 64
 __device__ __forceinline__ int order_level(u32 n)
 {
@@ -412,30 +412,44 @@ __device__ __forceinline__ int order_level(u32 n)
     const int q = e * 4 + frac;                                          // 4 levels per octave
     return ORDER_LEVELS - 2 - min(ORDER_LEVELS - 2, q);                  // n >= 2^15.5 share level 0
 }
+#define ORDER_SUB 32                       // sub-lists per level
 __global__ void __launch_bounds__(1024)
 tile_order_kernel(const uint2* __restrict__ ranges, int T, uint4* __restrict__ tile_desc, u32* __restrict__ n_active)
 {
-    __shared__ u32 s_cur[ORDER_LEVELS];
-    const int tid = threadIdx.x;
-    if (tid < ORDER_LEVELS) s_cur[tid] = 0;
+    // Neighbouring tiles mostly share a level, and same-address LDS atomics retire one lane per clock: a single counter
+    // per level made the two passes ~16 k serialised atomics (most of the kernel's 11 us; peeling a wave's distinct
+    // levels with ballots instead was 4x slower still).  Every level therefore has ORDER_SUB counters, picked by
+    // (tile >> 3) & 31: the 64 tiles one wave handles per round spread over 8 of them, and runs of 8 neighbouring tiles
+    // stay together in the list (they share splats, hence L2 lines, when their workgroups run side by side).
+    __shared__ u32 s_cur[ORDER_LEVELS * ORDER_SUB];                      // 8 KB
+    __shared__ u32 s_wave[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    s_cur[tid] = 0; s_cur[tid + 1024] = 0;
     __syncthreads();
+    auto counter_of = [&](int t, u32 n) -> int { return order_level(n) * ORDER_SUB + ((t >> 3) & (ORDER_SUB - 1)); };
 #pragma unroll 4
-    for (int t = tid; t < T; t += 1024) { const uint2 r = ranges[t]; atomicAdd(&s_cur[order_level(r.y - r.x)], 1u); }
+    for (int t = tid; t < T; t += 1024) { const uint2 r = ranges[t]; atomicAdd(&s_cur[counter_of(t, r.y - r.x)], 1u); }
     __syncthreads();
-    if (tid < 64) {                                                      // exclusive scan of the level counts (one wave)
-        const u32 c = s_cur[tid];
-        u32 inc = c;
+    {   // exclusive scan over the 2048 counters: two per thread, wave scan, 16 wave totals
+        const u32 c0 = s_cur[2 * tid], c1 = s_cur[2 * tid + 1];
+        u32 inc = c0 + c1;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)inc, d); if (tid >= d) inc += o; }
-        s_cur[tid] = inc - c;
-        if (tid == ORDER_LEVELS - 1) *n_active = inc - c;                // everything in front of the empty tiles
+        for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)inc, d); if (lane >= d) inc += o; }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        u32 before = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) before += (w < wave) ? s_wave[w] : 0u;
+        const u32 excl = before + inc - (c0 + c1);
+        s_cur[2 * tid] = excl; s_cur[2 * tid + 1] = excl + c0;
+        if (2 * tid == (ORDER_LEVELS - 1) * ORDER_SUB) *n_active = excl; // everything in front of the empty tiles
     }
     __syncthreads();
 #pragma unroll 4
     for (int t = tid; t < T; t += 1024) {
         const uint2 r = ranges[t];
         const u32 n = r.y - r.x;
-        tile_desc[atomicAdd(&s_cur[order_level(n)], 1u)] = make_uint4((u32)t, r.x, n, 0u);
+        tile_desc[atomicAdd(&s_cur[counter_of(t, n)], 1u)] = make_uint4((u32)t, r.x, n, 0u);
     }
 }
 
