@@ -132,7 +132,23 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     const float4 q3 = (i < P) ? g2d[4 * (size_t)i + 3] : make_float4(0.f, 0.f, 0.f, 0.f);
     const bool live = (i < P) && (__float_as_uint(q3.y) > 0);
 
+    float x = 0.f, y = 0.f, z = 0.f;
     if (live) {
+        // Every input row of the Gaussian is requested here, in one batch: loads issued
+        // further down, behind values that depend on earlier loads, each cost a full memory round trip of their own
+        // (a wave's life in this kernel is a handful of round trips, not arithmetic).
+        x = means3D[3 * i + 0]; y = means3D[3 * i + 1]; z = means3D[3 * i + 2];
+        float in_s0 = 0.f, in_s1 = 0.f, in_s2 = 0.f;
+        float4 in_q = make_float4(0.f, 0.f, 0.f, 0.f);
+        float in_c[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (cov3D_precomp) {
+            const float* c = cov3D_precomp + 6 * (size_t)i;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) in_c[t] = c[t];
+        } else {
+            in_s0 = scales[3 * i + 0]; in_s1 = scales[3 * i + 1]; in_s2 = scales[3 * i + 2];
+            in_q = reinterpret_cast<const float4*>(rotations)[i];
+        }
         // ---- 1. sum the per-instance records
         float s[12];
         {
@@ -154,7 +170,6 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         gdx = s[9] * (0.5f * (float)W); gdy = s[10] * (0.5f * (float)H);
 
         // ---- recompute the forward chain
-        const float x = means3D[3 * i + 0], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
         const float tx = x * v[0] + y * v[4] + z * v[8] + v[12];
         const float ty = x * v[1] + y * v[5] + z * v[9] + v[13];
         const float tz = x * v[2] + y * v[6] + z * v[10] + v[14];
@@ -172,11 +187,10 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         float s0 = 0, s1 = 0, s2 = 0, qr = 0, qx = 0, qy = 0, qz = 0;
         float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
         if (cov3D_precomp) {
-            const float* c = cov3D_precomp + 6 * (size_t)i;
-            c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3]; c4 = c[4]; c5 = c[5];
+            c0 = in_c[0]; c1 = in_c[1]; c2 = in_c[2]; c3 = in_c[3]; c4 = in_c[4]; c5 = in_c[5];
         } else {
-            s0 = scales[3 * i + 0] * mod; s1 = scales[3 * i + 1] * mod; s2 = scales[3 * i + 2] * mod;
-            const float4 q = reinterpret_cast<const float4*>(rotations)[i];
+            s0 = in_s0 * mod; s1 = in_s1 * mod; s2 = in_s2 * mod;
+            const float4 q = in_q;
             qr = q.x; qx = q.y; qy = q.z; qz = q.w;
             r00 = 1.0f - 2.0f * (qy * qy + qz * qz); r01 = 2.0f * (qx * qy - qr * qz); r02 = 2.0f * (qx * qz + qr * qy);
             r10 = 2.0f * (qx * qy + qr * qz); r11 = 1.0f - 2.0f * (qx * qx + qz * qz); r12 = 2.0f * (qy * qz - qr * qx);
@@ -298,6 +312,18 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
             gqz = 2.f * (-2.f * qz * d00 - qr * d01 + qx * d02 + qr * d10 - 2.f * qz * d11 + qy * d12 + qx * d20 + qy * d21);
         }
 
+    }
+    // ---- 5a. pose Jacobians of the geometry chain: wave -> LDS now, so their 32 registers are free while the SH row
+    // is in flight below (every lane takes part: the sums must not sit inside the divergent branch)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < 35; ++t) {
+        if (t >= 29 && t <= 31) continue;
+        const float r = wave_sum(pose[t]);
+        if (lane == 0) wpose[wave][t] = r;
+    }
+    float cp0 = 0.f, cp1 = 0.f, cp2 = 0.f;            // dL/dcampos of this Gaussian
+    if (live) {
         // ---- colour
         if (!colors_precomp) {
             const u32 cl = __float_as_uint(q3.z);
@@ -318,11 +344,17 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                 // 192-byte rows, 16-byte aligned: four coefficients (12 floats) per step as 3 dwordx4 loads / stores
                 const float4* s4 = reinterpret_cast<const float4*>(sh);
                 float4* g4 = reinterpret_cast<float4*>(gsh);
+                // the whole row is requested before the first coefficient is touched: with a load -> compute -> store
+                // step per block of four coefficients every step waited for its loads AND (vmcnt counts stores on this
+                // part) for the previous step's stores, four serial round trips per Gaussian
+                float4 wrow[12];
+#pragma unroll
+                for (int t = 0; t < 12; ++t) wrow[t] = (4 * (t / 3) < nb) ? s4[t] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int tb = 0; tb < 4; ++tb) {
                     float c[12], o[12];
                     if (tb * 4 < nb) {
-                        const float4 w0 = s4[3 * tb], w1 = s4[3 * tb + 1], w2 = s4[3 * tb + 2];
+                        const float4 w0 = wrow[3 * tb], w1 = wrow[3 * tb + 1], w2 = wrow[3 * tb + 2];
                         c[0] = w0.x; c[1] = w0.y; c[2] = w0.z; c[3] = w0.w; c[4] = w1.x; c[5] = w1.y; c[6] = w1.z; c[7] = w1.w;
                         c[8] = w2.x; c[9] = w2.y; c[10] = w2.z; c[11] = w2.w;
                     } else {
@@ -356,7 +388,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
             const float dot = ux_ * ddx + uy_ * ddy + uz_ * ddz;
             const float px_ = (ddx - ux_ * dot) * il, py_ = (ddy - uy_ * dot) * il, pz_ = (ddz - uz_ * dot) * il;
             dmx += px_; dmy += py_; dmz += pz_;
-            pose[29] = -px_; pose[30] = -py_; pose[31] = -pz_;
+            cp0 = -px_; cp1 = -py_; cp2 = -pz_;
         }
     } else if (i < P && g_shs && !colors_precomp) {
         float* gsh = g_shs + (size_t)i * M * 3;
@@ -382,12 +414,10 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         }
     }
 
-    // ---- 5. pose Jacobians: wave -> workgroup -> slab row
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int t = 0; t < 35; ++t) {
-        const float r = wave_sum(pose[t]);
-        if (lane == 0) wpose[wave][t] = r;
+    // ---- 5b. the view-direction part (campos), then workgroup -> slab row
+    {
+        const float r0 = wave_sum(cp0), r1 = wave_sum(cp1), r2 = wave_sum(cp2);
+        if (lane == 0) { wpose[wave][29] = r0; wpose[wave][30] = r1; wpose[wave][31] = r2; }
     }
     __syncthreads();
     if (threadIdx.x < POSE_VALS) {
