@@ -245,24 +245,28 @@ def main():
                         traffic = tj[dom]["fetch_bytes"] + tj[dom]["write_bytes"]
                 except (OSError, KeyError, ValueError):
                     pass
+                try:
+                    va = tj[dom]["valu_active_cycles"] if traffic is not None else None
+                    src = tj.get("source", "profiles/r01")
+                except (KeyError, NameError):
+                    va, src = None, "profiles/r01"
+                busy = None if va is None else va / (1024 * 2.4e9 * stages[dom] * 1e-3)
                 out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
                                    "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic,
                                    "alg_bytes_per_launch": alg[dom], "mean_launch_ms": stages[dom],
-                                   "note": "kernel is VALU-issue / latency bound (63 % of SIMD issue cycles busy, PMC in "
-                                           "profiles/r01/pmc_blend_v7.txt), not HBM bound; traffic = FETCH_SIZE + "
+                                   "note": "the kernel is latency bound (3 waves per SIMD, each serialised on LDS / DPP / exp "
+                                           "chains; VALU issue and LDS both below saturation, PMC in " + src + "), not HBM "
+                                           "bound: its HBM traffic equals its algorithmic bytes; traffic = FETCH_SIZE + "
                                            "WRITE_SIZE of a separate --pmc pass, fetch side uncorrected (gathers)"}
-                # the blend kernels are VALU-issue bound, so the fraction of SIMD issue cycles they keep busy is
-                # reported next to the HBM figure (cycles from a separate rocprofv3 --pmc pass; 1024 SIMDs at 2.4 GHz), and the
-                # atomic roofline is moot: the rasterizer issues no global atomics at all.
-                try:
-                    va = tj[dom]["valu_active_cycles"] if traffic is not None else None
-                except (KeyError, NameError):
-                    va = None
-                out["roofline_valu"] = {"kernel": dom, "busy_frac": None if va is None else va / (1024 * 2.4e9 * stages[dom] * 1e-3),
+                # the blend kernels are compute/latency bound, so the share of SIMD issue cycles they keep busy is
+                # reported next to the HBM figure (cycles from a separate rocprofv3 --pmc pass; 1024 SIMDs, 2.4 GHz assumed --
+                # the same formula gives 1.08 for blend_fwd, i.e. the scale is only good to ~10 %), and the atomic roofline is
+                # moot: the rasterizer issues no global atomics at all.
+                out["roofline_valu"] = {"kernel": dom, "busy_frac": busy,
                                         "valu_active_cycles": va, "simds": 1024, "clock_ghz": 2.4,
-                                        "source": "profiles/r01/pmc_blend_v7.txt (SQ_ACTIVE_INST_VALU x 4)"}
+                                        "source": src + " (SQ_ACTIVE_INST_VALU x 4)"}
                 out["roofline_atomic"] = {"global_float_atomics_per_step": 0,
-                                          "note": "gradients are reduced through per-wave LDS copies and one 64-B record per instance"}
+                                          "note": "gradients are reduced through per-wave LDS copies and one 48-B record per instance"}
             dev_ms = sum(stages.values())
             out["op_roofline"] = {"bound": "hbm", "alg_bytes_per_step": b_alg, "device_ms_per_step": dev_ms,
                                   "achieved": b_alg / (dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

@@ -182,7 +182,7 @@ static int enqueue_finish(const BagsSettings* s, const BagsInputs* in, const Geo
     const int W = s->image_width, H = s->image_height;
     const int gx = cdiv(W, BAGS_TILE), gy = cdiv(H, BAGS_TILE);
     if (I > 0) {
-        { ProfScope ps(ST_EMIT, st); HIP_TRY(launch_emit(g, g.vals_b, in->P, gx, b.keys_b, b.vals_b, (u32)I, st, n_dev)); }
+        { ProfScope ps(ST_EMIT, st); HIP_TRY(launch_emit(g, g.vals_b, in->P, gx, b.keys_b, b.vals_b, (u32)I, st, n_dev, b.ranges, gx * gy)); }
         DEBUG_SYNC(s, st, "emit");
         { ProfScope ps(ST_TILE_SORT, st);
           HIP_TRY(launch_radix_sort(b.keys_b, b.vals_b, b.keys_a, b.vals_a, b.keys_b, b.vals_b, I, b.passes * RADIX_BITS,
@@ -190,7 +190,7 @@ static int enqueue_finish(const BagsSettings* s, const BagsInputs* in, const Geo
         DEBUG_SYNC(s, st, "tile sort");
     }
     { ProfScope ps(ST_RANGES, st);
-      HIP_TRY(launch_tile_ranges(b.tile_sorted, I, b.ranges, gx * gy, st, n_dev));
+      HIP_TRY(launch_tile_ranges(b.tile_sorted, I, b.ranges, gx * gy, st, n_dev, I > 0));
       HIP_TRY(launch_tile_order(b.ranges, gx * gy, im.tile_desc, im.n_active, st)); }
     DEBUG_SYNC(s, st, "tile ranges");
     { ProfScope ps(ST_BLEND_FWD, st); HIP_TRY(launch_blend_fwd(*s, g, b, im, *out, st)); }

@@ -10,7 +10,7 @@
 //     ballot-compacted list; no scalar branches inside the walk.
 //   * BACKWARD (blend_bwd_scan_kernel): lane = splat.  The per-pixel recurrences of compositing (transmittance in
 //     front of a splat, colour behind it) are wave64 DPP prefix scans over a block's list, so every lane owns its
-//     splat's 11 gradient sums outright: no cross-lane reduction and NO atomics.  One 64-byte record per sorted
+//     splat's 11 gradient sums outright: no cross-lane reduction and NO atomics.  One 48-byte record per sorted
 //     instance is written at the instance's emission slot; preprocess_bwd sums each Gaussian's consecutive records.
 //     Gradients are bitwise reproducible run to run.
 // PMC history that led here is in profiles/r01 and DESIGN.md section 5 (the first lane = pixel kernels saturated VALU

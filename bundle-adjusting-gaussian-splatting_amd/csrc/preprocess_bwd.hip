@@ -1,7 +1,7 @@
 // preprocess_bwd.hip -- K8/K9/K10: per-Gaussian backward + camera-pose Jacobians.
 //
 // One thread per Gaussian:
-//   1. sums the Gaussian's consecutive 64-byte partial records written by blend_bwd (no atomics anywhere);
+//   1. sums the Gaussian's consecutive 48-byte partial records written by blend_bwd (no atomics anywhere);
 //   2. moments -> dL/d{mean2D, conic, opacity, rgb};
 //   3. conic -> cov2D -> (J, Wc, Sigma) -> dL/d{means3D, scales, rotations | cov3D_precomp};
 //   4. pixel centre -> p_hom -> dL/dmeans3D; colour -> dL/d{shs | colors_precomp}, view direction -> dL/dmeans3D;
@@ -31,6 +31,7 @@ __device__ __forceinline__ float wave_sum(float x)
 // more than SUM_COOP records are summed by the whole wave (lane k takes records k, k+64, ...; fixed-order shuffle
 // tree), so a splat covering thousands of tiles does not serialise one lane.
 #define SUM_COOP 64
+#define RQ (PART_FLOATS / 4)          // float4s per record
 __global__ void __launch_bounds__(256)
 sum_partials_kernel(int P, const float4* __restrict__ g2d, const float* __restrict__ partials, float4* __restrict__ sums)
 {
@@ -46,8 +47,8 @@ sum_partials_kernel(int P, const float4* __restrict__ g2d, const float* __restri
         const float4* rec = reinterpret_cast<const float4*>(partials + (size_t)first * PART_FLOATS);
         u32 r = 0;
         for (; r + 1 < nrec; r += 2) {
-            const float4 a0 = rec[4 * r], b0 = rec[4 * r + 1], c0 = rec[4 * r + 2];
-            const float4 a1 = rec[4 * r + 4], b1 = rec[4 * r + 5], c1 = rec[4 * r + 6];
+            const float4 a0 = rec[RQ * r], b0 = rec[RQ * r + 1], c0 = rec[RQ * r + 2];
+            const float4 a1 = rec[RQ * r + RQ], b1 = rec[RQ * r + RQ + 1], c1 = rec[RQ * r + RQ + 2];
             s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
             s1.x += b0.x; s1.y += b0.y; s1.z += b0.z; s1.w += b0.w;
             s2.x += c0.x; s2.y += c0.y; s2.z += c0.z;
@@ -56,7 +57,7 @@ sum_partials_kernel(int P, const float4* __restrict__ g2d, const float* __restri
             s2.x += c1.x; s2.y += c1.y; s2.z += c1.z;
         }
         if (r < nrec) {
-            const float4 a0 = rec[4 * r], b0 = rec[4 * r + 1], c0 = rec[4 * r + 2];
+            const float4 a0 = rec[RQ * r], b0 = rec[RQ * r + 1], c0 = rec[RQ * r + 2];
             s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
             s1.x += b0.x; s1.y += b0.y; s1.z += b0.z; s1.w += b0.w;
             s2.x += c0.x; s2.y += c0.y; s2.z += c0.z;
@@ -72,7 +73,7 @@ sum_partials_kernel(int P, const float4* __restrict__ g2d, const float* __restri
 #pragma unroll
         for (int t = 0; t < 11; ++t) v[t] = 0.f;
         for (u32 r = lane; r < bn; r += 64) {
-            const float4 a0 = rec[4 * r], b0 = rec[4 * r + 1], c0 = rec[4 * r + 2];
+            const float4 a0 = rec[RQ * r], b0 = rec[RQ * r + 1], c0 = rec[RQ * r + 2];
             v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += b0.x; v[5] += b0.y; v[6] += b0.z; v[7] += b0.w;
             v[8] += c0.x; v[9] += c0.y; v[10] += c0.z;
         }

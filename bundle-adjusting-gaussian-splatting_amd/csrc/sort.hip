@@ -216,8 +216,8 @@ hipError_t launch_radix_sort(const u32* src_k, const u32* src_v, u32* a_k, u32* 
 }
 
 // ------------------------------------------------------------------------------------------------ offsets scan
-// Exclusive scan of tiles_touched in depth order.  Three small kernels: workgroup sums, scan of the sums (+ total),
-// rescan with the carried prefix.
+// Exclusive scan of tiles_touched in depth order.  Two small kernels: workgroup sums, then a rescan in which every
+// workgroup first adds up the sums of the workgroups in front of it.
 __global__ void __launch_bounds__(SCAN_BLOCK)
 offsets_partial_kernel(const u32* __restrict__ sorted_ids, const u32* __restrict__ tiles_touched, int P,
                        u32* __restrict__ partials)
@@ -241,42 +241,13 @@ offsets_partial_kernel(const u32* __restrict__ sorted_ids, const u32* __restrict
     }
 }
 
-__global__ void __launch_bounds__(256)
-offsets_top_kernel(u32* __restrict__ partials, int nparts, u32* __restrict__ total)
-{
-    __shared__ u32 wsum[4];
-    __shared__ u32 carry_s;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < nparts; base += 256) {
-        const int i = base + threadIdx.x;
-        const u32 v = (i < nparts) ? partials[i] : 0u;
-        u32 incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const u32 t = __shfl_up(incl, d);
-            if (lane >= d) incl += t;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        u32 wbase = 0;
-        for (int w = 0; w < wave; ++w) wbase += wsum[w];
-        const u32 carry = carry_s;
-        if (i < nparts) partials[i] = carry + wbase + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 255) carry_s = carry + wbase + incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) total[0] = carry_s;
-}
-
 // item order inside a workgroup here is (thread, item) with SCAN_ITEMS consecutive ranks per thread
 __global__ void __launch_bounds__(SCAN_BLOCK)
 offsets_final_kernel(const u32* __restrict__ sorted_ids, const u32* __restrict__ tiles_touched, int P,
-                     const u32* __restrict__ partials, u32* __restrict__ rank_offset, float4* __restrict__ g2d)
+                     const u32* __restrict__ partials, u32* __restrict__ rank_offset, float4* __restrict__ g2d,
+                     u32* __restrict__ total)
 {
-    __shared__ u32 wsum[SCAN_BLOCK / 64];
+    __shared__ u32 wsum[SCAN_BLOCK / 64], wpre[SCAN_BLOCK / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j0 = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     u32 id[SCAN_ITEMS], t[SCAN_ITEMS];
@@ -295,15 +266,24 @@ offsets_final_kernel(const u32* __restrict__ sorted_ids, const u32* __restrict__
         if (lane >= d) incl += u;
     }
     if (lane == 63) wsum[wave] = incl;
+    // what the earlier workgroups hold: every workgroup adds their sums up itself (a few hundred values; a kernel of its
+    // own for this scan cost 4.6 us plus a launch gap)
+    u32 before = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += SCAN_BLOCK) before += partials[b];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
+    if (lane == 0) wpre[wave] = before;
     __syncthreads();
-    u32 run = partials[blockIdx.x] + incl - s;
-    for (int w = 0; w < wave; ++w) run += wsum[w];
+    u32 run = incl - s;
+#pragma unroll
+    for (int w = 0; w < SCAN_BLOCK / 64; ++w) run += wpre[w] + ((w < wave) ? wsum[w] : 0u);
 #pragma unroll
     for (int r = 0; r < SCAN_ITEMS; ++r) {
         const int j = j0 + r;
         if (j < P) { rank_offset[j] = run; reinterpret_cast<u32*>(g2d)[16 * (size_t)id[r] + 12] = run; }   // q3.x
         run += t[r];
     }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_BLOCK - 1) total[0] = run;       // the instance count
 }
 
 hipError_t launch_offsets_scan(const GeomView& g, const u32* sorted_ids, int P, hipStream_t st)
@@ -311,9 +291,8 @@ hipError_t launch_offsets_scan(const GeomView& g, const u32* sorted_ids, int P, 
     if (P == 0) { return hipMemsetAsync(g.num_rendered, 0, sizeof(u32), st); }
     const int nb = g.nblocks_scan;
     hipLaunchKernelGGL(offsets_partial_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, st, sorted_ids, g.tiles_touched, P, g.scan_partials);
-    hipLaunchKernelGGL(offsets_top_kernel, dim3(1), dim3(256), 0, st, g.scan_partials, nb, g.num_rendered);
     hipLaunchKernelGGL(offsets_final_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, st, sorted_ids, g.tiles_touched, P,
-                       g.scan_partials, g.rank_offset, g.g2d);
+                       g.scan_partials, g.rank_offset, g.g2d, g.num_rendered);
     return hipGetLastError();
 }
 
@@ -325,8 +304,12 @@ hipError_t launch_offsets_scan(const GeomView& g, const u32* sorted_ids, int P, 
 __global__ void __launch_bounds__(256)
 emit_kernel(const u32* __restrict__ sorted_ids, const u32* __restrict__ rank_offset, const uint2* __restrict__ rect,
             const u32* __restrict__ tiles_touched, int P, int grid_x, u32* __restrict__ keys, u32* __restrict__ vals,
-            u32 capacity, const u32* __restrict__ n_dev)
+            u32 capacity, const u32* __restrict__ n_dev, uint2* __restrict__ ranges, int T)
 {
+    // tile_ranges only writes the tiles that hold instances: the others must read (0, 0).  Cleared here, two kernels ahead
+    // of their use (a memset node of its own cost 4.6 us of stream time), and before the early exit below: a failed
+    // speculative pass still runs the blend over these ranges.
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) ranges[t] = make_uint2(0u, 0u);
     if (n_dev && *n_dev > capacity) return;                 // speculative capacity exceeded: nothing is emitted, the caller reruns
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -364,11 +347,11 @@ emit_kernel(const u32* __restrict__ sorted_ids, const u32* __restrict__ rank_off
 }
 
 hipError_t launch_emit(const GeomView& g, const u32* sorted_ids, int P, int grid_x, u32* keys, u32* vals, u32 capacity,
-                       hipStream_t st, const u32* n_dev)
+                       hipStream_t st, const u32* n_dev, uint2* ranges, int T)
 {
-    if (P == 0) return hipSuccess;
+    if (P == 0) return hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, st);
     hipLaunchKernelGGL(emit_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, sorted_ids, g.rank_offset, g.rect,
-                       g.tiles_touched, P, grid_x, keys, vals, capacity, n_dev);
+                       g.tiles_touched, P, grid_x, keys, vals, capacity, n_dev, ranges, T);
     return hipGetLastError();
 }
 
@@ -388,9 +371,11 @@ tile_ranges_kernel(const u32* __restrict__ tile_sorted, long long I_cap, const u
     if (i == I - 1) ranges[t].y = (u32)I;
 }
 
-hipError_t launch_tile_ranges(const u32* tile_sorted, long long I, uint2* ranges, int T, hipStream_t st, const u32* n_dev)
+// `cleared`: launch_emit has already zeroed the ranges on this stream
+hipError_t launch_tile_ranges(const u32* tile_sorted, long long I, uint2* ranges, int T, hipStream_t st, const u32* n_dev,
+                              bool cleared)
 {
-    hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, st);
+    hipError_t e = cleared ? hipSuccess : hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, st);
     if (e != hipSuccess || I == 0) return e;
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(cdiv(I, 256)), dim3(256), 0, st, tile_sorted, I, n_dev, ranges);
     return hipGetLastError();
