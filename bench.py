@@ -256,7 +256,7 @@ def main():
                                    "alg_bytes_per_launch": alg[dom], "mean_launch_ms": stages[dom],
                                    "note": "the kernel is latency bound (3 waves per SIMD, each serialised on LDS / DPP / exp "
                                            "chains; VALU issue and LDS both below saturation, PMC in " + src + "), not HBM "
-                                           "bound: its HBM traffic equals its algorithmic bytes; traffic = FETCH_SIZE + "
+                                           "bound: its HBM traffic stays within 20 % of its algorithmic bytes; traffic = FETCH_SIZE + "
                                            "WRITE_SIZE of a separate --pmc pass, fetch side uncorrected (gathers)"}
                 # the blend kernels are compute/latency bound, so the share of SIMD issue cycles they keep busy is
                 # reported next to the HBM figure (cycles from a separate rocprofv3 --pmc pass; 1024 SIMDs, 2.4 GHz assumed --
