@@ -17,6 +17,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import NamedTuple, Optional
 
+import math
+
 import torch
 
 from . import _lib as L
@@ -247,16 +249,29 @@ class _RasterizeGaussians(torch.autograd.Function):
             def new(shape, flag):
                 return torch.empty(shape, dtype=torch.float32, device=dev) if flag else None
             k = pk.keep
-            g_means3D = new((P, 3), need[0])
+            # The gradients of the replicated Gaussian parameters are carved out of ONE buffer (64-float aligned slices), so
+            # the view-sharded exchange is a single RCCL all-reduce over it instead of one per tensor
+            # (bags_raster/sharding.py finds the common storage); to autograd they are ordinary tensors.
+            want = [("means3D", (P, 3), need[0]),
+                    ("sh", ctx.shapes["sh"], need[4] and k["shs"] is not None),
+                    ("col", (P, 3), need[5] and k["colors_precomp"] is not None),
+                    ("opac", ctx.shapes["opac"], need[6]),
+                    ("scales", (P, 3), need[7] and k["scales"] is not None),
+                    ("rot", (P, 4), need[8] and k["rotations"] is not None),
+                    ("cov", (P, 6), need[9] and k["cov3D_precomp"] is not None)]
+            sizes = {n: (math.prod(sh) if f else 0) for n, sh, f in want}
+            total = sum((v + 63) // 64 * 64 for v in sizes.values())
+            flat = torch.empty(total, dtype=torch.float32, device=dev) if total else None
+            carved, off = {}, 0
+            for n, sh, f in want:
+                carved[n] = flat[off:off + sizes[n]].view(sh) if f else None
+                off += (sizes[n] + 63) // 64 * 64
+            del flat
+            g_means3D, g_sh, g_col, g_opac = carved["means3D"], carved["sh"], carved["col"], carved["opac"]
+            g_scales, g_rot, g_cov = carved["scales"], carved["rot"], carved["cov"]
             g_means2D = new((P, 3), need[1])
             g_densify = new((P, 3), need[2])
             g_shift = new((3,), need[3])
-            g_sh = new(ctx.shapes["sh"], need[4] and k["shs"] is not None)
-            g_col = new((P, 3), need[5] and k["colors_precomp"] is not None)
-            g_opac = new(ctx.shapes["opac"], need[6])
-            g_scales = new((P, 3), need[7] and k["scales"] is not None)
-            g_rot = new((P, 4), need[8] and k["rotations"] is not None)
-            g_cov = new((P, 6), need[9] and k["cov3D_precomp"] is not None)
             g_view = new((4, 4), need[10])
             g_proj = new((4, 4), need[11])
             g_intr = new((4, 4), need[12])

@@ -24,6 +24,36 @@ def shard_views(num_views: int, rank: int, world: int) -> List[int]:
     return list(range(rank, num_views, world))
 
 
+def coalesce_by_storage(grads: Sequence[torch.Tensor], max_waste: float = 0.02) -> List[torch.Tensor]:
+    """Tensors to all-reduce in place of ``grads``: contiguous tensors of one dtype that were carved out of one buffer
+    (bags_raster.rasterizer's backward does that for the Gaussian-parameter gradients) are replaced by ONE flat view
+    spanning them, provided the padding between them stays below ``max_waste`` of the span and the storage holds nothing
+    else inside it that the sum could disturb (the span only covers bytes between the first and last tensor; padding is
+    uninitialised but never read).  Everything else is passed through.  One large collective instead of five: the
+    per-call latency of a ring over 8 GPUs is paid once."""
+    groups: Dict[tuple, List[torch.Tensor]] = {}
+    out: List[torch.Tensor] = []
+    for g in grads:
+        if g.is_contiguous() and g.layout == torch.strided and g.numel() > 0:
+            groups.setdefault((g.untyped_storage().data_ptr(), g.dtype, g.device), []).append(g)
+        else:
+            out.append(g)
+    for (_, dtype, device), ts in groups.items():
+        if len(ts) == 1:
+            out.append(ts[0])
+            continue
+        ts = sorted(ts, key=lambda t: t.storage_offset())
+        lo, hi = ts[0].storage_offset(), max(t.storage_offset() + t.numel() for t in ts)
+        used = sum(t.numel() for t in ts)
+        overlap = any(a.storage_offset() + a.numel() > b.storage_offset() for a, b in zip(ts, ts[1:]))
+        if overlap or used < (1.0 - max_waste) * (hi - lo):
+            out.extend(ts)
+            continue
+        flat = torch.empty(0, dtype=dtype, device=device).set_(ts[0].untyped_storage(), lo, (hi - lo,), (1,))
+        out.append(flat)
+    return out
+
+
 class GradAllReducer:
     """Sum-all-reduce of ``.grad`` of the replicated Gaussian parameters, in place, asynchronously."""
 
@@ -36,7 +66,7 @@ class GradAllReducer:
         if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
             return
         grads = [p.grad for p in self.params if p.grad is not None]
-        for g in sorted(grads, key=lambda t: -t.numel()):
+        for g in sorted(coalesce_by_storage(grads), key=lambda t: -t.numel()):
             self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self) -> None:

@@ -105,3 +105,24 @@ def test_single_process_passthrough():
     res = r.step([1.0, 2.0, 3.0])
     assert res["views"] == [0, 1, 2] and torch.allclose(w.grad, torch.full((3,), 6.0))
     GradAllReducer([w]).all_reduce()      # no-op
+
+
+def test_coalesce_by_storage_groups_carved_gradients():
+    """Gradients carved out of one buffer are exchanged as one flat tensor; strangers and sparse layouts pass through."""
+    from bags_raster.sharding import coalesce_by_storage
+    flat = torch.arange(64 * 5, dtype=torch.float32)
+    a, b, c = flat[0:30].view(10, 3), flat[64:64 + 40].view(10, 4), flat[128:128 + 192].view(4, 16, 3)
+    lone = torch.ones(7)
+    out = coalesce_by_storage([a, lone, c, b], max_waste=0.5)
+    assert len(out) == 2
+    big = max(out, key=lambda t: t.numel())
+    assert big.numel() == 128 + 192 and big.data_ptr() == flat.data_ptr()
+    big += 1.0                                   # what an in-place all-reduce does
+    assert torch.equal(a, (torch.arange(30, dtype=torch.float32) + 1).view(10, 3))
+    assert torch.equal(c.reshape(-1), torch.arange(128, 320, dtype=torch.float32) + 1)
+    # too much padding between the pieces: left alone
+    out = coalesce_by_storage([flat[0:8], flat[300:308]])
+    assert len(out) == 2 and all(t.numel() == 8 for t in out)
+    # overlapping views of one storage are never merged
+    out = coalesce_by_storage([flat[0:16], flat[8:24]])
+    assert len(out) == 2
