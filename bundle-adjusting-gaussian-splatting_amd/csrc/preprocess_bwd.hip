@@ -90,6 +90,9 @@ sum_partials_kernel(int P, const float4* __restrict__ g2d, const float* __restri
     if (i < P) { sums[3 * (size_t)i] = s0; sums[3 * (size_t)i + 1] = s1; sums[3 * (size_t)i + 2] = s2; }
 }
 
+#ifndef SH_STAGE
+#define SH_STAGE 1
+#endif
 #ifndef PRE_BWD_WAVES
 #define PRE_BWD_WAVES 1
 #endif
@@ -121,6 +124,27 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const float* v = cam.v; const float* m = cam.m; const float* k = cam.k;
+#if SH_STAGE
+    // The SH rows (and later the SH-gradient rows) of the workgroup's 256 Gaussians are ONE contiguous 48 KB span.  A
+    // thread reading or writing its own 192-byte row 16 bytes at a time puts 64 separate requests per instruction on the
+    // L2 channels (24 such instructions per Gaussian); here the span crosses the memory system as whole lines -- thread
+    // t moves float4 number k*256 + t -- and the per-row access happens in LDS.  The loads are issued now, next to the
+    // geometry inputs, and wait in LDS (no registers) until the colour section.
+    __shared__ float4 srow[256 * 12];
+    const bool stage = (M == 16) && (colors_precomp == nullptr) && (shs != nullptr);      // uniform
+    const size_t base4 = (size_t)blockIdx.x * (256 * 12), lim4 = (size_t)P * 12;
+    if (stage) {
+        const float4* s4g = reinterpret_cast<const float4*>(shs);
+        float4 tmp[12];
+#pragma unroll
+        for (int t = 0; t < 12; ++t) {
+            const size_t e = base4 + (size_t)t * 256 + threadIdx.x;
+            tmp[t] = (e < lim4) ? s4g[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int t = 0; t < 12; ++t) srow[t * 256 + threadIdx.x] = tmp[t];
+    }
+#endif
 
     float pose[POSE_VALS];
 #pragma unroll
@@ -324,6 +348,9 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         if (lane == 0) wpose[wave][t] = r;
     }
     float cp0 = 0.f, cp1 = 0.f, cp2 = 0.f;            // dL/dcampos of this Gaussian
+#if SH_STAGE
+    if (stage) __syncthreads();                      // every thread's staged float4s are in LDS
+#endif
     if (live) {
         // ---- colour
         if (!colors_precomp) {
@@ -343,8 +370,13 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
             float ddx = 0.f, ddy = 0.f, ddz = 0.f;
             if (M == 16) {
                 // 192-byte rows, 16-byte aligned: four coefficients (12 floats) per step as 3 dwordx4 loads / stores
+#if SH_STAGE
+                const float4* s4 = &srow[threadIdx.x * 12];          // staged above; published by the barrier in 5a
+                float4* g4 = &srow[threadIdx.x * 12];                // the gradient row replaces it (each element is read first)
+#else
                 const float4* s4 = reinterpret_cast<const float4*>(sh);
                 float4* g4 = reinterpret_cast<float4*>(gsh);
+#endif
                 // the whole row is requested before the first coefficient is touched: with a load -> compute -> store
                 // step per block of four coefficients every step waited for its loads AND (vmcnt counts stores on this
                 // part) for the previous step's stores, four serial round trips per Gaussian
@@ -394,12 +426,27 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     } else if (i < P && g_shs && !colors_precomp) {
         float* gsh = g_shs + (size_t)i * M * 3;
         if (M == 16) {
+#if SH_STAGE
+            float4* g4 = &srow[threadIdx.x * 12];
+#else
             float4* g4 = reinterpret_cast<float4*>(gsh);
+#endif
 #pragma unroll
             for (int t = 0; t < 12; ++t) g4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
         } else
             for (int t = 0; t < 3 * M; ++t) gsh[t] = 0.f;
     }
+#if SH_STAGE
+    if (stage && g_shs) {                            // the workgroup's gradient rows leave as whole lines
+        __syncthreads();
+        float4* g4g = reinterpret_cast<float4*>(g_shs);
+#pragma unroll
+        for (int t = 0; t < 12; ++t) {
+            const size_t e = base4 + (size_t)t * 256 + threadIdx.x;
+            if (e < lim4) g4g[e] = srow[t * 256 + threadIdx.x];
+        }
+    }
+#endif
 
     if (i < P) {
         if (g_means3D) { g_means3D[3 * i] = dmx; g_means3D[3 * i + 1] = dmy; g_means3D[3 * i + 2] = dmz; }
