@@ -418,3 +418,21 @@ def test_side_stream_and_non_contiguous_inputs():
     strided = run(None, True)
     for a, b, c in zip(base, side, strided):
         assert torch.equal(a, b) and torch.equal(a, c)
+
+
+@pytest.mark.parametrize("W,H,P,sm,shrink,fovy", [
+    (10, 7, 200, 3.0, 1.0, None),            # less than one tile
+    (16, 2000, 1500, 0.2, 1.0, None),        # one column of 125 tiles
+    (2100, 48, 1500, 0.3, 1.0, 0.0313),      # three rows of 132 tiles: more than one run of 128 descriptors (fovx = 1.2 rad)
+    (530, 270, 2500, 1.5, 0.25, None)])      # scene in the image centre: most of the 578 tiles are empty
+def test_tile_list_shapes(W, H, P, sm, shrink, fovy):
+    """Both blend launches take their tiles from the heavy-first descriptor list (tile_order_kernel): every tile must be
+    rendered exactly once whatever the tile count (below, at and above multiples of the 128-descriptor runs) and however
+    many tiles are empty (they come last in the list; the backward skips them)."""
+    kw = {} if fovy is None else dict(fovy=fovy)
+    scene, cam = make_case(P, W, H, sm, 2, seed=W + H, **kw)
+    scene["means3D"] = scene["means3D"] * shrink
+    rep = compare(scene, cam, 2, check_fp64=False)
+    _report(rep)
+    assert rep["num_rendered"][0] > 0
+    assert_report(rep)
