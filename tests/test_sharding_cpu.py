@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _views_and_scene():
     from bags_raster.synth import sphere_views, synth_scene
-    scene = synth_scene(300, 3, 3.0, 1)
+    scene = synth_scene(320, 3, 3.0, 1)                    # 320: every gradient is a multiple of 64 floats (no padding in the flat buffer)
     cams = sphere_views(5, 48, 32, noise=0.05)            # 5 views: uneven split over 2 ranks (3 + 2)
     return scene, cams
 
@@ -38,7 +38,17 @@ def _make_render_fn(params):
             from oracle import raster_oracle as O2
             with torch.enable_grad():
                 _, gr = O2.render_and_grad(ctx.inp, ctx.s, g)
-            return (None,) + tuple(gr[n] for n in ("means3D", "scales", "rotations", "opacities", "shs"))
+            # like the product's backward (bags_raster/rasterizer.py): the gradients are views of ONE buffer, 64-float
+            # aligned, so that the exchange is a single collective
+            names = ("means3D", "scales", "rotations", "opacities", "shs")
+            sizes = [gr[n].numel() for n in names]
+            flat = torch.empty(sum((v + 63) // 64 * 64 for v in sizes), dtype=gr["means3D"].dtype)
+            views, off = [], 0
+            for n, v in zip(names, sizes):
+                views.append(flat[off:off + v].view(gr[n].shape).copy_(gr[n]))
+                off += (v + 63) // 64 * 64
+            del flat
+            return (None,) + tuple(views)
 
     def render(cam):
         img = _Op.apply(cam, *params)
@@ -60,6 +70,8 @@ def _worker(rank, world, port, out):
     r = ViewShardedRenderer(params, _make_render_fn(params))
     res = r.step(cams)
     assert res["views"] == shard_views(len(cams), rank, world)
+    from bags_raster.sharding import coalesce_by_storage
+    assert len(coalesce_by_storage([p.grad for p in params])) == 1, "the carved gradients did not reach the reducer as one buffer"
     if rank == 0:
         torch.save({"grads": [p.grad.clone() for p in params], "loss": res["loss_sum"]}, out)
     # every rank must hold the same summed gradients
