@@ -51,6 +51,12 @@ struct __attribute__((aligned(16))) SplatRec {
 //   * the long tiles start first and the launch does not end on a few late heavy ones,
 //   * descriptors of a run are mostly neighbouring tiles, which share splats, and stay on one L2.
 // Placement only affects speed: every tile is computed independently of where and when it runs.
+#ifndef PRIO_SERIAL
+#define PRIO_SERIAL 3       // wave priority in the serial section between a chunk's two barriers ...
+#endif
+#ifndef PRIO_GROUPS
+#define PRIO_GROUPS 0       // ... and in its list-building / scan phase
+#endif
 #ifndef TILE_ILV
 #define TILE_ILV 16
 #endif
@@ -327,7 +333,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         if (tid < BCHUNK) { recs[tid] = rec; masks[tid] = rec.mask; }   // safe without a barrier: after the previous chunk's second barrier nobody reads them
         lds_barrier();
         PH_MARK(2);    // barrier 1
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(PRIO_GROUPS);
         const u32 nx_cnt = min(lo, (u32)BCHUNK), nx_lo = lo - nx_cnt;                  // chunk k+1 = [nx_lo, lo)
         Raw raw_n = fetch(lo > 0 ? gid1 : 0xFFFFFFFFu);                             // gathers of chunk k+1
         const u32 gid2 = (nx_lo > 0) ? fetch_id(A.rx, nx_lo) : 0xFFFFFFFFu;          // ids of chunk k+2
@@ -479,7 +485,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         // The short serial section between the two barriers shares its SIMDs with another workgroup that is usually in
         // its VALU-saturated group phase; without priority the four waves crawl through it at different speeds and
         // the skew is paid at the next barrier.
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(PRIO_SERIAL);
         // ---- next chunk: its gathers were issued before the groups; turn them into the staged record
         const ChunkRec cur = rec;
         // Keep every loaded register -- also the components nobody reads (q1 z, q3 yzw are not loaded; q2.y, the view
