@@ -584,7 +584,7 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
     const u32 n = desc.z;
 
     __shared__ SplatRec recs[CHUNK];                 // x y ap bp | cp o r g | b z mask pos
-    __shared__ unsigned char lists[16][CHUNK];
+    __shared__ unsigned char lists[16 * CHUNK + 16];        // [16][CHUNK] + padding for the walk's one-ahead read
     __shared__ u32 masks[CHUNK];
     __shared__ int s_live[4];
 
@@ -631,22 +631,25 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
             const u32 m = masks[slot] >> qb;                 // bits 0,1,4,5 = this wave's rows 0..3
             const bool h0 = r0 && (m & 1u), h1 = r1 && (m & 2u), h2 = r2 && (m & 16u), h3 = r3 && (m & 32u);
             const u64 b0 = __ballot(h0), b1 = __ballot(h1), b2 = __ballot(h2), b3 = __ballot(h3);
-            if (h0) lists[qb][L0 + __popcll(b0 & lt_mask)] = (unsigned char)slot;
-            if (h1) lists[qb + 1][L1 + __popcll(b1 & lt_mask)] = (unsigned char)slot;
-            if (h2) lists[qb + 4][L2 + __popcll(b2 & lt_mask)] = (unsigned char)slot;
-            if (h3) lists[qb + 5][L3 + __popcll(b3 & lt_mask)] = (unsigned char)slot;
+            if (h0) lists[qb * CHUNK + L0 + __popcll(b0 & lt_mask)] = (unsigned char)slot;
+            if (h1) lists[(qb + 1) * CHUNK + L1 + __popcll(b1 & lt_mask)] = (unsigned char)slot;
+            if (h2) lists[(qb + 4) * CHUNK + L2 + __popcll(b2 & lt_mask)] = (unsigned char)slot;
+            if (h3) lists[(qb + 5) * CHUNK + L3 + __popcll(b3 & lt_mask)] = (unsigned char)slot;
             L0 += __popcll(b0); L1 += __popcll(b1); L2 += __popcll(b2); L3 += __popcll(b3);
         }
         const int Lrow = (row == 0) ? L0 : (row == 1) ? L1 : (row == 2) ? L2 : L3;
         const int Lmax = max(max(L0, L1), max(L2, L3));
         __builtin_amdgcn_wave_barrier();
         // ---- every row walks its own list; the next list entry is fetched while the current splat is composited
-        const unsigned char* mylist = &lists[blk][0];
-        int slot = (Lrow > 0) ? (int)mylist[0] : 0;
+        // This kernel is issue bound, so the walk's bookkeeping counts: the next entry is read unconditionally (a row past
+        // the end of its list reads a stale byte, i.e. some valid slot, and `act` discards the result; the array is padded
+        // so that entry Lmax of the last list exists) and the record address is one 24-bit multiply, not v_mul_lo_u32.
+        const unsigned char* mylist = &lists[blk * CHUNK];
+        u32 slot = (u32)mylist[0];
         for (int i = 0; i < Lmax; ++i) {
             const bool act = i < Lrow;
-            const SplatRec s = recs[slot];
-            slot = (i + 1 < Lrow) ? (int)mylist[i + 1] : 0;
+            const SplatRec s = *reinterpret_cast<const SplatRec*>(reinterpret_cast<const char*>(recs) + __umul24(slot, (u32)sizeof(SplatRec)));
+            slot = (u32)mylist[i + 1];
             const float dx = s.x - pxf, dy = s.y - pyf;
             const float p2 = pair_power2(dx, dy, s.ap, s.bp, s.cp);
             const float G = __builtin_amdgcn_exp2f(p2);
