@@ -21,7 +21,7 @@
 #define ALPHA_MIN (1.0f / 255.0f)
 #define T_EPS 0.0001f
 
-// tuning knobs (tools/variants.sh sweeps them with -D...)
+// tuning knobs (tools/sweep_blend.sh sweeps them with -D...)
 #ifndef CHUNK
 #define CHUNK 256           // splats staged per step (LDS: 48 B record + 4 x 48 B accumulator copies + 16 list bytes each)
 #endif
@@ -33,6 +33,12 @@
 #endif
 #ifndef SCAN_UNROLL
 #define SCAN_UNROLL 1
+#endif
+#ifndef PRIO_SERIAL
+#define PRIO_SERIAL 3       // backward: wave priority in the serial section between a chunk's two barriers ...
+#endif
+#ifndef PRIO_GROUPS
+#define PRIO_GROUPS 0       // ... and in its list-building / scan phase (0/0, 1/0, 3/1 measured: flat)
 #endif
 
 struct __attribute__((aligned(16))) SplatRec {
@@ -51,12 +57,6 @@ struct __attribute__((aligned(16))) SplatRec {
 //   * the long tiles start first and the launch does not end on a few late heavy ones,
 //   * descriptors of a run are mostly neighbouring tiles, which share splats, and stay on one L2.
 // Placement only affects speed: every tile is computed independently of where and when it runs.
-#ifndef PRIO_SERIAL
-#define PRIO_SERIAL 3       // wave priority in the serial section between a chunk's two barriers ...
-#endif
-#ifndef PRIO_GROUPS
-#define PRIO_GROUPS 0       // ... and in its list-building / scan phase
-#endif
 #ifndef TILE_ILV
 #define TILE_ILV 16
 #endif
