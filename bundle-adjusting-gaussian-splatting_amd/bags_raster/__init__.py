@@ -8,6 +8,8 @@ from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, rast
 
 from .render import render, PipelineParams
 from .gaussians import GaussianBag, eval_sh
+from .io import save_ply, load_ply, save_checkpoint, load_checkpoint
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "debug_views",
-           "compute_relocation", "render", "PipelineParams", "GaussianBag", "eval_sh"]
+           "compute_relocation", "render", "PipelineParams", "GaussianBag", "eval_sh",
+           "save_ply", "load_ply", "save_checkpoint", "load_checkpoint"]
