@@ -111,3 +111,39 @@ class ViewShardedRenderer:
         if world > 1:
             dist.all_reduce(total, group=self.group)
         return {"loss_sum": total, "views": mine}
+
+
+class DensificationSync:
+    """Keeps the densification statistics of a view-sharded run equal to the single-process ones.
+
+    Every rank feeds ``GaussianBag.add_densification_stats`` with ITS views only, so ``xyz_gradient_accum`` / ``denom``
+    (sums over views, scene/gaussian_model.py:449-455) and ``max_radii2D`` (maximum over views, train.py's
+    ``gaussians.max_radii2D[visibility_filter] = max(...)``) drift apart between ranks.  ``sync`` exchanges what each rank
+    added since the previous call: sum all-reduce of the increments, max all-reduce of the radii.  Call it before anything
+    that reads the statistics (densify_and_prune), on every rank.  A no-op without a process group."""
+
+    def __init__(self, pc, group=None):
+        self.pc, self.group = pc, group
+        self._base_accum = pc.xyz_gradient_accum.detach().clone()
+        self._base_denom = pc.denom.detach().clone()
+
+    def sync(self) -> None:
+        pc = self.pc
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            d_accum = pc.xyz_gradient_accum.detach() - self._base_accum
+            d_denom = pc.denom.detach() - self._base_denom
+            work = [dist.all_reduce(d_accum, op=dist.ReduceOp.SUM, group=self.group, async_op=True),
+                    dist.all_reduce(d_denom, op=dist.ReduceOp.SUM, group=self.group, async_op=True),
+                    dist.all_reduce(pc.max_radii2D, op=dist.ReduceOp.MAX, group=self.group, async_op=True)]
+            for w in work:
+                w.wait()
+            pc.xyz_gradient_accum = self._base_accum + d_accum
+            pc.denom = self._base_denom + d_denom
+        self._base_accum = pc.xyz_gradient_accum.detach().clone()
+        self._base_denom = pc.denom.detach().clone()
+
+    def rebase(self) -> None:
+        """After the statistics were reset or re-sized (densify / prune zero them, scene/gaussian_model.py:356-358)."""
+        self._base_accum = self.pc.xyz_gradient_accum.detach().clone()
+        self._base_denom = self.pc.denom.detach().clone()
+

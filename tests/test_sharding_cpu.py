@@ -138,3 +138,55 @@ def test_coalesce_by_storage_groups_carved_gradients():
     # overlapping views of one storage are never merged
     out = coalesce_by_storage([flat[0:16], flat[8:24]])
     assert len(out) == 2
+
+
+def _stats_worker(rank, world, port, out):
+    for p in (ROOT, os.path.join(ROOT, "bundle-adjusting-gaussian-splatting_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bags_raster.sharding import DensificationSync, shard_views
+    pc, views = _stats_case()
+    sync = DensificationSync(pc)
+    for it in range(2):                                   # two exchange intervals: the increments must not be counted twice
+        for v in shard_views(len(views), rank, world):
+            _feed(pc, views[v], it)
+        sync.sync()
+    if rank == 0:
+        torch.save({"accum": pc.xyz_gradient_accum, "denom": pc.denom, "radii": pc.max_radii2D}, out)
+    dist.destroy_process_group()
+
+
+def _stats_case():
+    from bags_raster.gaussians import GaussianBag
+    from bags_raster.synth import synth_scene
+    pc = GaussianBag.from_activated(synth_scene(50, 1, 1.0, 0), 0)
+    g = torch.Generator().manual_seed(3)
+    views = [dict(grad=torch.randn(50, 3, generator=g), seen=torch.rand(50, generator=g) < 0.6,
+                  radii=torch.randint(0, 40, (50,), generator=g).float()) for _ in range(5)]
+    return pc, views
+
+
+def _feed(pc, view, it):
+    """What train.py does per view: max of the radii of the visible Gaussians, then add_densification_stats."""
+    vp = torch.zeros(50, 3, requires_grad=True)
+    vp.grad = view["grad"] * (it + 1)
+    seen = view["seen"]
+    pc.max_radii2D[seen] = torch.max(pc.max_radii2D[seen], view["radii"][seen])
+    pc.add_densification_stats(vp, None, seen, abs_grad=False)
+
+
+@pytest.mark.timeout(120)
+def test_densification_stats_match_single_process(tmp_path):
+    out = str(tmp_path / "stats.pt")
+    port = 29500 + ((os.getpid() + 77) % 500)
+    mp.spawn(_stats_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    pc, views = _stats_case()
+    for it in range(2):
+        for v in views:
+            _feed(pc, v, it)
+    assert torch.allclose(got["accum"], pc.xyz_gradient_accum, rtol=1e-6, atol=1e-6)
+    assert torch.equal(got["denom"], pc.denom) and torch.equal(got["radii"], pc.max_radii2D)
+
