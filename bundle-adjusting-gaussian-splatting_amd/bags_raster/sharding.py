@@ -117,8 +117,7 @@ class DensificationSync:
     """Keeps the densification statistics of a view-sharded run equal to the single-process ones.
 
     Every rank feeds ``GaussianBag.add_densification_stats`` with ITS views only, so ``xyz_gradient_accum`` / ``denom``
-    (sums over views, scene/gaussian_model.py:449-455) and ``max_radii2D`` (maximum over views, train.py's
-    ``gaussians.max_radii2D[visibility_filter] = max(...)``) drift apart between ranks.  ``sync`` exchanges what each rank
+    (sums over views, scene/gaussian_model.py:449-455) and ``max_radii2D`` (maximum over views, train.py:377,400) drift apart between ranks.  ``sync`` exchanges what each rank
     added since the previous call: sum all-reduce of the increments, max all-reduce of the radii.  Call it before anything
     that reads the statistics (densify_and_prune), on every rank.  A no-op without a process group."""
 
@@ -143,7 +142,7 @@ class DensificationSync:
         self._base_denom = pc.denom.detach().clone()
 
     def rebase(self) -> None:
-        """After the statistics were reset or re-sized (densify / prune zero them, scene/gaussian_model.py:356-358)."""
+        """After the statistics were reset or re-sized (densification_postfix zeroes them, scene/gaussian_model.py:388-391)."""
         self._base_accum = self.pc.xyz_gradient_accum.detach().clone()
         self._base_denom = self.pc.denom.detach().clone()
 
