@@ -111,7 +111,25 @@ def cpu_baseline(P, W, H, sm, budget_s=15.0):
         n = min(T, int(n * max(2.0, 0.8 * budget_s / max(t_all - t_pre, 1e-3))))
     t_blend = max(t_all - t_pre, 0.0)
     est = t_pre + t_blend * (T / len(tiles))
-    return dict(value=P / est, unit="Gaussians/s", cores=cores, kind="port",
+    # the repo's own Python fallbacks next to the op, timed in isolation on the same host cores -- the
+    # convert_SHs_python colour path (utils/sh_utils.py:57-112 on all P Gaussians) and the SSIM the training loop
+    # evaluates every iteration (utils/loss_utils.py:48-76 at the bench resolution); device-agnostic ports, run on CPU
+    rows = {}
+    try:
+        from bags_raster.gaussians import eval_sh
+        from bags_raster.loss import ssim as ssim_py
+        sh = scene["shs"].transpose(1, 2).contiguous()               # (P, 3, 16) as gaussian_renderer/__init__.py:91 passes it
+        dirs = torch.nn.functional.normalize(scene["means3D"] - torch.tensor([0.0, 0.0, -4.0]), dim=1)
+        a, b = torch.rand(3, H, W, generator=torch.Generator().manual_seed(2)), torch.rand(3, H, W, generator=torch.Generator().manual_seed(3))
+        for name, fn in (("eval_sh_deg3_ms", lambda: eval_sh(DEG, sh, dirs)), ("ssim_ms", lambda: ssim_py(a, b))):
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                fn()
+            rows[name] = round((time.perf_counter() - t0) / 3 * 1e3, 2)
+    except Exception as e:                                           # a reported extra, never a reason to lose the bench line
+        rows["error"] = repr(e)[:200]
+    return dict(value=P / est, unit="Gaussians/s", cores=cores, kind="port", python_rows=rows,
                 sample=f"oracle/raster_oracle.py (PyTorch CPU fp32 autograd) on the bench workload: preprocess+sort+its "
                        f"backward for all {P} Gaussians ({t_pre:.1f}s) + blend fwd+bwd on {len(tiles)} of {T} tiles "
                        f"({t_blend:.1f}s), tile time scaled x{T / len(tiles):.1f}",
