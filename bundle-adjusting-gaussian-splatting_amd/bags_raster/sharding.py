@@ -1,19 +1,32 @@
 """View sharding across the GPUs of one node: one process per GPU, the Gaussian set replicated, rank r
-renders views {v : v mod N == r} of the iteration's batch, and the ONE exchange step of the path is a sum all-reduce of
-the Gaussian-parameter gradients (59 floats per Gaussian: xyz 3, f_dc 3, f_rest 45, opacity 1, scale 3, rotation 4 --
-scene/gaussian_model.py:197-204) over RCCL/xGMI.  Pose leaves belong to a view, hence to one rank: never reduced.
+renders views {v : v mod N == r} of the iteration's batch, accumulates their gradients locally, and the ONE exchange
+step of the path is a sum over ranks of the Gaussian-parameter gradients (59 floats per Gaussian: xyz 3, f_dc 3,
+f_rest 45, opacity 1, scale 3, rotation 4 -- scene/gaussian_model.py:197-204) over RCCL/xGMI.  Pose leaves belong to a
+view, hence to one rank: never reduced.
 
 The reference has no distributed code at all (it round-robins whole jobs over GPUs, high_resolution.sh:7-13); this is
 new, so its contract is: N-rank summed gradients == 1-process sum over the same views (tests/test_sharding_cpu.py,
-gloo world_size 2).
+gloo world_size 2, incl. batches with fewer views than ranks).
 
-xGMI is point-to-point (7 links/GPU): a 118 MB (P = 500 k) ring all-reduce is link-bound, so the reducer issues the
-per-tensor collectives asynchronously, largest first, on RCCL's own stream while the caller may keep enqueueing the
-next view's forward; `wait()` joins them.
+Design for xGMI (point-to-point, 7 links per GPU; a ring collective is per-link bound, so what counts is few, large
+collectives and as many views as possible behind each of them):
+  * ``FlatGradBucket``: ONE persistent fp32 buffer per rank whose layout is derived from the parameter SHAPES only, so
+    it is identical on every rank whatever a rank rendered.  Every ``p.grad`` is a view of it: autograd accumulates the
+    gradients of all the rank's views in place, a rank without a view contributes its zeros, and the exchange is always
+    the same single collective on the same length -- never one collective per tensor, never a rank-dependent layout.
+  * V views per rank per exchange (the reference's cubemap step already renders 5 views per iteration,
+    utils/cubemap_utils.py:229,263-265): local accumulation is free, the exchange is paid once per V views.
+  * ``mode="all_reduce"``: one ``ncclAllReduce`` of the bucket.  ``mode="reduce_scatter"``: ``ncclReduceScatter`` ->
+    optional per-shard hook (a sharded optimizer / clipping step sees only its 1/N of the rows) -> ``ncclAllGather``;
+    same bytes on the links, and the hook's work is divided by N.
+  * ``PipelinedExchange``: two buckets; the collective of batch k runs on RCCL's stream while batch k+1 renders into
+    the other bucket (forward AND backward: nothing of batch k+1 depends on it unless the caller says so by waiting).
+    Gradients arrive one batch late: a caller that steps its optimizer with them trades one step of staleness for an
+    exchange that costs nothing on the critical path.
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, Iterable, List, Optional, Sequence
+from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -24,59 +37,176 @@ def shard_views(num_views: int, rank: int, world: int) -> List[int]:
     return list(range(rank, num_views, world))
 
 
-def coalesce_by_storage(grads: Sequence[torch.Tensor], max_waste: float = 0.02) -> List[torch.Tensor]:
-    """Tensors to all-reduce in place of ``grads``: contiguous tensors of one dtype that were carved out of one buffer
-    (bags_raster.rasterizer's backward does that for the Gaussian-parameter gradients) are replaced by ONE flat view
-    spanning them, provided the padding between them stays below ``max_waste`` of the span and the storage holds nothing
-    else inside it that the sum could disturb (the span only covers bytes between the first and last tensor; padding is
-    uninitialised but never read).  Everything else is passed through.  One large collective instead of five: the
-    per-call latency of a ring over 8 GPUs is paid once."""
-    groups: Dict[tuple, List[torch.Tensor]] = {}
-    out: List[torch.Tensor] = []
-    for g in grads:
-        if g.is_contiguous() and g.layout == torch.strided and g.numel() > 0:
-            groups.setdefault((g.untyped_storage().data_ptr(), g.dtype, g.device), []).append(g)
-        else:
-            out.append(g)
-    for (_, dtype, device), ts in groups.items():
-        if len(ts) == 1:
-            out.append(ts[0])
-            continue
-        ts = sorted(ts, key=lambda t: t.storage_offset())
-        lo, hi = ts[0].storage_offset(), max(t.storage_offset() + t.numel() for t in ts)
-        used = sum(t.numel() for t in ts)
-        overlap = any(a.storage_offset() + a.numel() > b.storage_offset() for a, b in zip(ts, ts[1:]))
-        if overlap or used < (1.0 - max_waste) * (hi - lo):
-            out.extend(ts)
-            continue
-        flat = torch.empty(0, dtype=dtype, device=device).set_(ts[0].untyped_storage(), lo, (hi - lo,), (1,))
-        out.append(flat)
-    return out
+def _world(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
-class GradAllReducer:
-    """Sum-all-reduce of ``.grad`` of the replicated Gaussian parameters, in place, asynchronously."""
+class FlatGradBucket:
+    """One flat buffer for the gradients of ``params``; ``views[i]`` has the shape of ``params[i]``.
 
-    def __init__(self, params: Sequence[torch.Tensor], group=None):
+    The layout depends on the parameter shapes and ``world`` only (each slice starts on a 64-float boundary; the total
+    is padded to a multiple of 64 * world so that a reduce-scatter splits it evenly) -- identical on every rank.  The
+    padding is zeroed with the rest: the collective never reads uninitialised memory."""
+
+    def __init__(self, params: Sequence[torch.Tensor], world: int = 1, align: int = 64):
         self.params = list(params)
-        self.group = group
-        self._pending = []
+        if not self.params:
+            raise ValueError("FlatGradBucket needs at least one parameter")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        for p in self.params:
+            if p.device != dev or p.dtype != dt:
+                raise ValueError("all bucketed parameters must share one device and dtype")
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + align - 1) // align * align
+        unit = align * max(int(world), 1)
+        self.numel = max((off + unit - 1) // unit * unit, unit)
+        self.flat = torch.zeros(self.numel, dtype=dt, device=dev)
+        self.views = [self.flat[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, self.params)]
+
+    def zero_(self) -> None:
+        self.flat.zero_()
+
+    def bind(self) -> None:
+        """Point every ``p.grad`` at its slice: autograd's accumulation (``p.grad += g``) then lands in the bucket."""
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def bound(self) -> bool:
+        return all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(self.params, self.views))
+
+    def absorb(self) -> None:
+        """Safety net for callers that replaced a ``p.grad`` (``zero_grad(set_to_none=True)``, ``p.grad = None``) after
+        ``bind``: whatever autograd left in a foreign tensor is added into the slice and the slice is bound again."""
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                p.grad = v
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.add_(p.grad.reshape(v.shape))
+                p.grad = v
+
+
+class GradExchange:
+    """Sum over ranks of one ``FlatGradBucket``, in place: always ONE collective (or one reduce-scatter + all-gather
+    pair) of the same length on every rank."""
+
+    def __init__(self, bucket: FlatGradBucket, group=None, mode: str = "all_reduce",
+                 shard_hook: Optional[Callable[[torch.Tensor, int, int], None]] = None):
+        if mode not in ("all_reduce", "reduce_scatter"):
+            raise ValueError("mode must be 'all_reduce' or 'reduce_scatter'")
+        self.bucket, self.group, self.mode, self.shard_hook = bucket, group, mode, shard_hook
+        self._pending: List[object] = []
+        self._shard: Optional[torch.Tensor] = None
+        self.collectives_issued = 0            # diagnostics / tests: collectives started so far
 
     def start(self) -> None:
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        world = _world(self.group)
+        if world == 1:
+            if self.shard_hook is not None:
+                self.shard_hook(self.bucket.flat, 0, self.bucket.numel)
             return
-        grads = [p.grad for p in self.params if p.grad is not None]
-        for g in sorted(coalesce_by_storage(grads), key=lambda t: -t.numel()):
-            self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        flat = self.bucket.flat
+        if self.mode == "all_reduce":
+            self._pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.collectives_issued += 1
+            return
+        if flat.numel() % world:
+            raise RuntimeError(f"bucket of {flat.numel()} elements was not laid out for world size {world}")
+        n = flat.numel() // world
+        rank = dist.get_rank(self.group)
+        if self._shard is None or self._shard.numel() != n:
+            self._shard = torch.empty(n, dtype=flat.dtype, device=flat.device)   # 1/N of the bucket, kept between steps
+        shard = self._shard                     # out of place: not every backend accepts a shard aliasing its input
+        w = dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.collectives_issued += 1
+        if self.shard_hook is not None:
+            w.wait()                            # the hook reads the reduced shard (stream-ordered under RCCL)
+            self.shard_hook(shard, rank * n, n)
+        else:
+            self._pending.append(w)
+        self._pending.append(dist.all_gather_into_tensor(flat, shard, group=self.group, async_op=True))
+        self.collectives_issued += 1
 
     def wait(self) -> None:
         for w in self._pending:
             w.wait()
         self._pending = []
 
+    def run(self) -> None:
+        self.start()
+        self.wait()
+
+
+class GradAllReducer:
+    """Sum-all-reduce of ``.grad`` of the replicated Gaussian parameters through a persistent ``FlatGradBucket``.
+
+    Usage per iteration: ``begin()`` (zero the bucket, bind ``p.grad``), any number of ``loss.backward()`` calls, then
+    ``all_reduce()`` (or ``start()`` ... ``wait()``).  ``all_reduce()`` without a preceding ``begin()`` still works:
+    gradients autograd put elsewhere are absorbed into the bucket first (one extra copy)."""
+
+    def __init__(self, params: Sequence[torch.Tensor], group=None, mode: str = "all_reduce", shard_hook=None):
+        self.params = list(params)
+        self.group = group
+        self.bucket = FlatGradBucket(self.params, _world(group))
+        self.exchange = GradExchange(self.bucket, group, mode, shard_hook)
+
+    def begin(self) -> None:
+        self.bucket.zero_()
+        self.bucket.bind()
+
+    def start(self) -> None:
+        if not self.bucket.bound():
+            self.bucket.absorb()
+        self.exchange.start()
+
+    def wait(self) -> None:
+        self.exchange.wait()
+
     def all_reduce(self) -> None:
         self.start()
         self.wait()
+
+
+class PipelinedExchange:
+    """Two buckets: while the collective of batch k is in flight on the communication stream, batch k+1 accumulates
+    into the other bucket.  ``begin()`` returns nothing and binds the free bucket; ``submit()`` starts the collective of
+    the bucket just filled; ``reduced()`` waits for and returns the views of the OLDEST submitted bucket (one batch
+    late).  ``drain()`` waits for everything (end of an epoch / before anything reads ``p.grad`` directly)."""
+
+    def __init__(self, params: Sequence[torch.Tensor], group=None, mode: str = "all_reduce"):
+        world = _world(group)
+        self.buckets = [FlatGradBucket(params, world), FlatGradBucket(params, world)]
+        self.exchanges = [GradExchange(b, group, mode) for b in self.buckets]
+        self._cur = 0
+        self._in_flight: List[int] = []
+
+    def begin(self) -> None:
+        if self._cur in self._in_flight:          # its collective must have finished before it is zeroed again
+            self.exchanges[self._cur].wait()
+            self._in_flight.remove(self._cur)
+        self.buckets[self._cur].zero_()
+        self.buckets[self._cur].bind()
+
+    def submit(self) -> None:
+        b = self.buckets[self._cur]
+        if not b.bound():
+            b.absorb()
+        self.exchanges[self._cur].start()
+        self._in_flight.append(self._cur)
+        self._cur ^= 1
+
+    def reduced(self) -> Optional[List[torch.Tensor]]:
+        if not self._in_flight:
+            return None
+        i = self._in_flight.pop(0)
+        self.exchanges[i].wait()
+        return self.buckets[i].views
+
+    def drain(self) -> None:
+        for i in self._in_flight:
+            self.exchanges[i].wait()
+        self._in_flight = []
 
 
 class ViewShardedRenderer:
@@ -84,28 +214,27 @@ class ViewShardedRenderer:
 
     ``render_fn(view) -> scalar loss`` must run forward for one view and return the loss whose backward populates the
     shared parameters' ``.grad`` (the product passes a closure over bags_raster.GaussianRasterizer; the gloo CPU tests
-    pass a closure over the oracle -- the sharding logic is identical)."""
+    pass a closure over the oracle -- the sharding logic is identical).  A batch of N*V views is V views per rank behind
+    ONE exchange; batches that do not divide evenly, or hold fewer views than ranks, are fine: every rank always joins
+    the same collective on the same bucket."""
 
-    def __init__(self, params: Sequence[torch.Tensor], render_fn: Callable[[object], torch.Tensor], group=None):
+    def __init__(self, params: Sequence[torch.Tensor], render_fn: Callable[[object], torch.Tensor], group=None,
+                 mode: str = "all_reduce"):
         self.params = list(params)
         self.render_fn = render_fn
         self.group = group
-        self.reducer = GradAllReducer(self.params, group)
+        self.reducer = GradAllReducer(self.params, group, mode)
 
     def step(self, views: Sequence[object]) -> Dict[str, object]:
-        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
-        for p in self.params:
-            p.grad = None
+        world = _world(self.group)
+        rank = dist.get_rank(self.group) if world > 1 else 0
+        self.reducer.begin()
         mine = shard_views(len(views), rank, world)
         losses = []
         for v in mine:
             loss = self.render_fn(views[v])
-            loss.backward()                      # grads of this rank's views accumulate locally
+            loss.backward()                      # grads of this rank's views accumulate in the bucket
             losses.append(loss.detach())
-        for p in self.params:                    # a rank with no view still joins the collective
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
         self.reducer.all_reduce()
         total = torch.stack(losses).sum() if losses else torch.zeros((), device=self.params[0].device)
         if world > 1:
@@ -117,9 +246,11 @@ class DensificationSync:
     """Keeps the densification statistics of a view-sharded run equal to the single-process ones.
 
     Every rank feeds ``GaussianBag.add_densification_stats`` with ITS views only, so ``xyz_gradient_accum`` / ``denom``
-    (sums over views, scene/gaussian_model.py:449-455) and ``max_radii2D`` (maximum over views, train.py:377,400) drift apart between ranks.  ``sync`` exchanges what each rank
-    added since the previous call: sum all-reduce of the increments, max all-reduce of the radii.  Call it before anything
-    that reads the statistics (densify_and_prune), on every rank.  A no-op without a process group."""
+    (sums over views, scene/gaussian_model.py:449-455) and ``max_radii2D`` (maximum over views, train.py:377,400) drift
+    apart between ranks.  ``sync`` exchanges what each rank added since the previous call: sum all-reduce of the
+    increments, max all-reduce of the radii.  Call it before anything that reads the statistics (densify_and_prune), on
+    every rank.  A no-op without a process group.  After the statistics were reset, re-sized or RESTORED from a
+    checkpoint (``bags_raster.io.load_checkpoint`` + ``restore``), call ``rebase()`` before the next ``sync``."""
 
     def __init__(self, pc, group=None):
         self.pc, self.group = pc, group
@@ -128,7 +259,7 @@ class DensificationSync:
 
     def sync(self) -> None:
         pc = self.pc
-        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if _world(self.group) > 1:
             d_accum = pc.xyz_gradient_accum.detach() - self._base_accum
             d_denom = pc.denom.detach() - self._base_denom
             work = [dist.all_reduce(d_accum, op=dist.ReduceOp.SUM, group=self.group, async_op=True),
@@ -142,7 +273,7 @@ class DensificationSync:
         self._base_denom = pc.denom.detach().clone()
 
     def rebase(self) -> None:
-        """After the statistics were reset or re-sized (densification_postfix zeroes them, scene/gaussian_model.py:388-391)."""
+        """After the statistics were reset or re-sized (densification_postfix zeroes them, scene/gaussian_model.py:388-391)
+        or restored from a checkpoint."""
         self._base_accum = self.pc.xyz_gradient_accum.detach().clone()
         self._base_denom = self.pc.denom.detach().clone()
-

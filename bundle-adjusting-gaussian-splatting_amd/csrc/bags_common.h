@@ -30,6 +30,28 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline int bit_length(u32 v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
 
+// theta = atan2(rho, tz) for rho >= 0, tz > 0 from operations every IEEE implementation rounds identically (min / max / div /
+// mul / add, no libm call), so that the depth keys and tile rectangles stay bit-comparable with the fp32 oracle when the
+// shift_factors polynomial is non-zero (oracle/raster_oracle.py: _atan2_pos repeats the sequence in torch).  Both callers are
+// compiled with -ffp-contract=off.  u = min/max in [0,1]; above tan(pi/8) it is folded with atan(u) = pi/4 + atan((u-1)/(u+1));
+// |w| <= tan(pi/8): atan(w) = w + w (s P(s)), s = w^2, P fitted to 6e-8 relative (fp32 rounding level).
+__device__ __forceinline__ float det_atan2_pos(float rho, float tz)
+{
+    const float lo = fminf(rho, tz), hi = fmaxf(rho, tz);
+    const float u = lo / hi;
+    const bool red = u > 0.414213568f;
+    const float w = red ? (u - 1.0f) / (u + 1.0f) : u;
+    const float s = w * w;
+    float p = -0.0607120693f;
+    p = p * s + 0.105907366f;
+    p = p * s + -0.142430589f;
+    p = p * s + 0.199984416f;
+    p = p * s + -0.333333135f;
+    float a = w + w * (s * p);
+    if (red) a = 0.785398185f + a;
+    return (rho > tz) ? 1.57079637f - a : a;
+}
+
 // ---- carved views of the three caller-owned state buffers -------------------------------------------------
 struct GeomView {            // per Gaussian, indexed by Gaussian id unless stated
     u32*    depth_key;       // float bits of the sort depth, KEY_CULLED when not rendered

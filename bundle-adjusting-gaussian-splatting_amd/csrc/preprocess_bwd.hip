@@ -199,7 +199,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         const float ty = x * v[1] + y * v[5] + z * v[9] + v[13];
         const float tz = x * v[2] + y * v[6] + z * v[10] + v[14];
         const float rho = sqrtf(tx * tx + ty * ty + 1e-20f);
-        const float theta = atan2f(rho, tz);
+        const float theta = det_atan2_pos(rho, tz);
         const float th2 = theta * theta, th3 = th2 * theta;
         const float shift = cam.sf[0] * th3 + cam.sf[1] * (th3 * th2) + cam.sf[2] * (th3 * th2 * th2);
         const float tzs = tz + shift;

@@ -56,7 +56,7 @@ preprocess_fwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     if (ok) {
         // D2: entrance-pupil shift (zero factors => exact identity)
         const float rho = sqrtf(tx * tx + ty * ty + 1e-20f);
-        const float theta = atan2f(rho, tz);
+        const float theta = det_atan2_pos(rho, tz);
         const float th2 = theta * theta;
         const float th3 = th2 * theta;
         const float shift = cam.sf[0] * th3 + cam.sf[1] * (th3 * th2) + cam.sf[2] * (th3 * th2 * th2);

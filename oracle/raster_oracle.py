@@ -33,6 +33,7 @@ Semantics decided here because the fork is unavailable (also listed in DESIGN.md
       the frustum clamp keeps the static tanfovx/tanfovy of the settings.
   D2  shift_factors f: theta = angle(p_view, +z); s = f0 th^3 + f1 th^5 + f2 th^7 (train.py:210-222);
       p_view.z += s and p_hom += s * intrinsic[2,:].  Identity at f = 0 (the only reference behaviour).
+      theta comes from a libm-free atan (same operation sequence as the kernels) so indices stay bit-exact for f != 0.
   D3  alpha = min(0.99, o*G) back-propagates straight through the clamp (stock CUDA behaviour).
   D4  means2D is an additive NDC offset (zeros) => its gradient is in NDC units (x W/2 of pixel units),
       means2D_densify receives sum over pixels of |per-pixel NDC gradient| (abs-grad densification,
@@ -133,6 +134,27 @@ def _sqrt(x: torch.Tensor) -> torch.Tensor:
     return torch.sqrt(x)
 
 
+def _atan2_pos(rho: torch.Tensor, tz: torch.Tensor) -> torch.Tensor:
+    """atan2(rho, tz) for rho >= 0, tz > 0.  fp32: the kernels' libm-free sequence (csrc/bags_common.h: det_atan2_pos), op
+    for op, so that depth keys and rectangles stay bit-comparable when shift_factors != 0 (autograd differentiates the
+    polynomial: its derivative is 1/(1+w^2) to ~1e-6).  fp64: torch.atan2, the gradient reference."""
+    if rho.dtype != torch.float32:
+        return torch.atan2(rho, tz)
+    f = lambda v: _f(v, rho)
+    lo, hi = torch.minimum(rho, tz), torch.maximum(rho, tz)
+    u = lo / hi
+    red = u.detach() > f(0.414213568)
+    w = torch.where(red, (u - 1.0) / (u + 1.0), u)
+    s = w * w
+    p = f(-0.0607120693) * s + f(0.105907366)
+    p = p * s + f(-0.142430589)
+    p = p * s + f(0.199984416)
+    p = p * s + f(-0.333333135)
+    a = w + w * (s * p)
+    a = torch.where(red, f(0.785398185) + a, a)
+    return torch.where(rho.detach() > tz.detach(), f(1.57079637) - a, a)
+
+
 def preprocess(means3D, means2D, shift_factors, shs, colors_precomp, opacities, scales, rotations,
                cov3D_precomp, s: OracleSettings, dtype=torch.float32,
                discrete: Optional[Dict[str, torch.Tensor]] = None) -> Preprocessed:
@@ -175,7 +197,7 @@ def preprocess(means3D, means2D, shift_factors, shs, colors_precomp, opacities, 
 
     # D2: entrance-pupil shift along the optical axis (identity when shift_factors == 0)
     rho = _sqrt(tx * tx + ty * ty + 1e-20)
-    theta = torch.atan2(rho, tz)
+    theta = _atan2_pos(rho, tz)
     th2 = theta * theta
     th3 = th2 * theta
     shift = sf[0] * th3 + sf[1] * (th3 * th2) + sf[2] * (th3 * th2 * th2)

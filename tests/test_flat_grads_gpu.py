@@ -1,5 +1,6 @@
-"""The op's backward hands autograd views of ONE buffer for the replicated Gaussian parameters, so that the view-sharded
-exchange (bags_raster/sharding.py) is a single collective.  This must survive autograd's gradient accumulation."""
+"""The view-sharded exchange (bags_raster/sharding.py) sums ONE persistent flat bucket whose slices are the parameters'
+``.grad``: the HIP op's backward (direct call and through render() + GaussianBag's fused activations) must accumulate
+into it in place, view after view."""
 import pytest
 import torch
 
@@ -8,35 +9,61 @@ from scenes import hip_settings, make_case
 pytestmark = pytest.mark.gpu
 
 
-def test_gaussian_gradients_share_one_storage_and_coalesce():
+def test_op_gradients_accumulate_in_the_flat_bucket():
     from bags_raster import GaussianRasterizer
-    from bags_raster.sharding import coalesce_by_storage
+    from bags_raster.sharding import GradAllReducer
     dev = torch.device("cuda", 0)
     scene, cam = make_case(3000, 160, 96, 1.5, 3, seed=2)
     leaves = {k: v.to(dev).clone().requires_grad_(True) for k, v in scene.items()}
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
     P = leaves["means3D"].shape[0]
     m2d = torch.zeros(P, 3, device=dev, requires_grad=True)
     rast = GaussianRasterizer(hip_settings(cam, 3, dev))
-    img = rast(means3D=leaves["means3D"], means2D=m2d, means2D_densify=None, shift_factors=None, shs=leaves["shs"],
-               colors_precomp=None, opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"],
-               cov3D_precomp=None)[0]
-    img.sum().backward()
-    grads = [leaves[k].grad for k in ("means3D", "shs", "opacities", "scales", "rotations")]
-    assert all(g is not None and torch.isfinite(g).all() for g in grads)
-    assert len({g.untyped_storage().data_ptr() for g in grads}) == 1, "autograd cloned the carved gradients"
-    merged = coalesce_by_storage(grads + [m2d.grad])
-    assert len(merged) == 2                                    # the flat buffer + the means2D gradient (a tensor of its own)
-    flat = max(merged, key=lambda t: t.numel())
-    assert flat.numel() >= sum(g.numel() for g in grads)
-    # summing "over one rank" through the flat view must be the identity on every gradient
-    before = [g.clone() for g in grads]
-    flat.mul_(2.0)
-    for g, b in zip(grads, before):
-        assert torch.equal(g, 2.0 * b)
-    # a second backward accumulates into the same tensors (no re-carving needed for correctness)
-    img2 = rast(means3D=leaves["means3D"], means2D=m2d, means2D_densify=None, shift_factors=None, shs=leaves["shs"],
-                colors_precomp=None, opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"],
-                cov3D_precomp=None)[0]
-    img2.sum().backward()
-    for g, b in zip(grads, before):
-        assert torch.allclose(g, 3.0 * b, rtol=1e-5, atol=1e-6)
+
+    def backward_once():
+        img = rast(means3D=leaves["means3D"], means2D=m2d, means2D_densify=None, shift_factors=None, shs=leaves["shs"],
+                   colors_precomp=None, opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"],
+                   cov3D_precomp=None)[0]
+        img.sum().backward()
+    backward_once()
+    ref = [leaves[k].grad.clone() for k in names]             # plain autograd result of one view
+    red = GradAllReducer([leaves[k] for k in names])
+    red.begin()
+    assert red.bucket.bound() and float(red.bucket.flat.abs().sum()) == 0.0
+    backward_once()
+    backward_once()                                           # V = 2 views behind one exchange
+    assert red.bucket.bound(), "autograd replaced a bucket slice instead of accumulating into it"
+    for k, r, o in zip(names, ref, red.bucket.offsets):
+        assert torch.allclose(leaves[k].grad, 2.0 * r, rtol=1e-5, atol=1e-6), k
+        assert leaves[k].grad.data_ptr() == red.bucket.flat.data_ptr() + 4 * o
+    red.all_reduce()                                          # no process group: a no-op, gradients untouched
+    assert torch.allclose(leaves["means3D"].grad, 2.0 * ref[0], rtol=1e-5, atol=1e-6)
+    red.begin()                                               # next iteration starts from zeros
+    assert float(red.bucket.flat.abs().sum()) == 0.0
+
+
+def test_render_path_raw_leaves_accumulate_in_the_flat_bucket():
+    """render() + GaussianBag: the raw leaves' gradients come out of the fused-activation backward as tensors of their
+    own; with the bucket bound they are added into its slices (ONE collective for the exchange)."""
+    from bags_raster.gaussians import GaussianBag
+    from bags_raster.render import PipelineParams, render
+    from bags_raster.sharding import GradAllReducer
+    from bags_raster.synth import sphere_views
+    dev = "cuda"
+    scene, _ = make_case(1500, 160, 128, 1.5, 3, seed=17)
+    cams = sphere_views(3, 160, 128, noise=0.05, device=dev)
+    bg = torch.zeros(3, device=dev)
+    g = torch.randn(3, 128, 160, generator=torch.Generator().manual_seed(3)).to(dev)
+    pc = GaussianBag.from_activated(scene, 3, device=dev)
+    for c in cams:
+        render(c, pc, PipelineParams(), bg)["render"].backward(g)
+    ref = [p.grad.clone() for p in pc.leaves()]
+    pc2 = GaussianBag.from_activated(scene, 3, device=dev)
+    red = GradAllReducer(pc2.leaves())
+    red.begin()
+    for c in cams:
+        render(c, pc2, PipelineParams(), bg)["render"].backward(g)
+    assert red.bucket.bound()
+    for p, r in zip(pc2.leaves(), ref):
+        assert torch.allclose(p.grad, r, rtol=1e-5, atol=1e-6)
+    assert red.exchange.collectives_issued == 0               # single process: nothing to exchange

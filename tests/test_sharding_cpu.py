@@ -57,25 +57,35 @@ def _make_render_fn(params):
     return render
 
 
-def _worker(rank, world, port, out):
+def _setup(rank, world, port):
     for p in (ROOT, os.path.join(ROOT, "bundle-adjusting-gaussian-splatting_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _params(scene):
+    return [scene[k].clone().requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs")]
+
+
+def _worker(rank, world, port, out, n_views, mode):
+    _setup(rank, world, port)
     from bags_raster.sharding import ViewShardedRenderer, shard_views
     scene, cams = _views_and_scene()
-    params = [scene[k].clone().requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs")]
-    r = ViewShardedRenderer(params, _make_render_fn(params))
-    res = r.step(cams)
+    cams = cams[:n_views]
+    params = _params(scene)
+    r = ViewShardedRenderer(params, _make_render_fn(params), mode=mode)
+    for it in range(2):                                   # twice: the bucket must be zeroed between iterations
+        res = r.step(cams)
     assert res["views"] == shard_views(len(cams), rank, world)
-    from bags_raster.sharding import coalesce_by_storage
-    assert len(coalesce_by_storage([p.grad for p in params])) == 1, "the carved gradients did not reach the reducer as one buffer"
+    # ONE exchange per step whatever this rank rendered (no view at all included): 1 all-reduce, or 1 reduce-scatter + 1 all-gather
+    assert r.reducer.exchange.collectives_issued == 2 * (1 if mode == "all_reduce" else 2)
+    assert r.reducer.bucket.bound(), "p.grad is no longer a view of the flat bucket"
     if rank == 0:
         torch.save({"grads": [p.grad.clone() for p in params], "loss": res["loss_sum"]}, out)
-    # every rank must hold the same summed gradients
-    for p in params:
+    for p in params:                                      # every rank must hold the same summed gradients
         ref = p.grad.clone()
         dist.broadcast(ref, src=0)
         assert torch.equal(ref, p.grad)
@@ -88,25 +98,116 @@ def test_shard_views_round_robin():
     assert shard_views(3, 5, 8) == [] and sorted(sum((shard_views(200, r, 8) for r in range(8)), [])) == list(range(200))
 
 
-@pytest.mark.timeout(300)
-def test_two_rank_sum_equals_single_process(tmp_path):
-    out = str(tmp_path / "rank0.pt")
-    port = 29500 + (os.getpid() % 500)
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
-    got = torch.load(out)
-    # single process, all 5 views
+def _single_process_reference(n_views):
     scene, cams = _views_and_scene()
-    params = [scene[k].clone().requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs")]
+    params = _params(scene)
     render = _make_render_fn(params)
     total = 0.0
-    for c in cams:
+    for c in cams[:n_views]:
         loss = render(c)
         loss.backward()
         total += float(loss)
+    return params, total
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("n_views,mode", [(5, "all_reduce"),        # V = 3 and 2 views behind one exchange (uneven split)
+                                          (5, "reduce_scatter"),    # the same through reduce-scatter + all-gather
+                                          (1, "all_reduce")])       # fewer views than ranks: rank 1 renders nothing
+def test_two_rank_sum_equals_single_process(tmp_path, n_views, mode):
+    out = str(tmp_path / "rank0.pt")
+    port = 29500 + ((os.getpid() + 7 * n_views + len(mode)) % 500)
+    mp.spawn(_worker, args=(2, port, out, n_views, mode), nprocs=2, join=True)
+    got = torch.load(out)
+    params, total = _single_process_reference(n_views)
     assert abs(float(got["loss"]) - total) < 1e-5 * max(1.0, abs(total))
     for g2, p in zip(got["grads"], params):
         denom = p.grad.norm().item()
         assert (g2 - p.grad).norm().item() <= 1e-6 * max(denom, 1e-12), "N-rank sum differs from 1-process sum"
+
+
+def _raw_leaf_worker(rank, world, port, out):
+    """The training path: raw (pre-activation) leaves of a GaussianBag -> activations -> op.  The leaf gradients come out
+    of the activation backward as unrelated tensors; the exchange must still be ONE collective."""
+    _setup(rank, world, port)
+    from bags_raster.gaussians import GaussianBag
+    from bags_raster.sharding import ViewShardedRenderer
+    scene, cams = _views_and_scene()
+    pc = GaussianBag.from_activated(scene, 1)
+    leaves = list(pc.leaves())
+    acts = lambda: [pc.get_xyz, pc.get_scaling, pc.get_rotation, pc.get_opacity, pc.get_features]
+
+    class _Lazy(list):                                     # _make_render_fn reads `params` at call time
+        def __iter__(self):
+            return iter(acts())
+    render = _make_render_fn(_Lazy())
+    r = ViewShardedRenderer(leaves, render)
+    r.step(cams)
+    assert r.reducer.exchange.collectives_issued == 1
+    assert all(p.grad is not None and p.grad.abs().sum() > 0 for p in leaves)
+    if rank == 0:
+        torch.save([p.grad.clone() for p in leaves], out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_raw_leaves_of_a_gaussian_bag_exchange_as_one_collective(tmp_path):
+    out = str(tmp_path / "leaves.pt")
+    port = 29500 + ((os.getpid() + 191) % 500)
+    mp.spawn(_raw_leaf_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    from bags_raster.gaussians import GaussianBag
+    scene, cams = _views_and_scene()
+    pc = GaussianBag.from_activated(scene, 1)
+
+    class _Lazy(list):
+        def __iter__(self):
+            return iter([pc.get_xyz, pc.get_scaling, pc.get_rotation, pc.get_opacity, pc.get_features])
+    render = _make_render_fn(_Lazy())
+    for c in cams:
+        render(c).backward()
+    for g2, p in zip(got, pc.leaves()):
+        assert (g2 - p.grad).norm().item() <= 1e-6 * max(p.grad.norm().item(), 1e-12)
+
+
+def _pipelined_worker(rank, world, port, out):
+    _setup(rank, world, port)
+    from bags_raster.sharding import PipelinedExchange, shard_views
+    scene, cams = _views_and_scene()
+    params = _params(scene)
+    render = _make_render_fn(params)
+    pipe = PipelinedExchange(params)
+    batches = [cams[0:2], cams[2:5], cams[1:4]]           # three batches: both buckets get reused
+    got = []
+    for batch in batches:
+        pipe.begin()
+        for v in shard_views(len(batch), rank, world):
+            render(batch[v]).backward()
+        pipe.submit()
+        if len(pipe._in_flight) == 2:                     # gradients of the batch before this one: one batch late
+            got.append([g.clone() for g in pipe.reduced()])
+    while pipe._in_flight:
+        got.append([g.clone() for g in pipe.reduced()])
+    if rank == 0:
+        torch.save(got, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_pipelined_exchange_delivers_every_batch_in_order(tmp_path):
+    out = str(tmp_path / "pipe.pt")
+    port = 29500 + ((os.getpid() + 313) % 500)
+    mp.spawn(_pipelined_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    scene, cams = _views_and_scene()
+    assert len(got) == 3
+    for batch, grads in zip([cams[0:2], cams[2:5], cams[1:4]], got):
+        params = _params(scene)
+        render = _make_render_fn(params)
+        for c in batch:
+            render(c).backward()
+        for g2, p in zip(grads, params):
+            assert (g2 - p.grad).norm().item() <= 1e-6 * max(p.grad.norm().item(), 1e-12)
 
 
 def test_single_process_passthrough():
@@ -119,25 +220,22 @@ def test_single_process_passthrough():
     GradAllReducer([w]).all_reduce()      # no-op
 
 
-def test_coalesce_by_storage_groups_carved_gradients():
-    """Gradients carved out of one buffer are exchanged as one flat tensor; strangers and sparse layouts pass through."""
-    from bags_raster.sharding import coalesce_by_storage
-    flat = torch.arange(64 * 5, dtype=torch.float32)
-    a, b, c = flat[0:30].view(10, 3), flat[64:64 + 40].view(10, 4), flat[128:128 + 192].view(4, 16, 3)
-    lone = torch.ones(7)
-    out = coalesce_by_storage([a, lone, c, b], max_waste=0.5)
-    assert len(out) == 2
-    big = max(out, key=lambda t: t.numel())
-    assert big.numel() == 128 + 192 and big.data_ptr() == flat.data_ptr()
-    big += 1.0                                   # what an in-place all-reduce does
-    assert torch.equal(a, (torch.arange(30, dtype=torch.float32) + 1).view(10, 3))
-    assert torch.equal(c.reshape(-1), torch.arange(128, 320, dtype=torch.float32) + 1)
-    # too much padding between the pieces: left alone
-    out = coalesce_by_storage([flat[0:8], flat[300:308]])
-    assert len(out) == 2 and all(t.numel() == 8 for t in out)
-    # overlapping views of one storage are never merged
-    out = coalesce_by_storage([flat[0:16], flat[8:24]])
-    assert len(out) == 2
+def test_flat_bucket_layout_and_absorb():
+    """The bucket's layout depends on shapes and world size only; gradients autograd left outside it are absorbed."""
+    from bags_raster.sharding import FlatGradBucket
+    a, b = torch.zeros(10, 3, requires_grad=True), torch.zeros(7, requires_grad=True)
+    bk = FlatGradBucket([a, b], world=8)
+    assert bk.offsets == [0, 64] and bk.numel % (64 * 8) == 0 and bk.flat.abs().sum() == 0
+    bk.bind()
+    (a.sum() * 2 + b.sum() * 3).backward()
+    assert bk.bound() and torch.equal(bk.flat[:30], torch.full((30,), 2.0)) and torch.equal(bk.flat[64:71], torch.full((7,), 3.0))
+    a.grad = None                                         # a caller's zero_grad(set_to_none=True)
+    (a.sum() * 5).backward()                              # autograd now owns a fresh tensor
+    assert not bk.bound()
+    bk.absorb()
+    assert bk.bound() and torch.equal(bk.flat[:30], torch.full((30,), 7.0))
+    with pytest.raises(ValueError):
+        FlatGradBucket([a, torch.zeros(3, dtype=torch.float64)])
 
 
 def _stats_worker(rank, world, port, out):
