@@ -192,6 +192,23 @@ __device__ unsigned long long g_phase_cycles[8];
 #else
 #define PH_MARK(i) do {} while (0)
 #endif
+#ifdef DIAG_PAIRS
+// Diagnostic build (tools/diag_pairs.sh): (pixel, splat) pairs the blend kernels EVALUATE (every pixel of every 4x4 block a
+// staged splat's reach mask admits) against the pairs that CONTRIBUTE (pass the alpha / power / n_contrib tests), summed
+// over all launches since the last read: [0] backward evaluated, [1] backward contributing, [2] / [3] the same, forward.
+__device__ unsigned long long g_pair_counts[4];
+extern "C" void bags_diag_pairs(unsigned long long* out, int reset)
+{
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pair_counts), sizeof(unsigned long long) * 4);
+    if (reset) { const unsigned long long z[4] = {0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(g_pair_counts), z, sizeof(z)); }
+}
+__device__ __forceinline__ void diag_pairs_flush(int slot, u32 ev, u32 co)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { ev += (u32)__shfl_xor((int)ev, d); co += (u32)__shfl_xor((int)co, d); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&g_pair_counts[slot], (unsigned long long)ev); atomicAdd(&g_pair_counts[slot + 1], (unsigned long long)co); }
+}
+#endif
 struct TileRef { int tx, ty; u32 rx, n, maxc; };   // wave-uniform: tile coordinates, first instance, instances, deepest contributor
 
 template <bool ABS>
@@ -325,6 +342,9 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     const int qx = (wave & 1) * 2, qy = (wave >> 1) * 2;
     const int myblk = (qy + (row >> 1)) * 4 + qx + (row & 1);
     float4* const pixb = &pixq[myblk][0];
+#ifdef DIAG_PAIRS
+    u32 dg_eval = 0, dg_con = 0;
+#endif
 
     for (u32 hi = A.maxc;;) {
         const u32 cnt = min(hi, (u32)BCHUNK);
@@ -372,6 +392,9 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                 const bool v2 = live & (pb.x <= 0.f) & (aub.x >= ALPHA_MIN) & (s.pos <= __float_as_uint(q12.z));
                 const bool v3 = live & (pb.y <= 0.f) & (aub.y >= ALPHA_MIN) & (s.pos <= __float_as_uint(q12.w));
                 aua.x = v0 ? aua.x : 0.f; aua.y = v1 ? aua.y : 0.f; aub.x = v2 ? aub.x : 0.f; aub.y = v3 ? aub.y : 0.f;
+#ifdef DIAG_PAIRS
+                dg_eval += live ? 4u : 0u; dg_con += (u32)v0 + (u32)v1 + (u32)v2 + (u32)v3;
+#endif
                 const f2 ala = {fminf(0.99f, aua.x), fminf(0.99f, aua.y)}, alb = {fminf(0.99f, aub.x), fminf(0.99f, aub.y)};
                 const f2 oma = 1.f - ala, omb = 1.f - alb;
                 const f2 g0a = {q00.x, q00.y}, g1a = {q00.z, q00.w}, g2a = {q01.x, q01.y};
@@ -526,6 +549,9 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
 #ifdef DIAG_PHASES
     if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_cycles[i], ph[i]);
 #endif
+#ifdef DIAG_PAIRS
+    diag_pairs_flush(0, dg_eval, dg_con);
+#endif
 }
 #ifdef DIAG_PHASES
 extern "C" void bags_diag_phases(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 8); }
@@ -596,6 +622,9 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
     float Tq = 1.f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dq = 0.f;
     u32 last = 0;
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#ifdef DIAG_PAIRS
+    u32 dg_eval = 0, dg_con = 0;
+#endif
     // blocks of this wave's rows 0..3
     const int qb = (wave >> 1) * 8 + (wave & 1) * 2;         // block index of row 0; rows: +0, +1, +4, +5
 
@@ -655,6 +684,9 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
             const float G = __builtin_amdgcn_exp2f(p2);
             const float alpha = fminf(0.99f, s.o * G);
             const bool contrib = act && (p2 <= 0.f) && (alpha >= ALPHA_MIN) && !done;
+#ifdef DIAG_PAIRS
+            dg_eval += act ? 1u : 0u; dg_con += contrib ? 1u : 0u;
+#endif
             if (contrib) {
                 const float test_T = Tq * (1.f - alpha);
                 if (test_T < T_EPS) {
@@ -688,6 +720,9 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
     if (lane == 0) s_live[wave] = (int)m;
     __syncthreads();
     if (tid == 0) tile_desc[dslot].w = (u32)max(max(s_live[0], s_live[1]), max(s_live[2], s_live[3]));
+#ifdef DIAG_PAIRS
+    diag_pairs_flush(2, dg_eval, dg_con);
+#endif
 }
 
 hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,

@@ -41,6 +41,11 @@ Semantics decided here because the fork is unavailable (also listed in DESIGN.md
   D5  extra outputs: depth (1,H,W) = sum w_i z_i, weights (1,H,W) = 1 - T_final, mean2D (P,2) pixel
       centres; depth/weights/mean2D carry no gradient.
   D6  depth key = view-space z (README.md:126 default) or Euclidean distance (``depth_key='distance'``).
+  D8  frustum clamp: for a point outside 1.3 x the field of view the EWA Jacobian uses t.x = +-1.3 tanfovx * t.z.  Here
+      (and in preprocess_bwd.hip) that expression is differentiated EXACTLY: dL/dt.x = 0 and dL/dt.z sees t.x move with
+      t.z.  Upstream 3DGS zeroes dL/dt.x too (x_grad_mul) but keeps the clamped t.x constant inside dL/dt.z, which doubles
+      that one term for clamped points; ``clamp_grad="stock"`` reproduces it so that a test can show the two differ only on
+      clamped Gaussians (tests/test_parity_gpu.py::test_frustum_clamp_gradient_semantic).  Forward values are identical.
 """
 from __future__ import annotations
 
@@ -102,6 +107,7 @@ class OracleSettings:
     debug_iter: Optional[int] = None
     depth_key: str = "z"
     tile_bounds: str = "opacity"      # "aabb": stock 3-sigma square; "opacity": intersected with the alpha >= 1/255 bounds
+    clamp_grad: str = "exact"         # D8; "stock": upstream's x_grad_mul treatment of frustum-clamped points (tests only)
 
 
 @dataclass
@@ -248,6 +254,14 @@ def preprocess(means3D, means2D, shift_factors, shs, colors_precomp, opacities, 
     tytz = ty / tzs
     cx_ = torch.minimum(limx, torch.maximum(-limx, txtz)) * tzs
     cy_ = torch.minimum(limy, torch.maximum(-limy, tytz)) * tzs
+    if s.clamp_grad == "stock":
+        # Upstream 3DGS (computeCov2DCUDA backward): a clamped t.x is a CONSTANT in J (x_grad_mul zeroes dL/dt.x, and dL/dt.z
+        # takes 2 h_x t.x / t.z^3 with that constant), although t.x = +-1.3 tanfov * t.z moves with t.z.  Values identical.
+        with torch.no_grad():
+            clx = (txtz < -limx) | (txtz > limx)
+            cly = (tytz < -limy) | (tytz > limy)
+        cx_ = torch.where(clx, cx_.detach(), cx_)
+        cy_ = torch.where(cly, cy_.detach(), cy_)
     itz = 1.0 / tzs
     itz2 = itz * itz
     j00 = fx * itz

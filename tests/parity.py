@@ -4,6 +4,22 @@ import torch
 from oracle import raster_oracle as O
 from scenes import camera_tensors, hip_settings, oracle_settings, rel_err
 
+import json
+import os
+
+
+def dump_report(name, rep):
+    """Append a parity report to gpurun_out/parity_reports.jsonl when that directory exists (GPU box / local runs), so the
+    measured errors of a green run can be quoted in DESIGN.md and profiles/."""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        try:
+            with open(os.path.join(d, "parity_reports.jsonl"), "a") as f:
+                f.write(json.dumps({"test": name, **{k: v for k, v in rep.items() if not torch.is_tensor(v)}}, default=str) + "\n")
+        except OSError:
+            pass
+
+
 GRAD_NAMES = ("means3D", "means2D", "means2D_densify", "shift_factors", "shs", "colors_precomp", "opacities", "scales",
               "rotations", "cov3D_precomp", "viewmatrix", "projmatrix", "intrinsic", "campos")
 
@@ -46,8 +62,9 @@ def run_hip(scene, cam, deg, grad_image=None, device="cuda", bg=None, shift=None
 
 
 def run_oracle(scene, cam, deg, grad_image=None, dtype=torch.float32, bg=None, shift=None, colors=None, cov3D=None,
-               scale_modifier=1.0, depth_key="z", discrete=None, means2D=None, tile_bounds="opacity"):
-    s = oracle_settings(cam, deg, bg=bg, scale_modifier=scale_modifier, depth_key=depth_key, tile_bounds=tile_bounds)
+               scale_modifier=1.0, depth_key="z", discrete=None, means2D=None, tile_bounds="opacity", clamp_grad="exact"):
+    s = oracle_settings(cam, deg, bg=bg, scale_modifier=scale_modifier, depth_key=depth_key, tile_bounds=tile_bounds,
+                        clamp_grad=clamp_grad)
     inp = dict(scene)
     inp["shift_factors"] = torch.zeros(3) if shift is None else shift
     if means2D is not None:

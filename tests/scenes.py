@@ -15,12 +15,12 @@ def camera_tensors(cam, device="cpu"):
                     campos=cam.get_camera_center().detach().to(device).contiguous())
 
 
-def oracle_settings(cam, sh_degree, bg=None, scale_modifier=1.0, depth_key="z", tile_bounds="opacity"):
+def oracle_settings(cam, sh_degree, bg=None, scale_modifier=1.0, depth_key="z", tile_bounds="opacity", clamp_grad="exact"):
     ct = camera_tensors(cam)
     return O.OracleSettings(image_height=cam.image_height, image_width=cam.image_width,
                             tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
                             bg=torch.zeros(3) if bg is None else bg, scale_modifier=scale_modifier,
-                            sh_degree=sh_degree, depth_key=depth_key, tile_bounds=tile_bounds, **ct)
+                            sh_degree=sh_degree, depth_key=depth_key, tile_bounds=tile_bounds, clamp_grad=clamp_grad, **ct)
 
 
 def hip_settings(cam, sh_degree, device, bg=None, scale_modifier=1.0, depth_key="z", tensors=None, debug=False,
