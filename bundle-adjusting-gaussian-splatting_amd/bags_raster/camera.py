@@ -6,8 +6,9 @@ Device-agnostic restatement of the reference's learnable camera:
   * ``PoseCamera.world_view_transform / full_proj_transform / camera_center / intrinsic``
                                      <- scene/cameras.py:95-113, 356-381
 The reference classes cannot be imported off-GPU (``.cuda()`` in constructors and default arguments), so the
-bench/tests build their cameras here; values and Jacobians are pinned against the reference functions by
-tests/golden/camera_chain.npz.
+bench/tests build their cameras here; values and Jacobians are pinned against the reference by tests/golden/
+camera_chain.npz (getProjectionMatrix, quaternion_to_rotation_matrix) and camera_pose_chain.npz (the composed chain as
+the reference's own Camera METHODS compute it, incl. global alignment; make_golden.py runs their bodies on a stub self).
 """
 from __future__ import annotations
 

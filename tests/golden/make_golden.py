@@ -10,6 +10,10 @@ inputs and expected outputs are stored).
                     gradients of the two terms stored separately
   resample.npz      utils/util_distortion.py:58-77 center_crop and :271-311 apply_distortion (apply2gt=False, flow given):
                     warped image, mask and d/d{image, flow} on a seeded image and a coarse control flow
+  camera_pose_chain.npz  scene/cameras.py:356-381  the METHODS Camera.get_world_view_transform / get_full_proj_transform /
+                    get_camera_center / get_intrinsic (bodies extracted from the class, run on a stub `self` on the CPU), with
+                    and without the global alignment (R <- G R, translation scale): values and the Jacobians with respect to
+                    delta_quaternion, delta_translation, learnable_fovx, learnable_fovy, G and the scale
   gaussian_activations.npz  utils/general_utils.py:114-163 build_rotation / build_scaling_rotation / strip_lowerdiag and
                     scene/gaussian_model.py:27-31 covariance activation (values + d/d{scaling, rotation}),
                     gaussian_renderer/__init__.py:19-28 quaternion_multiply, utils/general_utils.py inverse_sigmoid
@@ -163,5 +167,72 @@ def main():
     print("golden vectors written to", OUT)
 
 
+def pose_chain():
+    """scene/cameras.py:356-381 on a stub self.  The method bodies are taken from the class as they stand; only their
+    default arguments (tensors built with device='cuda' at definition time) are dropped -- every call below passes both
+    arguments explicitly -- and Tensor.cuda() is the identity for the duration of the calls."""
+    import types
+    path = "scene/cameras.py"
+    tree = ast.parse(open(os.path.join(REF, path)).read())
+    (getProjectionMatrix,) = extract("utils/graphics_utils.py", ["getProjectionMatrix"])
+    (quaternion_to_rotation_matrix,) = extract(path, ["quaternion_to_rotation_matrix"])
+    ns = {"torch": torch, "math": math, "np": np, "getProjectionMatrix": getProjectionMatrix,
+          "quaternion_to_rotation_matrix": quaternion_to_rotation_matrix}
+    want = ("get_world_view_transform", "get_full_proj_transform", "get_camera_center", "get_intrinsic")
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == "Camera":
+            for fn in node.body:
+                if isinstance(fn, ast.FunctionDef) and fn.name in want:
+                    fn.args.defaults = []
+                    fn.decorator_list = []
+                    exec(compile(ast.Module([fn], []), path, "exec"), ns)
+    g = torch.Generator().manual_seed(4321)
+    cases, out = [], {}
+    for i in range(4):
+        q0 = torch.randn(4, generator=g); q0 = q0 / q0.norm()
+        t0 = torch.randn(3, 1, generator=g) + torch.tensor([[0.0], [0.0], [4.0]])
+        dq = 0.05 * torch.randn(4, generator=g); dt = 0.1 * torch.randn(3, 1, generator=g)
+        fov = torch.tensor([1.1, 0.7]) + 0.1 * torch.randn(2, generator=g)
+        if i < 2:                                            # no global alignment: identity rotation, scale 1
+            G, sc = torch.eye(3), torch.tensor([1.0])
+        else:
+            G = quaternion_to_rotation_matrix(torch.tensor([1.0, 0.0, 0.0, 0.0]) + 0.1 * torch.randn(4, generator=g))
+            sc = torch.tensor([1.0 + 0.5 * float(torch.rand(1, generator=g))])
+        cases.append((q0, t0, dq, dt, fov, G, sc))
+
+    def run(x, q0, t0):
+        dq, dt, fx, fy, G, sc = x[0:4], x[4:7].view(3, 1), x[7], x[8], x[9:18].view(3, 3), x[18:19]
+        me = types.SimpleNamespace(init_quaternion=q0, delta_quaternion=dq, init_translation=t0, delta_translation=dt,
+                                   last_row=torch.tensor([[0.0, 0.0, 0.0, 1.0]]), znear=0.01, zfar=100.0,
+                                   learnable_fovx=fx, learnable_fovy=fy)
+        for n in want:
+            setattr(me, n, types.MethodType(ns[n], me))
+        V = me.get_world_view_transform(G, sc)
+        M = me.get_full_proj_transform(G, sc)
+        C = me.get_camera_center(G, sc)
+        K = me.get_intrinsic()                               # the projection matrix get_full_proj_transform has just stored
+        return torch.cat([V.reshape(-1), M.reshape(-1), K.reshape(-1), C.reshape(-1)])
+    saved_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        xs, ys, js = [], [], []
+        for q0, t0, dq, dt, fov, G, sc in cases:
+            x = torch.cat([dq, dt.reshape(-1), fov, G.reshape(-1), sc])
+            xs.append(x.numpy()); ys.append(run(x, q0, t0).detach().numpy())
+            js.append(torch.autograd.functional.jacobian(lambda v: run(v, q0, t0), x).numpy())
+    finally:
+        torch.Tensor.cuda = saved_cuda
+    out = dict(init_quaternion=np.stack([c[0].numpy() for c in cases]), init_translation=np.stack([c[1].numpy() for c in cases]),
+               x=np.stack(xs), y=np.stack(ys), dy_dx=np.stack(js),
+               x_layout=np.array("delta_quaternion 4 | delta_translation 3 | fovx | fovy | global_rotation 9 (row major) | global_translation_scale"),
+               y_layout=np.array("world_view_transform 16 | full_proj_transform 16 | intrinsic (projection_matrix) 16 | camera_center 3"))
+    np.savez(os.path.join(OUT, "camera_pose_chain.npz"), **out)
+    print("camera_pose_chain.npz written")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "pose_chain":   # only the new file: the others stay byte-identical
+        pose_chain()
+    else:
+        main()
+        pose_chain()

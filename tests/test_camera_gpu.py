@@ -89,3 +89,31 @@ def test_render_uses_fused_chain_and_reaches_pose_leaves():
     assert (res[0][0] - res[1][0]).abs().max().item() < 2e-4
     for a, b in zip(res[0][1], res[1][1]):
         assert (a - b).norm().item() <= 2e-3 * b.norm().item() + 1e-6, (a, b)
+
+
+def test_fused_camera_chain_matches_reference_methods(golden_dir):
+    """csrc/camera.hip against tests/golden/camera_pose_chain.npz: the values and Jacobians the reference's own Camera methods
+    (scene/cameras.py:356-381, run on a stub self by make_golden.py) produce, with and without global alignment."""
+    import os
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, "camera_pose_chain.npz"))
+    rs = np.random.RandomState(0)
+    for i in range(g["x"].shape[0]):
+        x = torch.tensor(g["x"][i], device=DEV)
+        leaves = [x[0:4].clone().requires_grad_(True), x[4:7].clone().view(3, 1).requires_grad_(True), x[7].clone().requires_grad_(True),
+                  x[8].clone().requires_grad_(True), x[9:18].clone().view(3, 3).requires_grad_(True), x[18:19].clone().requires_grad_(True)]
+        q0 = torch.tensor(g["init_quaternion"][i], device=DEV); t0 = torch.tensor(g["init_translation"][i], device=DEV)
+        V, M, K, C = cam.fused_camera_chain(leaves[0], leaves[1], leaves[2], leaves[3], q0, t0, 0.01, 100.0, leaves[4], leaves[5])
+        y = torch.cat([V.reshape(-1), M.reshape(-1), K.reshape(-1), C.reshape(-1)])
+        assert np.allclose(y.detach().cpu().numpy(), g["y"][i], rtol=2e-5, atol=2e-6), np.abs(y.detach().cpu().numpy() - g["y"][i]).max()
+        J = g["dy_dx"][i].astype(np.float64)
+        for _ in range(4):                                    # vector-Jacobian products with random cotangents
+            c = rs.randn(51)
+            gs = torch.autograd.grad(y, leaves, torch.tensor(c, dtype=torch.float32, device=DEV), retain_graph=True)
+            got = torch.cat([a.reshape(-1) for a in gs]).cpu().numpy().astype(np.float64)
+            want = c @ J
+            assert np.abs(got - want).max() <= 3e-4 * np.abs(want).max() + 1e-5, (i, np.abs(got - want).max(), np.abs(want).max())
+        if i < 2:                                             # no alignment: the None / None call gives the same four tensors
+            V0, M0, K0, C0 = cam.fused_camera_chain(leaves[0], leaves[1], leaves[2], leaves[3], q0, t0)
+            y0 = torch.cat([V0.reshape(-1), M0.reshape(-1), K0.reshape(-1), C0.reshape(-1)])
+            assert np.allclose(y0.detach().cpu().numpy(), g["y"][i], rtol=2e-5, atol=2e-6)
