@@ -196,11 +196,11 @@ __device__ unsigned long long g_phase_cycles[8];
 // Diagnostic build (tools/diag_pairs.sh): (pixel, splat) pairs the blend kernels EVALUATE (every pixel of every 4x4 block a
 // staged splat's reach mask admits) against the pairs that CONTRIBUTE (pass the alpha / power / n_contrib tests), summed
 // over all launches since the last read: [0] backward evaluated, [1] backward contributing, [2] / [3] the same, forward.
-__device__ unsigned long long g_pair_counts[4];
+__device__ unsigned long long g_pair_counts[8];   // [4] backward (splat, block) entries, [5] entries without a contributing pixel, [6] wave steps, [7] chunks x waves
 extern "C" void bags_diag_pairs(unsigned long long* out, int reset)
 {
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pair_counts), sizeof(unsigned long long) * 4);
-    if (reset) { const unsigned long long z[4] = {0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(g_pair_counts), z, sizeof(z)); }
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pair_counts), sizeof(unsigned long long) * 8);
+    if (reset) { const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(g_pair_counts), z, sizeof(z)); }
 }
 __device__ __forceinline__ void diag_pairs_flush(int slot, u32 ev, u32 co)
 {
@@ -240,6 +240,11 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     __shared__ u32 masks[BCHUNK];                     //  0.5 KB: block reach masks, compact (the 48-B record stride bank-conflicts)
     __shared__ float acc[4][BCHUNK][12];              // 24 KB, one copy per wave (LDS float atomics on a shared copy were 1.6x slower)
     __shared__ u32 blk_maxc[16];                     // last contributor over the 16 pixels of each block
+#ifdef LDS_PAD                                       // experiment knob: extra LDS per workgroup lowers the occupancy without touching the code
+    __shared__ u32 lds_pad[LDS_PAD / 4];
+    if (threadIdx.x == 0xFFFF) lds_pad[blockIdx.x & 7] = 1u;
+    asm volatile("" :: "v"(lds_pad[threadIdx.x & 7]));
+#endif
 
 #ifdef DIAG_PHASES
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -343,7 +348,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     const int myblk = (qy + (row >> 1)) * 4 + qx + (row & 1);
     float4* const pixb = &pixq[myblk][0];
 #ifdef DIAG_PAIRS
-    u32 dg_eval = 0, dg_con = 0;
+    u32 dg_eval = 0, dg_con = 0, dg_ent = 0, dg_ent0 = 0, dg_steps = 0, dg_chunks = 0;
 #endif
 
     for (u32 hi = A.maxc;;) {
@@ -452,12 +457,20 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                 }
             }
         };
+        // the two halves of every packed accumulator are added ONCE per step (h*), outside the four row phases below: each
+        // phase is issued for the whole wave although only one 16-lane row takes part in it
+        float4 h0, h1, h2;
+        auto fold_pairs = [&]() {
+            h0 = make_float4(a0.x + a0.y, a1.x + a1.y, a2.x + a2.y, a3.x + a3.y);
+            h1 = make_float4(a4.x + a4.y, a5.x + a5.y, a6.x + a6.y, a7.x + a7.y);
+            h2 = make_float4(a8.x + a8.y, a9.x + a9.y, a10.x + a10.y, 0.f);
+        };
         auto add_to_copy = [&](const int slot) {      // plain read-modify-write of the wave's own copy
             float4* d4 = reinterpret_cast<float4*>(&acc[wave][slot][0]);
             float4 r0 = d4[0], r1 = d4[1], r2 = d4[2];
-            r0.x += a0.x + a0.y; r0.y += a1.x + a1.y; r0.z += a2.x + a2.y; r0.w += a3.x + a3.y;
-            r1.x += a4.x + a4.y; r1.y += a5.x + a5.y; r1.z += a6.x + a6.y; r1.w += a7.x + a7.y;
-            r2.x += a8.x + a8.y; r2.y += a9.x + a9.y; r2.z += a10.x + a10.y;
+            r0.x += h0.x; r0.y += h0.y; r0.z += h0.z; r0.w += h0.w;
+            r1.x += h1.x; r1.y += h1.y; r1.z += h1.z; r1.w += h1.w;
+            r2.x += h2.x; r2.y += h2.y; r2.z += h2.z;
             d4[0] = r0; d4[1] = r1; d4[2] = r2;
         };
         u32 mreg[(BCHUNK + 63) / 64];
@@ -495,14 +508,24 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
             const ChunkRec s = recs[slot];
             // the next step's list entry is read now: list byte -> record is a chain of two LDS latencies otherwise
             slot_next = (li < gend - 16) ? (int)lists[myblk][gend - 17 - li] : 0;
+#ifdef DIAG_PAIRS
+            const u32 dg_before = dg_con;
+#endif
             block_rows(s, live, bx0, by0, pixb, (li == 15) && (gend > 0));
+#ifdef DIAG_PAIRS
+            dg_ent += live ? 1u : 0u; dg_ent0 += (live && dg_con == dg_before) ? 1u : 0u; dg_steps += (lane == 0) ? 1u : 0u;
+#endif
             // the same splat can sit in several rows (it reaches several blocks of the quadrant): one row at a time
+            fold_pairs();
 #pragma unroll
             for (int ph = 0; ph < 4; ++ph)
                 if (row == ph && live) add_to_copy(slot);
             PH_MARK(4);    // groups
         }
         PH_MARK(3);
+#ifdef DIAG_PAIRS
+        dg_chunks += (lane == 0) ? 1u : 0u;
+#endif
         lds_barrier();
         PH_MARK(5);    // barrier 2
         // The short serial section between the two barriers shares its SIMDs with another workgroup that is usually in
@@ -551,6 +574,8 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
 #endif
 #ifdef DIAG_PAIRS
     diag_pairs_flush(0, dg_eval, dg_con);
+    diag_pairs_flush(4, dg_ent, dg_ent0);
+    diag_pairs_flush(6, dg_steps, dg_chunks);
 #endif
 }
 #ifdef DIAG_PHASES

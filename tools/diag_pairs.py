@@ -8,7 +8,7 @@ P, W, H, sm = 500000, 1920, 1080, 0.5
 res = {"key": {"P": P, "width": W, "height": H, "sm": sm}}
 dev = torch.device('cuda', 0)
 lib = _lib.load()
-out = (C.c_ulonglong * 4)()
+out = (C.c_ulonglong * 8)()
 scene, cam = bench.build_case(P, W, H, sm, 0, dev)
 for tb in ("opacity", "aabb"):
     step, params, ct = bench.make_step(scene, cam, dev, tile_bounds=tb)
@@ -20,5 +20,6 @@ for tb in ("opacity", "aabb"):
     lib.bags_diag_pairs(out, 1)
     v = [x / n for x in out]
     res[tb] = {"instances_I": int(R.LAST_NUM_RENDERED), "bwd_pairs_evaluated": v[0], "bwd_pairs_contributing": v[1],
-               "fwd_pairs_evaluated": v[2], "fwd_pairs_contributing": v[3]}
+               "fwd_pairs_evaluated": v[2], "fwd_pairs_contributing": v[3],
+               "bwd_entries": v[4], "bwd_entries_without_contribution": v[5], "bwd_wave_steps": v[6], "bwd_wave_chunks": v[7]}
 print(json.dumps(res))
