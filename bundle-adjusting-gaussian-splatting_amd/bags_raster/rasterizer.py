@@ -43,6 +43,9 @@ class GaussianRasterizationSettings(NamedTuple):
     # "opacity": bin a Gaussian only into tiles its alpha >= 1/255 ellipse can reach (same image / gradients, fewer
     # sorted instances); "aabb": the stock 3-sigma square of upstream 3DGS (identical instance lists to the CUDA code)
     tile_bounds: str = "opacity"
+    # "auto": per-tile lists from the (block, tile) count matrix + per-tile LDS sort (csrc/binning.hip) when the image has
+    # <= 32768 tiles; "radix": depth sort of the Gaussians + stable radix sort of the instances (csrc/sort.hip).  Same lists.
+    binning: str = "auto"
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -117,12 +120,15 @@ class _Packed:
             raise ValueError("depth_key must be 'z' or 'distance'")
         if settings.tile_bounds not in ("opacity", "aabb"):
             raise ValueError("tile_bounds must be 'opacity' or 'aabb'")
+        if settings.binning not in ("auto", "radix"):
+            raise ValueError("binning must be 'auto' or 'radix'")
         self.settings = L.BagsSettings(
             int(settings.image_height), int(settings.image_width), float(settings.tanfovx), float(settings.tanfovy),
             float(settings.scale_modifier), int(settings.sh_degree), int(M),
             L.DEPTH_DISTANCE if settings.depth_key == "distance" else L.DEPTH_Z, int(bool(settings.debug)),
             int(settings.debug_iter) if settings.debug_iter is not None else -1,
-            L.TILES_OPACITY if settings.tile_bounds == "opacity" else L.TILES_AABB, 0,
+            L.TILES_OPACITY if settings.tile_bounds == "opacity" else L.TILES_AABB,
+            L.BINNING_RADIX if settings.binning == "radix" else L.BINNING_AUTO,
             _ptr(k["bg"]), _ptr(k["viewmatrix"]), _ptr(k["projmatrix"]), _ptr(k["intrinsic"]), _ptr(k["campos"]))
         self.inputs = L.BagsInputs(P, _ptr(k["means3D"]), _ptr(k["means2D"]), _ptr(k["shift_factors"]), _ptr(k["shs"]),
                                    _ptr(k["colors_precomp"]), _ptr(k["opacities"]), _ptr(k["scales"]),

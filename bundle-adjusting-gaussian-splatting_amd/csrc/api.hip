@@ -67,20 +67,21 @@ size_t carve_geom(void* base, int P, GeomView* v)
     const size_t n = (size_t)(P > 0 ? P : 1);
     g.nblocks_sort = radix_blocks_for((long long)n);
     g.nblocks_scan = cdiv((long long)n, SCAN_TILE);
-    take(p, g.depth_key, n); take(p, g.g2d, 4 * n); take(p, g.rect, n); take(p, g.tiles_touched, n);
+    take(p, g.depth_key, n); take(p, g.g2d, 4 * n); take(p, g.rect, n); take(p, g.tiles_touched, n); take(p, g.inst_off, n);
     take(p, g.keys_a, n); take(p, g.keys_b, n); take(p, g.vals_a, n); take(p, g.vals_b, n);
     take(p, g.rank_offset, n);
     take(p, g.scan_partials, (size_t)g.nblocks_scan + 1);
     take(p, g.radix_hist, (size_t)RADIX_BINS * g.nblocks_sort);
     take(p, g.digit_totals, RADIX_BINS);
     take(p, g.num_rendered, 64);
+    take(p, g.local_off, n); take(p, g.block_total, 256); take(p, g.block_base, 256);
     if (v) *v = g;
     return (size_t)(p - reinterpret_cast<char*>(base));
 }
 
 static int tile_passes(int T) { return (bit_length((u32)(T > 1 ? T - 1 : 1)) + RADIX_BITS - 1) / RADIX_BITS; }
 
-size_t carve_binning(void* base, long long I, int W, int H, BinView* v)
+size_t carve_binning(void* base, long long I, int W, int H, BinView* v, bool binned)
 {
     char* p = reinterpret_cast<char*>(base);
     BinView b;
@@ -88,13 +89,20 @@ size_t carve_binning(void* base, long long I, int W, int H, BinView* v)
     const int T = cdiv(W, BAGS_TILE) * cdiv(H, BAGS_TILE);
     b.nblocks_sort = radix_blocks_for((long long)n);
     b.passes = tile_passes(T);
-    take(p, b.keys_a, n); take(p, b.vals_a, n); take(p, b.keys_b, n); take(p, b.vals_b, n);
-    take(p, b.ranges, (size_t)(T > 0 ? T : 1));
-    take(p, b.radix_hist, (size_t)RADIX_BINS * b.nblocks_sort);
-    take(p, b.digit_totals, RADIX_BINS);
-    // emission writes the *_b half; pass 0: b -> a, pass 1: a -> b, ...
-    b.point_list = (b.passes & 1) ? b.vals_a : b.vals_b;
-    b.tile_sorted = (b.passes & 1) ? b.keys_a : b.keys_b;
+    b.kv = nullptr; b.ids = nullptr;
+    if (binned) {                                            // tile-binned path: 12 bytes per instance
+        take(p, b.ids, n); take(p, b.kv, n); take(p, b.point_list, n);
+        b.keys_a = b.keys_b = b.vals_a = b.vals_b = nullptr; b.ranges = nullptr; b.radix_hist = b.digit_totals = nullptr;
+        b.tile_sorted = nullptr;
+    } else {
+        take(p, b.keys_a, n); take(p, b.vals_a, n); take(p, b.keys_b, n); take(p, b.vals_b, n);
+        take(p, b.ranges, (size_t)(T > 0 ? T : 1));
+        take(p, b.radix_hist, (size_t)RADIX_BINS * b.nblocks_sort);
+        take(p, b.digit_totals, RADIX_BINS);
+        // emission writes the *_b half; pass 0: b -> a, pass 1: a -> b, ...
+        b.point_list = (b.passes & 1) ? b.vals_a : b.vals_b;
+        b.tile_sorted = (b.passes & 1) ? b.keys_a : b.keys_b;
+    }
     if (v) *v = b;
     return (size_t)(p - reinterpret_cast<char*>(base));
 }
@@ -107,6 +115,7 @@ size_t carve_image(void* base, int W, int H, ImgView* v)
     take(p, im.final_T, n); take(p, im.n_contrib, n);
     const size_t T = (size_t)cdiv(W > 0 ? W : 1, BAGS_TILE) * cdiv(H > 0 ? H : 1, BAGS_TILE);
     take(p, im.tile_desc, T); take(p, im.n_active, 64);
+    take(p, im.cnt_rows, 256 * ((T + 1) / 2)); take(p, im.pre, 256 * T); take(p, im.tile_total, T); take(p, im.ranges, T);
     if (v) *v = im;
     return (size_t)(p - reinterpret_cast<char*>(base));
 }
@@ -146,7 +155,11 @@ int bags_abi_version(void) { return BAGS_ABI_VERSION; }
 const char* bags_last_error(void) { return g_err; }
 
 size_t bags_geom_size(int32_t P) { return carve_geom(nullptr, P, nullptr) + 256; }
-size_t bags_binning_size(int64_t I, int32_t W, int32_t H) { return carve_binning(nullptr, I, W, H, nullptr) + 256; }
+size_t bags_binning_size(int64_t I, int32_t W, int32_t H)
+{   // the caller does not know which path a call takes: the larger of the two layouts
+    const size_t a = carve_binning(nullptr, I, W, H, nullptr, false), b = carve_binning(nullptr, I, W, H, nullptr, true);
+    return (a > b ? a : b) + 256;
+}
 size_t bags_image_size(int32_t W, int32_t H) { return carve_image(nullptr, W, H, nullptr) + 256; }
 size_t bags_backward_workspace_size(int32_t P, int64_t I)
 {
@@ -156,13 +169,28 @@ size_t bags_backward_workspace_size(int32_t P, int64_t I)
     return part + slab + sums + 256;
 }
 
+// tile-binned lists (binning.hip) unless the caller asked for the radix path or the problem is outside their limits
+static bool use_binned(const BagsSettings* s, int P)
+{
+    const int T = cdiv(s->image_width, BAGS_TILE) * cdiv(s->image_height, BAGS_TILE);
+    return s->binning != BAGS_BINNING_RADIX && binned_supported(P, T);
+}
+
 static inline void* align256(void* p) { return reinterpret_cast<void*>(align_up(reinterpret_cast<size_t>(p), 256)); }
 
-// K1 + depth ordering + offsets; leaves the instance count in g.num_rendered (device)
-static int enqueue_prepare(const BagsSettings* s, const BagsInputs* in, const GeomView& g, const BagsForwardOut* out, hipStream_t st)
+// K1 + everything the instance count needs; leaves it in g.num_rendered (device)
+static int enqueue_prepare(const BagsSettings* s, const BagsInputs* in, const GeomView& g, const ImgView& im, const BagsForwardOut* out,
+                           hipStream_t st)
 {
     { ProfScope ps(ST_PRE_FWD, st); HIP_TRY(launch_preprocess_fwd(*s, *in, g, out->radii, out->mean2D, st)); }
     DEBUG_SYNC(s, st, "preprocess_fwd");
+    if (use_binned(s, in->P)) {
+        // (block of Gaussians, tile) count matrix -> column prefixes -> tile ranges, instance count, heavy-first tile list
+        const int gx = cdiv(s->image_width, BAGS_TILE), gy = cdiv(s->image_height, BAGS_TILE);
+        { ProfScope ps(ST_OFFSETS, st); HIP_TRY(launch_binned_prepare(g, im, in->P, gx, gx * gy, st)); }
+        DEBUG_SYNC(s, st, "tile count / prefix / ranges");
+        return BAGS_OK;
+    }
     // depth order of the Gaussians: 4 stable 8-bit passes over the float bits (positive floats order like u32)
     { ProfScope ps(ST_DEPTH_SORT, st);
       HIP_TRY(launch_radix_sort(g.depth_key, nullptr, g.keys_a, g.vals_a, g.keys_b, g.vals_b, in->P, 32, true,
@@ -174,13 +202,24 @@ static int enqueue_prepare(const BagsSettings* s, const BagsInputs* in, const Ge
     return BAGS_OK;
 }
 
-// emission, per-tile ordering, ranges, blend.  n_dev != nullptr: the instance count is read on the device and
-// clamped to `I` (the capacity the binning buffer was sized for)
+// emission, per-tile ordering, blend.  n_dev != nullptr: the instance count is read on the device and checked against
+// `I` (the capacity the binning buffer was sized for)
 static int enqueue_finish(const BagsSettings* s, const BagsInputs* in, const GeomView& g, const BinView& b, const ImgView& im,
                           const BagsForwardOut* out, int64_t I, const u32* n_dev, hipStream_t st)
 {
     const int W = s->image_width, H = s->image_height;
     const int gx = cdiv(W, BAGS_TILE), gy = cdiv(H, BAGS_TILE);
+    if (use_binned(s, in->P)) {
+        if (in->P == 0) HIP_TRY(launch_binned_empty(g, im, gx * gy, st));      // no prepare phase ran: an all-empty tile list
+        if (I > 0 && in->P > 0) {
+            ProfScope ps(ST_TILE_SORT, st);
+            HIP_TRY(launch_binned_finish(g, im, in->P, gx, gx * gy, b.ids, b.kv, b.point_list, (u32)I, n_dev, st));
+        }
+        DEBUG_SYNC(s, st, "emit / tile sort");
+        { ProfScope ps(ST_BLEND_FWD, st); HIP_TRY(launch_blend_fwd(*s, g, b, im, *out, st, n_dev, (u32)I)); }
+        DEBUG_SYNC(s, st, "blend_fwd");
+        return BAGS_OK;
+    }
     if (I > 0) {
         { ProfScope ps(ST_EMIT, st); HIP_TRY(launch_emit(g, g.vals_b, in->P, gx, b.keys_b, b.vals_b, (u32)I, st, n_dev, b.ranges, gx * gy)); }
         DEBUG_SYNC(s, st, "emit");
@@ -206,9 +245,10 @@ int bags_forward_prepare(const BagsSettings* s, const BagsInputs* in, const Bags
     if (!out || !out->radii || !host_num_rendered) return fail(BAGS_ERR_ARG, "radii / host_num_rendered must be given");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     GeomView g; carve_geom(align256(stt->geom), in->P, &g);
+    ImgView im; carve_image(align256(stt->image), s->image_width, s->image_height, &im);
     *host_num_rendered = 0;
     if (in->P == 0) return BAGS_OK;
-    rc = enqueue_prepare(s, in, g, out, st);
+    rc = enqueue_prepare(s, in, g, im, out, st);
     if (rc) return rc;
     u32 host_I = 0;
     HIP_TRY(hipMemcpyAsync(&host_I, g.num_rendered, sizeof(u32), hipMemcpyDeviceToHost, st));
@@ -228,7 +268,7 @@ int bags_forward_finish(const BagsSettings* s, const BagsInputs* in, const BagsS
     if (!stt->binning || stt->binning_bytes < bags_binning_size(I, W, H)) return fail(BAGS_ERR_SIZE, "binning buffer too small");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     GeomView g; carve_geom(align256(stt->geom), in->P, &g);
-    BinView b; carve_binning(align256(stt->binning), I, W, H, &b);
+    BinView b; carve_binning(align256(stt->binning), I, W, H, &b, use_binned(s, in->P));
     ImgView im; carve_image(align256(stt->image), W, H, &im);
     return enqueue_finish(s, in, g, b, im, out, I, nullptr, st);
 }
@@ -241,10 +281,11 @@ int bags_forward_prepare_async(const BagsSettings* s, const BagsInputs* in, cons
     if (!out || !out->radii || !host_num_rendered) return fail(BAGS_ERR_ARG, "radii / host_num_rendered must be given");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     GeomView g; carve_geom(align256(stt->geom), in->P, &g);
+    ImgView im; carve_image(align256(stt->image), s->image_width, s->image_height, &im);
     if (in->P == 0) {
         HIP_TRY(hipMemsetAsync(g.num_rendered, 0, sizeof(u32), st));
     } else {
-        rc = enqueue_prepare(s, in, g, out, st);
+        rc = enqueue_prepare(s, in, g, im, out, st);
         if (rc) return rc;
     }
     HIP_TRY(hipMemcpyAsync(host_num_rendered, g.num_rendered, sizeof(u32), hipMemcpyDeviceToHost, st));
@@ -262,7 +303,7 @@ int bags_forward_finish_speculative(const BagsSettings* s, const BagsInputs* in,
     if (!stt->binning || stt->binning_bytes < bags_binning_size(capacity, W, H)) return fail(BAGS_ERR_SIZE, "binning buffer too small");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     GeomView g; carve_geom(align256(stt->geom), in->P, &g);
-    BinView b; carve_binning(align256(stt->binning), capacity, W, H, &b);
+    BinView b; carve_binning(align256(stt->binning), capacity, W, H, &b, use_binned(s, in->P));
     ImgView im; carve_image(align256(stt->image), W, H, &im);
     return enqueue_finish(s, in, g, b, im, out, capacity, g.num_rendered, st);
 }
@@ -279,7 +320,7 @@ int bags_backward(const BagsSettings* s, const BagsInputs* in, const BagsState* 
     if (!a->workspace || a->workspace_bytes < bags_backward_workspace_size(in->P, I)) return fail(BAGS_ERR_SIZE, "backward workspace too small");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     GeomView g; carve_geom(align256(stt->geom), in->P, &g);
-    BinView b; carve_binning(align256(stt->binning), I, W, H, &b);
+    BinView b; carve_binning(align256(stt->binning), I, W, H, &b, use_binned(s, in->P));
     ImgView im; carve_image(align256(stt->image), W, H, &im);
     char* ws = reinterpret_cast<char*>(align256(a->workspace));
     float* partials = reinterpret_cast<float*>(ws);
@@ -316,10 +357,18 @@ int bags_debug_views(const BagsSettings* s, const BagsInputs* in, const BagsStat
     if (d->final_T) HIP_TRY(hipMemcpyAsync(d->final_T, im.final_T, (size_t)W * H * 4, hipMemcpyDeviceToDevice, st));
     if (d->point_list || d->keys_sorted || d->ranges) {
         if (!stt->binning || stt->binning_bytes < bags_binning_size(I, W, H)) return fail(BAGS_ERR_SIZE, "binning buffer too small");
-        BinView b; carve_binning(align256(stt->binning), I, W, H, &b);
+        BinView b; carve_binning(align256(stt->binning), I, W, H, &b, use_binned(s, in->P));
+        const bool binned = use_binned(s, in->P);
+        const uint2* ranges = binned ? im.ranges : b.ranges;
         if (d->point_list && I) HIP_TRY(hipMemcpyAsync(d->point_list, b.point_list, (size_t)I * 4, hipMemcpyDeviceToDevice, st));
-        if (d->keys_sorted && I) HIP_TRY(launch_debug_keys(b.tile_sorted, b.point_list, g.depth_key, I, d->keys_sorted, st));
-        if (d->ranges) HIP_TRY(hipMemcpyAsync(d->ranges, b.ranges, T * 8, hipMemcpyDeviceToDevice, st));
+        if (d->keys_sorted && I) {
+            if (binned) HIP_TRY(launch_debug_keys_ranges(ranges, b.point_list, g.depth_key, (int)T, d->keys_sorted, st));
+            else HIP_TRY(launch_debug_keys(b.tile_sorted, b.point_list, g.depth_key, I, d->keys_sorted, st));
+        }
+        if (d->ranges) {
+            if (in->P == 0 || (binned && I == 0 && in->P == 0)) HIP_TRY(hipMemsetAsync(d->ranges, 0, T * 8, st));
+            else HIP_TRY(hipMemcpyAsync(d->ranges, ranges, T * 8, hipMemcpyDeviceToDevice, st));
+        }
     }
     return BAGS_OK;
 }

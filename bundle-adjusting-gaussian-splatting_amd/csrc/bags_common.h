@@ -58,8 +58,10 @@ struct GeomView {            // per Gaussian, indexed by Gaussian id unless stat
     // One 64-byte line per Gaussian with everything the blend kernels gather per (tile, Gaussian) instance, so an
     // instance costs ONE line fetch instead of five partial ones from id-ordered (spatially random) SoA arrays:
     //   q0 = conic a, b, c, opacity      q1 = pixel x, y, colour r, g
-    //   q2 = colour b, view depth z, rect.x, rect.y (bits)      q3 = inst_offset, tiles_touched, clamped mask, 0 (bits)
+    //   q2 = colour b, view depth z, rect.x, rect.y (bits)      q3 = -, tiles_touched, clamped mask, 0 (bits)
     float4* g2d;             // [4 * P]
+    u32*    inst_off;        // [P] first emission slot of the Gaussian's partial-gradient records (an array of its own: a 4-byte
+                             // write into every 64-byte line of g2d after the scan cost 6.6 us per frame)
     uint2*  rect;            // (minx | miny<<16, maxx | maxy<<16), max exclusive   (compact copy for emit)
     u32*    tiles_touched;   // compact copy for the offsets scan / emit
     // scratch (dead after forward)
@@ -69,6 +71,10 @@ struct GeomView {            // per Gaussian, indexed by Gaussian id unless stat
     u32*    radix_hist;      // [256][nblocks]
     u32*    digit_totals;    // [256]
     u32*    num_rendered;    // [1] (+ pad)
+    // tile-binned path (binning.hip)
+    u32*    local_off;       // [P] instance offset of a Gaussian inside its block of Gaussians (id order)
+    u32*    block_total;     // [256] instances per block
+    u32*    block_base;      // [256] exclusive scan of block_total
     int     nblocks_sort;    // radix workgroups for P keys
     int     nblocks_scan;
 };
@@ -79,8 +85,10 @@ struct BinView {
     u32*    digit_totals;
     int     nblocks_sort;
     int     passes;          // radix passes over the tile id
-    u32*    point_list;      // vals after the last pass
-    u32*    tile_sorted;     // keys after the last pass
+    u32*    point_list;      // vals after the last pass (radix path) / the per-tile sorted ids (tile-binned path)
+    u32*    tile_sorted;     // keys after the last pass (radix path only)
+    u32*    ids;             // tile-binned path: Gaussian id per instance, grouped by tile, unsorted inside a tile
+    uint2*  kv;              // tile-binned path: (depth key, id) scratch of the global-memory sort (lists of > 8192 entries only)
 };
 struct ImgView {
     float* final_T;          // [H*W]
@@ -89,12 +97,17 @@ struct ImgView {
     // x,y,z by tile_order_kernel, w by blend_fwd; decides which workgroup of a blend launch takes which tile.
     uint4* tile_desc;
     u32*   n_active;         // [1] tiles that hold at least one instance (they come first in tile_desc)
+    // tile-binned path (binning.hip): (block of Gaussians, tile) instance counts and their prefix over the blocks
+    u32*   cnt_rows;         // [256][(T+1)/2] packed 16-bit counters
+    u32*   pre;              // [256][T]
+    u32*   tile_total;       // [T]
+    uint2* ranges;           // [T]
 };
 
 int radix_items_for(long long n);
 int radix_blocks_for(long long n);
 size_t carve_geom(void* base, int P, GeomView* v);
-size_t carve_binning(void* base, long long I, int W, int H, BinView* v);
+size_t carve_binning(void* base, long long I, int W, int H, BinView* v, bool binned = false);
 size_t carve_image(void* base, int W, int H, ImgView* v);
 
 // ---- launchers (each enqueues on `st`; returns hipError_t) --------------------------------------------------
@@ -110,7 +123,7 @@ hipError_t launch_tile_ranges(const u32* tile_sorted, long long I, uint2* ranges
                               const u32* n_dev, bool cleared);
 hipError_t launch_tile_order(const uint2* ranges, int T, uint4* tile_desc, u32* n_active, hipStream_t st);
 hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
-                            const BagsForwardOut& out, hipStream_t st);
+                            const BagsForwardOut& out, hipStream_t st, const u32* n_dev = nullptr, u32 capacity = 0);
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
                             const float* grad_color, float* partials, bool want_abs, hipStream_t st);
 hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, const int32_t* radii_or_null,
@@ -145,5 +158,13 @@ hipError_t launch_activations_bwd(int P, int K, const float* dc, const float* re
 // knn.hip: mean squared distance to the three nearest neighbours (distCUDA2)
 size_t knn_workspace_bytes(int P);
 hipError_t launch_knn(const float* pts, int P, void* ws, float* out, hipStream_t st);
+// binning.hip: tile-binned instance lists (no global sort)
+int binned_per_block(int P);
+bool binned_supported(int P, int T);
+hipError_t launch_binned_empty(const GeomView& g, const ImgView& im, int T, hipStream_t st);
+hipError_t launch_binned_prepare(const GeomView& g, const ImgView& im, int P, int grid_x, int T, hipStream_t st);
+hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int grid_x, int T, u32* ids, uint2* kv, u32* point_list,
+                                u32 capacity, const u32* n_dev, hipStream_t st);
+hipError_t launch_debug_keys_ranges(const uint2* ranges, const u32* point_list, const u32* depth_key, int T, u64* out, hipStream_t st);
 hipError_t launch_debug_keys(const u32* tile_sorted, const u32* point_list, const u32* depth_key, long long I, u64* out, hipStream_t st);
 hipError_t launch_unpack_rect(const uint2* rect, int P, u32* out, hipStream_t st);

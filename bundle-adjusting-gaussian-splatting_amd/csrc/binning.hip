@@ -1,0 +1,552 @@
+// binning.hip -- K2..K5, tile-binned: per-tile depth-ordered instance lists without a global sort.
+//
+// The stock pipeline radix-sorts I (tile | depth) keys; the first version here sorted the P Gaussians by depth, emitted in
+// that order and stable-sorted the I instances by tile (sort.hip: 20 launches of 5-22 us each, every one of them bounded by
+// launch / dependency latency, 0.20 ms of a 1.0 ms step).  The same lists come out of FIVE launches that never order
+// anything globally:
+//   1. tile_count      one workgroup per block of ~P/256 consecutive Gaussians counts its instances per tile in LDS (packed
+//                      16-bit counters, integer LDS atomics: counts do not depend on arrival order) and writes one row of
+//                      the (block, tile) count matrix; also each Gaussian's instance offset inside its block
+//   2. tile_prefix     per tile: exclusive prefix of the matrix column over the blocks, and the tile's total
+//   3. ranges_order    ONE workgroup: exclusive scan of the tile totals = the tile ranges and the instance count; scan of
+//                      the block totals; the heavy-first tile descriptor list of the blend launches
+//   4. emit_binned     same workgroups as 1.: instance -> slot from a per-tile cursor in LDS (range start + column prefix,
+//                      bumped by a returning LDS atomic: arbitrary order inside a (block, tile) group), writes the Gaussian id
+//   5. tile_sort       one WAVE per tile sorts its (depth key, id) words in LDS (one-pass bucket sort; bitonic network for
+//                      clustered keys and for lists of more than 1024 entries)
+// (depth key, id) is a strict total order, so the sorted list is unique: bit-identical to the stable sort of the 64-bit
+// keys whatever order the atomics of step 4 retired in, and bitwise reproducible.  No global atomics anywhere.
+// Limits: tiles * 2 bytes of LDS (<= 32768 tiles: up to 4K images) and <= 65535 Gaussians per block (P <= 16.7 M);
+// beyond them, or on request (BagsSettings.binning), api.hip falls back to the radix path of sort.hip.
+#include "bags_common.h"
+
+#define BIN_COOP 64          // rectangles of more tiles than this are walked by the whole wave
+#define BIN_THREADS 1024     // count / emit workgroup: one block of Gaussians = one workgroup = one row of the count matrix;
+                             // 256 threads left every thread eight Gaussians to walk one after the other (latency bound)
+
+// ------------------------------------------------------------------------------------------------ 1. tile_count
+// Packed counters: tile t lives in the (t & 1) half of word t >> 1.  A half never overflows: a Gaussian covers a tile at
+// most once, so a (block, tile) count is at most the block size (<= 65535 by construction).
+__device__ __forceinline__ u32 lds_count_tile(u32* cnt, u32 t) { return atomicAdd(&cnt[t >> 1], 1u << ((t & 1u) * 16u)); }
+
+// COUNT: packed 16-bit counters.  EMIT: `cnt` holds one 32-bit slot cursor per tile (range start + column prefix of this
+// block, loaded as two coalesced rows); the returning LDS atomic hands the instance its final slot, and the Gaussian id is
+// the only thing written (the per-tile sort fetches the depth key by id: a 4-byte scattered store per instance instead of
+// two scattered loads and an 8-byte store -- the request rate of the L2 channels, not the bytes, bounded this kernel).
+template <bool EMIT>
+__device__ __forceinline__ void walk_rect(u32* cnt, uint2 rc, int grid_x, int lane, bool coop, u32 g, u32* __restrict__ ids)
+{
+    const int minx = rc.x & 0xFFFF, miny = rc.x >> 16, w = (int)(rc.y & 0xFFFF) - minx, h = (int)(rc.y >> 16) - miny;
+    const int nt = w * h;
+    for (int k = coop ? lane : 0; k < nt; k += coop ? 64 : 1) {
+        const int dy = k / w, dx = k - dy * w;
+        const u32 t = (u32)((miny + dy) * grid_x + minx + dx);
+        if (EMIT) ids[atomicAdd(&cnt[t], 1u)] = g;
+        else (void)lds_count_tile(cnt, t);
+    }
+}
+
+// Shared body of tile_count (EMIT = false) and emit_binned (EMIT = true): the block's Gaussians, thread by thread in
+// contiguous runs; small rectangles by their own lane, large ones by the whole wave.
+template <bool EMIT>
+__device__ __forceinline__ u32 walk_block(u32* cnt, int P, int per_block, int grid_x, const uint2* __restrict__ rect,
+                                          const u32* __restrict__ tiles_touched, u32* __restrict__ ids)
+{
+    const int lane = threadIdx.x & 63;
+    const int per_thread = per_block / BIN_THREADS;
+    const long long g0 = (long long)blockIdx.x * per_block + (long long)threadIdx.x * per_thread;
+    u32 mine = 0;
+    for (int k0 = 0; k0 < per_thread; k0 += 4) {            // uniform trip counts: the ballots below need every lane
+        // four Gaussians' counts and rectangles requested together, unconditionally (clamped index): one memory round trip
+        // per batch instead of two per Gaussian
+        u32 ntv[4]; uint2 rcv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long g = g0 + k0 + u;
+            const long long gc = g < P ? g : (long long)P - 1;
+            ntv[u] = tiles_touched[gc]; rcv[u] = rect[gc];
+            if (!(g < P) || k0 + u >= per_thread) ntv[u] = 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long g = g0 + k0 + u;
+            const u32 nt = ntv[u]; const uint2 rc = rcv[u];
+            mine += nt;
+            if (nt > 0 && nt <= BIN_COOP) walk_rect<EMIT>(cnt, rc, grid_x, lane, false, (u32)g, ids);
+            u64 big = __ballot(nt > BIN_COOP);
+            while (big) {
+                const int src = __ffsll((long long)big) - 1;
+                big &= big - 1;
+                const uint2 brc = make_uint2((u32)__shfl((int)rc.x, src), (u32)__shfl((int)rc.y, src));
+                const u32 bg = (u32)__shfl((int)(u32)g, src);
+                walk_rect<EMIT>(cnt, brc, grid_x, lane, true, bg, ids);
+            }
+        }
+    }
+    return mine;
+}
+
+__global__ void __launch_bounds__(BIN_THREADS)
+tile_count_kernel(int P, int per_block, int grid_x, int T2, const uint2* __restrict__ rect, const u32* __restrict__ tiles_touched,
+                  u32* __restrict__ cnt_rows, u32* __restrict__ local_off, u32* __restrict__ block_total)
+{
+    extern __shared__ u32 cnt[];                             // T2 packed words
+    __shared__ u32 wsum[BIN_THREADS / 64];
+    for (int i = threadIdx.x; i < T2; i += BIN_THREADS) cnt[i] = 0u;
+    __syncthreads();
+    const u32 mine = walk_block<false>(cnt, P, per_block, grid_x, rect, tiles_touched, nullptr);
+    // instance offset of every Gaussian inside its block (id order): exclusive scan of the threads' sums, then a second
+    // walk over the thread's own run
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)incl, d); if (lane >= d) incl += o; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();                                         // also: every counter of the block is final
+    u32 run = incl - mine;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    const int per_thread = per_block / BIN_THREADS;
+    const long long g0 = (long long)blockIdx.x * per_block + (long long)threadIdx.x * per_thread;
+    for (int k = 0; k < per_thread; ++k) {
+        const long long g = g0 + k;
+        if (g < P) { local_off[g] = run; run += tiles_touched[g]; }
+    }
+    if (threadIdx.x == BIN_THREADS - 1) block_total[blockIdx.x] = run;
+    u32* row = cnt_rows + (size_t)blockIdx.x * T2;
+    for (int i = threadIdx.x; i < T2; i += BIN_THREADS) row[i] = cnt[i];
+}
+
+// ------------------------------------------------------------------------------------------------ 2. tile_prefix
+// lane = packed word (two tiles), wave = a quarter of the blocks; the lane's <= 64 words stay in registers between the
+// summing pass and the writing pass, so the matrix is read once and the prefix written once.
+__global__ void __launch_bounds__(256)
+tile_prefix_kernel(const u32* __restrict__ cnt_rows, int B, int T, int T2, u32* __restrict__ pre, u32* __restrict__ tile_total)
+{
+    __shared__ u32 qsum[4][64][2];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int w = blockIdx.x * 64 + lane;                    // packed word = tiles 2w, 2w + 1
+    const int per_q = (B + 3) / 4, b0 = q * per_q, b1 = min(B, b0 + per_q);
+    u32 v[64];
+    u32 s0 = 0, s1 = 0;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const int b = b0 + i;
+        v[i] = (w < T2 && b < b1) ? cnt_rows[(size_t)b * T2 + w] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < 64; ++i) { s0 += v[i] & 0xFFFFu; s1 += v[i] >> 16; }
+    qsum[q][lane][0] = s0; qsum[q][lane][1] = s1;
+    __syncthreads();
+    u32 r0 = 0, r1 = 0;
+    for (int p = 0; p < q; ++p) { r0 += qsum[p][lane][0]; r1 += qsum[p][lane][1]; }
+    const int t0 = 2 * w;
+    if (w < T2) {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const int b = b0 + i;
+            if (b < b1) {
+                u32* dst = pre + (size_t)b * T + t0;
+                dst[0] = r0;
+                if (t0 + 1 < T) dst[1] = r1;
+                r0 += v[i] & 0xFFFFu; r1 += v[i] >> 16;
+            }
+        }
+        if (q == 3) {                                        // the last quarter ends on the column totals
+            tile_total[t0] = r0;
+            if (t0 + 1 < T) tile_total[t0 + 1] = r1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ 3. ranges_order
+// One workgroup: tile ranges (exclusive scan of the tile totals), instance count, block bases, and the heavy-first tile
+// descriptor list (same ordering rule as tile_order_kernel of sort.hip; see there and blend.hip for why).
+#define TSORT_WAVE 1024                                     // longest list the one-wave-per-tile sort takes
+#define ORD_LEVELS 64
+#define ORD_SUB 32
+__device__ __forceinline__ int ord_level(u32 n)
+{
+    if (n == 0) return ORD_LEVELS - 1;
+    const int e = 31 - __clz((int)n);
+    const int frac = (e >= 2) ? (int)((n >> (e - 2)) & 3u) : (int)((n << (2 - e)) & 3u);
+    return ORD_LEVELS - 2 - min(ORD_LEVELS - 2, e * 4 + frac);
+}
+__device__ __forceinline__ u32 block_excl_scan_1024(u32 v, u32* s_wave /*[17]*/)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)incl, d); if (lane >= d) incl += o; }
+    __syncthreads();                                         // s_wave free again
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    u32 before = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) before += (w < wave) ? s_wave[w] : 0u;
+    if (threadIdx.x == 1023) s_wave[16] = before + incl;      // grand total
+    return before + incl - v;
+}
+#define ORD_PER_MAX 32                                      // tiles per thread: 1024 x 32 = 32768 tiles at most
+template <int ORD_PER>
+__global__ void __launch_bounds__(1024)
+ranges_order_kernel(const u32* __restrict__ tile_total, int T, uint2* __restrict__ ranges, uint4* __restrict__ tile_desc,
+                    u32* __restrict__ n_active, const u32* __restrict__ block_total, int B, u32* __restrict__ block_base,
+                    u32* __restrict__ num_rendered)
+{
+    __shared__ u32 s_cur[ORD_LEVELS * ORD_SUB];
+    __shared__ u32 s_wave[17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // thread tid owns the contiguous tiles [ta, tb): their counts stay in registers for all three passes
+    const int per = (T + 1023) / 1024;
+    const int ta = min(T, tid * per), tb = min(T, ta + per);
+    u32 cntv[ORD_PER];
+    u32 sum = 0;
+#pragma unroll
+    for (int i = 0; i < ORD_PER; ++i) { cntv[i] = (i < per && ta + i < tb) ? tile_total[ta + i] : 0u; sum += cntv[i]; }
+    const u32 first = block_excl_scan_1024(sum, s_wave);
+    {
+        u32 run = first;
+#pragma unroll
+        for (int i = 0; i < ORD_PER; ++i)
+            if (i < per && ta + i < tb) { ranges[ta + i] = make_uint2(run, run + cntv[i]); run += cntv[i]; }
+    }
+    __syncthreads();
+    if (tid == 0) num_rendered[0] = s_wave[16];
+    // ---- block bases (B <= 256)
+    {
+        const u32 v = (tid < B) ? block_total[tid] : 0u;
+        const u32 ex = block_excl_scan_1024(v, s_wave);
+        if (tid < B) block_base[tid] = ex;
+    }
+    // ---- heavy-first descriptor list: counting sort of the tiles by instance count (ORD_LEVELS levels, four per octave,
+    // ORD_SUB sub-counters per level picked by (tile >> 3) & 31: a thread's tiles are neighbours, so threads hit different
+    // sub-counters and runs of neighbouring tiles stay together in the list)
+    s_cur[tid] = 0; s_cur[tid + 1024] = 0;
+    __syncthreads();
+    auto counter_of = [&](int t, u32 n) -> int { return ord_level(n) * ORD_SUB + ((t >> 3) & (ORD_SUB - 1)); };
+#pragma unroll
+    for (int i = 0; i < ORD_PER; ++i)
+        if (i < per && ta + i < tb) atomicAdd(&s_cur[counter_of(ta + i, cntv[i])], 1u);
+    __syncthreads();
+    {
+        const u32 c0 = s_cur[2 * tid], c1 = s_cur[2 * tid + 1];
+        u32 inc = c0 + c1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)inc, d); if (lane >= d) inc += o; }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        u32 before = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) before += (w < wave) ? s_wave[w] : 0u;
+        const u32 excl = before + inc - (c0 + c1);
+        s_cur[2 * tid] = excl; s_cur[2 * tid + 1] = excl + c0;
+        if (2 * tid == (ORD_LEVELS - 1) * ORD_SUB) n_active[0] = excl;                       // everything in front of the empty tiles
+        // descriptors [0, n_active[1]) hold every tile of more than TSORT_WAVE instances (whole levels: a few shorter
+        // tiles of the boundary level come along and are skipped by the large-list sort)
+        if (2 * tid == (ord_level(TSORT_WAVE) + 1) * ORD_SUB) n_active[1] = excl;
+    }
+    __syncthreads();
+    {
+        u32 run = first;
+#pragma unroll
+        for (int i = 0; i < ORD_PER; ++i)
+            if (i < per && ta + i < tb) {
+                tile_desc[atomicAdd(&s_cur[counter_of(ta + i, cntv[i])], 1u)] = make_uint4((u32)(ta + i), run, cntv[i], 0u);
+                run += cntv[i];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ 4. emit_binned
+__global__ void __launch_bounds__(BIN_THREADS)
+emit_binned_kernel(int P, int per_block, int grid_x, int T, const uint2* __restrict__ rect,
+                   const u32* __restrict__ tiles_touched, const u32* __restrict__ pre,
+                   const uint2* __restrict__ ranges, const u32* __restrict__ local_off, const u32* __restrict__ block_base,
+                   u32* __restrict__ inst_off, u32* __restrict__ ids, u32 capacity, const u32* __restrict__ n_dev)
+{
+    extern __shared__ u32 cur[];                             // T slot cursors
+    // the instance offset of a Gaussian's records (blend_bwd's emission slots, preprocess_bwd's record sums): written even
+    // when a speculative capacity turns out too small -- the caller then reruns this launch on an exact buffer
+    {
+        const int per_thread = per_block / BIN_THREADS;
+        const long long g0 = (long long)blockIdx.x * per_block + (long long)threadIdx.x * per_thread;
+        const u32 base = block_base[blockIdx.x];
+        for (int k = 0; k < per_thread; ++k) {
+            const long long g = g0 + k;
+            if (g < P) inst_off[g] = base + local_off[g];
+        }
+    }
+    if (n_dev && *n_dev > capacity) return;
+    const u32* prow = pre + (size_t)blockIdx.x * T;
+    for (int t = threadIdx.x; t < T; t += BIN_THREADS) cur[t] = ranges[t].x + prow[t];
+    __syncthreads();
+    (void)walk_block<true>(cur, P, per_block, grid_x, rect, tiles_touched, ids);
+}
+
+// ------------------------------------------------------------------------------------------------ 5. tile_sort
+// Bitonic network in its all-ascending form (first sub-stage of a merge pairs i with its mirror image in the block, the
+// others are plain half-cleaners): with every compare-exchange ascending, the list may be thought of as padded with
+// +infinity up to the next power of two and a pair whose upper index is >= n is simply skipped.
+
+// One WAVE per tile (64-thread workgroup, no workgroup barriers): 8160 independent waves fill the chip in one round.
+// The sort is a one-pass bucket sort: depth keys of one tile are spread fairly evenly between the tile's nearest and
+// farthest splat, so with as many buckets as entries (bucket = floor((key - min) * n / (max - min + 1)), monotone in the
+// key) a bucket holds one or two entries; the rank of an entry is its bucket's start + the number of entries of the same
+// bucket that compare below it on the full (key, id) word.  ~100 instructions per 64 entries, against ~2600 per 512-entry
+// list for a bitonic network (which sorted the bench frame's lists in 52-58 us; it remains the fallback for a list whose
+// keys cluster -- more than TS_BUCKET_MAX entries in one bucket -- so the worst case stays O(n log^2 n)).
+// Two size classes (lists of up to 512 and of 513..1024 entries, one launch each over all tiles): the short class needs 7 KB
+// of LDS and ~60 VGPRs per wave, so that the whole frame's 8160 waves are resident at once.
+#define TS_BUCKET_MAX 24
+template <int TS_PER>
+__global__ void __launch_bounds__(64)
+tile_sort_wave_kernel(const uint4* __restrict__ tile_desc, const u32* __restrict__ ids_in, const u32* __restrict__ depth_key,
+                      u32* __restrict__ point_list, u32 n_lo, u32 capacity, const u32* __restrict__ n_dev)
+{
+    __shared__ u64 t[64 * TS_PER];                           // bucket-grouped entries (or the bitonic fallback's array)
+    __shared__ u32 cnt[64 * TS_PER];                         // bucket counters, then bucket starts
+    __shared__ unsigned short bid[64 * TS_PER];              // bucket of the entry at a grouped position
+    if (n_dev && *n_dev > capacity) return;
+    const uint4 desc = tile_desc[blockIdx.x];
+    const u32 n = desc.z, start = desc.y;
+    if (n <= n_lo || n > 64 * TS_PER) return;                // empty, or the other class's
+    const u32 lane = threadIdx.x;
+    if (n == 1) { if (lane == 0) point_list[start] = ids_in[start]; return; }
+    const u32 rounds = (n + 63) >> 6;
+    // all id loads in one batch, then all key gathers in one batch (clamped indices instead of branches: a branch per round
+    // made every round wait for its own two memory round trips, 16 x 2 of them for a 1024-entry list)
+    u64 e[TS_PER];
+    u32 idv[TS_PER];
+    u32 kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+    for (u32 r = 0; r < TS_PER; ++r) idv[r] = ids_in[start + min(r * 64 + lane, n - 1)];
+#pragma unroll
+    for (u32 r = 0; r < TS_PER; ++r) {
+        const u32 key = depth_key[idv[r]];
+        const bool valid = r * 64 + lane < n;
+        e[r] = valid ? (((u64)key << 32) | (u64)idv[r]) : ~0ull;
+        kmin = min(kmin, valid ? key : 0xFFFFFFFFu); kmax = max(kmax, valid ? key : 0u);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { kmin = min(kmin, (u32)__shfl_xor((int)kmin, d)); kmax = max(kmax, (u32)__shfl_xor((int)kmax, d)); }
+    const u32 nb = n;
+    const float scale = (float)nb / ((float)(kmax - kmin) + 1.0f);
+    for (u32 i = lane; i < nb; i += 64) cnt[i] = 0u;
+    __syncthreads();                                          // a one-wave workgroup: orders the LDS accesses, costs nothing
+    u32 bk[TS_PER], rk[TS_PER];
+#pragma unroll
+    for (u32 r = 0; r < TS_PER; ++r) {
+        bk[r] = 0; rk[r] = 0;
+        if (r < rounds && r * 64 + lane < n) {
+            const u32 key = (u32)(e[r] >> 32);
+            bk[r] = min(nb - 1, (u32)((float)(key - kmin) * scale));
+            rk[r] = atomicAdd(&cnt[bk[r]], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the bucket counts (in place) and the fullest bucket
+    u32 carry = 0, maxc = 0;
+    for (u32 base = 0; base < nb; base += 64) {
+        const u32 c = (base + lane < nb) ? cnt[base + lane] : 0u;
+        maxc = max(maxc, c);
+        u32 incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)incl, d); if ((int)lane >= d) incl += o; }
+        if (base + lane < nb) cnt[base + lane] = carry + incl - c;
+        carry += (u32)__shfl((int)incl, 63);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) maxc = max(maxc, (u32)__shfl_xor((int)maxc, d));
+    __syncthreads();
+    if (maxc > TS_BUCKET_MAX) {                               // clustered keys: bitonic network on the whole list
+#pragma unroll
+        for (u32 r = 0; r < TS_PER; ++r)
+            if (r < rounds && r * 64 + lane < n) t[r * 64 + lane] = e[r];
+        u32 N = 2; while (N < n) N <<= 1;
+        __syncthreads();
+        for (u32 k = 2; k <= N; k <<= 1) {
+            const u32 hk = k >> 1;
+            for (u32 i = lane; i < (N >> 1); i += 64) {       // mirror stage
+                const u32 blk = i / hk, r = i - blk * hk;
+                const u32 a = blk * k + r, b = blk * k + (k - 1 - r);
+                if (b < n) { const u64 x = t[a], y = t[b]; if (y < x) { t[a] = y; t[b] = x; } }
+            }
+            __syncthreads();
+            for (u32 j = k >> 2; j >= 1; j >>= 1) {
+                for (u32 i = lane; i < (N >> 1); i += 64) {
+                    const u32 a = (i / j) * (2 * j) + (i & (j - 1)), b = a + j;
+                    if (b < n) { const u64 x = t[a], y = t[b]; if (y < x) { t[a] = y; t[b] = x; } }
+                }
+                __syncthreads();
+            }
+        }
+        for (u32 i = lane; i < n; i += 64) point_list[start + i] = (u32)t[i];
+        return;
+    }
+    // entries grouped by bucket (order inside a bucket = the order the atomics retired in: irrelevant, see below)
+#pragma unroll
+    for (u32 r = 0; r < TS_PER; ++r)
+        if (r < rounds && r * 64 + lane < n) {
+            const u32 p = cnt[bk[r]] + rk[r];
+            t[p] = e[r]; bid[p] = (unsigned short)bk[r];
+        }
+    __syncthreads();
+    // final position = bucket start + number of entries of the bucket below this one in (key, id) order: unique words, so
+    // every entry of a bucket gets a different rank whatever order they arrived in
+    for (u32 p = lane; p < n; p += 64) {
+        const u32 b = bid[p];
+        const u32 bs = cnt[b], be = (b + 1 < nb) ? cnt[b + 1] : n;
+        const u64 x = t[p];
+        u32 rank = 0;
+        for (u32 q = bs; q < be; ++q) rank += (t[q] < x) ? 1u : 0u;
+        point_list[start + bs + rank] = (u32)x;
+    }
+}
+
+// Lists of more than TSORT_WAVE entries: a fixed grid of 256-thread workgroups walks the front of the heavy-first
+// descriptor list (n_active[1] entries, all of them long lists plus a few of the boundary level).  Up to TSORT_LARGE
+// entries the network runs in LDS; beyond that (tens of thousands of splats over ONE tile: a camera far from the scene,
+// adversarial inputs) in global memory, with loads and stores at agent scope so that the waves of the workgroup see each
+// other's exchanges across the barriers.  Slow, correct, never on the path of an ordinary frame.
+#define TSORT_LARGE 8192
+__global__ void __launch_bounds__(256)
+tile_sort_large_kernel(const uint4* __restrict__ tile_desc, const u32* __restrict__ n_active, const u32* __restrict__ ids_in,
+                       const u32* __restrict__ depth_key, uint2* __restrict__ kv, u32* __restrict__ point_list, u32 capacity,
+                       const u32* __restrict__ n_dev)
+{
+    __shared__ u64 s[TSORT_LARGE];
+    if (n_dev && *n_dev > capacity) return;
+    const u32 n_long = n_active[1];
+    const int tid = threadIdx.x;
+    for (u32 d = blockIdx.x; d < n_long; d += gridDim.x) {
+        const uint4 desc = tile_desc[d];
+        const u32 n = desc.z, start = desc.y;
+        if (n <= TSORT_WAVE) continue;                        // uniform over the workgroup
+        u32 N = 2; while (N < n) N <<= 1;
+        if (n <= TSORT_LARGE) {
+            __syncthreads();                                  // the previous tile's read-out is complete
+            for (u32 i = tid; i < n; i += 256) { const u32 id = ids_in[start + i]; s[i] = ((u64)depth_key[id] << 32) | (u64)id; }
+            __syncthreads();
+            for (u32 k = 2; k <= N; k <<= 1) {
+                const u32 hk = k >> 1;
+                for (u32 i = tid; i < (N >> 1); i += 256) {
+                    const u32 blk = i / hk, r = i - blk * hk;
+                    const u32 a = blk * k + r, b = blk * k + (k - 1 - r);
+                    if (b < n) { const u64 x = s[a], y = s[b]; if (y < x) { s[a] = y; s[b] = x; } }
+                }
+                __syncthreads();
+                for (u32 j = k >> 2; j >= 1; j >>= 1) {
+                    for (u32 i = tid; i < (N >> 1); i += 256) {
+                        const u32 a = (i / j) * (2 * j) + (i & (j - 1)), b = a + j;
+                        if (b < n) { const u64 x = s[a], y = s[b]; if (y < x) { s[a] = y; s[b] = x; } }
+                    }
+                    __syncthreads();
+                }
+            }
+            for (u32 i = tid; i < n; i += 256) point_list[start + i] = (u32)s[i];
+            continue;
+        }
+        // (key, id) pairs of this tile into the scratch array; read back as one little-endian word the id is the HIGH half
+        for (u32 i = tid; i < n; i += 256) { const u32 id = ids_in[start + i]; kv[start + i] = make_uint2(depth_key[id], id); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __threadfence();
+        __syncthreads();
+        u64* gsm = reinterpret_cast<u64*>(kv + start);
+        auto ld = [&](u32 i) -> u64 { const u64 v = __hip_atomic_load(&gsm[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return (v << 32) | (v >> 32); };
+        auto st = [&](u32 i, u64 v) { __hip_atomic_store(&gsm[i], (v << 32) | (v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        for (u32 k = 2; k <= N; k <<= 1) {
+            const u32 hk = k >> 1;
+            for (u32 i = tid; i < (N >> 1); i += 256) {
+                const u32 blk = i / hk, r = i - blk * hk;
+                const u32 a = blk * k + r, b = blk * k + (k - 1 - r);
+                if (b < n) { const u64 x = ld(a), y = ld(b); if (y < x) { st(a, y); st(b, x); } }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (u32 j = k >> 2; j >= 1; j >>= 1) {
+                for (u32 i = tid; i < (N >> 1); i += 256) {
+                    const u32 a = (i / j) * (2 * j) + (i & (j - 1)), b = a + j;
+                    if (b < n) { const u64 x = ld(a), y = ld(b); if (y < x) { st(a, y); st(b, x); } }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+        for (u32 i = tid; i < n; i += 256) point_list[start + i] = (u32)ld(i);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+static void launch_ranges_order(const ImgView& im, const GeomView& g, int T, int B, hipStream_t st)
+{
+#define RO_ARGS dim3(1), dim3(1024), 0, st, im.tile_total, T, im.ranges, im.tile_desc, im.n_active, g.block_total, B, g.block_base, g.num_rendered
+    if (T <= 1024 * 8) hipLaunchKernelGGL(ranges_order_kernel<8>, RO_ARGS);
+    else if (T <= 1024 * 16) hipLaunchKernelGGL(ranges_order_kernel<16>, RO_ARGS);
+    else hipLaunchKernelGGL(ranges_order_kernel<32>, RO_ARGS);
+#undef RO_ARGS
+}
+int binned_per_block(int P)
+{
+    int per = (P + 255) / 256;                                // <= 256 blocks
+    per = (per + BIN_THREADS - 1) / BIN_THREADS * BIN_THREADS;   // a multiple of the workgroup size
+    return per < BIN_THREADS ? BIN_THREADS : per;
+}
+bool binned_supported(int P, int T)
+{
+    return T <= 1024 * ORD_PER_MAX && ((T + 1) / 2) * 4 <= 65536 && binned_per_block(P) <= 65535;
+}
+
+hipError_t launch_binned_prepare(const GeomView& g, const ImgView& im, int P, int grid_x, int T, hipStream_t st)
+{
+    const int per = binned_per_block(P), B = cdiv(P, per), T2 = (T + 1) / 2;
+    hipLaunchKernelGGL(tile_count_kernel, dim3(B), dim3(BIN_THREADS), (size_t)T2 * 4, st, P, per, grid_x, T2, g.rect, g.tiles_touched,
+                       im.cnt_rows, g.local_off, g.block_total);
+    hipLaunchKernelGGL(tile_prefix_kernel, dim3(cdiv(T2, 64)), dim3(256), 0, st, im.cnt_rows, B, T, T2, im.pre, im.tile_total);
+    launch_ranges_order(im, g, T, B, st);
+    return hipGetLastError();
+}
+
+// P == 0: no Gaussian block exists; the tile list is all empty tiles
+hipError_t launch_binned_empty(const GeomView& g, const ImgView& im, int T, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(im.tile_total, 0, sizeof(u32) * (size_t)T, st);
+    if (e != hipSuccess) return e;
+    launch_ranges_order(im, g, T, 0, st);
+    return hipGetLastError();
+}
+
+hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int grid_x, int T, u32* ids, uint2* kv, u32* point_list,
+                                u32 capacity, const u32* n_dev, hipStream_t st)
+{
+    const int per = binned_per_block(P), B = cdiv(P, per);
+    const size_t cursors = (size_t)T * 4;                     // up to 128 KB of LDS at 32768 tiles: one workgroup per CU
+    if (cursors > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(emit_binned_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cursors);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(emit_binned_kernel, dim3(B), dim3(BIN_THREADS), cursors, st, P, per, grid_x, T, g.rect, g.tiles_touched,
+                       im.pre, im.ranges, g.local_off, g.block_base, g.inst_off, ids, capacity, n_dev);
+    // long lists first: their few workgroups run beside the many short sorts of the second launch
+    hipLaunchKernelGGL(tile_sort_large_kernel, dim3(T < 128 ? T : 128), dim3(256), 0, st, im.tile_desc, im.n_active, ids, g.depth_key, kv,
+                       point_list, capacity, n_dev);
+    hipLaunchKernelGGL(tile_sort_wave_kernel<TSORT_WAVE / 64>, dim3(T), dim3(64), 0, st, im.tile_desc, ids, g.depth_key, point_list,
+                       (u32)(TSORT_WAVE / 2), capacity, n_dev);
+    hipLaunchKernelGGL(tile_sort_wave_kernel<TSORT_WAVE / 128>, dim3(T), dim3(64), 0, st, im.tile_desc, ids, g.depth_key, point_list, 0u,
+                       capacity, n_dev);
+    return hipGetLastError();
+}
+
+// 64-bit (tile | depth) keys of the sorted list, for the parity tests
+__global__ void debug_keys_ranges_kernel(const uint2* ranges, const u32* point_list, const u32* depth_key, int T, u64* out)
+{
+    const int t = blockIdx.x;
+    if (t >= T) return;
+    const uint2 r = ranges[t];
+    for (u32 i = r.x + threadIdx.x; i < r.y; i += blockDim.x) out[i] = ((u64)t << 32) | (u64)depth_key[point_list[i]];
+}
+hipError_t launch_debug_keys_ranges(const uint2* ranges, const u32* point_list, const u32* depth_key, int T, u64* out, hipStream_t st)
+{
+    if (T <= 0) return hipSuccess;
+    hipLaunchKernelGGL(debug_keys_ranges_kernel, dim3(T), dim3(128), 0, st, ranges, point_list, depth_key, T, out);
+    return hipGetLastError();
+}

@@ -214,9 +214,9 @@ struct TileRef { int tx, ty; u32 rx, n, maxc; };   // wave-uniform: tile coordin
 template <bool ABS>
 __global__ void __launch_bounds__(256, SCAN_WG_PER_CU)
 blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__ tile_desc,
-                      const u32* __restrict__ point_list, const float4* __restrict__ g2d, const float* __restrict__ bg,
-                      const float* __restrict__ final_T, const u32* __restrict__ n_contrib, const float* __restrict__ grad_color,
-                      float* __restrict__ partials)
+                      const u32* __restrict__ point_list, const float4* __restrict__ g2d, const u32* __restrict__ inst_off,
+                      const float* __restrict__ bg, const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
+                      const float* __restrict__ grad_color, float* __restrict__ partials)
 {
     // One workgroup per tile that holds at least one instance, heavy tiles first (slot_of_vblock).  Tried and dropped:
     // persistent workgroups that run the chunk pipeline over the flattened (tile, chunk) sequence, with the next tile's
@@ -260,7 +260,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         Raw r; r.q0 = make_float4(0.f, 0.f, 0.f, 0.f); r.q1 = r.q0; r.q2 = r.q0; r.io = 0u;
         if (g != 0xFFFFFFFFu) {                       // one 64-byte line
             const float4* rec = g2d + 4 * (size_t)g;
-            r.q0 = rec[0]; r.q1 = rec[1]; r.q2 = rec[2]; r.io = __float_as_uint(rec[3].x);
+            r.q0 = rec[0]; r.q1 = rec[1]; r.q2 = rec[2]; r.io = inst_off[g];
         }
         return r;
     };
@@ -311,7 +311,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         for (u32 p = t.maxc + tid; p < t.n; p += 256) {
             const u32 g = point_list[t.rx + p];
             const float4 t2 = g2d[4 * (size_t)g + 2];
-            const u32 e = emission_slot(__float_as_uint(g2d[4 * (size_t)g + 3].x), make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)), t.tx, t.ty);
+            const u32 e = emission_slot(inst_off[g], make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)), t.tx, t.ty);
             float4* dst = reinterpret_cast<float4*>(partials + (size_t)e * PART_FLOATS);
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
             dst[0] = z4; dst[1] = z4; dst[2] = z4;
@@ -591,11 +591,11 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     const int grid = cdiv(T, TILE_RUN) * TILE_RUN;
     if (want_abs)
         hipLaunchKernelGGL(blend_bwd_scan_kernel<true>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
-                           im.tile_desc, b.point_list, g.g2d, s.bg,
+                           im.tile_desc, b.point_list, g.g2d, g.inst_off, s.bg,
                            im.final_T, im.n_contrib, grad_color, partials);
     else
         hipLaunchKernelGGL(blend_bwd_scan_kernel<false>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
-                           im.tile_desc, b.point_list, g.g2d, s.bg,
+                           im.tile_desc, b.point_list, g.g2d, g.inst_off, s.bg,
                            im.final_T, im.n_contrib, grad_color, partials);
     return hipGetLastError();
 }
@@ -622,11 +622,14 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU)
 blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_desc, const u32* __restrict__ point_list,
                       const float4* __restrict__ g2d, const float* __restrict__ bg, float* __restrict__ out_color,
                       float* __restrict__ out_depth, float* __restrict__ out_weights, float* __restrict__ final_T,
-                      u32* __restrict__ n_contrib)
+                      u32* __restrict__ n_contrib, const u32* __restrict__ n_dev, u32 capacity)
 {
     const int dslot = slot_of_vblock(blockIdx.x);            // heavy tiles first, balanced over the XCDs
     if (dslot >= T) return;
-    const uint4 desc = tile_desc[dslot];                     // {tile, first instance, instances, -}
+    uint4 desc = tile_desc[dslot];                           // {tile, first instance, instances, -}
+    // speculative forward on the tile-binned path: the ranges are known before the lists exist; a list that did not fit
+    // its buffer was never written, so the tile is rendered empty (the caller reruns the phase on an exact buffer)
+    if (n_dev && *n_dev > capacity) desc.z = 0u;
     const int tile = (int)desc.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4, li = lane & 15;
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
@@ -751,7 +754,7 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
 }
 
 hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
-                            const BagsForwardOut& out, hipStream_t st)
+                            const BagsForwardOut& out, hipStream_t st, const u32* n_dev, u32 capacity)
 {
     const int gx = cdiv(s.image_width, BAGS_TILE), gy = cdiv(s.image_height, BAGS_TILE);
     const int T = gx * gy;
@@ -759,6 +762,6 @@ hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinV
     const int grid = cdiv(T, TILE_RUN) * TILE_RUN;
     hipLaunchKernelGGL(blend_fwd_rows_kernel<0>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
                        im.tile_desc, b.point_list, g.g2d, s.bg, out.color, out.depth, out.weights,
-                       im.final_T, im.n_contrib);
+                       im.final_T, im.n_contrib, n_dev, capacity);
     return hipGetLastError();
 }

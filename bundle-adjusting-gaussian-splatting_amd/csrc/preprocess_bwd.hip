@@ -33,7 +33,8 @@ __device__ __forceinline__ float wave_sum(float x)
 #define SUM_COOP 64
 #define RQ (PART_FLOATS / 4)          // float4s per record
 __global__ void __launch_bounds__(256)
-sum_partials_kernel(int P, const float4* __restrict__ g2d, const float* __restrict__ partials, float4* __restrict__ sums)
+sum_partials_kernel(int P, const float4* __restrict__ g2d, const u32* __restrict__ inst_off, const float* __restrict__ partials,
+                    float4* __restrict__ sums)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -41,7 +42,7 @@ sum_partials_kernel(int P, const float4* __restrict__ g2d, const float* __restri
     u32 nrec = 0, first = 0;
     if (i < P) {
         const float4 q3 = g2d[4 * (size_t)i + 3];
-        nrec = __float_as_uint(q3.y); first = __float_as_uint(q3.x);
+        nrec = __float_as_uint(q3.y); first = inst_off[i];
     }
     if (nrec > 0 && nrec <= SUM_COOP) {
         const float4* rec = reinterpret_cast<const float4*>(partials + (size_t)first * PART_FLOATS);
@@ -475,51 +476,53 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     }
 }
 
-// rows -> the five pose tensors, summed in fp64 (25 row-groups x 40 values in flight, fixed order: deterministic)
-#define POSE_GROUPS 25
-__global__ void __launch_bounds__(1024)
+// rows -> the five pose tensors, summed in fp64.  One workgroup per slab column (35 used): thread t adds rows t, t + 256, ...
+// in row order, the 64 partial sums of a wave are added by a fixed shuffle tree, the four wave sums in wave order, so the
+// result is deterministic.  (One 1024-thread workgroup for all 40 columns took 10.5 us: 78 dependent-latency-bound loads
+// per thread; here every thread has its 8 loads in flight at once.)
+__global__ void __launch_bounds__(256)
 pose_reduce_kernel(const float* __restrict__ slab, int nblocks, float* __restrict__ g_view, float* __restrict__ g_proj,
                    float* __restrict__ g_intr, float* __restrict__ g_campos, float* __restrict__ g_shift)
 {
-    __shared__ double part[POSE_GROUPS][POSE_VALS];
-    __shared__ float tot[POSE_VALS];
-    const int t = threadIdx.x % POSE_VALS, grp = threadIdx.x / POSE_VALS;
-    if (grp < POSE_GROUPS) {
-        // rows grp, grp+25, ...: eight independent loads in flight, added in row order (fixed => deterministic)
-        double acc = 0.0;
-        int b = grp;
-        for (; b + 7 * POSE_GROUPS < nblocks; b += 8 * POSE_GROUPS) {
-            float v[8];
+    __shared__ double wsum[4];
+    const int t = blockIdx.x;                            // slab column
+    double acc = 0.0;
+    int b = threadIdx.x;
+    for (; b + 7 * 256 < nblocks; b += 8 * 256) {
+        float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(b + u * POSE_GROUPS) * POSE_VALS + t];
+        for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(b + u * 256) * POSE_VALS + t];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc += (double)v[u];
-        }
-        for (; b < nblocks; b += POSE_GROUPS) acc += (double)slab[(size_t)b * POSE_VALS + t];
-        part[grp][t] = acc;
+        for (int u = 0; u < 8; ++u) acc += (double)v[u];
     }
+    for (; b < nblocks; b += 256) acc += (double)slab[(size_t)b * POSE_VALS + t];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x < POSE_VALS) {
-        double acc = 0.0;
-        for (int g = 0; g < POSE_GROUPS; ++g) acc += part[g][threadIdx.x];
-        tot[threadIdx.x] = (float)acc;
-    }
-    __syncthreads();
-    const int i = threadIdx.x;
-    if (i < 16) {
-        const int r = i >> 2, c = i & 3;
-        if (g_view) g_view[i] = (c < 3) ? tot[r * 3 + c] : 0.f;
-        if (g_proj) g_proj[i] = (c == 2) ? 0.f : tot[12 + r * 3 + (c == 3 ? 2 : c)];
+    if (threadIdx.x != 0) return;
+    const float val = (float)(((wsum[0] + wsum[1]) + wsum[2]) + wsum[3]);
+    // slab layout: [0..11] viewmatrix rows 0..3 x cols 0..2, [12..23] projmatrix rows 0..3 x cols 0,1,3,
+    //              [24] k0 [25] k5 [26] k8 [27] k9 [28] k11, [29..31] campos, [32..34] shift_factors.
+    // The entries of the 4x4 outputs no Gaussian contributes to are written as zeros by the column next to them.
+    if (t < 12) {
+        if (g_view) { g_view[(t / 3) * 4 + t % 3] = val; if (t % 3 == 2) g_view[(t / 3) * 4 + 3] = 0.f; }
+    } else if (t < 24) {
+        const int u = t - 12, r = u / 3, k = u % 3;
+        if (g_proj) { g_proj[r * 4 + (k == 2 ? 3 : k)] = val; if (k == 2) g_proj[r * 4 + 2] = 0.f; }
+    } else if (t < 29) {
+        const int at[5] = {0, 5, 8, 9, 11};
         if (g_intr) {
-            float val = 0.f;
-            if (i == 0) val = tot[24]; else if (i == 5) val = tot[25]; else if (i == 8) val = tot[26];
-            else if (i == 9) val = tot[27]; else if (i == 11) val = tot[28];
-            g_intr[i] = val;
+            g_intr[at[t - 24]] = val;
+            if (t == 24) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) if (i != 0 && i != 5 && i != 8 && i != 9 && i != 11) g_intr[i] = 0.f;
+            }
         }
-    }
-    if (i < 3) {
-        if (g_campos) g_campos[i] = tot[29 + i];
-        if (g_shift) g_shift[i] = tot[32 + i];
+    } else if (t < 32) {
+        if (g_campos) g_campos[t - 29] = val;
+    } else if (t < 35) {
+        if (g_shift) g_shift[t - 32] = val;
     }
 }
 
@@ -531,7 +534,7 @@ hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, co
     const int nb = cdiv(P, 256);
     *nblocks_out = nb;
     if (P == 0) return hipSuccess;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(nb), dim3(256), 0, st, P, g.g2d, partials_records,
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(nb), dim3(256), 0, st, P, g.g2d, g.inst_off, partials_records,
                        reinterpret_cast<float4*>(sums));
     const float* partials = sums;
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nb), dim3(256), 0, st, P, s.sh_coeffs, s.sh_degree, s.image_width,
@@ -545,7 +548,7 @@ hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, co
 
 hipError_t launch_pose_reduce(const float* pose_slab, int nblocks, const BagsBackwardArgs& a, hipStream_t st)
 {
-    hipLaunchKernelGGL(pose_reduce_kernel, dim3(1), dim3(1024), 0, st, pose_slab, nblocks, a.grad_viewmatrix,
+    hipLaunchKernelGGL(pose_reduce_kernel, dim3(35), dim3(256), 0, st, pose_slab, nblocks, a.grad_viewmatrix,
                        a.grad_projmatrix, a.grad_intrinsic, a.grad_campos, a.grad_shift_factors);
     return hipGetLastError();
 }

@@ -244,7 +244,7 @@ offsets_partial_kernel(const u32* __restrict__ sorted_ids, const u32* __restrict
 // item order inside a workgroup here is (thread, item) with SCAN_ITEMS consecutive ranks per thread
 __global__ void __launch_bounds__(SCAN_BLOCK)
 offsets_final_kernel(const u32* __restrict__ sorted_ids, const u32* __restrict__ tiles_touched, int P,
-                     const u32* __restrict__ partials, u32* __restrict__ rank_offset, float4* __restrict__ g2d,
+                     const u32* __restrict__ partials, u32* __restrict__ rank_offset, u32* __restrict__ inst_off,
                      u32* __restrict__ total)
 {
     __shared__ u32 wsum[SCAN_BLOCK / 64], wpre[SCAN_BLOCK / 64];
@@ -280,7 +280,7 @@ offsets_final_kernel(const u32* __restrict__ sorted_ids, const u32* __restrict__
 #pragma unroll
     for (int r = 0; r < SCAN_ITEMS; ++r) {
         const int j = j0 + r;
-        if (j < P) { rank_offset[j] = run; reinterpret_cast<u32*>(g2d)[16 * (size_t)id[r] + 12] = run; }   // q3.x
+        if (j < P) { rank_offset[j] = run; inst_off[id[r]] = run; }
         run += t[r];
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_BLOCK - 1) total[0] = run;       // the instance count
@@ -292,7 +292,7 @@ hipError_t launch_offsets_scan(const GeomView& g, const u32* sorted_ids, int P, 
     const int nb = g.nblocks_scan;
     hipLaunchKernelGGL(offsets_partial_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, st, sorted_ids, g.tiles_touched, P, g.scan_partials);
     hipLaunchKernelGGL(offsets_final_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, st, sorted_ids, g.tiles_touched, P,
-                       g.scan_partials, g.rank_offset, g.g2d, g.num_rendered);
+                       g.scan_partials, g.rank_offset, g.inst_off, g.num_rendered);
     return hipGetLastError();
 }
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BAGS_ABI_VERSION 2
+#define BAGS_ABI_VERSION 3
 #define BAGS_TILE 16
 
 enum { BAGS_OK = 0, BAGS_ERR_ARG = -1, BAGS_ERR_HIP = -2, BAGS_ERR_SIZE = -3, BAGS_ERR_DEVICE = -4 };
@@ -43,6 +43,11 @@ enum { BAGS_DEPTH_Z = 0, BAGS_DEPTH_DISTANCE = 1 };   /* README.md:126: sort key
  * by the compositing loop anyway, so image, radii and every gradient are unchanged while the sorted instance list
  * shrinks (27 % on BASELINE config 3). */
 enum { BAGS_TILES_AABB = 0, BAGS_TILES_OPACITY = 1 };
+/* How the per-tile depth-ordered instance lists are built.  AUTO: tile-binned (csrc/binning.hip: (block, tile) count matrix
+ * in LDS, per-tile sort of (depth, id) pairs in LDS; five launches, no global sort) whenever the image has at most 32768
+ * tiles and P <= 16.7 M, else RADIX.  RADIX: depth-sort the Gaussians, emit, stable radix sort by tile (csrc/sort.hip).
+ * Both produce the same lists bit for bit. */
+enum { BAGS_BINNING_AUTO = 0, BAGS_BINNING_RADIX = 1 };
 
 /* GaussianRasterizationSettings (gaussian_renderer/__init__.py:50-65) */
 typedef struct BagsSettings {
@@ -55,7 +60,7 @@ typedef struct BagsSettings {
     int32_t debug;                   /* !=0: synchronise + check after every kernel */
     int32_t debug_iter;              /* carried for error messages only */
     int32_t tile_bounds;             /* BAGS_TILES_AABB | BAGS_TILES_OPACITY */
-    int32_t reserved0;               /* keeps the pointers 8-byte aligned; must be 0 */
+    int32_t binning;                 /* BAGS_BINNING_AUTO | BAGS_BINNING_RADIX (also keeps the pointers 8-byte aligned) */
     const float* bg;                 /* (3)   */
     const float* viewmatrix;         /* (4,4) world->view, transposed (W2C^T) */
     const float* projmatrix;         /* (4,4) viewmatrix * intrinsic */

@@ -24,7 +24,7 @@ def oracle_settings(cam, sh_degree, bg=None, scale_modifier=1.0, depth_key="z", 
 
 
 def hip_settings(cam, sh_degree, device, bg=None, scale_modifier=1.0, depth_key="z", tensors=None, debug=False,
-                 tile_bounds="opacity"):
+                 tile_bounds="opacity", binning="auto"):
     from bags_raster import GaussianRasterizationSettings
     ct = tensors if tensors is not None else camera_tensors(cam, device)
     bg = torch.zeros(3) if bg is None else bg
@@ -33,7 +33,7 @@ def hip_settings(cam, sh_degree, device, bg=None, scale_modifier=1.0, depth_key=
                                          bg=bg.to(device), scale_modifier=scale_modifier, viewmatrix=ct["viewmatrix"],
                                          projmatrix=ct["projmatrix"], intrinsic=ct["intrinsic"], sh_degree=sh_degree,
                                          campos=ct["campos"], prefiltered=False, debug=debug, debug_iter=0,
-                                         depth_key=depth_key, tile_bounds=tile_bounds)
+                                         depth_key=depth_key, tile_bounds=tile_bounds, binning=binning)
 
 
 def make_case(P, W, H, sm=1.0, deg=3, seed=0, dist=4.0, **cam_kw):

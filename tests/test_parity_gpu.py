@@ -527,6 +527,47 @@ def test_side_stream_and_non_contiguous_inputs():
         assert torch.equal(a, b) and torch.equal(a, c)
 
 
+@pytest.mark.parametrize("P,W,H,sm,deg", [(3000, 200, 136, 1.5, 3), (150, 256, 192, 25.0, 1)])
+def test_binning_paths_give_identical_lists(P, W, H, sm, deg):
+    """binning="auto" (tile-binned: count matrix + per-tile LDS sort, csrc/binning.hip) and binning="radix" (depth sort of
+    the Gaussians + stable radix sort of the instances, csrc/sort.hip) must produce the same sorted lists, tile ranges,
+    outputs and gradients bit for bit -- and the radix path stays held to the oracle."""
+    scene, cam = make_case(P, W, H, sm, deg, seed=P)
+    if P == 150:
+        scene["opacities"] = scene["opacities"] * 0.5
+    g = torch.randn(3, H, W, generator=torch.Generator().manual_seed(2))
+    o_a, g_a, v_a = run_hip(scene, cam, deg, g, binning="auto")
+    o_r, g_r, v_r = run_hip(scene, cam, deg, g, binning="radix")
+    assert v_a["num_rendered"] == v_r["num_rendered"] > 0
+    for k in ("point_list", "keys_sorted", "n_contrib", "tiles_touched", "rect"):
+        assert torch.equal(v_a[k], v_r[k]), k
+    nz = (v_r["ranges"][:, 1] - v_r["ranges"][:, 0]) > 0
+    assert torch.equal(v_a["ranges"][nz], v_r["ranges"][nz])
+    assert torch.equal(v_a["ranges"][:, 1] - v_a["ranges"][:, 0], v_r["ranges"][:, 1] - v_r["ranges"][:, 0])
+    for a, b in zip(o_a, o_r):
+        assert torch.equal(a, b)
+    for k in g_a:
+        if g_a[k] is not None:
+            assert torch.equal(g_a[k], g_r[k]), k
+    rep = compare(scene, cam, deg, binning="radix", check_fp64=False)
+    assert_report(rep, grad_tol=2e-4)
+
+
+@pytest.mark.parametrize("P,shrink", [(3000, 0.04), (20000, 0.02)])
+def test_long_tile_lists_take_the_large_sort_paths(P, shrink):
+    """Thousands of splats over a handful of tiles (a camera far from a compact scene): the per-tile sort leaves its 1024-entry
+    LDS kernel for the 8192-entry one (P = 3000) and for the global-memory network (P = 20000: > 8192 instances in one tile)."""
+    scene, cam = make_case(P, 64, 48, 1.0, 0, seed=P + 1)
+    scene["means3D"] = scene["means3D"] * shrink
+    scene["opacities"] = scene["opacities"] * 0.05                     # keep the pixels from saturating: every splat contributes
+    rep = compare(scene, cam, 0, check_fp64=False)
+    _report({k: rep[k] for k in ("num_rendered", "image_max_err", "n_contrib_mismatch_frac", "grad_rel_fp32")})
+    out, _, views = run_hip(scene, cam, 0)
+    longest = int((views["ranges"][:, 1] - views["ranges"][:, 0]).max())
+    assert longest > (8192 if P == 20000 else 1024), longest
+    assert_report(rep, grad_tol=3e-4, skip_zero=("campos",))
+
+
 @pytest.mark.parametrize("W,H,P,sm,shrink,fovy", [
     (10, 7, 200, 3.0, 1.0, None),            # less than one tile
     (16, 2000, 1500, 0.2, 1.0, None),        # one column of 125 tiles
