@@ -174,8 +174,18 @@ def save_checkpoint(pc: GaussianBag, iteration: int, path: str, optimizer_state:
     torch.save((capture(pc, optimizer_state, spatial_lr_scale), iteration), path)
 
 
-def load_checkpoint(path: str, sh_degree: int, device=None) -> Tuple[GaussianBag, dict, float, int]:
-    """Inverse of ``save_checkpoint`` and of the reference's own checkpoints (train.py:132-135 restores them the same way)."""
-    model_args, iteration = torch.load(path, map_location=device, weights_only=False)
+def load_checkpoint(path: str, sh_degree: int, device=None, trust_pickle: bool = False) -> Tuple[GaussianBag, dict, float, int]:
+    """Inverse of ``save_checkpoint`` and of the reference's own checkpoints (train.py:132-135 restores them the same way).
+
+    The tuple holds tensors, numbers and an optimizer state dict only, so it is read with ``weights_only=True`` (no code from
+    the file is executed).  A checkpoint that needs the full unpickler (the reference writes ``nn.Parameter`` objects, which
+    the safe loader accepts; anything else does not) is only read with ``trust_pickle=True`` -- the reference's own behaviour,
+    to be used on files you wrote yourself.  A view-sharded run must call ``DensificationSync.rebase()`` after restoring."""
+    try:
+        model_args, iteration = torch.load(path, map_location=device, weights_only=True)
+    except Exception:
+        if not trust_pickle:
+            raise
+        model_args, iteration = torch.load(path, map_location=device, weights_only=False)
     pc, opt, lr_scale = restore(model_args, sh_degree, device)
     return pc, opt, lr_scale, int(iteration)

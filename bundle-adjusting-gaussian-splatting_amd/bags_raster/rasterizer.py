@@ -18,6 +18,7 @@ import ctypes as C
 from typing import NamedTuple, Optional
 
 import math
+import threading
 
 import torch
 
@@ -156,8 +157,30 @@ class _Forwarded:
 # Speculative forward (bags_forward_speculative): the instance count of the previous call with the same problem shape
 # is the capacity guess for the next one, so the steady state has no host round trip in the middle of the forward.
 SPECULATE = True
-_capacity_hint = {}          # (device index, P, W, H) -> last instance count
-_pinned_count = {}           # device index -> pinned int32[1] receiving the asynchronous count
+_capacity_hint = {}          # (device index, P, W, H) -> last instance count (a hint only: a stale value costs one redo)
+_hint_lock = threading.Lock()
+
+
+class _PinnedSlots:
+    """Pinned int32 words that receive the asynchronous instance count.  One word per call in flight: two forwards on
+    different streams (or threads) of one device must not share the word their counts are copied into.  A slot goes back
+    to the pool once its call has read it."""
+
+    def __init__(self):
+        self._free, self._lock = [], threading.Lock()
+
+    def take(self) -> torch.Tensor:
+        with self._lock:
+            if self._free:
+                return self._free.pop()
+        return torch.zeros(1, dtype=torch.int32).pin_memory()
+
+    def give(self, t: torch.Tensor) -> None:
+        with self._lock:
+            self._free.append(t)
+
+
+_pinned = _PinnedSlots()
 
 
 def _run_forward(lib, pk: _Packed, H: int, W: int, speculate: bool = True):
@@ -176,14 +199,13 @@ def _run_forward(lib, pk: _Packed, H: int, W: int, speculate: bool = True):
     state = L.BagsState(fw.geom.data_ptr(), fw.geom.numel(), None, 0, fw.image.data_ptr(), fw.image.numel())
     global LAST_NUM_RENDERED
     key = (dev.index, P, W, H)
-    hint = _capacity_hint.get(key) if (SPECULATE and speculate and not pk.settings.debug) else None
+    with _hint_lock:
+        hint = _capacity_hint.get(key) if (SPECULATE and speculate and not pk.settings.debug) else None
     if hint is not None:
         cap = int(hint * 1.2) + 8192
         fw.binning = _bytes(lib.bags_binning_size(cap, W, H), dev)
         state.binning, state.binning_bytes = fw.binning.data_ptr(), fw.binning.numel()
-        pinned = _pinned_count.get(dev.index)
-        if pinned is None:
-            pinned = _pinned_count[dev.index] = torch.zeros(1, dtype=torch.int32).pin_memory()
+        pinned = _pinned.take()
         L.check(lib.bags_forward_prepare_async(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(out),
                                                pinned.data_ptr(), stream), "bags_forward_prepare_async")
         ev = torch.cuda.Event()
@@ -192,7 +214,9 @@ def _run_forward(lib, pk: _Packed, H: int, W: int, speculate: bool = True):
                                                     cap, stream), "bags_forward_finish_speculative")
         ev.synchronize()                      # phase 2 is already queued behind the count: the GPU does not wait for us
         n = int(pinned[0].item()) & 0xFFFFFFFF
-        _capacity_hint[key] = n
+        _pinned.give(pinned)
+        with _hint_lock:
+            _capacity_hint[key] = n
         fw.num_rendered = LAST_NUM_RENDERED = n
         if n <= cap:
             fw.capacity = cap
@@ -209,7 +233,8 @@ def _run_forward(lib, pk: _Packed, H: int, W: int, speculate: bool = True):
                                      C.byref(n), stream), "bags_forward_prepare")
     fw.num_rendered = fw.capacity = int(n.value)
     LAST_NUM_RENDERED = fw.num_rendered
-    _capacity_hint[key] = fw.num_rendered
+    with _hint_lock:
+        _capacity_hint[key] = fw.num_rendered
     fw.binning = _bytes(lib.bags_binning_size(fw.num_rendered, W, H), dev)
     state.binning, state.binning_bytes = fw.binning.data_ptr(), fw.binning.numel()
     L.check(lib.bags_forward_finish(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(out),

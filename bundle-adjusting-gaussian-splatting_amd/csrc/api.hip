@@ -27,12 +27,16 @@ static int fail(int code, const char* fmt, ...)
 
 // ---------------------------------------------------------------------------------------------- stage profiler
 // Opt-in (bags_profile_enable): a start/stop hipEvent pair per stage per call, resolved in bags_profile_read.
+#include <mutex>
 #include <vector>
 enum Stage { ST_PRE_FWD, ST_DEPTH_SORT, ST_OFFSETS, ST_EMIT, ST_TILE_SORT, ST_RANGES, ST_BLEND_FWD, ST_BLEND_BWD,
              ST_PRE_BWD, ST_POSE_REDUCE, ST_COUNT };
 static const char* kStageNames[ST_COUNT] = {"preprocess_fwd", "depth_sort", "offsets_scan", "emit", "tile_sort",
                                             "tile_ranges", "blend_fwd", "blend_bwd", "preprocess_bwd", "pose_reduce"};
 struct ProfInterval { int stage; hipEvent_t a, b; };
+// The profiler is the library's only mutable global state (everything a call needs lives in the caller's buffers); calls
+// from several threads / streams may profile at once, so the lists are guarded.
+static std::mutex g_prof_mutex;
 static int g_prof_mode = 0;          // 0 off, 1 dominant kernel only (blend_bwd), 2 every stage
 static std::vector<ProfInterval> g_prof_pending;
 static std::vector<hipEvent_t> g_prof_free;
@@ -41,7 +45,10 @@ static long long g_prof_calls[ST_COUNT];
 
 static hipEvent_t prof_event()
 {
-    if (!g_prof_free.empty()) { hipEvent_t e = g_prof_free.back(); g_prof_free.pop_back(); return e; }
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mutex);
+        if (!g_prof_free.empty()) { hipEvent_t e = g_prof_free.back(); g_prof_free.pop_back(); return e; }
+    }
     hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
 }
 struct ProfScope {
@@ -49,7 +56,13 @@ struct ProfScope {
     ProfScope(int stage_, hipStream_t st_) : st(st_), stage(stage_) {
         if (g_prof_mode == 2 || (g_prof_mode == 1 && stage_ == ST_BLEND_BWD)) { a = prof_event(); (void)hipEventRecord(a, st); }
     }
-    ~ProfScope() { if (a) { hipEvent_t b = prof_event(); (void)hipEventRecord(b, st); g_prof_pending.push_back({stage, a, b}); } }
+    ~ProfScope() {
+        if (a) {
+            hipEvent_t b = prof_event(); (void)hipEventRecord(b, st);
+            std::lock_guard<std::mutex> lk(g_prof_mutex);
+            g_prof_pending.push_back({stage, a, b});
+        }
+    }
 };
 
 // ---------------------------------------------------------------------------------------------- buffer carving
@@ -381,6 +394,7 @@ int bags_profile_enable(int mode)
 
 int bags_profile_read(int max_stages, const char** names, double* total_ms, int64_t* calls)
 {
+    std::lock_guard<std::mutex> lk(g_prof_mutex);
     for (const ProfInterval& iv : g_prof_pending) {
         float ms = 0.f;
         if (hipEventSynchronize(iv.b) == hipSuccess && hipEventElapsedTime(&ms, iv.a, iv.b) == hipSuccess) {

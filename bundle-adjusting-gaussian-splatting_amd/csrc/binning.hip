@@ -20,6 +20,32 @@
 // beyond them, or on request (BagsSettings.binning), api.hip falls back to the radix path of sort.hip.
 #include "bags_common.h"
 
+// Wave-wide inclusive add scan on DPP (row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast:15 / row_bcast:31 across
+// them): six VALU instructions.  (__shfl_up goes through ds_bpermute: six dependent LDS round trips per scan, which is
+// what a one-wave sort spent most of its time waiting for.)
+__device__ __forceinline__ u32 wave_incl_scan(u32 x)
+{
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+    return x;
+}
+// wave-wide max / min on the same DPP pattern (the value of lane 63 of the inclusive scan), broadcast with readlane
+__device__ __forceinline__ u32 wave_max(u32 x)
+{
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));
+    return (u32)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ __forceinline__ u32 wave_min(u32 x) { return ~wave_max(~x); }
+
 #define BIN_COOP 64          // rectangles of more tiles than this are walked by the whole wave
 #define BIN_THREADS 1024     // count / emit workgroup: one block of Gaussians = one workgroup = one row of the count matrix;
                              // 256 threads left every thread eight Gaussians to walk one after the other (latency bound)
@@ -98,9 +124,7 @@ tile_count_kernel(int P, int per_block, int grid_x, int T2, const uint2* __restr
     // instance offset of every Gaussian inside its block (id order): exclusive scan of the threads' sums, then a second
     // walk over the thread's own run
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    u32 incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)incl, d); if (lane >= d) incl += o; }
+    const u32 incl = wave_incl_scan(mine);
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();                                         // also: every counter of the block is final
     u32 run = incl - mine;
@@ -174,9 +198,7 @@ __device__ __forceinline__ int ord_level(u32 n)
 __device__ __forceinline__ u32 block_excl_scan_1024(u32 v, u32* s_wave /*[17]*/)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    u32 incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)incl, d); if (lane >= d) incl += o; }
+    const u32 incl = wave_incl_scan(v);
     __syncthreads();                                         // s_wave free again
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
@@ -230,9 +252,7 @@ ranges_order_kernel(const u32* __restrict__ tile_total, int T, uint2* __restrict
     __syncthreads();
     {
         const u32 c0 = s_cur[2 * tid], c1 = s_cur[2 * tid + 1];
-        u32 inc = c0 + c1;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)inc, d); if (lane >= d) inc += o; }
+        const u32 inc = wave_incl_scan(c0 + c1);
         if (lane == 63) s_wave[wave] = inc;
         __syncthreads();
         u32 before = 0;
@@ -288,33 +308,109 @@ emit_binned_kernel(int P, int per_block, int grid_x, int T, const uint2* __restr
 // others are plain half-cleaners): with every compare-exchange ascending, the list may be thought of as padded with
 // +infinity up to the next power of two and a pair whose upper index is >= n is simply skipped.
 
-// One WAVE per tile (64-thread workgroup, no workgroup barriers): 8160 independent waves fill the chip in one round.
-// The sort is a one-pass bucket sort: depth keys of one tile are spread fairly evenly between the tile's nearest and
-// farthest splat, so with as many buckets as entries (bucket = floor((key - min) * n / (max - min + 1)), monotone in the
-// key) a bucket holds one or two entries; the rank of an entry is its bucket's start + the number of entries of the same
-// bucket that compare below it on the full (key, id) word.  ~100 instructions per 64 entries, against ~2600 per 512-entry
-// list for a bitonic network (which sorted the bench frame's lists in 52-58 us; it remains the fallback for a list whose
-// keys cluster -- more than TS_BUCKET_MAX entries in one bucket -- so the worst case stays O(n log^2 n)).
-// Two size classes (lists of up to 512 and of 513..1024 entries, one launch each over all tiles): the short class needs 7 KB
-// of LDS and ~60 VGPRs per wave, so that the whole frame's 8160 waves are resident at once.
+// ONE WAVE sorts n <= 64 * PER (key, id) words.  One-pass bucket sort: depth keys of one tile are spread fairly evenly
+// between the tile's nearest and farthest splat, so with as many buckets as entries (bucket = floor((key - min) * n /
+// (max - min + 1)), monotone in the key) a bucket holds one or two entries; an entry's rank is its bucket's start + the
+// number of entries of the same bucket that compare below it on the full word.  ~100 instructions per 64 entries against
+// ~2600 per 512-entry list for a bitonic network, which remains the fallback for lists whose keys cluster (more than
+// TS_BUCKET_MAX entries in one bucket), so the worst case stays O(n log^2 n).  The words are unique (ids are), hence the
+// result does not depend on the order in which the LDS atomics of the counting pass retire.
+// e[r] = word of entry r * 64 + lane (all ones beyond n).  t / cnt / bid: this wave's LDS (64 * PER entries each).  The
+// caller's workgroup may hold several waves, each sorting its own list: only wave-level synchronisation is used.
 #define TS_BUCKET_MAX 24
-template <int TS_PER>
+__device__ __forceinline__ void lds_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+
+template <int PER>
+__device__ __forceinline__ void wave_sort_words(const u64 (&e)[PER], u32 n, u32 kmin, u32 kmax, u32* __restrict__ out, u64* t, u32* cnt,
+                                                unsigned short* bid)
+{
+    const u32 lane = threadIdx.x & 63;
+    const u32 rounds = (n + 63) >> 6;
+    const u32 nb = n;
+    const float scale = (float)nb / ((float)(kmax - kmin) + 1.0f);
+    for (u32 i = lane; i < nb; i += 64) cnt[i] = 0u;
+    lds_wave_sync();
+    u32 bk[PER], rk[PER];
+#pragma unroll
+    for (u32 r = 0; r < PER; ++r) {
+        bk[r] = 0; rk[r] = 0;
+        if (r < rounds && r * 64 + lane < n) {
+            const u32 key = (u32)(e[r] >> 32);
+            bk[r] = min(nb - 1, (u32)((float)(key - kmin) * scale));
+            rk[r] = atomicAdd(&cnt[bk[r]], 1u);
+        }
+    }
+    lds_wave_sync();
+    // exclusive scan of the bucket counts (in place) and the fullest bucket
+    u32 carry = 0, maxc = 0;
+    for (u32 base = 0; base < nb; base += 64) {
+        const u32 c = (base + lane < nb) ? cnt[base + lane] : 0u;
+        maxc = max(maxc, c);
+        const u32 incl = wave_incl_scan(c);
+        if (base + lane < nb) cnt[base + lane] = carry + incl - c;
+        carry += (u32)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    maxc = wave_max(maxc);
+    lds_wave_sync();
+    if (maxc > TS_BUCKET_MAX) {                               // clustered keys: bitonic network on the whole list
+#pragma unroll
+        for (u32 r = 0; r < PER; ++r)
+            if (r < rounds && r * 64 + lane < n) t[r * 64 + lane] = e[r];
+        u32 N = 2; while (N < n) N <<= 1;
+        lds_wave_sync();
+        for (u32 k = 2; k <= N; k <<= 1) {
+            const u32 hk = k >> 1;
+            for (u32 i = lane; i < (N >> 1); i += 64) {       // mirror stage
+                const u32 blk = i / hk, r = i - blk * hk;
+                const u32 a = blk * k + r, b = blk * k + (k - 1 - r);
+                if (b < n) { const u64 x = t[a], y = t[b]; if (y < x) { t[a] = y; t[b] = x; } }
+            }
+            lds_wave_sync();
+            for (u32 j = k >> 2; j >= 1; j >>= 1) {
+                for (u32 i = lane; i < (N >> 1); i += 64) {
+                    const u32 a = (i / j) * (2 * j) + (i & (j - 1)), b = a + j;
+                    if (b < n) { const u64 x = t[a], y = t[b]; if (y < x) { t[a] = y; t[b] = x; } }
+                }
+                lds_wave_sync();
+            }
+        }
+        for (u32 i = lane; i < n; i += 64) out[i] = (u32)t[i];
+        return;
+    }
+    // entries grouped by bucket (order inside a bucket = the order the atomics retired in: irrelevant, see above)
+#pragma unroll
+    for (u32 r = 0; r < PER; ++r)
+        if (r < rounds && r * 64 + lane < n) {
+            const u32 p = cnt[bk[r]] + rk[r];
+            t[p] = e[r]; bid[p] = (unsigned short)bk[r];
+        }
+    lds_wave_sync();
+    for (u32 p = lane; p < n; p += 64) {
+        const u32 b = bid[p];
+        const u32 bs = cnt[b], be = (b + 1 < nb) ? cnt[b + 1] : n;
+        const u64 x = t[p];
+        u32 rank = 0;
+        for (u32 q = bs; q < be; ++q) rank += (t[q] < x) ? 1u : 0u;
+        out[bs + rank] = (u32)x;
+    }
+}
+
+// One WAVE per tile for lists of up to TSORT_WAVE entries: 8160 independent waves, no workgroup barriers.
+#define TS_PER (TSORT_WAVE / 64)
 __global__ void __launch_bounds__(64)
 tile_sort_wave_kernel(const uint4* __restrict__ tile_desc, const u32* __restrict__ ids_in, const u32* __restrict__ depth_key,
-                      u32* __restrict__ point_list, u32 n_lo, u32 capacity, const u32* __restrict__ n_dev)
+                      u32* __restrict__ point_list, u32 capacity, const u32* __restrict__ n_dev)
 {
-    __shared__ u64 t[64 * TS_PER];                           // bucket-grouped entries (or the bitonic fallback's array)
-    __shared__ u32 cnt[64 * TS_PER];                         // bucket counters, then bucket starts
-    __shared__ unsigned short bid[64 * TS_PER];              // bucket of the entry at a grouped position
+    __shared__ u64 t[TSORT_WAVE];
+    __shared__ u32 cnt[TSORT_WAVE];
+    __shared__ unsigned short bid[TSORT_WAVE];
     if (n_dev && *n_dev > capacity) return;
     const uint4 desc = tile_desc[blockIdx.x];
     const u32 n = desc.z, start = desc.y;
-    if (n <= n_lo || n > 64 * TS_PER) return;                // empty, or the other class's
+    if (n == 0 || n > TSORT_WAVE) return;
     const u32 lane = threadIdx.x;
     if (n == 1) { if (lane == 0) point_list[start] = ids_in[start]; return; }
-    const u32 rounds = (n + 63) >> 6;
-    // all id loads in one batch, then all key gathers in one batch (clamped indices instead of branches: a branch per round
-    // made every round wait for its own two memory round trips, 16 x 2 of them for a 1024-entry list)
+    // all id loads in one batch, then all key gathers in one batch (clamped indices, no branches)
     u64 e[TS_PER];
     u32 idv[TS_PER];
     u32 kmin = 0xFFFFFFFFu, kmax = 0u;
@@ -327,131 +423,108 @@ tile_sort_wave_kernel(const uint4* __restrict__ tile_desc, const u32* __restrict
         e[r] = valid ? (((u64)key << 32) | (u64)idv[r]) : ~0ull;
         kmin = min(kmin, valid ? key : 0xFFFFFFFFu); kmax = max(kmax, valid ? key : 0u);
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { kmin = min(kmin, (u32)__shfl_xor((int)kmin, d)); kmax = max(kmax, (u32)__shfl_xor((int)kmax, d)); }
-    const u32 nb = n;
-    const float scale = (float)nb / ((float)(kmax - kmin) + 1.0f);
-    for (u32 i = lane; i < nb; i += 64) cnt[i] = 0u;
-    __syncthreads();                                          // a one-wave workgroup: orders the LDS accesses, costs nothing
-    u32 bk[TS_PER], rk[TS_PER];
-#pragma unroll
-    for (u32 r = 0; r < TS_PER; ++r) {
-        bk[r] = 0; rk[r] = 0;
-        if (r < rounds && r * 64 + lane < n) {
-            const u32 key = (u32)(e[r] >> 32);
-            bk[r] = min(nb - 1, (u32)((float)(key - kmin) * scale));
-            rk[r] = atomicAdd(&cnt[bk[r]], 1u);
-        }
-    }
-    __syncthreads();
-    // exclusive scan of the bucket counts (in place) and the fullest bucket
-    u32 carry = 0, maxc = 0;
-    for (u32 base = 0; base < nb; base += 64) {
-        const u32 c = (base + lane < nb) ? cnt[base + lane] : 0u;
-        maxc = max(maxc, c);
-        u32 incl = c;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((int)incl, d); if ((int)lane >= d) incl += o; }
-        if (base + lane < nb) cnt[base + lane] = carry + incl - c;
-        carry += (u32)__shfl((int)incl, 63);
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) maxc = max(maxc, (u32)__shfl_xor((int)maxc, d));
-    __syncthreads();
-    if (maxc > TS_BUCKET_MAX) {                               // clustered keys: bitonic network on the whole list
-#pragma unroll
-        for (u32 r = 0; r < TS_PER; ++r)
-            if (r < rounds && r * 64 + lane < n) t[r * 64 + lane] = e[r];
-        u32 N = 2; while (N < n) N <<= 1;
-        __syncthreads();
-        for (u32 k = 2; k <= N; k <<= 1) {
-            const u32 hk = k >> 1;
-            for (u32 i = lane; i < (N >> 1); i += 64) {       // mirror stage
-                const u32 blk = i / hk, r = i - blk * hk;
-                const u32 a = blk * k + r, b = blk * k + (k - 1 - r);
-                if (b < n) { const u64 x = t[a], y = t[b]; if (y < x) { t[a] = y; t[b] = x; } }
-            }
-            __syncthreads();
-            for (u32 j = k >> 2; j >= 1; j >>= 1) {
-                for (u32 i = lane; i < (N >> 1); i += 64) {
-                    const u32 a = (i / j) * (2 * j) + (i & (j - 1)), b = a + j;
-                    if (b < n) { const u64 x = t[a], y = t[b]; if (y < x) { t[a] = y; t[b] = x; } }
-                }
-                __syncthreads();
-            }
-        }
-        for (u32 i = lane; i < n; i += 64) point_list[start + i] = (u32)t[i];
-        return;
-    }
-    // entries grouped by bucket (order inside a bucket = the order the atomics retired in: irrelevant, see below)
-#pragma unroll
-    for (u32 r = 0; r < TS_PER; ++r)
-        if (r < rounds && r * 64 + lane < n) {
-            const u32 p = cnt[bk[r]] + rk[r];
-            t[p] = e[r]; bid[p] = (unsigned short)bk[r];
-        }
-    __syncthreads();
-    // final position = bucket start + number of entries of the bucket below this one in (key, id) order: unique words, so
-    // every entry of a bucket gets a different rank whatever order they arrived in
-    for (u32 p = lane; p < n; p += 64) {
-        const u32 b = bid[p];
-        const u32 bs = cnt[b], be = (b + 1 < nb) ? cnt[b + 1] : n;
-        const u64 x = t[p];
-        u32 rank = 0;
-        for (u32 q = bs; q < be; ++q) rank += (t[q] < x) ? 1u : 0u;
-        point_list[start + bs + rank] = (u32)x;
-    }
+    wave_sort_words<TS_PER>(e, n, wave_min(kmin), wave_max(kmax), point_list + start, t, cnt, bid);
 }
 
 // Lists of more than TSORT_WAVE entries: a fixed grid of 256-thread workgroups walks the front of the heavy-first
-// descriptor list (n_active[1] entries, all of them long lists plus a few of the boundary level).  Up to TSORT_LARGE
-// entries the network runs in LDS; beyond that (tens of thousands of splats over ONE tile: a camera far from the scene,
-// adversarial inputs) in global memory, with loads and stores at agent scope so that the waves of the workgroup see each
-// other's exchanges across the barriers.  Slow, correct, never on the path of an ordinary frame.
-#define TSORT_LARGE 8192
+// descriptor list (n_active[1] entries: every long list plus a few of the boundary level).
+//   * up to TSORT_LARGE entries: two levels.  The workgroup cuts the depth range of the list into slabs of ~512 entries
+//     (coarse buckets, again monotone in the key), groups the (key, id) words by slab in the global scratch array `kv`,
+//     and its four waves then sort one slab each with wave_sort_words until none is left.  A slab that outgrows a wave's
+//     capacity (very uneven depths) sends the whole list to the network below.
+//   * beyond that (tens of thousands of splats over ONE tile: a camera far from the scene, adversarial inputs), or as that
+//     fallback: the bitonic network in global memory, loads and stores at agent scope so that the waves of the workgroup
+//     see each other's exchanges across the barriers.  Slow, correct, never on the path of an ordinary frame.
+#define TSORT_LARGE 16384
+#define TS_SLABS_MAX 64
 __global__ void __launch_bounds__(256)
 tile_sort_large_kernel(const uint4* __restrict__ tile_desc, const u32* __restrict__ n_active, const u32* __restrict__ ids_in,
                        const u32* __restrict__ depth_key, uint2* __restrict__ kv, u32* __restrict__ point_list, u32 capacity,
                        const u32* __restrict__ n_dev)
 {
-    __shared__ u64 s[TSORT_LARGE];
+    __shared__ u64 t[4][TSORT_WAVE];
+    __shared__ u32 cnt[4][TSORT_WAVE];
+    __shared__ unsigned short bid[4][TSORT_WAVE];
+    __shared__ u32 s_red[8];
+    __shared__ u32 slab_cnt[TS_SLABS_MAX + 1], slab_start[TS_SLABS_MAX + 1], s_next, s_bad;
     if (n_dev && *n_dev > capacity) return;
     const u32 n_long = n_active[1];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (u32 d = blockIdx.x; d < n_long; d += gridDim.x) {
         const uint4 desc = tile_desc[d];
         const u32 n = desc.z, start = desc.y;
         if (n <= TSORT_WAVE) continue;                        // uniform over the workgroup
-        u32 N = 2; while (N < n) N <<= 1;
-        if (n <= TSORT_LARGE) {
-            __syncthreads();                                  // the previous tile's read-out is complete
-            for (u32 i = tid; i < n; i += 256) { const u32 id = ids_in[start + i]; s[i] = ((u64)depth_key[id] << 32) | (u64)id; }
+        bool network = n > TSORT_LARGE;
+        if (!network) {
+            // ---- level 1: key range, slab of every entry, slab counts
+            const u32 K = min((u32)TS_SLABS_MAX, (n + 511) / 512);
+            u32 kmin = 0xFFFFFFFFu, kmax = 0u;
+            for (u32 i = tid; i < n; i += 256) { const u32 key = depth_key[ids_in[start + i]]; kmin = min(kmin, key); kmax = max(kmax, key); }
+            kmin = wave_min(kmin); kmax = wave_max(kmax);
+            __syncthreads();                                  // the previous list's state is no longer in use
+            if (lane == 0) { s_red[wave] = kmin; s_red[4 + wave] = kmax; }
+            if (tid <= TS_SLABS_MAX) slab_cnt[tid] = 0u;
+            if (tid == 0) { s_next = 0u; s_bad = 0u; }
             __syncthreads();
-            for (u32 k = 2; k <= N; k <<= 1) {
-                const u32 hk = k >> 1;
-                for (u32 i = tid; i < (N >> 1); i += 256) {
-                    const u32 blk = i / hk, r = i - blk * hk;
-                    const u32 a = blk * k + r, b = blk * k + (k - 1 - r);
-                    if (b < n) { const u64 x = s[a], y = s[b]; if (y < x) { s[a] = y; s[b] = x; } }
-                }
-                __syncthreads();
-                for (u32 j = k >> 2; j >= 1; j >>= 1) {
-                    for (u32 i = tid; i < (N >> 1); i += 256) {
-                        const u32 a = (i / j) * (2 * j) + (i & (j - 1)), b = a + j;
-                        if (b < n) { const u64 x = s[a], y = s[b]; if (y < x) { s[a] = y; s[b] = x; } }
-                    }
-                    __syncthreads();
-                }
+            kmin = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+            kmax = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+            const float scale = (float)K / ((float)(kmax - kmin) + 1.0f);
+            for (u32 i = tid; i < n; i += 256) {
+                const u32 key = depth_key[ids_in[start + i]];
+                atomicAdd(&slab_cnt[min(K - 1, (u32)((float)(key - kmin) * scale))], 1u);
             }
-            for (u32 i = tid; i < n; i += 256) point_list[start + i] = (u32)s[i];
-            continue;
+            __syncthreads();
+            if (tid == 0) {
+                u32 run = 0, bad = 0;
+                for (u32 k = 0; k < K; ++k) { slab_start[k] = run; run += slab_cnt[k]; bad |= (slab_cnt[k] > TSORT_WAVE) ? 1u : 0u; slab_cnt[k] = 0u; }
+                slab_start[K] = run; s_bad = bad;
+            }
+            __syncthreads();
+            network = s_bad != 0u;
+            if (!network) {
+                // ---- words grouped by slab in the scratch array (order inside a slab arbitrary)
+                for (u32 i = tid; i < n; i += 256) {
+                    const u32 id = ids_in[start + i], key = depth_key[id];
+                    const u32 k = min(K - 1, (u32)((float)(key - kmin) * scale));
+                    kv[start + slab_start[k] + atomicAdd(&slab_cnt[k], 1u)] = make_uint2(key, id);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __threadfence();
+                __syncthreads();
+                // ---- level 2: a wave per slab
+                for (;;) {
+                    u32 k = 0;
+                    if (lane == 0) k = atomicAdd(&s_next, 1u);
+                    k = (u32)__builtin_amdgcn_readfirstlane((int)k);
+                    if (k >= K) break;
+                    const u32 s0 = slab_start[k], m = slab_start[k + 1] - s0;
+                    if (m == 0) continue;
+                    u64 e[TS_PER];
+                    u32 lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+                    for (u32 r = 0; r < TS_PER; ++r) {
+                        // written by other waves of this workgroup just above: read at agent scope (L2), key in the low half
+                        const u64 raw = __hip_atomic_load(reinterpret_cast<const u64*>(&kv[start + s0 + min(r * 64 + (u32)lane, m - 1)]),
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const u32 wkey = (u32)raw, wid = (u32)(raw >> 32);
+                        const bool valid = r * 64 + lane < m;
+                        e[r] = valid ? (((u64)wkey << 32) | (u64)wid) : ~0ull;
+                        lo = min(lo, valid ? wkey : 0xFFFFFFFFu); hi = max(hi, valid ? wkey : 0u);
+                    }
+                    if (m == 1) { if (lane == 0) point_list[start + s0] = (u32)e[0]; continue; }
+                    wave_sort_words<TS_PER>(e, m, wave_min(lo), wave_max(hi), point_list + start + s0, t[wave], cnt[wave], bid[wave]);
+                }
+                continue;
+            }
         }
-        // (key, id) pairs of this tile into the scratch array; read back as one little-endian word the id is the HIGH half
+        // ---- the network in global memory
+        u32 N = 2; while (N < n) N <<= 1;
+        __syncthreads();
         for (u32 i = tid; i < n; i += 256) { const u32 id = ids_in[start + i]; kv[start + i] = make_uint2(depth_key[id], id); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __threadfence();
         __syncthreads();
-        u64* gsm = reinterpret_cast<u64*>(kv + start);
+        u64* gsm = reinterpret_cast<u64*>(kv + start);        // (key, id) read as one little-endian word: the id is the HIGH half
         auto ld = [&](u32 i) -> u64 { const u64 v = __hip_atomic_load(&gsm[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return (v << 32) | (v >> 32); };
         auto st = [&](u32 i, u64 v) { __hip_atomic_store(&gsm[i], (v << 32) | (v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
         for (u32 k = 2; k <= N; k <<= 1) {
@@ -527,12 +600,9 @@ hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int
     hipLaunchKernelGGL(emit_binned_kernel, dim3(B), dim3(BIN_THREADS), cursors, st, P, per, grid_x, T, g.rect, g.tiles_touched,
                        im.pre, im.ranges, g.local_off, g.block_base, g.inst_off, ids, capacity, n_dev);
     // long lists first: their few workgroups run beside the many short sorts of the second launch
-    hipLaunchKernelGGL(tile_sort_large_kernel, dim3(T < 128 ? T : 128), dim3(256), 0, st, im.tile_desc, im.n_active, ids, g.depth_key, kv,
+    hipLaunchKernelGGL(tile_sort_large_kernel, dim3(T < 512 ? T : 512), dim3(256), 0, st, im.tile_desc, im.n_active, ids, g.depth_key, kv,
                        point_list, capacity, n_dev);
-    hipLaunchKernelGGL(tile_sort_wave_kernel<TSORT_WAVE / 64>, dim3(T), dim3(64), 0, st, im.tile_desc, ids, g.depth_key, point_list,
-                       (u32)(TSORT_WAVE / 2), capacity, n_dev);
-    hipLaunchKernelGGL(tile_sort_wave_kernel<TSORT_WAVE / 128>, dim3(T), dim3(64), 0, st, im.tile_desc, ids, g.depth_key, point_list, 0u,
-                       capacity, n_dev);
+    hipLaunchKernelGGL(tile_sort_wave_kernel, dim3(T), dim3(64), 0, st, im.tile_desc, ids, g.depth_key, point_list, capacity, n_dev);
     return hipGetLastError();
 }
 

@@ -553,18 +553,28 @@ def test_binning_paths_give_identical_lists(P, W, H, sm, deg):
     assert_report(rep, grad_tol=2e-4)
 
 
-@pytest.mark.parametrize("P,shrink", [(3000, 0.04), (20000, 0.02)])
-def test_long_tile_lists_take_the_large_sort_paths(P, shrink):
-    """Thousands of splats over a handful of tiles (a camera far from a compact scene): the per-tile sort leaves its 1024-entry
-    LDS kernel for the 8192-entry one (P = 3000) and for the global-memory network (P = 20000: > 8192 instances in one tile)."""
+@pytest.mark.parametrize("P,shrink,flat", [(3000, 0.04, False), (20000, 0.02, False), (40000, 0.012, False),
+                                           (600, 0.3, True), (5000, 0.03, True)])
+def test_long_and_clustered_tile_lists_take_every_sort_path(P, shrink, flat):
+    """The per-tile sort of the tile-binned path (csrc/binning.hip) has four ways through it; each must give the oracle's list:
+    thousands of splats over a handful of tiles (a camera far from a compact scene) leave the one-wave bucket sort for the
+    two-level slab sort (> 1024 entries: P = 3000, 20000) and for the global-memory network (> 16384 entries: P = 40000);
+    `flat` puts every splat at the SAME depth (identical 32-bit keys: the order is decided by the Gaussian id alone), which
+    overflows the buckets / slabs and takes the bitonic fallbacks (in LDS for P = 600, in global memory for P = 5000)."""
     scene, cam = make_case(P, 64, 48, 1.0, 0, seed=P + 1)
     scene["means3D"] = scene["means3D"] * shrink
-    scene["opacities"] = scene["opacities"] * 0.05                     # keep the pixels from saturating: every splat contributes
+    if flat:
+        scene["means3D"][:, 2] = 0.25
+    scene["opacities"] = scene["opacities"] * (0.05 if not flat else 0.2)      # keep the pixels from saturating
     rep = compare(scene, cam, 0, check_fp64=False)
     _report({k: rep[k] for k in ("num_rendered", "image_max_err", "n_contrib_mismatch_frac", "grad_rel_fp32")})
     out, _, views = run_hip(scene, cam, 0)
     longest = int((views["ranges"][:, 1] - views["ranges"][:, 0]).max())
-    assert longest > (8192 if P == 20000 else 1024), longest
+    if flat:
+        vis = views["depth_bits"][out[1] > 0]
+        assert vis.numel() > 100 and int((vis != vis[0]).sum()) == 0, "depth keys are not identical"
+    else:
+        assert longest > {3000: 1024, 20000: 8192, 40000: 16384}[P], longest
     assert_report(rep, grad_tol=3e-4, skip_zero=("campos",))
 
 
@@ -584,3 +594,44 @@ def test_tile_list_shapes(W, H, P, sm, shrink, fovy):
     _report(rep)
     assert rep["num_rendered"][0] > 0
     assert_report(rep)
+
+
+@pytest.mark.gpu
+def test_two_views_in_flight_on_two_streams():
+    """Two views of one problem shape rendered concurrently on two streams (what a multi-view batch does): each call has its
+    own pinned word for the asynchronous instance count and its own state buffers, so both must reproduce, bit for bit, what
+    they give when run one after the other on the default stream."""
+    from bags_raster import GaussianRasterizer
+    from bags_raster.synth import sphere_views
+    from scenes import hip_settings
+    dev = torch.device("cuda")
+    scene, _ = make_case(6000, 256, 192, 1.2, 3, seed=51)
+    cams = sphere_views(4, 256, 192, noise=0.05)[2:4]
+    cot = torch.randn(3, 192, 256, generator=torch.Generator().manual_seed(9)).to(dev)
+    base = {k: v.to(dev) for k, v in scene.items()}
+
+    def run(cam, stream):
+        t = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        with torch.cuda.stream(stream):
+            st = hip_settings(cam, 3, dev)
+            out = GaussianRasterizer(st)(means3D=t["means3D"], means2D=torch.zeros(6000, 3, device=dev), means2D_densify=torch.zeros(6000, 3, device=dev),
+                                         shift_factors=torch.zeros(3, device=dev), shs=t["shs"], colors_precomp=None, opacities=t["opacities"],
+                                         scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
+            out[0].backward(cot)
+        return out, t
+    cur = torch.cuda.current_stream()
+    ref = []
+    for c in cams:                                            # twice each: the second call of a shape takes the speculative path
+        run(c, cur); o, t = run(c, cur)
+        torch.cuda.synchronize()
+        ref.append((o[0].detach().clone(), o[1].clone(), {k: v.grad.clone() for k, v in t.items()}))
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    sa.wait_stream(cur); sb.wait_stream(cur)
+    for rep in range(3):
+        oa, ta = run(cams[0], sa)
+        ob, tb = run(cams[1], sb)
+        torch.cuda.synchronize()
+        for (o, t), r in (((oa, ta), ref[0]), ((ob, tb), ref[1])):
+            assert torch.equal(o[0].detach(), r[0]) and torch.equal(o[1], r[1])
+            for k in r[2]:
+                assert torch.equal(t[k].grad, r[2][k]), k
