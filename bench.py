@@ -45,7 +45,7 @@ def build_case(P, W, H, sm, rank, dev):
     return scene, cam
 
 
-def make_step(scene, cam, dev, pose_grads=True, tile_bounds="opacity", leaves=None):
+def make_step(scene, cam, dev, pose_grads=True, tile_bounds="opacity", leaves=None, binning="auto"):
     """One view's fwd+bwd closure.  ``leaves``: the (shared, replicated) Gaussian parameter tensors of an earlier view, in
     scene order -- every view of a rank differentiates the same parameters, only the camera tensors are its own."""
     from bags_raster import GaussianRasterizationSettings, GaussianRasterizer
@@ -63,7 +63,7 @@ def make_step(scene, cam, dev, pose_grads=True, tile_bounds="opacity", leaves=No
                                        bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=ct["viewmatrix"],
                                        projmatrix=ct["projmatrix"], intrinsic=ct["intrinsic"], sh_degree=DEG,
                                        campos=ct["campos"], prefiltered=False, debug=False, debug_iter=0,
-                                       tile_bounds=tile_bounds)
+                                       tile_bounds=tile_bounds, binning=binning)
     rast = GaussianRasterizer(st)
     cot = torch.randn(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(1)).to(dev)
     params = list(leaves)
@@ -200,6 +200,8 @@ def main():
     ap.add_argument("--tile-bounds", default="opacity", choices=("opacity", "aabb"),
                     help="opacity: bin a Gaussian into the tiles its alpha >= 1/255 ellipse can reach (default; same image and "
                          "gradients); aabb: the stock 3-sigma square (upstream's instance list)")
+    ap.add_argument("--binning", default="auto", choices=("auto", "radix"),
+                    help="auto: tile-binned instance lists (count matrix + per-tile LDS sort); radix: depth sort + stable radix sort")
     ap.add_argument("--fixed-pose", action="store_true", help="config 2 exactly: no pose/intrinsic gradients requested")
     ap.add_argument("--views-per-exchange", type=int, default=0,
                     help="views every rank renders (fwd+bwd, gradients accumulated locally) behind ONE exchange; 0 = 1 view at "
@@ -246,10 +248,11 @@ def main():
     cams = [cam0] if (world == 1 and V == 1) else [sphere_views(world * V, W, H, noise=0.05)[rank + world * j] for j in range(V)]
 
     def make_views(tile_bounds):
-        step0, params, ct = make_step(scene, cams[0], dev, pose_grads=not args.fixed_pose, tile_bounds=tile_bounds)
+        step0, params, ct = make_step(scene, cams[0], dev, pose_grads=not args.fixed_pose, tile_bounds=tile_bounds, binning=args.binning)
         fns = [step0]
         for c in cams[1:]:
-            fns.append(make_step(scene, c, dev, pose_grads=not args.fixed_pose, tile_bounds=tile_bounds, leaves=params)[0])
+            fns.append(make_step(scene, c, dev, pose_grads=not args.fixed_pose, tile_bounds=tile_bounds, leaves=params,
+                                 binning=args.binning)[0])
         return fns, params
 
     view_fns, params = make_views(args.tile_bounds)
@@ -331,6 +334,7 @@ def main():
             "tile_sort": I * 36,
             "emit": I * 12,
             "depth_sort": P * 96,
+            "offsets_scan": P * 16,
         }
         b_alg = G * 850 + (P - G) * 28 + I * 168 + HWp * 40
         cfg_n = "2" if args.fixed_pose else "3"
@@ -341,7 +345,7 @@ def main():
             "config": {"workload": f"BASELINE config {cfg_n}: synth({P}, seed 0, sm {args.sm}), "
                                    f"{V} camera{'s' if V > 1 else ''}/rank/step @{W}x{H}, SH deg 3, fwd+bwd"
                                    f"{'' if args.fixed_pose else ' incl. pose/intrinsic gradients'}",
-                       "P": P, "visible_G": G, "instances_I": I, "tile_bounds": args.tile_bounds, "width": W, "height": H,
+                       "P": P, "visible_G": G, "instances_I": I, "tile_bounds": args.tile_bounds, "binning": args.binning, "width": W, "height": H,
                        "views_per_rank_per_exchange": V,
                        "parallelism": f"view-sharded x{world}" + (f", {args.exchange} of the flat Gaussian-gradient bucket"
                                                                   f"{' (pipelined, one step late)' if args.overlap else ''}"
@@ -359,33 +363,48 @@ def main():
             dom = max(stages, key=lambda k: stages[k])
             if dom in alg:
                 ach = alg[dom] / (stages[dom] * 1e-3)
-                traffic = None      # PMC bytes of this kernel, measured in a separate rocprofv3 --pmc pass (profiles/)
-                try:
-                    tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))
-                    if tj["key"] == {"P": P, "width": W, "height": H, "sm": args.sm, "tile_bounds": args.tile_bounds} and dom in tj:
-                        traffic = tj[dom]["fetch_bytes"] + tj[dom]["write_bytes"]
-                except (OSError, KeyError, ValueError):
-                    pass
-                try:
-                    va = tj[dom]["valu_active_cycles"] if traffic is not None else None
-                    src = tj.get("source", "profiles/r01")
-                except (KeyError, NameError):
-                    va, src = None, "profiles/r01"
-                busy = None if va is None else va / (1024 * 2.4e9 * stages[dom] * 1e-3)
+                # HBM bytes of this kernel from the newest committed PMC pass of this workload (profiles/rNN/traffic.json:
+                # separate rocprofv3 --pmc runs for FETCH_SIZE and WRITE_SIZE; KiB counters x 1024; FETCH_SIZE doubled as
+                # MI355X_MICROARCH.md prescribes for gfx950 -- an upper bound here, the reads being 64-byte line gathers)
+                tj, src = None, None
+                key = {"P": P, "width": W, "height": H, "sm": args.sm, "tile_bounds": args.tile_bounds}
+                for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+                    try:
+                        cand = json.load(open(os.path.join(ROOT, "profiles", rnd, "traffic.json")))
+                        if cand.get("key") == key and dom in cand:
+                            tj, src = cand, cand.get("source", "profiles/" + rnd)
+                            break
+                    except (OSError, ValueError):
+                        continue
+                traffic = va = None
+                if tj is not None:
+                    traffic = 2 * tj[dom]["fetch_bytes"] + tj[dom]["write_bytes"]
+                    va = tj[dom].get("valu_insts")
                 out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
                                    "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic,
+                                   "traffic_uncorrected": None if tj is None else tj[dom]["fetch_bytes"] + tj[dom]["write_bytes"],
                                    "alg_bytes_per_launch": alg[dom], "mean_launch_ms": stages[dom],
-                                   "note": "the kernel is latency bound (3 waves per SIMD, each serialised on LDS / DPP / exp "
-                                           "chains; VALU issue and LDS both below saturation, PMC in " + src + "), not HBM "
-                                           "bound: its HBM traffic stays within 20 % of its algorithmic bytes; traffic = FETCH_SIZE + "
-                                           "WRITE_SIZE of a separate --pmc pass, fetch side uncorrected (gathers)"}
-                # the blend kernels are compute/latency bound, so the share of SIMD issue cycles they keep busy is
-                # reported next to the HBM figure (cycles from a separate rocprofv3 --pmc pass; 1024 SIMDs, 2.4 GHz assumed --
-                # the same formula gives 1.08 for blend_fwd, i.e. the scale is only good to ~10 %), and the atomic roofline is
-                # moot: the rasterizer issues no global atomics at all.
-                out["roofline_valu"] = {"kernel": dom, "busy_frac": busy,
-                                        "valu_active_cycles": va, "simds": 1024, "clock_ghz": 2.4,
-                                        "source": src + " (SQ_ACTIVE_INST_VALU x 4)"}
+                                   "note": "this kernel is bound by vector-instruction throughput, not by HBM (DESIGN.md section 3: at one "
+                                           "workgroup per CU it already runs at 82 % of a single wave's issue rate; HBM traffic stays near "
+                                           "its algorithmic bytes); PMC source: " + str(src)}
+                # the blend kernels are VALU bound.  flop_frac = contributing (pixel, splat) pairs of forward +
+                # backward x ~100 flop / (t_fwd + t_bwd) / 157.3 TFLOP/s; the pair counts come from a DIAG_PAIRS build of the
+                # same workload (tools/diag_pairs.sh -> profiles/rNN/pairs.json).
+                rv = {"kernel": dom, "valu_insts_per_launch": va, "peak_tflops": 157.3}
+                for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+                    try:
+                        pj = json.load(open(os.path.join(ROOT, "profiles", rnd, "pairs.json")))
+                        if pj.get("key") == {"P": P, "width": W, "height": H, "sm": args.sm} and args.tile_bounds in pj:
+                            pp = pj[args.tile_bounds]
+                            t_blend = (stages.get("blend_fwd", 0.0) + stages.get("blend_bwd", 0.0)) * 1e-3
+                            rv.update(pairs_evaluated=pp["bwd_pairs_evaluated"], pairs_contributing=pp["bwd_pairs_contributing"],
+                                      lane_fill=pp["bwd_entries"] / max(1.0, 64.0 * pp["bwd_wave_steps"]) if "bwd_entries" in pp else None,
+                                      flop_frac=(pp["fwd_pairs_contributing"] + pp["bwd_pairs_contributing"]) * 100.0 / t_blend / 157.3e12,
+                                      source="profiles/" + rnd + "/pairs.json")
+                            break
+                    except (OSError, ValueError, KeyError):
+                        continue
+                out["roofline_valu"] = rv
                 out["roofline_atomic"] = {"global_float_atomics_per_step": 0,
                                           "note": "gradients are reduced through per-wave LDS copies and one 48-B record per instance"}
             dev_ms = sum(stages.values())
