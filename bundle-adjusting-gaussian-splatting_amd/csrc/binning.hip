@@ -426,8 +426,87 @@ tile_sort_wave_kernel(const uint4* __restrict__ tile_desc, const u32* __restrict
     wave_sort_words<TS_PER>(e, n, wave_min(kmin), wave_max(kmax), point_list + start, t, cnt, bid);
 }
 
+// The same bucket sort run by a whole 256-thread workgroup on n <= 256 * PER words (lists of 1025..4096 entries: the bulk
+// of the tiles of a dense scene, e.g. 718 instances per tile on average at scale multiplier 1.0).  e[r] = word of entry
+// r * 256 + tid.  s_tmp: 8 words of scratch.
+template <int PER>
+__device__ __forceinline__ void block_sort_words(const u64 (&e)[PER], u32 n, u32 kmin, u32 kmax, u32* __restrict__ out, u64* t, u32* cnt,
+                                                 unsigned short* bid, u32* s_tmp)
+{
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 nb = n;
+    const float scale = (float)nb / ((float)(kmax - kmin) + 1.0f);
+    for (u32 i = tid; i < nb; i += 256) cnt[i] = 0u;
+    __syncthreads();
+    u32 bk[PER], rk[PER];
+#pragma unroll
+    for (u32 r = 0; r < PER; ++r) {
+        bk[r] = 0; rk[r] = 0;
+        if (r * 256 + tid < n) {
+            const u32 key = (u32)(e[r] >> 32);
+            bk[r] = min(nb - 1, (u32)((float)(key - kmin) * scale));
+            rk[r] = atomicAdd(&cnt[bk[r]], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the bucket counts: thread tid owns the contiguous buckets [c0, c1)
+    const u32 per = (nb + 255) >> 8, c0 = min(nb, tid * per), c1 = min(nb, c0 + per);
+    u32 sum = 0, maxc = 0;
+    for (u32 c = c0; c < c1; ++c) { const u32 v = cnt[c]; sum += v; maxc = max(maxc, v); }
+    const u32 incl = wave_incl_scan(sum);
+    maxc = wave_max(maxc);
+    if (lane == 63) { s_tmp[wave] = incl; s_tmp[4 + wave] = maxc; }
+    __syncthreads();
+    u32 run = incl - sum;
+    for (u32 w = 0; w < wave; ++w) run += s_tmp[w];
+    maxc = max(max(s_tmp[4], s_tmp[5]), max(s_tmp[6], s_tmp[7]));
+    for (u32 c = c0; c < c1; ++c) { const u32 v = cnt[c]; cnt[c] = run; run += v; }
+    __syncthreads();
+    if (maxc > TS_BUCKET_MAX) {                               // clustered keys: bitonic network in LDS
+#pragma unroll
+        for (u32 r = 0; r < PER; ++r)
+            if (r * 256 + tid < n) t[r * 256 + tid] = e[r];
+        u32 N = 2; while (N < n) N <<= 1;
+        __syncthreads();
+        for (u32 k = 2; k <= N; k <<= 1) {
+            const u32 hk = k >> 1;
+            for (u32 i = tid; i < (N >> 1); i += 256) {
+                const u32 blk = i / hk, r = i - blk * hk;
+                const u32 a = blk * k + r, b = blk * k + (k - 1 - r);
+                if (b < n) { const u64 x = t[a], y = t[b]; if (y < x) { t[a] = y; t[b] = x; } }
+            }
+            __syncthreads();
+            for (u32 j = k >> 2; j >= 1; j >>= 1) {
+                for (u32 i = tid; i < (N >> 1); i += 256) {
+                    const u32 a = (i / j) * (2 * j) + (i & (j - 1)), b = a + j;
+                    if (b < n) { const u64 x = t[a], y = t[b]; if (y < x) { t[a] = y; t[b] = x; } }
+                }
+                __syncthreads();
+            }
+        }
+        for (u32 i = tid; i < n; i += 256) out[i] = (u32)t[i];
+        return;
+    }
+#pragma unroll
+    for (u32 r = 0; r < PER; ++r)
+        if (r * 256 + tid < n) {
+            const u32 p = cnt[bk[r]] + rk[r];
+            t[p] = e[r]; bid[p] = (unsigned short)bk[r];
+        }
+    __syncthreads();
+    for (u32 p = tid; p < n; p += 256) {
+        const u32 b = bid[p];
+        const u32 bs = cnt[b], be = (b + 1 < nb) ? cnt[b + 1] : n;
+        const u64 x = t[p];
+        u32 rank = 0;
+        for (u32 q = bs; q < be; ++q) rank += (t[q] < x) ? 1u : 0u;
+        out[bs + rank] = (u32)x;
+    }
+}
+
 // Lists of more than TSORT_WAVE entries: a fixed grid of 256-thread workgroups walks the front of the heavy-first
 // descriptor list (n_active[1] entries: every long list plus a few of the boundary level).
+//   * up to TSORT_BLOCK entries: block_sort_words, the whole workgroup on one list.
 //   * up to TSORT_LARGE entries: two levels.  The workgroup cuts the depth range of the list into slabs of ~512 entries
 //     (coarse buckets, again monotone in the key), groups the (key, id) words by slab in the global scratch array `kv`,
 //     and its four waves then sort one slab each with wave_sort_words until none is left.  A slab that outgrows a wave's
@@ -435,6 +514,7 @@ tile_sort_wave_kernel(const uint4* __restrict__ tile_desc, const u32* __restrict
 //   * beyond that (tens of thousands of splats over ONE tile: a camera far from the scene, adversarial inputs), or as that
 //     fallback: the bitonic network in global memory, loads and stores at agent scope so that the waves of the workgroup
 //     see each other's exchanges across the barriers.  Slow, correct, never on the path of an ordinary frame.
+#define TSORT_BLOCK 4096
 #define TSORT_LARGE 16384
 #define TS_SLABS_MAX 64
 __global__ void __launch_bounds__(256)
@@ -442,9 +522,9 @@ tile_sort_large_kernel(const uint4* __restrict__ tile_desc, const u32* __restric
                        const u32* __restrict__ depth_key, uint2* __restrict__ kv, u32* __restrict__ point_list, u32 capacity,
                        const u32* __restrict__ n_dev)
 {
-    __shared__ u64 t[4][TSORT_WAVE];
-    __shared__ u32 cnt[4][TSORT_WAVE];
-    __shared__ unsigned short bid[4][TSORT_WAVE];
+    __shared__ u64 t_all[TSORT_BLOCK];                       // one list of <= 4096 words, or four waves x 1024 (slab sort)
+    __shared__ u32 cnt_all[TSORT_BLOCK];
+    __shared__ unsigned short bid_all[TSORT_BLOCK];
     __shared__ u32 s_red[8];
     __shared__ u32 slab_cnt[TS_SLABS_MAX + 1], slab_start[TS_SLABS_MAX + 1], s_next, s_bad;
     if (n_dev && *n_dev > capacity) return;
@@ -454,6 +534,30 @@ tile_sort_large_kernel(const uint4* __restrict__ tile_desc, const u32* __restric
         const uint4 desc = tile_desc[d];
         const u32 n = desc.z, start = desc.y;
         if (n <= TSORT_WAVE) continue;                        // uniform over the workgroup
+        if (n <= TSORT_BLOCK) {
+            // ---- one workgroup, one list: ids and keys in two batches of loads, then the block-wide bucket sort
+            constexpr int BP = TSORT_BLOCK / 256;
+            u64 e[BP]; u32 idv[BP];
+            u32 lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+            for (u32 r = 0; r < BP; ++r) idv[r] = ids_in[start + min(r * 256 + (u32)tid, n - 1)];
+#pragma unroll
+            for (u32 r = 0; r < BP; ++r) {
+                const u32 key = depth_key[idv[r]];
+                const bool valid = r * 256 + tid < n;
+                e[r] = valid ? (((u64)key << 32) | (u64)idv[r]) : ~0ull;
+                lo = min(lo, valid ? key : 0xFFFFFFFFu); hi = max(hi, valid ? key : 0u);
+            }
+            lo = wave_min(lo); hi = wave_max(hi);
+            __syncthreads();                                  // the previous list's LDS state is no longer in use
+            if (lane == 0) { s_red[wave] = lo; s_red[4 + wave] = hi; }
+            __syncthreads();
+            lo = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+            hi = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+            __syncthreads();                                  // s_red is reused as scratch below
+            block_sort_words<BP>(e, n, lo, hi, point_list + start, t_all, cnt_all, bid_all, s_red);
+            continue;
+        }
         bool network = n > TSORT_LARGE;
         if (!network) {
             // ---- level 1: key range, slab of every entry, slab counts
@@ -512,7 +616,8 @@ tile_sort_large_kernel(const uint4* __restrict__ tile_desc, const u32* __restric
                         lo = min(lo, valid ? wkey : 0xFFFFFFFFu); hi = max(hi, valid ? wkey : 0u);
                     }
                     if (m == 1) { if (lane == 0) point_list[start + s0] = (u32)e[0]; continue; }
-                    wave_sort_words<TS_PER>(e, m, wave_min(lo), wave_max(hi), point_list + start + s0, t[wave], cnt[wave], bid[wave]);
+                    wave_sort_words<TS_PER>(e, m, wave_min(lo), wave_max(hi), point_list + start + s0, t_all + wave * TSORT_WAVE,
+                                            cnt_all + wave * TSORT_WAVE, bid_all + wave * TSORT_WAVE);
                 }
                 continue;
             }

@@ -554,13 +554,14 @@ def test_binning_paths_give_identical_lists(P, W, H, sm, deg):
 
 
 @pytest.mark.parametrize("P,shrink,flat", [(3000, 0.04, False), (20000, 0.02, False), (40000, 0.012, False),
-                                           (600, 0.3, True), (5000, 0.03, True)])
+                                           (600, 0.3, True), (2500, 0.03, True), (5000, 0.03, True)])
 def test_long_and_clustered_tile_lists_take_every_sort_path(P, shrink, flat):
     """The per-tile sort of the tile-binned path (csrc/binning.hip) has four ways through it; each must give the oracle's list:
     thousands of splats over a handful of tiles (a camera far from a compact scene) leave the one-wave bucket sort for the
-    two-level slab sort (> 1024 entries: P = 3000, 20000) and for the global-memory network (> 16384 entries: P = 40000);
-    `flat` puts every splat at the SAME depth (identical 32-bit keys: the order is decided by the Gaussian id alone), which
-    overflows the buckets / slabs and takes the bitonic fallbacks (in LDS for P = 600, in global memory for P = 5000)."""
+    workgroup-wide one (1025..4096 entries: P = 3000), the two-level slab sort (P = 20000) and the global-memory network
+    (> 16384 entries: P = 40000); `flat` puts every splat at the SAME depth (identical 32-bit keys: the order is decided by the
+    Gaussian id alone), which overflows the buckets / slabs and takes the bitonic fallbacks (in LDS for P = 600 and 2500, in
+    global memory for P = 5000)."""
     scene, cam = make_case(P, 64, 48, 1.0, 0, seed=P + 1)
     scene["means3D"] = scene["means3D"] * shrink
     if flat:
