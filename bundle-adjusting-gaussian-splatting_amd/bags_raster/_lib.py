@@ -95,7 +95,7 @@ SYMBOLS = {
     "bags_camera_forward": (C.c_int, [C.POINTER(BagsCamera), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bags_camera_backward": (C.c_int, [C.POINTER(BagsCamera)] + [C.c_void_p] * 11),
     "bags_resample_forward": (C.c_int, [C.c_void_p] + [C.c_int32] * 3 + [C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p] * 4),
-    "bags_resample_workspace_size": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "bags_resample_workspace_size": (C.c_size_t, [C.c_int32] * 4),
     "bags_resample_backward": (C.c_int, [C.c_void_p] + [C.c_int32] * 3 + [C.c_void_p] + [C.c_int32] * 6 +
                                [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bags_activations_forward": (C.c_int, [C.POINTER(BagsRawGaussians)] + [C.c_void_p] * 5),

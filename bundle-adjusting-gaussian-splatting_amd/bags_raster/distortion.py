@@ -72,7 +72,7 @@ class _Resample(torch.autograd.Function):
         g_ctl = torch.empty_like(ctl) if ctx.needs_input_grad[1] else None
         lib = L.load()
         with torch.cuda.device(img.device):
-            nbytes = lib.bags_resample_workspace_size(Hc, Wc) if g_ctl is not None else 0
+            nbytes = lib.bags_resample_workspace_size(H, W, Hc, Wc)
             ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=img.device)
             L.check(lib.bags_resample_backward(img.data_ptr(), Cn, H, W, ctl.data_ptr(), h, w, Hf, Wf, Hc, Wc, g_out.data_ptr(),
                                                ws.data_ptr(), nbytes, None if g_img is None else g_img.data_ptr(),

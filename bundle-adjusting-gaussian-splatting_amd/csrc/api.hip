@@ -492,7 +492,10 @@ int bags_resample_forward(const float* image, int32_t C, int32_t H, int32_t W, c
     return BAGS_OK;
 }
 
-size_t bags_resample_workspace_size(int32_t Hc, int32_t Wc) { return resample_workspace_bytes(Hc > 0 ? Hc : 1, Wc > 0 ? Wc : 1); }
+size_t bags_resample_workspace_size(int32_t H, int32_t W, int32_t Hc, int32_t Wc)
+{
+    return resample_workspace_bytes(H > 0 ? H : 1, W > 0 ? W : 1, Hc > 0 ? Hc : 1, Wc > 0 ? Wc : 1);
+}
 
 int bags_resample_backward(const float* image, int32_t C, int32_t H, int32_t W, const float* ctrl, int32_t h, int32_t w,
                            int32_t Hf, int32_t Wf, int32_t Hc, int32_t Wc, const float* grad_out, void* workspace,
@@ -501,8 +504,9 @@ int bags_resample_backward(const float* image, int32_t C, int32_t H, int32_t W, 
     int rc = check_resample(C, H, W, h, w, Hf, Wf, Hc, Wc);
     if (rc) return rc;
     if (!image || !ctrl || !grad_out) return fail(BAGS_ERR_ARG, "resample_backward: null pointer");
-    if (grad_ctrl && (!workspace || workspace_bytes < resample_workspace_bytes(Hc, Wc)))
-        return fail(BAGS_ERR_SIZE, "resample_backward: grad_ctrl needs a workspace of %zu bytes", resample_workspace_bytes(Hc, Wc));
+    if (!grad_image && !grad_ctrl) return BAGS_OK;
+    if (!workspace || workspace_bytes < resample_workspace_bytes(H, W, Hc, Wc))
+        return fail(BAGS_ERR_SIZE, "resample_backward: needs a workspace of %zu bytes", resample_workspace_bytes(H, W, Hc, Wc));
     HIP_TRY(launch_resample_bwd(image, C, H, W, ctrl, h, w, Hf, Wf, Hc, Wc, grad_out, workspace, grad_image, grad_ctrl, (hipStream_t)stream));
     return BAGS_OK;
 }

@@ -147,7 +147,7 @@ hipError_t launch_resample_fwd(const float* image, int C, int H, int W, const fl
                                float* out, float* mask, float* flow_out, hipStream_t st);
 hipError_t launch_resample_bwd(const float* image, int C, int H, int W, const float* ctrl, int h, int w, int Hf, int Wf, int Hc, int Wc,
                                const float* grad_out, void* workspace, float* grad_image, float* grad_ctrl, hipStream_t st);
-size_t resample_workspace_bytes(int Hc, int Wc);
+size_t resample_workspace_bytes(int H, int W, int Hc, int Wc);
 // activations.hip: cat / sigmoid / exp / normalize of the raw Gaussian parameters, and the adjoint
 hipError_t launch_activations_fwd(int P, int K, const float* dc, const float* rest, const float* opacity, const float* scaling,
                                   const float* rotation, float* shs, float* o_opacity, float* o_scales, float* o_rot, hipStream_t st);

@@ -222,8 +222,9 @@ int bags_camera_backward(const BagsCamera* cam, const float* g_viewmatrix, const
  * Pass h == flow_H, w == flow_W to resample with an already dense flow (the cached flow_apply2_gt_or_img path).
  * Backward: grad_image (C,H,W) is zero-filled and accumulated with float atomics (summation order is not fixed, as in
  * PyTorch's grid_sample backward); grad_ctrl (h,w,2) is gathered per control node in a fixed order and needs a caller-owned
- * workspace of bags_resample_workspace_size(crop_H, crop_W) bytes.  Either gradient may be NULL. */
-size_t bags_resample_workspace_size(int32_t crop_H, int32_t crop_W);
+ * workspace of bags_resample_workspace_size(H, W, crop_H, crop_W) bytes (per-tile lists and the dense dL/dflow).  Either gradient
+ * may be NULL.  No global atomics; dL/dimage is accumulated in 64-bit fixed point, so both gradients are bitwise reproducible. */
+size_t bags_resample_workspace_size(int32_t H, int32_t W, int32_t crop_H, int32_t crop_W);
 int bags_resample_forward(const float* image, int32_t C, int32_t H, int32_t W, const float* ctrl_flow, int32_t h, int32_t w,
                           int32_t flow_H, int32_t flow_W, int32_t crop_H, int32_t crop_W, float* out, float* mask,
                           float* flow_out, void* stream);

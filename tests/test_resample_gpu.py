@@ -88,6 +88,27 @@ def test_resample_full_size_against_pytorch_pipeline():
         print(f"resample fwd+bwd @1080p {name}: {e0.elapsed_time(e1) / 10:.3f} ms")
 
 
+def test_resample_backward_is_bitwise_reproducible_and_handles_minification():
+    """dL/dimage is accumulated per source tile in 64-bit fixed point (no global atomics): two runs must agree bit for bit.
+    The second flow squeezes the whole 160x208 output into the centre of the image, so that far more than 32 output tiles
+    sample one source tile: the per-tile lists overflow and the gather falls back to testing every output tile's box."""
+    rng = np.random.default_rng(11)
+    C, H, W, h, w, fhw, chw = 3, 96, 128, 6, 8, (176, 224), (160, 208)
+    image = rng.random((C, H, W), dtype=np.float32)
+    cot = rng.standard_normal((C,) + chw).astype(np.float32)
+    for span in (1.05, 0.08):
+        gy, gx = np.meshgrid(np.linspace(-span, span, h), np.linspace(-span, span, w), indexing="ij")
+        ctrl = (np.stack((gx, gy), -1) + 0.02 * span * rng.standard_normal((h, w, 2))).astype(np.float32)
+        a = _hip(image, ctrl, fhw, chw, cot)
+        b = _hip(image, ctrl, fhw, chw, cot)
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+        gi_w, gc_w = RO.backward(image, ctrl, fhw, chw, cot)
+        np.testing.assert_allclose(a[2], gi_w, atol=2e-4 * max(1.0, np.abs(gi_w).max()))
+        np.testing.assert_allclose(a[3], gc_w, atol=2e-3 * max(1e-6, np.abs(gc_w).max()))
+        if span < 0.5:
+            assert (np.abs(gi_w).reshape(C, -1).sum(0) > 0).mean() < 0.05      # everything lands in a small patch of the image
+
+
 def test_resample_rejects_bad_arguments():
     with pytest.raises(RuntimeError, match="GPU tensor"):
         resample_image(torch.rand(3, 8, 8), torch.rand(2, 2, 2), (8, 8), (8, 8))
