@@ -636,3 +636,14 @@ def test_two_views_in_flight_on_two_streams():
             assert torch.equal(o[0].detach(), r[0]) and torch.equal(o[1], r[1])
             for k in r[2]:
                 assert torch.equal(t[k].grad, r[2][k]), k
+
+
+@pytest.mark.gpu
+def test_more_than_32768_tiles_falls_back_to_the_radix_path():
+    """34 170 tiles (3216x2720): beyond the tile-binned path's LDS limits, so binning="auto" must take the radix path by
+    itself -- same bit-exact lists; blending checked on 48 sampled tiles."""
+    scene, cam = make_case(3000, 3216, 2720, 0.25, 1, seed=3)
+    rep = compare_sampled(scene, cam, 1, sample_tiles(3216, 2720, 48, seed=1))
+    print({k: rep[k] for k in ("num_rendered", "instances_in_sample", "image_max_err", "grad_rel_fp32")})
+    assert rep["num_rendered"][0] > 100_000
+    _assert_sampled(rep, grad_tol=2e-4)
