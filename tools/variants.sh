@@ -10,6 +10,6 @@ for v in "$@"; do
   timeout 200 python bench.py --no-cpu-baseline --steps ${STEPS:-15} --warmup 3 ${BENCH_ARGS} 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); s=d['stage_ms']
-print('  ms/step %.3f  fwd %.3f bwd %.3f pre_bwd %.3f sort %.3f  all:'%(d['ms_per_step'], s['blend_fwd'], s['blend_bwd'], s['preprocess_bwd'], s['depth_sort']+s['tile_sort']), s)"
+print('  ms/step %.4f  fwd %.4f bwd %.4f pre_bwd %.4f binning %.4f  all:'%(d['ms_per_step'], s['blend_fwd'], s['blend_bwd'], s['preprocess_bwd'], sum(v for k, v in s.items() if k in ('depth_sort','offsets_scan','emit','tile_sort','tile_ranges'))), s)"
 done
 rm -rf $CS/build; make -C $CS -j8 > /dev/null 2>&1
