@@ -647,3 +647,26 @@ def test_more_than_32768_tiles_falls_back_to_the_radix_path():
     print({k: rep[k] for k in ("num_rendered", "instances_in_sample", "image_max_err", "grad_rel_fp32")})
     assert rep["num_rendered"][0] > 100_000
     _assert_sampled(rep, grad_tol=2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("binning", ["auto", "radix"])
+def test_zero_gaussians_render_the_background(binning):
+    """P = 0 (a scene pruned to nothing): no prepare phase runs at all; the forward must still produce the background, the
+    backward zeros for the camera tensors."""
+    from bags_raster import GaussianRasterizer
+    from bags_raster.synth import look_at_origin_camera
+    from scenes import camera_tensors, hip_settings
+    dev = torch.device("cuda")
+    cam = look_at_origin_camera(80, 48)
+    ct = {k: v.clone().requires_grad_(True) for k, v in camera_tensors(cam, dev).items()}
+    bg = torch.tensor([0.1, 0.5, 0.9])
+    st = hip_settings(cam, 2, dev, bg=bg, tensors=ct, binning=binning)
+    z = lambda *s: torch.zeros(*s, device=dev)
+    out = GaussianRasterizer(st)(means3D=z(0, 3), means2D=z(0, 3), means2D_densify=z(0, 3), shift_factors=z(3), shs=z(0, 9, 3),
+                                 colors_precomp=None, opacities=z(0, 1), scales=z(0, 3), rotations=z(0, 4), cov3D_precomp=None)
+    assert out[0].shape == (3, 48, 80) and out[1].numel() == 0
+    assert torch.allclose(out[0].cpu(), bg[:, None, None].expand(3, 48, 80))
+    out[0].sum().backward()
+    for k, v in ct.items():
+        assert v.grad is None or float(v.grad.abs().max()) == 0.0, k
