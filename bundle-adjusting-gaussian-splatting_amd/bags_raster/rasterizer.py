@@ -53,12 +53,12 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def _f32c(t: Optional[torch.Tensor], name: str, device: torch.device, shape=None) -> Optional[torch.Tensor]:
+def _f32c(t: Optional[torch.Tensor], name: str, device: torch.device, shape=None, empty_ok: bool = False) -> Optional[torch.Tensor]:
     if t is None:
         return None
     if not torch.is_tensor(t):
         raise TypeError(f"{name} must be a tensor")
-    if t.numel() == 0 and shape is None:
+    if t.numel() == 0 and shape is None and not (empty_ok and t.dim() > 1):
         return None                       # the fork's wrapper passes torch.Tensor([]) for "absent"
     if t.device != device:
         raise RuntimeError(f"{name} is on {t.device}, expected {device}")
@@ -87,12 +87,13 @@ class _Packed:
         k["means3D"] = _f32c(means3D, "means3D", dev, (P, 3))
         k["means2D"] = _f32c(means2D, "means2D", dev, (P, 3)) if means2D is not None else None
         k["shift_factors"] = _f32c(shift_factors, "shift_factors", dev, (3,)) if shift_factors is not None else None
-        k["shs"] = _f32c(sh, "shs", dev)
-        k["colors_precomp"] = _f32c(colors_precomp, "colors_precomp", dev)
-        k["opacities"] = _f32c(opacities, "opacities", dev)
-        k["scales"] = _f32c(scales, "scales", dev)
-        k["rotations"] = _f32c(rotations, "rotations", dev)
-        k["cov3D_precomp"] = _f32c(cov3D_precomp, "cov3D_precomp", dev)
+        e0 = P == 0                          # an empty scene: (0, n) tensors are real arguments, not the "absent" marker
+        k["shs"] = _f32c(sh, "shs", dev, empty_ok=e0)
+        k["colors_precomp"] = _f32c(colors_precomp, "colors_precomp", dev, empty_ok=e0)
+        k["opacities"] = _f32c(opacities, "opacities", dev, empty_ok=e0)
+        k["scales"] = _f32c(scales, "scales", dev, empty_ok=e0)
+        k["rotations"] = _f32c(rotations, "rotations", dev, empty_ok=e0)
+        k["cov3D_precomp"] = _f32c(cov3D_precomp, "cov3D_precomp", dev, empty_ok=e0)
         if (k["shs"] is None) == (k["colors_precomp"] is None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
         if ((k["scales"] is None or k["rotations"] is None) and k["cov3D_precomp"] is None) or \

@@ -258,7 +258,7 @@ int bags_forward_prepare(const BagsSettings* s, const BagsInputs* in, const Bags
 {
     int rc = check_common(s, in, stt);
     if (rc) return rc;
-    if (!out || !out->radii || !host_num_rendered) return fail(BAGS_ERR_ARG, "radii / host_num_rendered must be given");
+    if (!out || (in->P > 0 && !out->radii) || !host_num_rendered) return fail(BAGS_ERR_ARG, "radii / host_num_rendered must be given");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     GeomView g; carve_geom(align256(stt->geom), in->P, &g);
     ImgView im; carve_image(align256(stt->image), s->image_width, s->image_height, &im);
@@ -294,7 +294,7 @@ int bags_forward_prepare_async(const BagsSettings* s, const BagsInputs* in, cons
 {
     int rc = check_common(s, in, stt);
     if (rc) return rc;
-    if (!out || !out->radii || !host_num_rendered) return fail(BAGS_ERR_ARG, "radii / host_num_rendered must be given");
+    if (!out || (in->P > 0 && !out->radii) || !host_num_rendered) return fail(BAGS_ERR_ARG, "radii / host_num_rendered must be given");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     GeomView g; carve_geom(align256(stt->geom), in->P, &g);
     ImgView im; carve_image(align256(stt->image), s->image_width, s->image_height, &im);
