@@ -8,7 +8,7 @@
 //     mask = ~((img[0] == 0) & (img[1] == 0))
 // i.e. three full-resolution passes and their autograd backward.  Here one kernel each way touches only the cropped
 // pixels: the control flow is interpolated at the pixel, the image is sampled once; the backward accumulates dL/dimage per
-// 16x16 source tile in LDS as 64-bit fixed-point integers (no global atomics, bitwise reproducible) and GATHERS
+// 16x16 source tile in LDS as 64-bit fixed-point integers (no global float atomics, bitwise reproducible) and GATHERS
 // dL/d(control flow) per control node.
 // The crop is taken as exact integer indexing (the reference's second grid_sample reproduces integer positions only to
 // ~1e-4 px after normalising and un-normalising the grid; the difference is below 2e-4 of the image range).
@@ -91,7 +91,7 @@ resample_fwd_kernel(ResampleGeom g, const float* __restrict__ image, const float
 }
 
 // ---------------------------------------------------------------------------------------------------- backward
-// dL/dimage without global atomics and bitwise reproducible.  (The first version scattered 4 x C float atomics per output
+// dL/dimage without global float atomics and bitwise reproducible.  (The first version scattered 4 x C float atomics per output
 // pixel: 0.6 ms at 1080p, 17x the forward, the one place of the library that used the ~1.3 TB/s atomic path, and the
 // summation order changed from run to run.)  Two kernels:
 //   1. resample_bwd_pixels_kernel, one workgroup per 16x16 OUTPUT tile: dL/dflow of every pixel (for the control-flow

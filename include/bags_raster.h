@@ -223,7 +223,8 @@ int bags_camera_backward(const BagsCamera* cam, const float* g_viewmatrix, const
  * Backward: grad_image (C,H,W) is zero-filled and accumulated with float atomics (summation order is not fixed, as in
  * PyTorch's grid_sample backward); grad_ctrl (h,w,2) is gathered per control node in a fixed order and needs a caller-owned
  * workspace of bags_resample_workspace_size(H, W, crop_H, crop_W) bytes (per-tile lists and the dense dL/dflow).  Either gradient
- * may be NULL.  No global atomics; dL/dimage is accumulated in 64-bit fixed point, so both gradients are bitwise reproducible. */
+ * may be NULL.  No global float atomics (integer ones only on per-tile list counters); dL/dimage is accumulated in 64-bit fixed
+ * point, so both gradients are bitwise reproducible. */
 size_t bags_resample_workspace_size(int32_t H, int32_t W, int32_t crop_H, int32_t crop_W);
 int bags_resample_forward(const float* image, int32_t C, int32_t H, int32_t W, const float* ctrl_flow, int32_t h, int32_t w,
                           int32_t flow_H, int32_t flow_W, int32_t crop_H, int32_t crop_W, float* out, float* mask,
