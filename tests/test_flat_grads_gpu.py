@@ -67,3 +67,41 @@ def test_render_path_raw_leaves_accumulate_in_the_flat_bucket():
     for p, r in zip(pc2.leaves(), ref):
         assert torch.allclose(p.grad, r, rtol=1e-5, atol=1e-6)
     assert red.exchange.collectives_issued == 0               # single process: nothing to exchange
+
+
+def test_five_views_with_distance_depth_key_accumulate_to_the_oracle_sum():
+    """The cubemap step of the reference issues five op calls per iteration with the Euclidean-distance sort key
+    (utils/cubemap_utils.py:229,263-265, README.md:126) and backpropagates their summed loss.  Five views through
+    ViewShardedRenderer.step (one process: V = 5 views behind one exchange point), depth_key="distance": the gradients
+    accumulated in the flat bucket must equal the sum of the oracle's five per-view gradients."""
+    from bags_raster import GaussianRasterizer
+    from bags_raster.sharding import ViewShardedRenderer
+    from bags_raster.synth import sphere_views
+    from parity import run_oracle
+    from scenes import rel_err
+    dev = torch.device("cuda", 0)
+    W, H, deg = 128, 96, 2
+    scene, _ = make_case(2500, W, H, 1.5, deg, seed=61)
+    cams = sphere_views(5, W, H, noise=0.1, seed=7)
+    cots = [torch.randn(3, H, W, generator=torch.Generator().manual_seed(70 + k)) for k in range(5)]
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+    leaves = {k: scene[k].to(dev).clone().requires_grad_(True) for k in names}
+    P = scene["means3D"].shape[0]
+
+    def render_fn(view):
+        k, cam = view
+        st = hip_settings(cam, deg, dev, depth_key="distance")
+        img = GaussianRasterizer(st)(means3D=leaves["means3D"], means2D=torch.zeros(P, 3, device=dev), means2D_densify=None,
+                                     shift_factors=None, shs=leaves["shs"], colors_precomp=None, opacities=leaves["opacities"],
+                                     scales=leaves["scales"], rotations=leaves["rotations"], cov3D_precomp=None)[0]
+        return (img * cots[k].to(dev)).sum()
+    r = ViewShardedRenderer([leaves[k] for k in names], render_fn)
+    res = r.step(list(enumerate(cams)))
+    assert res["views"] == [0, 1, 2, 3, 4] and r.reducer.bucket.bound()
+    want = {k: torch.zeros_like(scene[k]) for k in names}
+    for k, cam in enumerate(cams):
+        _, gr = run_oracle(scene, cam, deg, cots[k], torch.float32, depth_key="distance")
+        for n in names:
+            want[n] += gr[n]
+    for n in names:
+        assert rel_err(leaves[n].grad.cpu(), want[n]) < 1e-4, (n, rel_err(leaves[n].grad.cpu(), want[n]))
