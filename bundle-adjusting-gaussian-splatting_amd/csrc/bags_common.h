@@ -52,18 +52,41 @@ __device__ __forceinline__ float det_atan2_pos(float rho, float tz)
     return (rho > tz) ? 1.57079637f - a : a;
 }
 
+// ---- tile masks of small rectangles (GeomView::keep) ------------------------------------------------------
+// A rectangle of at most 8 x 8 tiles carries a 64-bit mask of the tiles it emits, bit ry * 8 + rx; a larger one emits all.
+__device__ __forceinline__ bool rect_small(int w, int h) { return w <= 8 && h <= 8; }
+__device__ __forceinline__ u64 rect_full_mask(int w, int h)
+{
+    if (w <= 0 || h <= 0) return 0ull;
+    if (!rect_small(w, h)) return ~0ull;
+    return ((1ull << w) - 1ull) * (0x0101010101010101ull >> (8 * (8 - h)));
+}
+// rank of tile (rx, ry) among the emitted tiles of its Gaussian = index of its partial-gradient record
+__device__ __forceinline__ u32 rect_tile_rank(u64 keep, int w, int h, int rx, int ry)
+{
+    return rect_small(w, h) ? (u32)__popcll(keep & ((1ull << (ry * 8 + rx)) - 1ull)) : (u32)(ry * w + rx);
+}
+// position (ry * 8 + rx) of the n-th emitted tile of a small rectangle
+__device__ __forceinline__ int rect_nth_tile(u64 keep, u32 n)
+{
+    for (u32 i = 0; i < n; ++i) keep &= keep - 1ull;
+    return __ffsll((long long)keep) - 1;
+}
+
 // ---- carved views of the three caller-owned state buffers -------------------------------------------------
 struct GeomView {            // per Gaussian, indexed by Gaussian id unless stated
     u32*    depth_key;       // float bits of the sort depth, KEY_CULLED when not rendered
     // One 64-byte line per Gaussian with everything the blend kernels gather per (tile, Gaussian) instance, so an
     // instance costs ONE line fetch instead of five partial ones from id-ordered (spatially random) SoA arrays:
     //   q0 = conic a, b, c, opacity      q1 = pixel x, y, colour r, g
-    //   q2 = colour b, view depth z, rect.x, rect.y (bits)      q3 = -, tiles_touched, clamped mask, 0 (bits)
+    //   q2 = colour b, view depth z, rect.x, rect.y (bits)      q3 = keep lo, tiles_touched, clamped mask, keep hi (bits)
     float4* g2d;             // [4 * P]
     u32*    inst_off;        // [P] first emission slot of the Gaussian's partial-gradient records (an array of its own: a 4-byte
                              // write into every 64-byte line of g2d after the scan cost 6.6 us per frame)
     uint2*  rect;            // (minx | miny<<16, maxx | maxy<<16), max exclusive   (compact copy for emit)
-    u32*    tiles_touched;   // compact copy for the offsets scan / emit
+    u32*    tiles_touched;   // instances the Gaussian emits (compact copy for the offsets scan / emit)
+    u64*    keep;            // tile mask of a rectangle of at most 8 x 8 tiles: bit ry * 8 + rx set = tile (minx + rx, miny + ry)
+                             // is emitted (D7: the alpha >= 1/255 ellipse reaches it); larger rectangles emit every tile
     // scratch (dead after forward)
     u32 *keys_a, *keys_b, *vals_a, *vals_b;   // depth ordering of Gaussians (ping-pong)
     u32*    rank_offset;     // exclusive instance offset per depth rank

@@ -71,35 +71,54 @@ __device__ __forceinline__ void walk_rect(u32* cnt, uint2 rc, int grid_x, int la
         else (void)lds_count_tile(cnt, t);
     }
 }
+// A rectangle of at most 8 x 8 tiles: the set bits of its tile mask (GeomView::keep), no division.
+template <bool EMIT>
+__device__ __forceinline__ void walk_mask(u32* cnt, uint2 rc, u64 m, int grid_x, u32 g, u32* __restrict__ ids)
+{
+    const int minx = rc.x & 0xFFFF, miny = rc.x >> 16;
+    const u32 t0 = (u32)(miny * grid_x + minx);
+    while (m) {
+        const int bit = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        const u32 t = t0 + (u32)((bit >> 3) * grid_x + (bit & 7));
+        if (EMIT) ids[atomicAdd(&cnt[t], 1u)] = g;
+        else (void)lds_count_tile(cnt, t);
+    }
+}
 
 // Shared body of tile_count (EMIT = false) and emit_binned (EMIT = true): the block's Gaussians, thread by thread in
 // contiguous runs; small rectangles by their own lane, large ones by the whole wave.
 template <bool EMIT>
 __device__ __forceinline__ u32 walk_block(u32* cnt, int P, int per_block, int grid_x, const uint2* __restrict__ rect,
-                                          const u32* __restrict__ tiles_touched, u32* __restrict__ ids)
+                                          const u32* __restrict__ tiles_touched, const u64* __restrict__ keep,
+                                          u32* __restrict__ ids)
 {
     const int lane = threadIdx.x & 63;
     const int per_thread = per_block / BIN_THREADS;
     const long long g0 = (long long)blockIdx.x * per_block + (long long)threadIdx.x * per_thread;
     u32 mine = 0;
     for (int k0 = 0; k0 < per_thread; k0 += 4) {            // uniform trip counts: the ballots below need every lane
-        // four Gaussians' counts and rectangles requested together, unconditionally (clamped index): one memory round trip
-        // per batch instead of two per Gaussian
-        u32 ntv[4]; uint2 rcv[4];
+        // four Gaussians' counts, rectangles and masks requested together, unconditionally (clamped index): one memory
+        // round trip per batch instead of three per Gaussian
+        u32 ntv[4]; uint2 rcv[4]; u64 kpv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const long long g = g0 + k0 + u;
             const long long gc = g < P ? g : (long long)P - 1;
-            ntv[u] = tiles_touched[gc]; rcv[u] = rect[gc];
+            ntv[u] = tiles_touched[gc]; rcv[u] = rect[gc]; kpv[u] = keep[gc];
             if (!(g < P) || k0 + u >= per_thread) ntv[u] = 0u;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const long long g = g0 + k0 + u;
             const u32 nt = ntv[u]; const uint2 rc = rcv[u];
-            mine += nt;
-            if (nt > 0 && nt <= BIN_COOP) walk_rect<EMIT>(cnt, rc, grid_x, lane, false, (u32)g, ids);
-            u64 big = __ballot(nt > BIN_COOP);
+            const int w = (int)(rc.y & 0xFFFF) - (int)(rc.x & 0xFFFF), h = (int)(rc.y >> 16) - (int)(rc.x >> 16);
+            mine += nt;                                     // a large rectangle emits every tile: nt is its area
+            if (nt > 0) {
+                if (rect_small(w, h)) walk_mask<EMIT>(cnt, rc, kpv[u], grid_x, (u32)g, ids);
+                else if (nt <= BIN_COOP) walk_rect<EMIT>(cnt, rc, grid_x, lane, false, (u32)g, ids);
+            }
+            u64 big = __ballot(nt > BIN_COOP);              // never a small rectangle (at most 64 tiles)
             while (big) {
                 const int src = __ffsll((long long)big) - 1;
                 big &= big - 1;
@@ -114,13 +133,14 @@ __device__ __forceinline__ u32 walk_block(u32* cnt, int P, int per_block, int gr
 
 __global__ void __launch_bounds__(BIN_THREADS)
 tile_count_kernel(int P, int per_block, int grid_x, int T2, const uint2* __restrict__ rect, const u32* __restrict__ tiles_touched,
+                  const u64* __restrict__ keep,
                   u32* __restrict__ cnt_rows, u32* __restrict__ local_off, u32* __restrict__ block_total)
 {
     extern __shared__ u32 cnt[];                             // T2 packed words
     __shared__ u32 wsum[BIN_THREADS / 64];
     for (int i = threadIdx.x; i < T2; i += BIN_THREADS) cnt[i] = 0u;
     __syncthreads();
-    const u32 mine = walk_block<false>(cnt, P, per_block, grid_x, rect, tiles_touched, nullptr);
+    const u32 mine = walk_block<false>(cnt, P, per_block, grid_x, rect, tiles_touched, keep, nullptr);
     // instance offset of every Gaussian inside its block (id order): exclusive scan of the threads' sums, then a second
     // walk over the thread's own run
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -280,7 +300,7 @@ ranges_order_kernel(const u32* __restrict__ tile_total, int T, uint2* __restrict
 // ------------------------------------------------------------------------------------------------ 4. emit_binned
 __global__ void __launch_bounds__(BIN_THREADS)
 emit_binned_kernel(int P, int per_block, int grid_x, int T, const uint2* __restrict__ rect,
-                   const u32* __restrict__ tiles_touched, const u32* __restrict__ pre,
+                   const u32* __restrict__ tiles_touched, const u64* __restrict__ keep, const u32* __restrict__ pre,
                    const uint2* __restrict__ ranges, const u32* __restrict__ local_off, const u32* __restrict__ block_base,
                    u32* __restrict__ inst_off, u32* __restrict__ ids, u32 capacity, const u32* __restrict__ n_dev)
 {
@@ -300,7 +320,7 @@ emit_binned_kernel(int P, int per_block, int grid_x, int T, const uint2* __restr
     const u32* prow = pre + (size_t)blockIdx.x * T;
     for (int t = threadIdx.x; t < T; t += BIN_THREADS) cur[t] = ranges[t].x + prow[t];
     __syncthreads();
-    (void)walk_block<true>(cur, P, per_block, grid_x, rect, tiles_touched, ids);
+    (void)walk_block<true>(cur, P, per_block, grid_x, rect, tiles_touched, keep, ids);
 }
 
 // ------------------------------------------------------------------------------------------------ 5. tile_sort
@@ -678,7 +698,7 @@ hipError_t launch_binned_prepare(const GeomView& g, const ImgView& im, int P, in
 {
     const int per = binned_per_block(P), B = cdiv(P, per), T2 = (T + 1) / 2;
     hipLaunchKernelGGL(tile_count_kernel, dim3(B), dim3(BIN_THREADS), (size_t)T2 * 4, st, P, per, grid_x, T2, g.rect, g.tiles_touched,
-                       im.cnt_rows, g.local_off, g.block_total);
+                       g.keep, im.cnt_rows, g.local_off, g.block_total);
     hipLaunchKernelGGL(tile_prefix_kernel, dim3(cdiv(T2, 64)), dim3(256), 0, st, im.cnt_rows, B, T, T2, im.pre, im.tile_total);
     launch_ranges_order(im, g, T, B, st);
     return hipGetLastError();
@@ -703,7 +723,7 @@ hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(emit_binned_kernel, dim3(B), dim3(BIN_THREADS), cursors, st, P, per, grid_x, T, g.rect, g.tiles_touched,
-                       im.pre, im.ranges, g.local_off, g.block_base, g.inst_off, ids, capacity, n_dev);
+                       g.keep, im.pre, im.ranges, g.local_off, g.block_base, g.inst_off, ids, capacity, n_dev);
     // long lists first: their few workgroups run beside the many short sorts of the second launch
     hipLaunchKernelGGL(tile_sort_large_kernel, dim3(T < 512 ? T : 512), dim3(256), 0, st, im.tile_desc, im.n_active, ids, g.depth_key, kv,
                        point_list, capacity, n_dev);

@@ -251,22 +251,26 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
 #endif
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    struct Raw { float4 q0, q1, q2; u32 io; };      // conic+opacity | x y r g | b z rect | inst_offset
+    struct Raw { float4 q0, q1, q2; u32 io; u64 kp; };      // conic+opacity | x y r g | b z rect | inst_offset | tile mask
     auto fetch_id = [&](u32 rx_, u32 hi_) -> u32 {   // id of this thread's slot in the chunk of a tile's list that ends at hi_
         const u32 c_ = min(hi_, (u32)BCHUNK);
         return ((u32)tid < c_) ? point_list[rx_ + (hi_ - c_) + tid] : 0xFFFFFFFFu;
     };
     auto fetch = [&](u32 g) {
-        Raw r; r.q0 = make_float4(0.f, 0.f, 0.f, 0.f); r.q1 = r.q0; r.q2 = r.q0; r.io = 0u;
+        Raw r; r.q0 = make_float4(0.f, 0.f, 0.f, 0.f); r.q1 = r.q0; r.q2 = r.q0; r.io = 0u; r.kp = 0ull;
         if (g != 0xFFFFFFFFu) {                       // one 64-byte line
             const float4* rec = g2d + 4 * (size_t)g;
             r.q0 = rec[0]; r.q1 = rec[1]; r.q2 = rec[2]; r.io = inst_off[g];
+            const float4 q3 = rec[3];
+            r.kp = (u64)__float_as_uint(q3.x) | ((u64)__float_as_uint(q3.w) << 32);
         }
         return r;
     };
-    // emission slot of a Gaussian's record for tile (tx, ty): its rectangle is walked y outer, x inner
-    auto emission_slot = [&](u32 io, uint2 rc, int tx, int ty) -> u32 {
-        return io + (u32)(ty - (int)(rc.x >> 16)) * ((rc.y & 0xFFFF) - (rc.x & 0xFFFF)) + (u32)(tx - (int)(rc.x & 0xFFFF));
+    // emission slot of a Gaussian's record for tile (tx, ty): the tile's rank among the tiles the Gaussian emits (its
+    // rectangle y outer, x inner, minus what the tile mask of a small rectangle drops)
+    auto emission_slot = [&](u32 io, uint2 rc, u64 kp, int tx, int ty) -> u32 {
+        const int minx = (int)(rc.x & 0xFFFF), miny = (int)(rc.x >> 16);
+        return io + rect_tile_rank(kp, (int)(rc.y & 0xFFFF) - minx, (int)(rc.y >> 16) - miny, tx - minx, ty - miny);
     };
     auto make_rec = [&](const Raw& rw, const TileRef& t, u32 lo_, u32 cnt_) {
         ChunkRec rec; rec.mask = 0; rec.e = 0;
@@ -274,7 +278,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         if ((u32)tid < cnt_) {
             const float2 c2 = make_float2(rw.q1.x, rw.q1.y); const float4 co = rw.q0;
             const float4 cz = make_float4(rw.q1.z, rw.q1.w, rw.q2.x, rw.q2.y);
-            rec.e = emission_slot(rw.io, make_uint2(__float_as_uint(rw.q2.z), __float_as_uint(rw.q2.w)), t.tx, t.ty);
+            rec.e = emission_slot(rw.io, make_uint2(__float_as_uint(rw.q2.z), __float_as_uint(rw.q2.w)), rw.kp, t.tx, t.ty);
             rec.x = c2.x; rec.y = c2.y;
             rec.ap = -0.5f * LOG2E * co.x; rec.bp = -LOG2E * co.y; rec.cp = -0.5f * LOG2E * co.z; rec.o = co.w;
             rec.r = cz.x; rec.g = cz.y; rec.b = cz.z;
@@ -310,8 +314,9 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         }
         for (u32 p = t.maxc + tid; p < t.n; p += 256) {
             const u32 g = point_list[t.rx + p];
-            const float4 t2 = g2d[4 * (size_t)g + 2];
-            const u32 e = emission_slot(inst_off[g], make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)), t.tx, t.ty);
+            const float4 t2 = g2d[4 * (size_t)g + 2], t3 = g2d[4 * (size_t)g + 3];
+            const u32 e = emission_slot(inst_off[g], make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)),
+                                        (u64)__float_as_uint(t3.x) | ((u64)__float_as_uint(t3.w) << 32), t.tx, t.ty);
             float4* dst = reinterpret_cast<float4*>(partials + (size_t)e * PART_FLOATS);
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
             dst[0] = z4; dst[1] = z4; dst[2] = z4;

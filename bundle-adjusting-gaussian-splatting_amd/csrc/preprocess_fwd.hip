@@ -14,6 +14,40 @@ struct CamConst {
     float sf[3];
 };
 
+// D7, second half: which tiles of a rectangle of w x h <= 8 x 8 tiles the ellipse Q(d) = a dx^2 + 2 b dx dy + c dy^2 <= tau2m
+// around (px, py) reaches.  The minimum of the convex Q over the square of a tile's pixel centres [X0, X0 + 15] x [Y0, Y0 +
+// 15] is 0 for a centre inside it; otherwise it lies on an edge that faces the centre, at the 1-D minimiser along that edge
+// clamped to the edge.  tau2m carries the margins (1e-3 + 0.02 on 2 ln, then 2 %): the blend kernels evaluate the same Q
+// from the same a, b, c, px, py with offsets of at most 8 tiles, so their rounding (~1e-6 Q) cannot cross it -- a dropped
+// tile holds no pixel with alpha >= 1/255, the image and every gradient are those of the full rectangle.
+// Adds, multiplies, two reciprocals, min/max only, contraction off: oracle/raster_oracle.py:_tile_reach repeats them in
+// torch and gets the same bits.  Bit ry * 8 + rx of the result = tile (ex0 + rx, ey0 + ry) is emitted.
+__device__ __forceinline__ u64 tile_reach(float px, float py, float a, float b, float c, float tau2m, int ex0, int ey0, int w, int h)
+{
+    const float ra = 1.0f / a, rc = 1.0f / c, b2 = 2.0f * b;
+    u64 keep = 0ull;
+    for (int ry = 0; ry < h; ++ry) {
+        const float Y0 = (float)((ey0 + ry) * BAGS_TILE), Y1 = Y0 + 15.0f;
+        const bool yin = (py >= Y0) && (py <= Y1);
+        const float dyE = ((py < Y0) ? Y0 : Y1) - py;                  // the horizontal edge that faces the centre (if !yin)
+        const float xs = px - (b * dyE) * ra;                           // unconstrained minimiser along it
+        const float cdd = (c * dyE) * dyE;
+        for (int rx = 0; rx < w; ++rx) {
+            const float X0 = (float)((ex0 + rx) * BAGS_TILE), X1 = X0 + 15.0f;
+            const bool xin = (px >= X0) && (px <= X1);
+            const float dx = fminf(fmaxf(xs, X0), X1) - px;
+            const float qh = (a * dx) * dx + (b2 * dx) * dyE + cdd;
+            const float dxE = ((px < X0) ? X0 : X1) - px;               // the vertical edge that faces the centre (if !xin)
+            const float ys = py - (b * dxE) * rc;
+            const float dy = fminf(fmaxf(ys, Y0), Y1) - py;
+            const float qv = (a * dxE) * dxE + (b2 * dxE) * dy + (c * dy) * dy;
+            const float q = fminf(yin ? INFINITY : qh, xin ? INFINITY : qv);
+            if ((xin && yin) || !(q > tau2m)) keep |= 1ull << (ry * 8 + rx);
+        }
+    }
+    return keep;
+}
+
 __global__ void __launch_bounds__(256)
 preprocess_fwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod, int depth_mode, int tile_bounds,
                       const float* __restrict__ means3D, const float* __restrict__ means2D,
@@ -24,7 +58,8 @@ preprocess_fwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                       const float* __restrict__ projmatrix, const float* __restrict__ intrinsic,
                       const float* __restrict__ campos_p,
                       u32* __restrict__ depth_key, float4* __restrict__ g2d, uint2* __restrict__ rect_out,
-                      u32* __restrict__ tiles_touched, int32_t* __restrict__ radii, float* __restrict__ mean2D_out)
+                      u32* __restrict__ tiles_touched, u64* __restrict__ keep_out, int32_t* __restrict__ radii,
+                      float* __restrict__ mean2D_out)
 {
     __shared__ CamConst cam;
     if (threadIdx.x < 16) {
@@ -44,6 +79,7 @@ preprocess_fwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     // defaults for a culled Gaussian
     u32 key = KEY_CULLED; u32 tiles = 0; int radius = 0;
     uint2 rect = make_uint2(0u, 0u);
+    u64 keep = ~0ull; bool masked = false;
     float2 pxy = make_float2(0.f, 0.f);
     float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), rgbz_v = q0;
     u32 clamp_bits = 0;
@@ -165,9 +201,17 @@ preprocess_fwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                             ex1 = min(ex1, min(gx, max(0, (int)fminf(big, fmaxf(-big, (px + rx) / 16.0f)) + 1)));
                             ey1 = min(ey1, min(gy, max(0, (int)fminf(big, fmaxf(-big, (py + ry) / 16.0f)) + 1)));
                             if (ex1 <= ex0 || ey1 <= ey0) { ex1 = ex0; ey1 = ey0; }
+#ifndef NO_TILE_MASKS            // experiment switch (tools/ab_masks.sh): rectangles only, as before the masks
+                            else if (ex1 - ex0 <= 8 && ey1 - ey0 <= 8 && con_a > 0.0f && con_c > 0.0f &&
+                                     con_a * con_c - con_b * con_b > 0.0f) {
+                                keep = tile_reach(px, py, con_a, con_b, con_c, tau2 * 1.02f, ex0, ey0, ex1 - ex0, ey1 - ey0);
+                                masked = true;
+                            }
+#endif
                         }
                     }
-                    tiles = (u32)((ex1 - ex0) * (ey1 - ey0));
+                    if (!masked) keep = rect_full_mask(ex1 - ex0, ey1 - ey0);
+                    tiles = masked ? (u32)__popcll(keep) : (u32)((ex1 - ex0) * (ey1 - ey0));
                     radius = (int)rad_f;
                     rect = make_uint2((u32)ex0 | ((u32)ey0 << 16), (u32)ex1 | ((u32)ey1 << 16));
                     pxy = make_float2(px, py);
@@ -216,11 +260,13 @@ preprocess_fwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     depth_key[i] = key;
     tiles_touched[i] = tiles;
     rect_out[i] = rect;
+    keep_out[i] = keep;
     float4* rec = g2d + 4 * (size_t)i;            // one full 64-byte line per thread
     rec[0] = q0;
     rec[1] = make_float4(pxy.x, pxy.y, rgbz_v.x, rgbz_v.y);
     rec[2] = make_float4(rgbz_v.z, rgbz_v.w, __uint_as_float(rect.x), __uint_as_float(rect.y));
-    rec[3] = make_float4(__uint_as_float(0u), __uint_as_float(tiles), __uint_as_float(clamp_bits), 0.f);
+    rec[3] = make_float4(__uint_as_float((u32)keep), __uint_as_float(tiles), __uint_as_float(clamp_bits),
+                         __uint_as_float((u32)(keep >> 32)));
     radii[i] = radius;
     if (mean2D_out) { mean2D_out[2 * i] = pxy.x; mean2D_out[2 * i + 1] = pxy.y; }
 }
@@ -234,6 +280,6 @@ hipError_t launch_preprocess_fwd(const BagsSettings& s, const BagsInputs& in, co
                        s.image_width, s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, s.depth_key, s.tile_bounds,
                        in.means3D, in.means2D, in.shift_factors, in.shs, in.colors_precomp, in.opacities, in.scales,
                        in.rotations, in.cov3D_precomp, s.viewmatrix, s.projmatrix, s.intrinsic, s.campos,
-                       g.depth_key, g.g2d, g.rect, g.tiles_touched, radii, mean2D);
+                       g.depth_key, g.g2d, g.rect, g.tiles_touched, g.keep, radii, mean2D);
     return hipGetLastError();
 }

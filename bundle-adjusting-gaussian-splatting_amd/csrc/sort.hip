@@ -303,7 +303,7 @@ hipError_t launch_offsets_scan(const GeomView& g, const u32* sorted_ids, int P, 
 #define EMIT_COOP 32
 __global__ void __launch_bounds__(256)
 emit_kernel(const u32* __restrict__ sorted_ids, const u32* __restrict__ rank_offset, const uint2* __restrict__ rect,
-            const u32* __restrict__ tiles_touched, int P, int grid_x, u32* __restrict__ keys, u32* __restrict__ vals,
+            const u32* __restrict__ tiles_touched, const u64* __restrict__ keep, int P, int grid_x, u32* __restrict__ keys, u32* __restrict__ vals,
             u32 capacity, const u32* __restrict__ n_dev, uint2* __restrict__ ranges, int T)
 {
     // tile_ranges only writes the tiles that hold instances: the others must read (0, 0).  Cleared here, two kernels ahead
@@ -315,10 +315,11 @@ emit_kernel(const u32* __restrict__ sorted_ids, const u32* __restrict__ rank_off
     const int lane = threadIdx.x & 63;
     u32 g = 0, nt = 0, off = 0;
     uint2 rc = make_uint2(0u, 0u);
+    u64 kp = 0ull;                                          // tile mask of a small rectangle (GeomView::keep)
     if (j < P) {
         g = sorted_ids[j];
         nt = tiles_touched[g];
-        if (nt) { rc = rect[g]; off = rank_offset[j]; }
+        if (nt) { rc = rect[g]; off = rank_offset[j]; kp = keep[g]; }
         if ((unsigned long long)off + nt > (unsigned long long)capacity) nt = 0;
     }
     // Rectangles of up to EMIT_COOP tiles: the wave expands its 64 rectangles TOGETHER, lane = output element, so the
@@ -342,10 +343,12 @@ emit_kernel(const u32* __restrict__ sorted_ids, const u32* __restrict__ rank_off
         const int ol = have ? (int)owner[wave][e] : 0;
         const u32 g_o = (u32)__shfl((int)g, ol), off_o = (u32)__shfl((int)off, ol), lp_o = (u32)__shfl((int)lp, ol);
         const u32 rx = (u32)__shfl((int)rc.x, ol), ry = (u32)__shfl((int)rc.y, ol);
+        const u64 kp_o = (u64)(u32)__shfl((int)(u32)kp, ol) | ((u64)(u32)__shfl((int)(u32)(kp >> 32), ol) << 32);
         const u32 kk = e - lp_o;                                   // element of the owner's rectangle, y outer, x inner
-        const int minx = rx & 0xFFFF, miny = rx >> 16, w = (int)(ry & 0xFFFF) - minx;
-        const int dy = (int)(((float)kk + 0.5f) / (float)w);       // exact: kk < 32, w <= 32
-        const int dx = (int)kk - dy * w;
+        const int minx = rx & 0xFFFF, miny = rx >> 16, w = (int)(ry & 0xFFFF) - minx, h = (int)(ry >> 16) - miny;
+        int dy = (int)(((float)kk + 0.5f) / (float)w);             // exact: kk < 32, w <= 32
+        int dx = (int)kk - dy * w;
+        if (have && rect_small(w, h)) { const int bit = rect_nth_tile(kp_o, kk); dy = bit >> 3; dx = bit & 7; }
         if (have) {
             keys[off_o + kk] = (u32)((miny + dy) * grid_x + minx + dx);
             vals[off_o + kk] = g_o;
@@ -357,9 +360,11 @@ emit_kernel(const u32* __restrict__ sorted_ids, const u32* __restrict__ rank_off
         big &= big - 1;
         const u32 bg_ = __shfl(g, src), bn = __shfl(nt, src), bo = __shfl(off, src);
         const u32 bx = __shfl(rc.x, src), by = __shfl(rc.y, src);
-        const int minx = bx & 0xFFFF, miny = bx >> 16, w = (int)(by & 0xFFFF) - minx;
+        const u64 bk = (u64)(u32)__shfl((int)(u32)kp, src) | ((u64)(u32)__shfl((int)(u32)(kp >> 32), src) << 32);
+        const int minx = bx & 0xFFFF, miny = bx >> 16, w = (int)(by & 0xFFFF) - minx, h = (int)(by >> 16) - miny;
         for (u32 k = lane; k < bn; k += 64) {
-            const int y = miny + (int)(k / (u32)w), x = minx + (int)(k % (u32)w);
+            int y = miny + (int)(k / (u32)w), x = minx + (int)(k % (u32)w);
+            if (rect_small(w, h)) { const int bit = rect_nth_tile(bk, k); y = miny + (bit >> 3); x = minx + (bit & 7); }
             keys[bo + k] = (u32)(y * grid_x + x);
             vals[bo + k] = bg_;
         }
@@ -371,7 +376,7 @@ hipError_t launch_emit(const GeomView& g, const u32* sorted_ids, int P, int grid
 {
     if (P == 0) return hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, st);
     hipLaunchKernelGGL(emit_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, sorted_ids, g.rank_offset, g.rect,
-                       g.tiles_touched, P, grid_x, keys, vals, capacity, n_dev, ranges, T);
+                       g.tiles_touched, g.keep, P, grid_x, keys, vals, capacity, n_dev, ranges, T);
     return hipGetLastError();
 }
 

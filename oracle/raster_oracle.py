@@ -121,7 +121,9 @@ class Preprocessed:
     # discrete artefacts
     radii: torch.Tensor       # (P,) int32
     rect: torch.Tensor        # (P,4) int32  minx, miny, maxx, maxy (max exclusive)
-    tiles_touched: torch.Tensor  # (P,) int32
+    tiles_touched: torch.Tensor  # (P,) int32  instances emitted for the Gaussian (tiles of `rect` that `keep` retains)
+    keep: torch.Tensor        # (P,) int64  bit ry * 8 + rx: tile (rect.minx + rx, rect.miny + ry) is emitted; only read for
+                              #             rectangles of at most 8 x 8 tiles (larger ones emit every tile)
     clamped: torch.Tensor     # (P,3) bool
     visible: torch.Tensor     # (P,) bool
     extras: Dict[str, torch.Tensor] = field(default_factory=dict)
@@ -159,6 +161,53 @@ def _atan2_pos(rho: torch.Tensor, tz: torch.Tensor) -> torch.Tensor:
     a = w + w * (s * p)
     a = torch.where(red, f(0.785398185) + a, a)
     return torch.where(rho.detach() > tz.detach(), f(1.57079637) - a, a)
+
+
+def _rect_full_mask(w, h):
+    """Tile mask of a rectangle that emits all its tiles (bags_common.h: rect_full_mask): bit ry * 8 + rx for rx < w, ry < h
+    when w, h <= 8; all ones for a larger rectangle; 0 for an empty one."""
+    small = (w <= 8) & (h <= 8)
+    ws, hs = torch.where(small, w, torch.ones_like(w)).clamp(min=1), torch.where(small, h, torch.ones_like(h)).clamp(min=1)
+    rows = torch.full_like(w, 0x0101010101010101) >> (8 * (8 - hs))
+    m = ((torch.ones_like(w) << ws) - 1) * rows
+    m = torch.where(small, m, torch.full_like(m, -1))
+    return torch.where((w <= 0) | (h <= 0), torch.zeros_like(m), m)
+
+
+def _tile_reach(px, py, a, b, c, tau2m, minx, miny, w, h):
+    """Which tiles of a small rectangle (w, h <= 8) the ellipse Q(d) = a dx^2 + 2 b dx dy + c dy^2 <= tau2m around (px, py)
+    reaches: the minimum of Q over the square of a tile's pixel centres [16 tx, 16 tx + 15] x [16 ty, 16 ty + 15] lies, for a
+    centre outside the square, on an edge that faces the centre (Q is convex with its minimum at the centre), and along
+    an edge at the clamped 1-D minimiser.  Same operations in the same order as tile_reach in preprocess_fwd.hip (adds,
+    multiplies, two reciprocals per Gaussian, min / max: correctly rounded in both), so the masks are bit-identical.
+    Returns (bits int64 -- bit ry * 8 + rx, count int64)."""
+    n = px.shape[0]
+    bits = torch.zeros(n, dtype=torch.int64)
+    cnt = torch.zeros(n, dtype=torch.int64)
+    ra, rc, b2 = 1.0 / a, 1.0 / c, 2.0 * b
+    inf = torch.full_like(px, float("inf"))
+    for ry in range(int(h.max())):
+        Y0 = ((miny + ry) * TILE).to(px.dtype); Y1 = Y0 + 15.0
+        yin = (py >= Y0) & (py <= Y1)
+        dyE = torch.where(py < Y0, Y0, Y1) - py
+        xs = px - (b * dyE) * ra
+        for rx in range(int(w.max())):
+            live = (ry < h) & (rx < w)
+            if not bool(live.any()):
+                continue
+            X0 = ((minx + rx) * TILE).to(px.dtype); X1 = X0 + 15.0
+            xin = (px >= X0) & (px <= X1)
+            dx = torch.minimum(torch.maximum(xs, X0), X1) - px
+            qh = (a * dx) * dx + (b2 * dx) * dyE + (c * dyE) * dyE
+            dxE = torch.where(px < X0, X0, X1) - px
+            ys = py - (b * dxE) * rc
+            dy = torch.minimum(torch.maximum(ys, Y0), Y1) - py
+            qv = (a * dxE) * dxE + (b2 * dxE) * dy + (c * dy) * dy
+            q = torch.minimum(torch.where(yin, inf, qh), torch.where(xin, inf, qv))
+            k = live & ((xin & yin) | ~(q > tau2m))
+            bits = bits | (k.to(torch.int64) << (ry * 8 + rx))
+            cnt = cnt + k.to(torch.int64)
+    return bits, cnt
 
 
 def preprocess(means3D, means2D, shift_factors, shs, colors_precomp, opacities, scales, rotations,
@@ -331,6 +380,8 @@ def preprocess(means3D, means2D, shift_factors, shs, colors_precomp, opacities, 
         miny, maxy = tile_lo(pyd, rd, gy), tile_hi(pyd, rd, gy)
         tiles = (maxx - minx) * (maxy - miny)
         vis_s = ok & (tiles > 0)                       # "visible" (radii > 0) is decided by the stock rectangle
+        keep_s = torch.full((n,), -1, dtype=torch.int64)
+        masked_s = torch.zeros(n, dtype=torch.bool)
         if s.tile_bounds == "opacity":
             # Decision D7 (include/bags_raster.h: BAGS_TILES_OPACITY): emit instances only for tiles inside the axis-aligned
             # bounds of the ellipse alpha >= 1/255.  Same operations, same order as preprocess_fwd.hip (every one of
@@ -358,28 +409,46 @@ def preprocess(means3D, means2D, shift_factors, shs, colors_precomp, opacities, 
             ex1 = torch.where(empty, ex0, ex1); ey1 = torch.where(empty, ey0, ey1)
             minx, maxx, miny, maxy = ex0, ex1, ey0, ey1
             tiles = (maxx - minx) * (maxy - miny)
+            # D7, second half: inside a rectangle of at most 8 x 8 tiles, a tile is emitted only if the ellipse
+            # d^T Q d <= 1.02 tau2 reaches the square of its pixel centres (_tile_reach; preprocess_fwd.hip: tile_reach).
+            ca, cb, cc = con_a.detach(), con_b.detach(), con_c.detach()
+            small = (vis_s & has & (tiles > 0) & ((maxx - minx) <= 8) & ((maxy - miny) <= 8)
+                     & (ca > 0) & (cc > 0) & ((ca * cc - cb * cb) > 0))
+            sel = torch.nonzero(small).reshape(-1)
+            if sel.numel():
+                bits, cnt = _tile_reach(pxd[sel], pyd[sel], ca[sel], cb[sel], cc[sel], tau2[sel] * f(1.02),
+                                        minx[sel], miny[sel], (maxx - minx)[sel], (maxy - miny)[sel])
+                keep_s = keep_s.index_copy(0, sel, bits)
+                masked_s = small
+                tiles = tiles.index_copy(0, sel, cnt)
+        keep_s = torch.where(masked_s, keep_s, _rect_full_mask(maxx - minx, maxy - miny))
+        keep_s = torch.where(vis_s, keep_s, torch.full_like(keep_s, -1))
         tiles = torch.where(vis_s, tiles, torch.zeros_like(tiles))
         radii_s = torch.where(vis_s, rd, torch.zeros_like(rd)).to(torch.int32)
         rect_s = torch.stack([minx, miny, maxx, maxy], 1).to(torch.int32)
         rect_s = torch.where(vis_s[:, None], rect_s, torch.zeros_like(rect_s))
         radii, rect, tiles_touched = full(radii_s, 0), full(rect_s, 0), full(tiles.to(torch.int32), 0)
+        keep = full(keep_s, -1)
         visible = full(vis_s, False)
     else:
         radii, rect, tiles_touched = discrete["radii"], discrete["rect"], discrete["tiles_touched"]
+        keep = discrete["keep"] if "keep" in discrete else torch.full((P,), -1, dtype=torch.int64)
         visible = radii > 0
 
     return Preprocessed(xy=full(torch.stack([px, py], 1)), conic=full(torch.stack([con_a, con_b, con_c], 1)),
                         opacity=full(op_s.reshape(n)), rgb=full(rgb), depth=full(depth), radii=radii, rect=rect,
-                        tiles_touched=tiles_touched, clamped=full(clamped_s, False), visible=visible,
+                        tiles_touched=tiles_touched, keep=keep, clamped=full(clamped_s, False), visible=visible,
                         extras={"cov2d": full(torch.stack([cxx, cxy, cyy], 1)), "tz": full(tzs),
                                 "_graph": {"idx": idx, "cov": (cxx, cxy, cyy), "A": (a00, a01, a02, a10, a11, a12),
                                            "sigma": (c0, c1, c2, c3, c4, c5)}})
 
 
-def bin_and_sort(depth32: torch.Tensor, rect: torch.Tensor, tiles_touched: torch.Tensor, gx: int, gy: int):
+def bin_and_sort(depth32: torch.Tensor, rect: torch.Tensor, tiles_touched: torch.Tensor, gx: int, gy: int,
+                 keep: Optional[torch.Tensor] = None):
     """Instance emission, (tile|depth) keys, stable sort, tile ranges  (SURVEY Appendix A.2).
 
     depth32: (P,) float32 (the fp32 run's depth: its bit pattern is the low half of the key).
+    keep: (P,) int64 tile masks of the rectangles of at most 8 x 8 tiles (Preprocessed.keep); None: every tile.
     Returns keys_sorted (I,) int64, point_list (I,) int32, ranges (T,2) int32, offsets (P,) int64 inclusive scan.
     """
     tt = tiles_touched.to(torch.int64)
@@ -389,12 +458,20 @@ def bin_and_sort(depth32: torch.Tensor, rect: torch.Tensor, tiles_touched: torch
     if I == 0:
         return (torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int32),
                 torch.zeros(T, 2, dtype=torch.int32), offsets)
-    gid = torch.repeat_interleave(torch.arange(tt.numel(), dtype=torch.int64), tt)
-    start = (offsets - tt)[gid]
-    local = torch.arange(I, dtype=torch.int64) - start
-    w = (rect[:, 2] - rect[:, 0]).to(torch.int64)[gid]
-    tyy = rect[:, 1].to(torch.int64)[gid] + local // w     # y outer, x inner
-    txx = rect[:, 0].to(torch.int64)[gid] + local % w
+    wv = (rect[:, 2] - rect[:, 0]).to(torch.int64)
+    hv = (rect[:, 3] - rect[:, 1]).to(torch.int64)
+    area = torch.where(tt > 0, wv * hv, torch.zeros_like(tt))       # walk the whole rectangle, y outer, x inner ...
+    gid = torch.repeat_interleave(torch.arange(tt.numel(), dtype=torch.int64), area)
+    local = torch.arange(gid.numel(), dtype=torch.int64) - (torch.cumsum(area, 0) - area)[gid]
+    w = wv[gid]
+    ry, rx = local // w, local % w
+    if keep is not None:                                            # ... and drop the tiles its mask does not retain
+        small = (wv <= 8) & (hv <= 8)
+        kept = (~small[gid]) | (((keep[gid] >> (ry * 8 + rx).clamp(max=63)) & 1) != 0)
+        gid, ry, rx = gid[kept], ry[kept], rx[kept]
+    assert gid.numel() == I, "tiles_touched does not match the rectangles and tile masks"
+    tyy = rect[:, 1].to(torch.int64)[gid] + ry
+    txx = rect[:, 0].to(torch.int64)[gid] + rx
     tile = tyy * gx + txx
     dbits = depth32.to(torch.float32).contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
     keys = (tile << 32) | dbits[gid]
@@ -480,7 +557,7 @@ def rasterize_forward(means3D, means2D, shift_factors, shs, colors_precomp, opac
         offsets = torch.cumsum(pre.tiles_touched.to(torch.int64), 0)
     else:
         d32 = discrete["depth32"] if discrete is not None else pre.depth.detach().to(torch.float32)
-        keys_sorted, point_list, ranges, offsets = bin_and_sort(d32, pre.rect, pre.tiles_touched, gx, gy)
+        keys_sorted, point_list, ranges, offsets = bin_and_sort(d32, pre.rect, pre.tiles_touched, gx, gy, pre.keep)
     st = OracleState()
     st.pre, st.s, st.dtype = pre, s, dtype
     st.decide32 = discrete is not None and dtype != torch.float32
@@ -605,6 +682,6 @@ def render_and_grad(inputs: Dict[str, Optional[torch.Tensor]], s: OracleSettings
 
 def discrete_of(st: OracleState) -> Dict[str, torch.Tensor]:
     """Discrete decisions of an fp32 run, to be replayed by the fp64 gradient reference."""
-    return dict(radii=st.pre.radii, rect=st.pre.rect, tiles_touched=st.pre.tiles_touched,
+    return dict(radii=st.pre.radii, rect=st.pre.rect, tiles_touched=st.pre.tiles_touched, keep=st.pre.keep,
                 keys_sorted=st.keys_sorted, point_list=st.point_list, ranges=st.ranges,
                 depth32=st.pre.depth.detach().to(torch.float32))
