@@ -41,7 +41,9 @@ enum { BAGS_DEPTH_Z = 0, BAGS_DEPTH_DISTANCE = 1 };   /* README.md:126: sort key
  * axis-aligned bounds of the ellipse alpha >= 1/255 (half extents sqrt(2 ln(255 o) cov_xx), sqrt(.. cov_yy), with a
  * 2 % + 0.1 px safety margin): every (tile, Gaussian) pair it drops has alpha < 1/255 on all 256 pixels, i.e. is skipped
  * by the compositing loop anyway, so image, radii and every gradient are unchanged while the sorted instance list
- * shrinks (27 % on BASELINE config 3). */
+ * shrinks.  Inside a rectangle of at most 8 x 8 tiles it further drops every tile the ellipse itself does not reach
+ * (minimum of d^T Q d over the square of the tile's pixel centres > 1.02 (2 ln(255 o) + 0.022)): the same guarantee.
+ * Together 40 % fewer instances on BASELINE config 3 (3.45 M -> 2.07 M). */
 enum { BAGS_TILES_AABB = 0, BAGS_TILES_OPACITY = 1 };
 /* How the per-tile depth-ordered instance lists are built.  AUTO: tile-binned (csrc/binning.hip: (block, tile) count matrix
  * in LDS, per-tile sort of (depth, id) pairs in LDS; five launches, no global sort) whenever the image has at most 32768
