@@ -651,10 +651,8 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
     const int px = tile_x * BAGS_TILE + bx * 4 + (li & 3), py = tile_y * BAGS_TILE + by * 4 + (li >> 2);
     const float pxf = (float)px, pyf = (float)py;
     const bool inside = (px < W) && (py < H);
-    // A finished pixel (T would fall below 1e-4, or outside the image) carries its transmittance NEGATED: one VGPR sign
-    // instead of a lane mask kept in scalar registers (four scalar instructions per step of a kernel that is as busy on
-    // its scalar unit as on its vector units).
-    float Tq = inside ? 1.f : -1.f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dq = 0.f;
+    bool done = !inside;
+    float Tq = 1.f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dq = 0.f;
     u32 last = 0;
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #ifdef DIAG_PAIRS
@@ -664,7 +662,7 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
     const int qb = (wave >> 1) * 8 + (wave & 1) * 2;         // block index of row 0; rows: +0, +1, +4, +5
 
     for (u32 base = 0; base < n; base += CHUNK) {
-        const u64 live_b = __ballot(Tq > 0.f);
+        const u64 live_b = __ballot(!done);
         if (lane == 0) s_live[wave] = (live_b != 0ull);
         __syncthreads();                                     // previous chunk consumed by every wave
         if (!(s_live[0] | s_live[1] | s_live[2] | s_live[3])) break;
@@ -718,14 +716,14 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
             const float p2 = pair_power2(dx, dy, s.ap, s.bp, s.cp);
             const float G = __builtin_amdgcn_exp2f(p2);
             const float alpha = fminf(0.99f, s.o * G);
-            const bool contrib = act && (p2 <= 0.f) && (alpha >= ALPHA_MIN) && (Tq > 0.f);
+            const bool contrib = act && (p2 <= 0.f) && (alpha >= ALPHA_MIN) && !done;
 #ifdef DIAG_PAIRS
             dg_eval += act ? 1u : 0u; dg_con += contrib ? 1u : 0u;
 #endif
             if (contrib) {
                 const float test_T = Tq * (1.f - alpha);
                 if (test_T < T_EPS) {
-                    Tq = -Tq;
+                    done = true;
                 } else {
                     const float w = alpha * Tq;
                     Cr = __fmaf_rn(w, s.r, Cr); Cg = __fmaf_rn(w, s.g, Cg); Cb = __fmaf_rn(w, s.b, Cb);
@@ -736,7 +734,6 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
             }
         }
     }
-    Tq = fabsf(Tq);
     if (inside) {
         const size_t HW = (size_t)W * H, pix = (size_t)py * W + px;
         out_color[pix] = Cr + Tq * bg[0];
