@@ -228,6 +228,7 @@ __device__ __forceinline__ u32 block_excl_scan_1024(u32 v, u32* s_wave /*[17]*/)
     if (threadIdx.x == 1023) s_wave[16] = before + incl;      // grand total
     return before + incl - v;
 }
+__device__ __forceinline__ void lds_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 #define ORD_PER_MAX 32                                      // tiles per thread: 1024 x 32 = 32768 tiles at most
 template <int ORD_PER>
 __global__ void __launch_bounds__(1024)
@@ -237,20 +238,44 @@ ranges_order_kernel(const u32* __restrict__ tile_total, int T, uint2* __restrict
 {
     __shared__ u32 s_cur[ORD_LEVELS * ORD_SUB];
     __shared__ u32 s_wave[17];
+    extern __shared__ u32 tr_all[];                          // 16 waves x ORD_TRW(ORD_PER) words: wave-local transposes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // thread tid owns the contiguous tiles [ta, tb): their counts stay in registers for all three passes
+    // thread tid owns the contiguous tiles [ta, tb): their counts stay in registers for all three passes.  One CU issues
+    // this kernel's every memory request, and a thread reading or writing its own run puts 64 requests per instruction
+    // on that CU's path (32 400 tiles: 99 us).  So the wave moves its span of 64 x per tiles in tile order -- 64
+    // consecutive words per instruction -- and the lanes pick their runs out of a padded LDS buffer (stride per + per / 32
+    // words: conflict free); the range starts go back the same way.
     const int per = (T + 1023) / 1024;
     const int ta = min(T, tid * per), tb = min(T, ta + per);
+    u32* tr = tr_all + wave * (64 * ORD_PER + 2 * ORD_PER);
+    const int span0 = wave * 64 * per;
+    auto pad = [](int i) -> int { return i + (i >> 5); };
+#pragma unroll 8
+    for (int j = 0; j < ORD_PER; ++j) {                      // load order: tile span0 + j * 64 + lane
+        const int t = span0 + j * 64 + lane;
+        const u32 v = (j < per && t < T) ? tile_total[t] : 0u;
+        if (j < per) tr[pad(j * 64 + lane)] = v;
+    }
+    lds_wave_sync();
     u32 cntv[ORD_PER];
     u32 sum = 0;
 #pragma unroll
-    for (int i = 0; i < ORD_PER; ++i) { cntv[i] = (i < per && ta + i < tb) ? tile_total[ta + i] : 0u; sum += cntv[i]; }
-    const u32 first = block_excl_scan_1024(sum, s_wave);
+    for (int i = 0; i < ORD_PER; ++i) { cntv[i] = (i < per) ? tr[pad(lane * per + i)] : 0u; sum += cntv[i]; }
+    __builtin_amdgcn_sched_barrier(0);
+    const u32 first = block_excl_scan_1024(sum, s_wave);     // (its barriers also order the two uses of `tr`)
     {
         u32 run = first;
 #pragma unroll
         for (int i = 0; i < ORD_PER; ++i)
-            if (i < per && ta + i < tb) { ranges[ta + i] = make_uint2(run, run + cntv[i]); run += cntv[i]; }
+            if (i < per) { tr[pad(lane * per + i)] = run; run += cntv[i]; }
+        __builtin_amdgcn_sched_barrier(0);
+        lds_wave_sync();
+#pragma unroll 8
+        for (int j = 0; j < ORD_PER; ++j) {
+            const int t = span0 + j * 64 + lane;
+            // (the count is read again, coalesced, rather than kept: 32 more live registers spill at 1024 threads)
+            if (j < per && t < T) { const u32 s0 = tr[pad(j * 64 + lane)]; ranges[t] = make_uint2(s0, s0 + tile_total[t]); }
+        }
     }
     __syncthreads();
     if (tid == 0) num_rendered[0] = s_wave[16];
@@ -261,14 +286,19 @@ ranges_order_kernel(const u32* __restrict__ tile_total, int T, uint2* __restrict
         if (tid < B) block_base[tid] = ex;
     }
     // ---- heavy-first descriptor list: counting sort of the tiles by instance count (ORD_LEVELS levels, four per octave,
-    // ORD_SUB sub-counters per level picked by (tile >> 3) & 31: a thread's tiles are neighbours, so threads hit different
-    // sub-counters and runs of neighbouring tiles stay together in the list)
+    // ORD_SUB sub-counters per level picked by the THREAD (tid & 31): the lanes of a wave hit 32 different counters of a
+    // level and a thread's run of neighbouring tiles stays together in the list.  (Picked by tile, (t >> 3) & 31, the 64
+    // lanes of a wave shared 8 counters once a thread held 32 tiles: eight-deep same-address LDS atomics, 99 us at
+    // 32 400 tiles.)  The unrolled loops are cut every 8 tiles so that the compiler keeps 8, not 32, atomics and their
+    // results in flight (124 spilled registers at 32 tiles per thread otherwise).
     s_cur[tid] = 0; s_cur[tid + 1024] = 0;
     __syncthreads();
-    auto counter_of = [&](int t, u32 n) -> int { return ord_level(n) * ORD_SUB + ((t >> 3) & (ORD_SUB - 1)); };
+    auto counter_of = [&](int t, u32 n) -> int { (void)t; return ord_level(n) * ORD_SUB + (tid & (ORD_SUB - 1)); };
 #pragma unroll
-    for (int i = 0; i < ORD_PER; ++i)
+    for (int i = 0; i < ORD_PER; ++i) {
         if (i < per && ta + i < tb) atomicAdd(&s_cur[counter_of(ta + i, cntv[i])], 1u);
+        if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
     __syncthreads();
     {
         const u32 c0 = s_cur[2 * tid], c1 = s_cur[2 * tid + 1];
@@ -289,11 +319,16 @@ ranges_order_kernel(const u32* __restrict__ tile_total, int T, uint2* __restrict
     {
         u32 run = first;
 #pragma unroll
-        for (int i = 0; i < ORD_PER; ++i)
+        for (int i = 0; i < ORD_PER; ++i) {
             if (i < per && ta + i < tb) {
-                tile_desc[atomicAdd(&s_cur[counter_of(ta + i, cntv[i])], 1u)] = make_uint4((u32)(ta + i), run, cntv[i], 0u);
-                run += cntv[i];
+                u32 c = cntv[i];
+                asm volatile("" : "+v"(c));                 // recompute the level here: carried over from the counting pass it
+                                                            // would be 32 more live registers
+                tile_desc[atomicAdd(&s_cur[counter_of(ta + i, c)], 1u)] = make_uint4((u32)(ta + i), run, c, 0u);
+                run += c;
             }
+            if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
@@ -338,7 +373,6 @@ emit_binned_kernel(int P, int per_block, int grid_x, int T, const uint2* __restr
 // e[r] = word of entry r * 64 + lane (all ones beyond n).  t / cnt / bid: this wave's LDS (64 * PER entries each).  The
 // caller's workgroup may hold several waves, each sorting its own list: only wave-level synchronisation is used.
 #define TS_BUCKET_MAX 24
-__device__ __forceinline__ void lds_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 
 template <int PER>
 __device__ __forceinline__ void wave_sort_words(const u64 (&e)[PER], u32 n, u32 kmin, u32 kmax, u32* __restrict__ out, u64* t, u32* cnt,
@@ -675,12 +709,18 @@ tile_sort_large_kernel(const uint4* __restrict__ tile_desc, const u32* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
+static size_t ord_tr_bytes(int per) { return (size_t)16 * (64 * per + 2 * per) * 4; }   // 34 / 68 / 135 KB
 static void launch_ranges_order(const ImgView& im, const GeomView& g, int T, int B, hipStream_t st)
 {
-#define RO_ARGS dim3(1), dim3(1024), 0, st, im.tile_total, T, im.ranges, im.tile_desc, im.n_active, g.block_total, B, g.block_base, g.num_rendered
-    if (T <= 1024 * 8) hipLaunchKernelGGL(ranges_order_kernel<8>, RO_ARGS);
-    else if (T <= 1024 * 16) hipLaunchKernelGGL(ranges_order_kernel<16>, RO_ARGS);
-    else hipLaunchKernelGGL(ranges_order_kernel<32>, RO_ARGS);
+#define RO_ARGS(PER) dim3(1), dim3(1024), ord_tr_bytes(PER), st, im.tile_total, T, im.ranges, im.tile_desc, im.n_active, g.block_total, B, g.block_base, g.num_rendered
+    if (T <= 1024 * 8) hipLaunchKernelGGL(ranges_order_kernel<8>, RO_ARGS(8));
+    else if (T <= 1024 * 16) {                               // more than 64 KB of dynamic LDS has to be asked for
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ranges_order_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ord_tr_bytes(16));
+        hipLaunchKernelGGL(ranges_order_kernel<16>, RO_ARGS(16));
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ranges_order_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ord_tr_bytes(32));
+        hipLaunchKernelGGL(ranges_order_kernel<32>, RO_ARGS(32));
+    }
 #undef RO_ARGS
 }
 int binned_per_block(int P)

@@ -59,7 +59,7 @@ def main():
         pre = O.preprocess(scene["means3D"], torch.zeros(Pn, 3), torch.zeros(3), scene["shs"], None, scene["opacities"], scene["scales"],
                            scene["rotations"], None, s, torch.float32, None)
     gx, gy = (W + 15) // 16, (H + 15) // 16
-    _, pl, ranges, _ = O.bin_and_sort(pre.depth.float(), pre.rect, pre.tiles_touched, gx, gy)
+    _, pl, ranges, _ = O.bin_and_sort(pre.depth.float(), pre.rect, pre.tiles_touched, gx, gy, pre.keep)
     pl = pl.numpy().astype(np.int64)
     ranges = ranges.numpy().astype(np.int64)
     n_t = ranges[:, 1] - ranges[:, 0]
