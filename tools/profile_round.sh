@@ -1,6 +1,7 @@
 #!/bin/bash
 # One call on the GPU box that produces everything profiles/ holds for a version tag:
-#   bench JSON (default bench.py run), rocprofv3 --kernel-trace --stats summary of the same workload, PMC passes
+#   bench JSON (default bench.py run), rocprofv3 --kernel-trace --stats summary of the same workload (without the second,
+#   tile_bounds="aabb" leg: it launches the same kernels on a longer list and would be averaged into them), PMC passes
 #   (FETCH_SIZE, WRITE_SIZE, SQ instruction / busy counters; separate passes as the guide prescribes).
 # usage: tools/profile_round.sh v8        -> gpurun_out/prof_v8/{bench.json,kernel_stats.csv,pmc.txt}
 set -o pipefail
@@ -12,7 +13,7 @@ mkdir -p $OUT
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || { echo "bench failed"; tail -5 $OUT/bench.err; exit 1; }
 echo "bench done: $(cut -c1-200 $OUT/bench.json)"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-profile > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-profile --no-aabb-leg > $OUT/trace.log 2>&1
 f=$(find $OUT/trace -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp "$f" $OUT/kernel_stats.csv && echo "kernel stats: $(head -3 $OUT/kernel_stats.csv | cut -c1-160)"
 rm -rf $OUT/trace
