@@ -375,33 +375,38 @@ emit_binned_kernel(int P, int per_block, int grid_x, int T, const uint2* __restr
 #define TS_BUCKET_MAX 24
 
 template <int PER>
-__device__ __forceinline__ void wave_sort_words(const u64 (&e)[PER], u32 n, u32 kmin, u32 kmax, u32* __restrict__ out, u64* t, u32* cnt,
-                                                unsigned short* bid)
+__device__ __forceinline__ void wave_sort_words(const u64 (&e)[PER], u32 n, u32 kmin, u32 kmax, u32* __restrict__ out, u64* t, u32* cnt)
 {
+    // LDS per list: the words (8 B per entry) and the bucket counters, two 16-bit counters per word (a count or an offset
+    // is at most n <= 64 * PER <= 65535); an entry's bucket is recomputed from its key where it is needed again instead
+    // of being stored.  10 KB per 1024-entry list instead of 14: 16 instead of 11 one-wave workgroups per CU.
     const u32 lane = threadIdx.x & 63;
     const u32 rounds = (n + 63) >> 6;
-    const u32 nb = n;
+    const u32 nb = n, nw = (nb + 1) >> 1;                       // buckets, packed counter words
     const float scale = (float)nb / ((float)(kmax - kmin) + 1.0f);
-    for (u32 i = lane; i < nb; i += 64) cnt[i] = 0u;
+    auto bucket_of = [&](u32 key) -> u32 { return min(nb - 1, (u32)((float)(key - kmin) * scale)); };
+    auto half = [](u32 w, u32 b) -> u32 { return (w >> ((b & 1u) * 16u)) & 0xFFFFu; };
+    for (u32 i = lane; i < nw; i += 64) cnt[i] = 0u;
     lds_wave_sync();
     u32 bk[PER], rk[PER];
 #pragma unroll
     for (u32 r = 0; r < PER; ++r) {
         bk[r] = 0; rk[r] = 0;
         if (r < rounds && r * 64 + lane < n) {
-            const u32 key = (u32)(e[r] >> 32);
-            bk[r] = min(nb - 1, (u32)((float)(key - kmin) * scale));
-            rk[r] = atomicAdd(&cnt[bk[r]], 1u);
+            bk[r] = bucket_of((u32)(e[r] >> 32));
+            rk[r] = half(atomicAdd(&cnt[bk[r] >> 1], 1u << ((bk[r] & 1u) * 16u)), bk[r]);
         }
     }
     lds_wave_sync();
     // exclusive scan of the bucket counts (in place) and the fullest bucket
     u32 carry = 0, maxc = 0;
-    for (u32 base = 0; base < nb; base += 64) {
-        const u32 c = (base + lane < nb) ? cnt[base + lane] : 0u;
-        maxc = max(maxc, c);
-        const u32 incl = wave_incl_scan(c);
-        if (base + lane < nb) cnt[base + lane] = carry + incl - c;
+    for (u32 base = 0; base < nw; base += 64) {
+        const u32 w = (base + lane < nw) ? cnt[base + lane] : 0u;
+        const u32 c0 = w & 0xFFFFu, c1 = w >> 16;
+        maxc = max(maxc, max(c0, c1));
+        const u32 incl = wave_incl_scan(c0 + c1);
+        const u32 ex = carry + incl - (c0 + c1);
+        if (base + lane < nw) cnt[base + lane] = ex | ((ex + c0) << 16);
         carry += (u32)__builtin_amdgcn_readlane((int)incl, 63);
     }
     maxc = wave_max(maxc);
@@ -434,15 +439,12 @@ __device__ __forceinline__ void wave_sort_words(const u64 (&e)[PER], u32 n, u32 
     // entries grouped by bucket (order inside a bucket = the order the atomics retired in: irrelevant, see above)
 #pragma unroll
     for (u32 r = 0; r < PER; ++r)
-        if (r < rounds && r * 64 + lane < n) {
-            const u32 p = cnt[bk[r]] + rk[r];
-            t[p] = e[r]; bid[p] = (unsigned short)bk[r];
-        }
+        if (r < rounds && r * 64 + lane < n) t[half(cnt[bk[r] >> 1], bk[r]) + rk[r]] = e[r];
     lds_wave_sync();
     for (u32 p = lane; p < n; p += 64) {
-        const u32 b = bid[p];
-        const u32 bs = cnt[b], be = (b + 1 < nb) ? cnt[b + 1] : n;
         const u64 x = t[p];
+        const u32 b = bucket_of((u32)(x >> 32));
+        const u32 bs = half(cnt[b >> 1], b), be = (b + 1 < nb) ? half(cnt[(b + 1) >> 1], b + 1) : n;
         u32 rank = 0;
         for (u32 q = bs; q < be; ++q) rank += (t[q] < x) ? 1u : 0u;
         out[bs + rank] = (u32)x;
@@ -456,8 +458,7 @@ tile_sort_wave_kernel(const uint4* __restrict__ tile_desc, const u32* __restrict
                       u32* __restrict__ point_list, u32 capacity, const u32* __restrict__ n_dev)
 {
     __shared__ u64 t[TSORT_WAVE];
-    __shared__ u32 cnt[TSORT_WAVE];
-    __shared__ unsigned short bid[TSORT_WAVE];
+    __shared__ u32 cnt[TSORT_WAVE / 2];
     if (n_dev && *n_dev > capacity) return;
     const uint4 desc = tile_desc[blockIdx.x];
     const u32 n = desc.z, start = desc.y;
@@ -477,7 +478,7 @@ tile_sort_wave_kernel(const uint4* __restrict__ tile_desc, const u32* __restrict
         e[r] = valid ? (((u64)key << 32) | (u64)idv[r]) : ~0ull;
         kmin = min(kmin, valid ? key : 0xFFFFFFFFu); kmax = max(kmax, valid ? key : 0u);
     }
-    wave_sort_words<TS_PER>(e, n, wave_min(kmin), wave_max(kmax), point_list + start, t, cnt, bid);
+    wave_sort_words<TS_PER>(e, n, wave_min(kmin), wave_max(kmax), point_list + start, t, cnt);
 }
 
 // The same bucket sort run by a whole 256-thread workgroup on n <= 256 * PER words (lists of 1025..4096 entries: the bulk
@@ -671,7 +672,7 @@ tile_sort_large_kernel(const uint4* __restrict__ tile_desc, const u32* __restric
                     }
                     if (m == 1) { if (lane == 0) point_list[start + s0] = (u32)e[0]; continue; }
                     wave_sort_words<TS_PER>(e, m, wave_min(lo), wave_max(hi), point_list + start + s0, t_all + wave * TSORT_WAVE,
-                                            cnt_all + wave * TSORT_WAVE, bid_all + wave * TSORT_WAVE);
+                                            cnt_all + wave * TSORT_WAVE);
                 }
                 continue;
             }
