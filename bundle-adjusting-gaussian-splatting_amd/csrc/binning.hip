@@ -486,28 +486,31 @@ tile_sort_wave_kernel(const uint4* __restrict__ tile_desc, const u32* __restrict
 // r * 256 + tid.  s_tmp: 8 words of scratch.
 template <int PER>
 __device__ __forceinline__ void block_sort_words(const u64 (&e)[PER], u32 n, u32 kmin, u32 kmax, u32* __restrict__ out, u64* t, u32* cnt,
-                                                 unsigned short* bid, u32* s_tmp)
+                                                 u32* s_tmp)
 {
+    // same scheme as wave_sort_words on 256 threads: packed 16-bit bucket counters (n <= TSORT_BLOCK = 4096), buckets
+    // recomputed from the key in the ranking pass
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u32 nb = n;
+    const u32 nb = n, nw = (nb + 1) >> 1;
     const float scale = (float)nb / ((float)(kmax - kmin) + 1.0f);
-    for (u32 i = tid; i < nb; i += 256) cnt[i] = 0u;
+    auto bucket_of = [&](u32 key) -> u32 { return min(nb - 1, (u32)((float)(key - kmin) * scale)); };
+    auto half = [](u32 w, u32 b) -> u32 { return (w >> ((b & 1u) * 16u)) & 0xFFFFu; };
+    for (u32 i = tid; i < nw; i += 256) cnt[i] = 0u;
     __syncthreads();
     u32 bk[PER], rk[PER];
 #pragma unroll
     for (u32 r = 0; r < PER; ++r) {
         bk[r] = 0; rk[r] = 0;
         if (r * 256 + tid < n) {
-            const u32 key = (u32)(e[r] >> 32);
-            bk[r] = min(nb - 1, (u32)((float)(key - kmin) * scale));
-            rk[r] = atomicAdd(&cnt[bk[r]], 1u);
+            bk[r] = bucket_of((u32)(e[r] >> 32));
+            rk[r] = half(atomicAdd(&cnt[bk[r] >> 1], 1u << ((bk[r] & 1u) * 16u)), bk[r]);
         }
     }
     __syncthreads();
-    // exclusive scan of the bucket counts: thread tid owns the contiguous buckets [c0, c1)
-    const u32 per = (nb + 255) >> 8, c0 = min(nb, tid * per), c1 = min(nb, c0 + per);
+    // exclusive scan of the bucket counts: thread tid owns the contiguous counter words [w0, w1)
+    const u32 per = (nw + 255) >> 8, w0 = min(nw, tid * per), w1 = min(nw, w0 + per);
     u32 sum = 0, maxc = 0;
-    for (u32 c = c0; c < c1; ++c) { const u32 v = cnt[c]; sum += v; maxc = max(maxc, v); }
+    for (u32 c = w0; c < w1; ++c) { const u32 v = cnt[c]; sum += (v & 0xFFFFu) + (v >> 16); maxc = max(maxc, max(v & 0xFFFFu, v >> 16)); }
     const u32 incl = wave_incl_scan(sum);
     maxc = wave_max(maxc);
     if (lane == 63) { s_tmp[wave] = incl; s_tmp[4 + wave] = maxc; }
@@ -515,7 +518,7 @@ __device__ __forceinline__ void block_sort_words(const u64 (&e)[PER], u32 n, u32
     u32 run = incl - sum;
     for (u32 w = 0; w < wave; ++w) run += s_tmp[w];
     maxc = max(max(s_tmp[4], s_tmp[5]), max(s_tmp[6], s_tmp[7]));
-    for (u32 c = c0; c < c1; ++c) { const u32 v = cnt[c]; cnt[c] = run; run += v; }
+    for (u32 c = w0; c < w1; ++c) { const u32 v = cnt[c]; const u32 lo = v & 0xFFFFu; cnt[c] = run | ((run + lo) << 16); run += lo + (v >> 16); }
     __syncthreads();
     if (maxc > TS_BUCKET_MAX) {                               // clustered keys: bitonic network in LDS
 #pragma unroll
@@ -544,15 +547,12 @@ __device__ __forceinline__ void block_sort_words(const u64 (&e)[PER], u32 n, u32
     }
 #pragma unroll
     for (u32 r = 0; r < PER; ++r)
-        if (r * 256 + tid < n) {
-            const u32 p = cnt[bk[r]] + rk[r];
-            t[p] = e[r]; bid[p] = (unsigned short)bk[r];
-        }
+        if (r * 256 + tid < n) t[half(cnt[bk[r] >> 1], bk[r]) + rk[r]] = e[r];
     __syncthreads();
     for (u32 p = tid; p < n; p += 256) {
-        const u32 b = bid[p];
-        const u32 bs = cnt[b], be = (b + 1 < nb) ? cnt[b + 1] : n;
         const u64 x = t[p];
+        const u32 b = bucket_of((u32)(x >> 32));
+        const u32 bs = half(cnt[b >> 1], b), be = (b + 1 < nb) ? half(cnt[(b + 1) >> 1], b + 1) : n;
         u32 rank = 0;
         for (u32 q = bs; q < be; ++q) rank += (t[q] < x) ? 1u : 0u;
         out[bs + rank] = (u32)x;
@@ -578,8 +578,7 @@ tile_sort_large_kernel(const uint4* __restrict__ tile_desc, const u32* __restric
                        const u32* __restrict__ n_dev)
 {
     __shared__ u64 t_all[TSORT_BLOCK];                       // one list of <= 4096 words, or four waves x 1024 (slab sort)
-    __shared__ u32 cnt_all[TSORT_BLOCK];
-    __shared__ unsigned short bid_all[TSORT_BLOCK];
+    __shared__ u32 cnt_all[TSORT_BLOCK / 2];                 // packed 16-bit counters
     __shared__ u32 s_red[8];
     __shared__ u32 slab_cnt[TS_SLABS_MAX + 1], slab_start[TS_SLABS_MAX + 1], s_next, s_bad;
     if (n_dev && *n_dev > capacity) return;
@@ -610,7 +609,7 @@ tile_sort_large_kernel(const uint4* __restrict__ tile_desc, const u32* __restric
             lo = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
             hi = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
             __syncthreads();                                  // s_red is reused as scratch below
-            block_sort_words<BP>(e, n, lo, hi, point_list + start, t_all, cnt_all, bid_all, s_red);
+            block_sort_words<BP>(e, n, lo, hi, point_list + start, t_all, cnt_all, s_red);
             continue;
         }
         bool network = n > TSORT_LARGE;
@@ -672,7 +671,7 @@ tile_sort_large_kernel(const uint4* __restrict__ tile_desc, const u32* __restric
                     }
                     if (m == 1) { if (lane == 0) point_list[start + s0] = (u32)e[0]; continue; }
                     wave_sort_words<TS_PER>(e, m, wave_min(lo), wave_max(hi), point_list + start + s0, t_all + wave * TSORT_WAVE,
-                                            cnt_all + wave * TSORT_WAVE);
+                                            cnt_all + wave * (TSORT_WAVE / 2));
                 }
                 continue;
             }
@@ -766,7 +765,7 @@ hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int
     hipLaunchKernelGGL(emit_binned_kernel, dim3(B), dim3(BIN_THREADS), cursors, st, P, per, grid_x, T, g.rect, g.tiles_touched,
                        g.keep, im.pre, im.ranges, g.local_off, g.block_base, g.inst_off, ids, capacity, n_dev);
     // long lists first: their few workgroups run beside the many short sorts of the second launch
-    hipLaunchKernelGGL(tile_sort_large_kernel, dim3(T < 512 ? T : 512), dim3(256), 0, st, im.tile_desc, im.n_active, ids, g.depth_key, kv,
+    hipLaunchKernelGGL(tile_sort_large_kernel, dim3(T < 768 ? T : 768), dim3(256), 0, st, im.tile_desc, im.n_active, ids, g.depth_key, kv,
                        point_list, capacity, n_dev);
     hipLaunchKernelGGL(tile_sort_wave_kernel, dim3(T), dim3(64), 0, st, im.tile_desc, ids, g.depth_key, point_list, capacity, n_dev);
     return hipGetLastError();
