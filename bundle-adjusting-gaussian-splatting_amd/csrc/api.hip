@@ -103,9 +103,9 @@ size_t carve_binning(void* base, long long I, int W, int H, BinView* v, bool bin
     const int T = cdiv(W, BAGS_TILE) * cdiv(H, BAGS_TILE);
     b.nblocks_sort = radix_blocks_for((long long)n);
     b.passes = tile_passes(T);
-    b.kv = nullptr; b.ids = nullptr;
-    if (binned) {                                            // tile-binned path: 12 bytes per instance
-        take(p, b.ids, n); take(p, b.kv, n); take(p, b.point_list, n);
+    b.words = nullptr; b.scratch = nullptr;
+    if (binned) {                                            // tile-binned path: 20 bytes per instance
+        take(p, b.words, n); take(p, b.scratch, n); take(p, b.point_list, n);
         b.keys_a = b.keys_b = b.vals_a = b.vals_b = nullptr; b.ranges = nullptr; b.radix_hist = b.digit_totals = nullptr;
         b.tile_sorted = nullptr;
     } else {
@@ -230,7 +230,7 @@ static int enqueue_finish(const BagsSettings* s, const BagsInputs* in, const Geo
         if (in->P == 0) HIP_TRY(launch_binned_empty(g, im, gx * gy, st));      // no prepare phase ran: an all-empty tile list
         if (I > 0 && in->P > 0) {
             ProfScope ps(ST_TILE_SORT, st);
-            HIP_TRY(launch_binned_finish(g, im, in->P, gx, gx * gy, b.ids, b.kv, b.point_list, (u32)I, n_dev, st));
+            HIP_TRY(launch_binned_finish(g, im, in->P, gx, gx * gy, b.words, b.scratch, b.point_list, (u32)I, n_dev, st));
         }
         DEBUG_SYNC(s, st, "emit / tile sort");
         { ProfScope ps(ST_BLEND_FWD, st); HIP_TRY(launch_blend_fwd(*s, g, b, im, *out, st, n_dev, (u32)I)); }

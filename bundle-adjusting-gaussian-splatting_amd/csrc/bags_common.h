@@ -110,8 +110,8 @@ struct BinView {
     int     passes;          // radix passes over the tile id
     u32*    point_list;      // vals after the last pass (radix path) / the per-tile sorted ids (tile-binned path)
     u32*    tile_sorted;     // keys after the last pass (radix path only)
-    u32*    ids;             // tile-binned path: Gaussian id per instance, grouped by tile, unsorted inside a tile
-    uint2*  kv;              // tile-binned path: (depth key, id) scratch of the global-memory sort (lists of > 8192 entries only)
+    u64*    words;           // tile-binned path: (depth key << 32 | Gaussian id) per instance, grouped by tile, unsorted inside a tile
+    u64*    scratch;         // tile-binned path: scratch of the two-level / global-memory sorts (lists of > 4096 entries only)
 };
 struct ImgView {
     float* final_T;          // [H*W]
@@ -186,7 +186,7 @@ int binned_per_block(int P);
 bool binned_supported(int P, int T);
 hipError_t launch_binned_empty(const GeomView& g, const ImgView& im, int T, hipStream_t st);
 hipError_t launch_binned_prepare(const GeomView& g, const ImgView& im, int P, int grid_x, int T, hipStream_t st);
-hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int grid_x, int T, u32* ids, uint2* kv, u32* point_list,
+hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int grid_x, int T, u64* words, u64* scratch, u32* point_list,
                                 u32 capacity, const u32* n_dev, hipStream_t st);
 hipError_t launch_debug_keys_ranges(const uint2* ranges, const u32* point_list, const u32* depth_key, int T, u64* out, hipStream_t st);
 hipError_t launch_debug_keys(const u32* tile_sorted, const u32* point_list, const u32* depth_key, long long I, u64* out, hipStream_t st);

@@ -60,20 +60,20 @@ __device__ __forceinline__ u32 lds_count_tile(u32* cnt, u32 t) { return atomicAd
 // the only thing written (the per-tile sort fetches the depth key by id: a 4-byte scattered store per instance instead of
 // two scattered loads and an 8-byte store -- the request rate of the L2 channels, not the bytes, bounded this kernel).
 template <bool EMIT>
-__device__ __forceinline__ void walk_rect(u32* cnt, uint2 rc, int grid_x, int lane, bool coop, u32 g, u32* __restrict__ ids)
+__device__ __forceinline__ void walk_rect(u32* cnt, uint2 rc, int grid_x, int lane, bool coop, u64 word, u64* __restrict__ words)
 {
     const int minx = rc.x & 0xFFFF, miny = rc.x >> 16, w = (int)(rc.y & 0xFFFF) - minx, h = (int)(rc.y >> 16) - miny;
     const int nt = w * h;
     for (int k = coop ? lane : 0; k < nt; k += coop ? 64 : 1) {
         const int dy = k / w, dx = k - dy * w;
         const u32 t = (u32)((miny + dy) * grid_x + minx + dx);
-        if (EMIT) ids[atomicAdd(&cnt[t], 1u)] = g;
+        if (EMIT) words[atomicAdd(&cnt[t], 1u)] = word;
         else (void)lds_count_tile(cnt, t);
     }
 }
 // A rectangle of at most 8 x 8 tiles: the set bits of its tile mask (GeomView::keep), no division.
 template <bool EMIT>
-__device__ __forceinline__ void walk_mask(u32* cnt, uint2 rc, u64 m, int grid_x, u32 g, u32* __restrict__ ids)
+__device__ __forceinline__ void walk_mask(u32* cnt, uint2 rc, u64 m, int grid_x, u64 word, u64* __restrict__ words)
 {
     const int minx = rc.x & 0xFFFF, miny = rc.x >> 16;
     const u32 t0 = (u32)(miny * grid_x + minx);
@@ -81,7 +81,7 @@ __device__ __forceinline__ void walk_mask(u32* cnt, uint2 rc, u64 m, int grid_x,
         const int bit = __ffsll((long long)m) - 1;
         m &= m - 1ull;
         const u32 t = t0 + (u32)((bit >> 3) * grid_x + (bit & 7));
-        if (EMIT) ids[atomicAdd(&cnt[t], 1u)] = g;
+        if (EMIT) words[atomicAdd(&cnt[t], 1u)] = word;
         else (void)lds_count_tile(cnt, t);
     }
 }
@@ -91,7 +91,7 @@ __device__ __forceinline__ void walk_mask(u32* cnt, uint2 rc, u64 m, int grid_x,
 template <bool EMIT>
 __device__ __forceinline__ u32 walk_block(u32* cnt, int P, int per_block, int grid_x, const uint2* __restrict__ rect,
                                           const u32* __restrict__ tiles_touched, const u64* __restrict__ keep,
-                                          u32* __restrict__ ids)
+                                          const u32* __restrict__ depth_key, u64* __restrict__ words)
 {
     const int lane = threadIdx.x & 63;
     const int per_thread = per_block / BIN_THREADS;
@@ -100,12 +100,13 @@ __device__ __forceinline__ u32 walk_block(u32* cnt, int P, int per_block, int gr
     for (int k0 = 0; k0 < per_thread; k0 += 4) {            // uniform trip counts: the ballots below need every lane
         // four Gaussians' counts, rectangles and masks requested together, unconditionally (clamped index): one memory
         // round trip per batch instead of three per Gaussian
-        u32 ntv[4]; uint2 rcv[4]; u64 kpv[4];
+        u32 ntv[4]; uint2 rcv[4]; u64 kpv[4]; u32 dkv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const long long g = g0 + k0 + u;
             const long long gc = g < P ? g : (long long)P - 1;
             ntv[u] = tiles_touched[gc]; rcv[u] = rect[gc]; kpv[u] = keep[gc];
+            dkv[u] = EMIT ? depth_key[gc] : 0u;
             if (!(g < P) || k0 + u >= per_thread) ntv[u] = 0u;
         }
 #pragma unroll
@@ -114,17 +115,18 @@ __device__ __forceinline__ u32 walk_block(u32* cnt, int P, int per_block, int gr
             const u32 nt = ntv[u]; const uint2 rc = rcv[u];
             const int w = (int)(rc.y & 0xFFFF) - (int)(rc.x & 0xFFFF), h = (int)(rc.y >> 16) - (int)(rc.x >> 16);
             mine += nt;                                     // a large rectangle emits every tile: nt is its area
+            const u64 word = ((u64)dkv[u] << 32) | (u64)(u32)g;   // what the per-tile sort orders: depth key, then id
             if (nt > 0) {
-                if (rect_small(w, h)) walk_mask<EMIT>(cnt, rc, kpv[u], grid_x, (u32)g, ids);
-                else if (nt <= BIN_COOP) walk_rect<EMIT>(cnt, rc, grid_x, lane, false, (u32)g, ids);
+                if (rect_small(w, h)) walk_mask<EMIT>(cnt, rc, kpv[u], grid_x, word, words);
+                else if (nt <= BIN_COOP) walk_rect<EMIT>(cnt, rc, grid_x, lane, false, word, words);
             }
             u64 big = __ballot(nt > BIN_COOP);              // never a small rectangle (at most 64 tiles)
             while (big) {
                 const int src = __ffsll((long long)big) - 1;
                 big &= big - 1;
                 const uint2 brc = make_uint2((u32)__shfl((int)rc.x, src), (u32)__shfl((int)rc.y, src));
-                const u32 bg = (u32)__shfl((int)(u32)g, src);
-                walk_rect<EMIT>(cnt, brc, grid_x, lane, true, bg, ids);
+                const u64 bw = ((u64)(u32)__shfl((int)dkv[u], src) << 32) | (u64)(u32)__shfl((int)(u32)g, src);
+                walk_rect<EMIT>(cnt, brc, grid_x, lane, true, bw, words);
             }
         }
     }
@@ -140,7 +142,7 @@ tile_count_kernel(int P, int per_block, int grid_x, int T2, const uint2* __restr
     __shared__ u32 wsum[BIN_THREADS / 64];
     for (int i = threadIdx.x; i < T2; i += BIN_THREADS) cnt[i] = 0u;
     __syncthreads();
-    const u32 mine = walk_block<false>(cnt, P, per_block, grid_x, rect, tiles_touched, keep, nullptr);
+    const u32 mine = walk_block<false>(cnt, P, per_block, grid_x, rect, tiles_touched, keep, nullptr, nullptr);
     // instance offset of every Gaussian inside its block (id order): exclusive scan of the threads' sums, then a second
     // walk over the thread's own run
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -337,7 +339,8 @@ __global__ void __launch_bounds__(BIN_THREADS)
 emit_binned_kernel(int P, int per_block, int grid_x, int T, const uint2* __restrict__ rect,
                    const u32* __restrict__ tiles_touched, const u64* __restrict__ keep, const u32* __restrict__ pre,
                    const uint2* __restrict__ ranges, const u32* __restrict__ local_off, const u32* __restrict__ block_base,
-                   u32* __restrict__ inst_off, u32* __restrict__ ids, u32 capacity, const u32* __restrict__ n_dev)
+                   u32* __restrict__ inst_off, const u32* __restrict__ depth_key, u64* __restrict__ words, u32 capacity,
+                   const u32* __restrict__ n_dev)
 {
     extern __shared__ u32 cur[];                             // T slot cursors
     // the instance offset of a Gaussian's records (blend_bwd's emission slots, preprocess_bwd's record sums): written even
@@ -355,7 +358,7 @@ emit_binned_kernel(int P, int per_block, int grid_x, int T, const uint2* __restr
     const u32* prow = pre + (size_t)blockIdx.x * T;
     for (int t = threadIdx.x; t < T; t += BIN_THREADS) cur[t] = ranges[t].x + prow[t];
     __syncthreads();
-    (void)walk_block<true>(cur, P, per_block, grid_x, rect, tiles_touched, keep, ids);
+    (void)walk_block<true>(cur, P, per_block, grid_x, rect, tiles_touched, keep, depth_key, words);
 }
 
 // ------------------------------------------------------------------------------------------------ 5. tile_sort
@@ -454,8 +457,8 @@ __device__ __forceinline__ void wave_sort_words(const u64 (&e)[PER], u32 n, u32 
 // One WAVE per tile for lists of up to TSORT_WAVE entries: 8160 independent waves, no workgroup barriers.
 #define TS_PER (TSORT_WAVE / 64)
 __global__ void __launch_bounds__(64)
-tile_sort_wave_kernel(const uint4* __restrict__ tile_desc, const u32* __restrict__ ids_in, const u32* __restrict__ depth_key,
-                      u32* __restrict__ point_list, u32 capacity, const u32* __restrict__ n_dev)
+tile_sort_wave_kernel(const uint4* __restrict__ tile_desc, const u64* __restrict__ words_in, u32* __restrict__ point_list,
+                      u32 capacity, const u32* __restrict__ n_dev)
 {
     __shared__ u64 t[TSORT_WAVE];
     __shared__ u32 cnt[TSORT_WAVE / 2];
@@ -464,18 +467,16 @@ tile_sort_wave_kernel(const uint4* __restrict__ tile_desc, const u32* __restrict
     const u32 n = desc.z, start = desc.y;
     if (n == 0 || n > TSORT_WAVE) return;
     const u32 lane = threadIdx.x;
-    if (n == 1) { if (lane == 0) point_list[start] = ids_in[start]; return; }
-    // all id loads in one batch, then all key gathers in one batch (clamped indices, no branches)
+    if (n == 1) { if (lane == 0) point_list[start] = (u32)words_in[start]; return; }
+    // the list's (depth key, id) words in one batch of coalesced loads (clamped indices, no branches)
     u64 e[TS_PER];
-    u32 idv[TS_PER];
     u32 kmin = 0xFFFFFFFFu, kmax = 0u;
 #pragma unroll
-    for (u32 r = 0; r < TS_PER; ++r) idv[r] = ids_in[start + min(r * 64 + lane, n - 1)];
-#pragma unroll
     for (u32 r = 0; r < TS_PER; ++r) {
-        const u32 key = depth_key[idv[r]];
+        const u64 w = words_in[start + min(r * 64 + lane, n - 1)];
         const bool valid = r * 64 + lane < n;
-        e[r] = valid ? (((u64)key << 32) | (u64)idv[r]) : ~0ull;
+        const u32 key = (u32)(w >> 32);
+        e[r] = valid ? w : ~0ull;
         kmin = min(kmin, valid ? key : 0xFFFFFFFFu); kmax = max(kmax, valid ? key : 0u);
     }
     wave_sort_words<TS_PER>(e, n, wave_min(kmin), wave_max(kmax), point_list + start, t, cnt);
@@ -573,9 +574,8 @@ __device__ __forceinline__ void block_sort_words(const u64 (&e)[PER], u32 n, u32
 #define TSORT_LARGE 16384
 #define TS_SLABS_MAX 64
 __global__ void __launch_bounds__(256)
-tile_sort_large_kernel(const uint4* __restrict__ tile_desc, const u32* __restrict__ n_active, const u32* __restrict__ ids_in,
-                       const u32* __restrict__ depth_key, uint2* __restrict__ kv, u32* __restrict__ point_list, u32 capacity,
-                       const u32* __restrict__ n_dev)
+tile_sort_large_kernel(const uint4* __restrict__ tile_desc, const u32* __restrict__ n_active, const u64* __restrict__ words_in,
+                       u64* __restrict__ scratch, u32* __restrict__ point_list, u32 capacity, const u32* __restrict__ n_dev)
 {
     __shared__ u64 t_all[TSORT_BLOCK];                       // one list of <= 4096 words, or four waves x 1024 (slab sort)
     __shared__ u32 cnt_all[TSORT_BLOCK / 2];                 // packed 16-bit counters
@@ -589,17 +589,16 @@ tile_sort_large_kernel(const uint4* __restrict__ tile_desc, const u32* __restric
         const u32 n = desc.z, start = desc.y;
         if (n <= TSORT_WAVE) continue;                        // uniform over the workgroup
         if (n <= TSORT_BLOCK) {
-            // ---- one workgroup, one list: ids and keys in two batches of loads, then the block-wide bucket sort
+            // ---- one workgroup, one list: its words in one batch of coalesced loads, then the block-wide bucket sort
             constexpr int BP = TSORT_BLOCK / 256;
-            u64 e[BP]; u32 idv[BP];
+            u64 e[BP];
             u32 lo = 0xFFFFFFFFu, hi = 0u;
 #pragma unroll
-            for (u32 r = 0; r < BP; ++r) idv[r] = ids_in[start + min(r * 256 + (u32)tid, n - 1)];
-#pragma unroll
             for (u32 r = 0; r < BP; ++r) {
-                const u32 key = depth_key[idv[r]];
+                const u64 w = words_in[start + min(r * 256 + (u32)tid, n - 1)];
                 const bool valid = r * 256 + tid < n;
-                e[r] = valid ? (((u64)key << 32) | (u64)idv[r]) : ~0ull;
+                const u32 key = (u32)(w >> 32);
+                e[r] = valid ? w : ~0ull;
                 lo = min(lo, valid ? key : 0xFFFFFFFFu); hi = max(hi, valid ? key : 0u);
             }
             lo = wave_min(lo); hi = wave_max(hi);
@@ -617,7 +616,7 @@ tile_sort_large_kernel(const uint4* __restrict__ tile_desc, const u32* __restric
             // ---- level 1: key range, slab of every entry, slab counts
             const u32 K = min((u32)TS_SLABS_MAX, (n + 511) / 512);
             u32 kmin = 0xFFFFFFFFu, kmax = 0u;
-            for (u32 i = tid; i < n; i += 256) { const u32 key = depth_key[ids_in[start + i]]; kmin = min(kmin, key); kmax = max(kmax, key); }
+            for (u32 i = tid; i < n; i += 256) { const u32 key = (u32)(words_in[start + i] >> 32); kmin = min(kmin, key); kmax = max(kmax, key); }
             kmin = wave_min(kmin); kmax = wave_max(kmax);
             __syncthreads();                                  // the previous list's state is no longer in use
             if (lane == 0) { s_red[wave] = kmin; s_red[4 + wave] = kmax; }
@@ -628,7 +627,7 @@ tile_sort_large_kernel(const uint4* __restrict__ tile_desc, const u32* __restric
             kmax = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
             const float scale = (float)K / ((float)(kmax - kmin) + 1.0f);
             for (u32 i = tid; i < n; i += 256) {
-                const u32 key = depth_key[ids_in[start + i]];
+                const u32 key = (u32)(words_in[start + i] >> 32);
                 atomicAdd(&slab_cnt[min(K - 1, (u32)((float)(key - kmin) * scale))], 1u);
             }
             __syncthreads();
@@ -642,9 +641,9 @@ tile_sort_large_kernel(const uint4* __restrict__ tile_desc, const u32* __restric
             if (!network) {
                 // ---- words grouped by slab in the scratch array (order inside a slab arbitrary)
                 for (u32 i = tid; i < n; i += 256) {
-                    const u32 id = ids_in[start + i], key = depth_key[id];
-                    const u32 k = min(K - 1, (u32)((float)(key - kmin) * scale));
-                    kv[start + slab_start[k] + atomicAdd(&slab_cnt[k], 1u)] = make_uint2(key, id);
+                    const u64 w = words_in[start + i];
+                    const u32 k = min(K - 1, (u32)((float)((u32)(w >> 32) - kmin) * scale));
+                    scratch[start + slab_start[k] + atomicAdd(&slab_cnt[k], 1u)] = w;
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __threadfence();
@@ -661,12 +660,12 @@ tile_sort_large_kernel(const uint4* __restrict__ tile_desc, const u32* __restric
                     u32 lo = 0xFFFFFFFFu, hi = 0u;
 #pragma unroll
                     for (u32 r = 0; r < TS_PER; ++r) {
-                        // written by other waves of this workgroup just above: read at agent scope (L2), key in the low half
-                        const u64 raw = __hip_atomic_load(reinterpret_cast<const u64*>(&kv[start + s0 + min(r * 64 + (u32)lane, m - 1)]),
+                        // written by other waves of this workgroup just above: read at agent scope (L2)
+                        const u64 raw = __hip_atomic_load(&scratch[start + s0 + min(r * 64 + (u32)lane, m - 1)],
                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const u32 wkey = (u32)raw, wid = (u32)(raw >> 32);
+                        const u32 wkey = (u32)(raw >> 32);
                         const bool valid = r * 64 + lane < m;
-                        e[r] = valid ? (((u64)wkey << 32) | (u64)wid) : ~0ull;
+                        e[r] = valid ? raw : ~0ull;
                         lo = min(lo, valid ? wkey : 0xFFFFFFFFu); hi = max(hi, valid ? wkey : 0u);
                     }
                     if (m == 1) { if (lane == 0) point_list[start + s0] = (u32)e[0]; continue; }
@@ -679,13 +678,13 @@ tile_sort_large_kernel(const uint4* __restrict__ tile_desc, const u32* __restric
         // ---- the network in global memory
         u32 N = 2; while (N < n) N <<= 1;
         __syncthreads();
-        for (u32 i = tid; i < n; i += 256) { const u32 id = ids_in[start + i]; kv[start + i] = make_uint2(depth_key[id], id); }
+        for (u32 i = tid; i < n; i += 256) scratch[start + i] = words_in[start + i];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __threadfence();
         __syncthreads();
-        u64* gsm = reinterpret_cast<u64*>(kv + start);        // (key, id) read as one little-endian word: the id is the HIGH half
-        auto ld = [&](u32 i) -> u64 { const u64 v = __hip_atomic_load(&gsm[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return (v << 32) | (v >> 32); };
-        auto st = [&](u32 i, u64 v) { __hip_atomic_store(&gsm[i], (v << 32) | (v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        u64* gsm = scratch + start;
+        auto ld = [&](u32 i) -> u64 { return __hip_atomic_load(&gsm[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        auto st = [&](u32 i, u64 v) { __hip_atomic_store(&gsm[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
         for (u32 k = 2; k <= N; k <<= 1) {
             const u32 hk = k >> 1;
             for (u32 i = tid; i < (N >> 1); i += 256) {
@@ -753,7 +752,7 @@ hipError_t launch_binned_empty(const GeomView& g, const ImgView& im, int T, hipS
     return hipGetLastError();
 }
 
-hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int grid_x, int T, u32* ids, uint2* kv, u32* point_list,
+hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int grid_x, int T, u64* words, u64* scratch, u32* point_list,
                                 u32 capacity, const u32* n_dev, hipStream_t st)
 {
     const int per = binned_per_block(P), B = cdiv(P, per);
@@ -763,11 +762,11 @@ hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(emit_binned_kernel, dim3(B), dim3(BIN_THREADS), cursors, st, P, per, grid_x, T, g.rect, g.tiles_touched,
-                       g.keep, im.pre, im.ranges, g.local_off, g.block_base, g.inst_off, ids, capacity, n_dev);
+                       g.keep, im.pre, im.ranges, g.local_off, g.block_base, g.inst_off, g.depth_key, words, capacity, n_dev);
     // long lists first: their few workgroups run beside the many short sorts of the second launch
-    hipLaunchKernelGGL(tile_sort_large_kernel, dim3(T < 768 ? T : 768), dim3(256), 0, st, im.tile_desc, im.n_active, ids, g.depth_key, kv,
+    hipLaunchKernelGGL(tile_sort_large_kernel, dim3(T < 768 ? T : 768), dim3(256), 0, st, im.tile_desc, im.n_active, words, scratch,
                        point_list, capacity, n_dev);
-    hipLaunchKernelGGL(tile_sort_wave_kernel, dim3(T), dim3(64), 0, st, im.tile_desc, ids, g.depth_key, point_list, capacity, n_dev);
+    hipLaunchKernelGGL(tile_sort_wave_kernel, dim3(T), dim3(64), 0, st, im.tile_desc, words, point_list, capacity, n_dev);
     return hipGetLastError();
 }
 
