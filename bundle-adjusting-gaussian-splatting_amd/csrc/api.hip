@@ -196,15 +196,18 @@ static bool use_binned(const BagsSettings* s, int P)
 static inline void* align256(void* p) { return reinterpret_cast<void*>(align_up(reinterpret_cast<size_t>(p), 256)); }
 
 // K1 + everything the instance count needs; leaves it in g.num_rendered (device)
+// host_count (optional): device-visible address of the caller's pinned host word; when the tile-binned path takes it, the
+// count is written there by the kernel that computes it and *host_written is set (no copy needed)
 static int enqueue_prepare(const BagsSettings* s, const BagsInputs* in, const GeomView& g, const ImgView& im, const BagsForwardOut* out,
-                           hipStream_t st)
+                           hipStream_t st, u32* host_count = nullptr, bool* host_written = nullptr)
 {
     { ProfScope ps(ST_PRE_FWD, st); HIP_TRY(launch_preprocess_fwd(*s, *in, g, out->radii, out->mean2D, st)); }
     DEBUG_SYNC(s, st, "preprocess_fwd");
     if (use_binned(s, in->P)) {
         // (block of Gaussians, tile) count matrix -> column prefixes -> tile ranges, instance count, heavy-first tile list
         const int gx = cdiv(s->image_width, BAGS_TILE), gy = cdiv(s->image_height, BAGS_TILE);
-        { ProfScope ps(ST_OFFSETS, st); HIP_TRY(launch_binned_prepare(g, im, in->P, gx, gx * gy, st)); }
+        { ProfScope ps(ST_OFFSETS, st); HIP_TRY(launch_binned_prepare(g, im, in->P, gx, gx * gy, st, host_count)); }
+        if (host_count && host_written) *host_written = true;
         DEBUG_SYNC(s, st, "tile count / prefix / ranges");
         return BAGS_OK;
     }
@@ -302,8 +305,16 @@ int bags_forward_prepare_async(const BagsSettings* s, const BagsInputs* in, cons
     if (in->P == 0) {
         HIP_TRY(hipMemsetAsync(g.num_rendered, 0, sizeof(u32), st));
     } else {
-        rc = enqueue_prepare(s, in, g, im, out, st);
+        // a pinned (page-locked, device-mapped) host word can be written by the kernel that computes the count
+        u32* dev_alias = nullptr;
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, host_num_rendered) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer)
+            dev_alias = static_cast<u32*>(attr.devicePointer);
+        else (void)hipGetLastError();                         // not a registered pointer: fall back to the copy
+        bool written = false;
+        rc = enqueue_prepare(s, in, g, im, out, st, dev_alias, &written);
         if (rc) return rc;
+        if (written) return BAGS_OK;
     }
     HIP_TRY(hipMemcpyAsync(host_num_rendered, g.num_rendered, sizeof(u32), hipMemcpyDeviceToHost, st));
     return BAGS_OK;

@@ -236,7 +236,7 @@ template <int ORD_PER>
 __global__ void __launch_bounds__(1024)
 ranges_order_kernel(const u32* __restrict__ tile_total, int T, uint2* __restrict__ ranges, uint4* __restrict__ tile_desc,
                     u32* __restrict__ n_active, const u32* __restrict__ block_total, int B, u32* __restrict__ block_base,
-                    u32* __restrict__ num_rendered)
+                    u32* __restrict__ num_rendered, u32* host_count)
 {
     __shared__ u32 s_cur[ORD_LEVELS * ORD_SUB];
     __shared__ u32 s_wave[17];
@@ -280,7 +280,12 @@ ranges_order_kernel(const u32* __restrict__ tile_total, int T, uint2* __restrict
         }
     }
     __syncthreads();
-    if (tid == 0) num_rendered[0] = s_wave[16];
+    if (tid == 0) {
+        num_rendered[0] = s_wave[16];
+        // the caller's pinned host word, written from here: a device-to-host copy of four bytes is a 5 us copy kernel on the
+        // stream between this launch and the emission
+        if (host_count) __hip_atomic_store(host_count, s_wave[16], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     // ---- block bases (B <= 256)
     {
         const u32 v = (tid < B) ? block_total[tid] : 0u;
@@ -709,9 +714,9 @@ tile_sort_large_kernel(const uint4* __restrict__ tile_desc, const u32* __restric
 
 // ------------------------------------------------------------------------------------------------ launchers
 static size_t ord_tr_bytes(int per) { return (size_t)16 * (64 * per + 2 * per) * 4; }   // 34 / 68 / 135 KB
-static void launch_ranges_order(const ImgView& im, const GeomView& g, int T, int B, hipStream_t st)
+static void launch_ranges_order(const ImgView& im, const GeomView& g, int T, int B, hipStream_t st, u32* host_count = nullptr)
 {
-#define RO_ARGS(PER) dim3(1), dim3(1024), ord_tr_bytes(PER), st, im.tile_total, T, im.ranges, im.tile_desc, im.n_active, g.block_total, B, g.block_base, g.num_rendered
+#define RO_ARGS(PER) dim3(1), dim3(1024), ord_tr_bytes(PER), st, im.tile_total, T, im.ranges, im.tile_desc, im.n_active, g.block_total, B, g.block_base, g.num_rendered, host_count
     if (T <= 1024 * 8) hipLaunchKernelGGL(ranges_order_kernel<8>, RO_ARGS(8));
     else if (T <= 1024 * 16) {                               // more than 64 KB of dynamic LDS has to be asked for
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ranges_order_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ord_tr_bytes(16));
@@ -733,13 +738,13 @@ bool binned_supported(int P, int T)
     return T <= 1024 * ORD_PER_MAX && ((T + 1) / 2) * 4 <= 65536 && binned_per_block(P) <= 65535;
 }
 
-hipError_t launch_binned_prepare(const GeomView& g, const ImgView& im, int P, int grid_x, int T, hipStream_t st)
+hipError_t launch_binned_prepare(const GeomView& g, const ImgView& im, int P, int grid_x, int T, hipStream_t st, u32* host_count)
 {
     const int per = binned_per_block(P), B = cdiv(P, per), T2 = (T + 1) / 2;
     hipLaunchKernelGGL(tile_count_kernel, dim3(B), dim3(BIN_THREADS), (size_t)T2 * 4, st, P, per, grid_x, T2, g.rect, g.tiles_touched,
                        g.keep, im.cnt_rows, g.local_off, g.block_total);
     hipLaunchKernelGGL(tile_prefix_kernel, dim3(cdiv(T2, 64)), dim3(256), 0, st, im.cnt_rows, B, T, T2, im.pre, im.tile_total);
-    launch_ranges_order(im, g, T, B, st);
+    launch_ranges_order(im, g, T, B, st, host_count);
     return hipGetLastError();
 }
 
