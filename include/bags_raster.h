@@ -149,8 +149,10 @@ int bags_forward_prepare(const BagsSettings*, const BagsInputs*, const BagsState
 int bags_forward_finish(const BagsSettings*, const BagsInputs*, const BagsState*, const BagsForwardOut*,
                         int64_t num_rendered, void* stream);
 /* Forward without a host round trip in the middle (speculative instance capacity).
- *   1. bags_forward_prepare_async: phase 1 as above, but instead of synchronising it enqueues an asynchronous copy of
- *      the instance count into *host_num_rendered (caller-owned PINNED host word).  The caller records an event here.
+ *   1. bags_forward_prepare_async: phase 1 as above, but instead of synchronising it delivers the instance count
+ *      asynchronously into *host_num_rendered (caller-owned PINNED host word: written by the counting kernel itself when
+ *      the word is device-mapped, as hipHostMalloc / torch pinned memory is, otherwise by an enqueued copy).  The caller
+ *      records an event here.
  *   2. bags_forward_finish_speculative: phase 2 enqueued immediately, sized for a caller-guessed upper bound `capacity`
  *      (e.g. 1.2 x the previous frame's count; state.binning holds bags_binning_size(capacity, W, H) bytes); the
  *      kernels read the true count on the device and clamp it to `capacity`.

@@ -679,6 +679,20 @@ def test_two_views_in_flight_on_two_streams():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("W,H", [(2560, 1440), (1936, 1088), (130, 1000)])
+def test_tile_counts_of_every_ranges_order_variant(W, H):
+    """The single-workgroup ranges / tile-order kernel is instantiated for 8, 16 and 32 tiles per thread (the last two
+    with more than 64 KB of dynamic LDS); 14 400 tiles (2560x1440) take the middle one, 8228 (one row past 1080p) the first
+    tile count above 8192, 567 a narrow image where most threads own no tile.  Lists bit-exact over all tiles, blending
+    on a sample."""
+    scene, cam = make_case(20000, W, H, 0.5, 1, seed=W)
+    rep = compare_sampled(scene, cam, 1, sample_tiles(W, H, 32, seed=2))
+    print({k: rep[k] for k in ("num_rendered", "instances_in_sample", "image_max_err")})
+    assert rep["num_rendered"][0] > 20_000
+    _assert_sampled(rep, grad_tol=2e-4)
+
+
+@pytest.mark.gpu
 def test_more_than_32768_tiles_falls_back_to_the_radix_path():
     """34 170 tiles (3216x2720): beyond the tile-binned path's LDS limits, so binning="auto" must take the radix path by
     itself -- same bit-exact lists; blending checked on 48 sampled tiles."""
