@@ -194,6 +194,9 @@ def main():
     ap.add_argument("--width", type=int, default=W_DEFAULT)
     ap.add_argument("--height", type=int, default=H_DEFAULT)
     ap.add_argument("--sm", type=float, default=SM_DEFAULT)
+    ap.add_argument("--settle-steps", type=int, default=300,
+                    help="untimed view renders before the warm-up steps, so that the timed region runs at the device's steady "
+                         "clocks (0: none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage hipEvents in the timed region")
     ap.add_argument("--no-aabb-leg", action="store_true", help="skip the second timed leg with the stock tile rule")
@@ -281,12 +284,21 @@ def main():
         ex_events.append((e0, e1))
         return radii
 
-    for _ in range(args.warmup):
+    # Clock settle (untimed, before the W warm-up steps).  After an idle gap an MI355X runs the same kernel ~14 % slower
+    # for its first ~30 launches (`tools/trace_order.sh`, profiles/r02/trace_order.txt: blend_bwd 465 us for launches 0-15
+    # after a 70 ms gap, 409 us from launch 35 on), so a 30-step region that starts on an idle device measures the ramp
+    # (0.87-0.89 ms/step) and not the rate a training loop sees (0.81).  The device is therefore kept busy from here to
+    # the timed region: nothing that syncs or loads code (the visible count below used to cost 70 ms of idle: torch
+    # loading its reduction kernel) sits between the warm-up and the K timed steps, which are unchanged: exactly K full steps.
+    (radii0 := full_step())
+    torch.cuda.synchronize()
+    G = int((radii0 > 0).sum())                               # also loads torch's reduction kernels now, not later
+    for _ in range(max(0, args.settle_steps) // max(1, V)):
+        full_step()
+    for _ in range(max(1, args.warmup)):
         radii = full_step()
     if pipe is not None:
         pipe.drain()
-    torch.cuda.synchronize()
-    G = int((radii > 0).sum())
     _lib.profile_read()
     # timed region: only the dominant kernel (blend_bwd) is bracketed by hipEvents -- a full per-stage breakdown costs
     # ~40 event records (~0.09 ms of stream bubbles) per step and is taken in a separate short pass below
@@ -314,7 +326,7 @@ def main():
     aabb = None
     if world == 1 and V == 1 and args.tile_bounds == "opacity" and not args.no_aabb_leg:
         fns_a, _ = make_views("aabb")
-        for _ in range(3):
+        for _ in range(max(3, min(60, args.settle_steps))):   # the setup above left the device idle: settle again
             fns_a[0](True)
         el = timed_leg(lambda: fns_a[0](True), args.steps, None, dev)
         aabb = {"ms_per_step": el / args.steps * 1e3, "value": P * args.steps / el,
@@ -347,6 +359,7 @@ def main():
                                    f"{'' if args.fixed_pose else ' incl. pose/intrinsic gradients'}",
                        "P": P, "visible_G": G, "instances_I": I, "tile_bounds": args.tile_bounds, "binning": args.binning, "width": W, "height": H,
                        "views_per_rank_per_exchange": V,
+                       "settle_steps": max(0, args.settle_steps) // max(1, V) * max(1, V),   # untimed view renders before the warm-up
                        "parallelism": f"view-sharded x{world}" + (f", {args.exchange} of the flat Gaussian-gradient bucket"
                                                                   f"{' (pipelined, one step late)' if args.overlap else ''}"
                                                                   if world > 1 else "")},
