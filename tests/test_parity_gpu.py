@@ -593,6 +593,36 @@ def test_binning_paths_give_identical_lists(P, W, H, sm, deg):
     assert_report(rep, grad_tol=2e-4)
 
 
+def test_binning_paths_agree_on_random_scenes():
+    """Randomised cross-check of the two list builders (no oracle: fast): odd image sizes, 1 .. 60 k Gaussians, mixed
+    anisotropy and opacity, both tile rules, both depth keys -- lists, ranges, outputs and gradients must be bit-identical."""
+    rng = torch.Generator().manual_seed(2024)
+    for trial in range(14):
+        P = int(torch.randint(1, 60000, (1,), generator=rng)) if trial else 1
+        W = int(torch.randint(17, 700, (1,), generator=rng)); H = int(torch.randint(17, 500, (1,), generator=rng))
+        sm = float(torch.empty(1).uniform_(0.3, 4.0, generator=rng))
+        deg = int(torch.randint(0, 4, (1,), generator=rng))
+        scene, cam = make_case(P, W, H, sm, deg, seed=1000 + trial)
+        if trial % 3 == 1:                                   # needles
+            scene["scales"] = scene["scales"] * torch.exp(1.5 * torch.randn(P, 3, generator=rng))
+        if trial % 4 == 2:
+            scene["opacities"] = torch.rand(P, 1, generator=rng) ** 3
+        kw = dict(tile_bounds="aabb" if trial % 5 == 3 else "opacity", depth_key="distance" if trial % 2 else "z")
+        g = torch.randn(3, H, W, generator=rng)
+        o_a, g_a, v_a = run_hip(scene, cam, deg, g, binning="auto", **kw)
+        o_r, g_r, v_r = run_hip(scene, cam, deg, g, binning="radix", **kw)
+        tag = (trial, P, W, H, round(sm, 2), deg, kw)
+        assert v_a["num_rendered"] == v_r["num_rendered"], tag
+        for k in ("point_list", "keys_sorted", "n_contrib", "tiles_touched", "rect"):
+            assert torch.equal(v_a[k], v_r[k]), (k, tag)
+        assert torch.equal(v_a["ranges"][:, 1] - v_a["ranges"][:, 0], v_r["ranges"][:, 1] - v_r["ranges"][:, 0]), tag
+        for a, b in zip(o_a, o_r):
+            assert torch.equal(a, b), tag
+        for k in g_a:
+            if g_a[k] is not None:
+                assert torch.equal(g_a[k], g_r[k]), (k, tag)
+
+
 @pytest.mark.parametrize("P,shrink,flat", [(3000, 0.04, False), (20000, 0.02, False), (40000, 0.012, False),
                                            (600, 0.3, True), (2500, 0.03, True), (5000, 0.03, True)])
 def test_long_and_clustered_tile_lists_take_every_sort_path(P, shrink, flat):
