@@ -569,7 +569,7 @@ __device__ __forceinline__ void block_sort_words(const u64 (&e)[PER], u32 n, u32
 // descriptor list (n_active[1] entries: every long list plus a few of the boundary level).
 //   * up to TSORT_BLOCK entries: block_sort_words, the whole workgroup on one list.
 //   * up to TSORT_LARGE entries: two levels.  The workgroup cuts the depth range of the list into slabs of ~512 entries
-//     (coarse buckets, again monotone in the key), groups the (key, id) words by slab in the global scratch array `kv`,
+//     (coarse buckets, again monotone in the key), groups the (key, id) words by slab in the global scratch array `scratch`,
 //     and its four waves then sort one slab each with wave_sort_words until none is left.  A slab that outgrows a wave's
 //     capacity (very uneven depths) sends the whole list to the network below.
 //   * beyond that (tens of thousands of splats over ONE tile: a camera far from the scene, adversarial inputs), or as that
