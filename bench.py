@@ -8,13 +8,15 @@ backward (bags_backward) of BASELINE config 2 -- synth(500 000 Gaussians, seed 0
 1920x1080, SH degree 3 -- with every input already resident in HBM and a fixed seeded dL/dimage cotangent.  At N > 1
 the views are sharded (rank r renders its own perturbed-pose view of the same replicated scene) and the step ends
 with the RCCL all-reduce of the Gaussian-parameter gradients (59 floats per Gaussian), the path's one exchange step;
-value = N * P * K / max-over-ranks time ("weak" scaling: per-GPU work is fixed).
+value = N * V * P * K / max-over-ranks time ("weak" scaling: per-GPU work is fixed; V = 1 view per rank per exchange at every N,
+the 4-view figure is a second leg of the same run, "v4").
 
 Extra objects on the JSON line:
   roofline      dominant kernel (blend_bwd): algorithmic bytes per launch / mean launch time, timed with hipEvents on the
                 launch stream inside the timed region (bags_profile_*), against the 8 TB/s HBM peak
   op_roofline   the same for the whole fwd+bwd with SURVEY.md 8d's B_alg = G*850 + (P-G)*28 + I*168 + H*W*40
   cpu_baseline  the CPU oracle (oracle/raster_oracle.py, PyTorch autograd, fp32) on a bounded sample of the same workload
+  pose_grad_rel_err   BASELINE.json metric part (ii): pose gradients of the bench workload against the fp32 / fp64 oracle
 """
 import argparse
 import json
@@ -143,6 +145,56 @@ def cpu_baseline(P, W, H, sm, budget_s=15.0):
                 seconds_measured=round(spent + t_pre, 1), est_seconds_full=round(est, 1))
 
 
+def pose_grad_rel_err(P, W, H, sm, n_tiles=96):
+    """BASELINE.json metric, part (ii): relative L2 error of the pose gradients of the bench workload against
+    the CPU oracle.  The cotangent is confined to `n_tiles` sampled tiles (tests/parity.py compare_sampled: the HIP backward
+    over the whole image then computes exactly what the oracle's backward over those tiles computes); preprocess, binning and
+    sort are compared for all P Gaussians on the way.  Reported against the fp32 oracle (the arithmetic of an fp32 reference
+    rasterizer), against its fp64 replay, and the fp32 oracle's own distance from fp64 (what fp32 arithmetic costs).  The
+    matrix gradients are also pushed through the pose chain (bags_raster/camera.py, scene/cameras.py:356-381) to the leaves
+    train.py:472-485 steps: delta_quaternion, delta_translation, fovx, fovy."""
+    from bags_raster.synth import synth_scene, look_at_origin_camera
+    from parity import compare_sampled, sample_tiles
+    from scenes import rel_err
+    scene = synth_scene(P, 0, sm, DEG)
+    cam = look_at_origin_camera(W, H)
+    rep, gr = compare_sampled(scene, cam, DEG, sample_tiles(W, H, n_tiles, seed=3), seed=2, check_fp64=True, return_grads=True)
+    mats = ("viewmatrix", "projmatrix", "intrinsic", "campos")
+
+    def leaves_of(g):                                          # vector-Jacobian product of the pose chain, on the CPU
+        cam2 = look_at_origin_camera(W, H)
+        outs = [cam2.get_world_view_transform(), cam2.get_full_proj_transform(), cam2.get_intrinsic(), cam2.get_camera_center()]
+        cot = [g[k].reshape(o.shape).to(o.dtype) for k, o in zip(mats, outs)]
+        lv = [p for p in cam2.pose_leaves() if p.requires_grad]
+        return torch.autograd.grad(outputs=outs, inputs=lv, grad_outputs=cot, allow_unused=True)
+
+    lh, l32, l64 = leaves_of(gr["hip"]), leaves_of(gr["oracle32"]), leaves_of(gr["oracle64"])
+    names = ("delta_quaternion", "delta_translation", "learnable_fovx", "learnable_fovy")
+    leaf = {}
+    for i, n in enumerate(names[:len(lh)]):
+        if lh[i] is not None and l32[i] is not None:
+            leaf[n] = {"vs_fp32_oracle": rel_err(lh[i], l32[i]), "vs_fp64_oracle": rel_err(lh[i], l64[i]),
+                       "fp32_oracle_vs_fp64": rel_err(l32[i], l64[i])}
+    per = {k: {"vs_fp32_oracle": rep["grad_rel_fp32"][k], "vs_fp64_oracle": rep["grad_rel_fp64"][k],
+               "fp32_oracle_vs_fp64": rep["oracle32_vs_64"][k]} for k in mats}
+    per.update(leaf)
+    gauss = ("means3D", "shs", "opacities", "scales", "rotations", "means2D", "means2D_densify")
+    ints = all(rep[k] for k in ("radii_equal", "tiles_touched_equal", "rect_equal", "depth_bits_equal", "point_list_equal",
+                                "keys_equal", "ranges_equal"))
+    return {"vs_fp32_oracle": max(v["vs_fp32_oracle"] for v in per.values()),
+            "vs_fp64_oracle": max(v["vs_fp64_oracle"] for v in per.values()),
+            "fp32_oracle_vs_fp64": max(v["fp32_oracle_vs_fp64"] for v in per.values()),
+            "per_tensor": per,
+            "gaussian_grads_vs_fp32_oracle": max(rep["grad_rel_fp32"][k] for k in gauss if k in rep["grad_rel_fp32"]),
+            "gaussian_grads_vs_fp64_oracle": max(rep["grad_rel_fp64"][k] for k in gauss if k in rep["grad_rel_fp64"]),
+            "integers_bit_exact": bool(ints), "instances_I": rep["num_rendered"][0],
+            "image_max_err": rep["image_max_err"], "n_contrib_mismatch_frac": rep["n_contrib_mismatch_frac"],
+            "sample": f"cotangent on {n_tiles} of {((W + 15) // 16) * ((H + 15) // 16)} tiles ({rep['instances_in_sample']} "
+                      f"instances); integers compared for all {P} Gaussians / {rep['num_rendered'][0]} instances",
+            "note": "reference CUDA rasterizer absent (empty submodule): the oracle is the CPU restatement, parity unpinned "
+                    "(oracle/raster_oracle.py header); tolerance of the tests: 1e-4 vs the fp32 oracle"}
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run (never exec: this
     process may not be replaced once anything touched the GPU, and it has not touched it yet), relay rank 0's JSON line and
@@ -208,7 +260,8 @@ def main():
     ap.add_argument("--fixed-pose", action="store_true", help="config 2 exactly: no pose/intrinsic gradients requested")
     ap.add_argument("--views-per-exchange", type=int, default=0,
                     help="views every rank renders (fwd+bwd, gradients accumulated locally) behind ONE exchange; 0 = 1 view at "
-                         "--gpus 1, 4 views at --gpus > 1 (the cubemap step of the reference renders 5 per iteration)")
+                         "every --gpus N (a second leg with 4 views is timed in the same run and reported as 'v4')")
+    ap.add_argument("--no-v4-leg", action="store_true", help="skip the second timed leg with 4 views per rank per exchange")
     ap.add_argument("--exchange", default="all_reduce", choices=("all_reduce", "reduce_scatter"),
                     help="one ncclAllReduce of the flat gradient bucket, or ncclReduceScatter + ncclAllGather")
     ap.add_argument("--overlap", action="store_true",
@@ -244,67 +297,85 @@ def main():
     from bags_raster import _lib
     from bags_raster.sharding import GradAllReducer, PipelinedExchange
     from bags_raster.synth import sphere_views
+    from bags_raster import rasterizer as R
     P, W, H = args.P, args.width, args.height
-    V = args.views_per_exchange if args.views_per_exchange > 0 else (1 if world == 1 else 4)
+    # ONE view per rank per exchange at every N (BASELINE configs 3-5: one view per GPU per iteration), so that the driver's
+    # N = 1, 2, 4, 8 curve compares like with like; the V = 4 figure (the cubemap step renders 5 views per iteration,
+    # utils/cubemap_utils.py:229,263-265) is a second leg of the same run, also at every N.
+    V = args.views_per_exchange if args.views_per_exchange > 0 else 1
     scene, cam0 = build_case(P, W, H, args.sm, rank, dev)
-    # views of this rank: view sharding gives rank r the views r, r + N, ... of the iteration's batch of N*V perturbed views
-    cams = [cam0] if (world == 1 and V == 1) else [sphere_views(world * V, W, H, noise=0.05)[rank + world * j] for j in range(V)]
 
-    def make_views(tile_bounds):
-        step0, params, ct = make_step(scene, cams[0], dev, pose_grads=not args.fixed_pose, tile_bounds=tile_bounds, binning=args.binning)
-        fns = [step0]
-        for c in cams[1:]:
-            fns.append(make_step(scene, c, dev, pose_grads=not args.fixed_pose, tile_bounds=tile_bounds, leaves=params,
-                                 binning=args.binning)[0])
+    def views_of(v_per_rank):      # view sharding: rank r takes views r, r + N, ... of the batch of N * V perturbed views
+        if world == 1 and v_per_rank == 1:
+            return [cam0]
+        return [sphere_views(world * v_per_rank, W, H, noise=0.05)[rank + world * j] for j in range(v_per_rank)]
+
+    def make_views(cams, tile_bounds, leaves=None):
+        fns, params = [], leaves
+        for c in cams:
+            st_, params_, _ = make_step(scene, c, dev, pose_grads=not args.fixed_pose, tile_bounds=tile_bounds, leaves=params,
+                                        binning=args.binning)
+            params = params if params is not None else params_
+            fns.append(st_)
         return fns, params
 
-    view_fns, params = make_views(args.tile_bounds)
-    reducer = pipe = None
-    if world > 1 or V > 1:
-        if args.overlap:
-            pipe = PipelinedExchange(params, mode=args.exchange)
-        else:
-            reducer = GradAllReducer(params, mode=args.exchange)
-    ex_events = []
+    def make_leg(v_per_rank, leaves=None, overlap=False):
+        """(full_step, finish, reducer-or-pipe, exchange event list, params) of a leg with v_per_rank views behind one exchange."""
+        fns, params = make_views(views_of(v_per_rank), args.tile_bounds, leaves)
+        red = pip = None
+        if world > 1 or v_per_rank > 1:
+            if overlap:
+                pip = PipelinedExchange(params, mode=args.exchange)
+            else:
+                red = GradAllReducer(params, mode=args.exchange)
+        evs = []
 
-    def full_step(fns=None):
-        fns = fns or view_fns
-        if reducer is None and pipe is None:
-            return fns[0](True)                               # single view, single GPU: autograd hands the gradients over as they are
-        (pipe or reducer).begin()                             # zero the bucket, p.grad = its slices
-        for f in fns:
-            radii = f(False)                                  # gradients of the rank's V views accumulate in the bucket
-        if pipe is not None:
-            pipe.submit()                                     # collective of this step overlaps the next step's rendering
-            return radii
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        reducer.all_reduce()
-        e1.record()
-        ex_events.append((e0, e1))
-        return radii
+        def full_step():
+            if red is None and pip is None:
+                return fns[0](True)                           # single view, single GPU: autograd hands the gradients over as they are
+            (pip or red).begin()                              # zero the bucket, p.grad = its slices
+            for f_ in fns:
+                radii_ = f_(False)                            # gradients of the rank's views accumulate in the bucket
+            if pip is not None:
+                pip.submit()                                  # collective of this step overlaps the next step's rendering
+                return radii_
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            red.all_reduce()
+            e1.record()
+            evs.append((e0, e1))
+            return radii_
+        return full_step, (pip.drain if pip is not None else None), (red or pip), evs, params
 
-    # Clock settle (untimed, before the W warm-up steps).  After an idle gap an MI355X runs the same kernel ~14 % slower
-    # for its first ~30 launches (`tools/trace_order.sh`, profiles/r02/trace_order.txt: blend_bwd 465 us for launches 0-15
-    # after a 70 ms gap, 409 us from launch 35 on), so a 30-step region that starts on an idle device measures the ramp
-    # (0.87-0.89 ms/step) and not the rate a training loop sees (0.81).  The device is therefore kept busy from here to
-    # the timed region: nothing that syncs or loads code (the visible count below used to cost 70 ms of idle: torch
-    # loading its reduction kernel) sits between the warm-up and the K timed steps, which are unchanged: exactly K full steps.
+    full_step, finish, exch, ex_events, params = make_leg(V, overlap=args.overlap)
+    pipe = exch if args.overlap else None
+
+    # Cold leg: the contract as written -- W warm-up steps from an idle device, then K timed steps.  After an idle gap an
+    # MI355X runs the same kernel ~14 % slower for its first ~30 launches (tools/trace_order.sh, profiles/r02/trace_order.txt),
+    # so this figure is the clock ramp, reported as ms_per_step_cold.
     (radii0 := full_step())
     torch.cuda.synchronize()
     G = int((radii0 > 0).sum())                               # also loads torch's reduction kernels now, not later
+    time.sleep(0.05)
+    for _ in range(max(1, args.warmup)):
+        full_step()
+    if finish is not None:
+        finish()
+    cold = timed_leg(full_step, args.steps, dist, dev, finish=finish)
+    # Steady leg (the headline): the device is kept busy from the settle steps through the warm-up into the timed region --
+    # nothing that syncs or loads code in between -- so the K timed steps run at the clocks a training loop sees.
     for _ in range(max(0, args.settle_steps) // max(1, V)):
         full_step()
     for _ in range(max(1, args.warmup)):
         radii = full_step()
-    if pipe is not None:
-        pipe.drain()
+    if finish is not None:
+        finish()
     _lib.profile_read()
     # timed region: only the dominant kernel (blend_bwd) is bracketed by hipEvents -- a full per-stage breakdown costs
     # ~40 event records (~0.09 ms of stream bubbles) per step and is taken in a separate short pass below
     _lib.profile_enable(0 if args.no_profile else 1)
     ex_events.clear()
-    elapsed = timed_leg(full_step, args.steps, dist, dev, finish=pipe.drain if pipe is not None else None)
+    elapsed = timed_leg(full_step, args.steps, dist, dev, finish=finish)
     _lib.profile_enable(0)
     exchange_ms = (sum(a.elapsed_time(b) for a, b in ex_events) / len(ex_events)) if ex_events else 0.0
     prof_dom = _lib.profile_read()
@@ -313,19 +384,34 @@ def main():
         _lib.profile_enable(2)
         for _ in range(min(args.steps, 10)):
             full_step()
-        if pipe is not None:
-            pipe.drain()
+        if finish is not None:
+            finish()
         torch.cuda.synchronize()
         _lib.profile_enable(0)
         prof = _lib.profile_read()
         if prof_dom.get("blend_bwd", (0.0, 0))[1] > 0:
             prof["blend_bwd"] = prof_dom["blend_bwd"]          # the roofline kernel: measured inside the timed region
-    from bags_raster import rasterizer as R
     I = int(getattr(R, "LAST_NUM_RENDERED", 0))
-    # second leg, rank-0 single-GPU runs only: the same workload with the stock 3-sigma tile rule, i.e. upstream's instance list
+    # second leg, every N: 4 views per rank behind ONE exchange (gradients accumulate in the flat bucket; at N = 1 the
+    # "exchange" is the bucket alone), same parameters, same timed-region rules
+    v4 = None
+    if not args.no_v4_leg and V != 4:
+        fs4, fin4, exch4, ev4, _ = make_leg(4, leaves=params, overlap=args.overlap)
+        for _ in range(max(3, min(20, args.settle_steps // 4))):
+            fs4()
+        if fin4 is not None:
+            fin4()
+        ev4.clear()
+        k4 = max(1, args.steps // 4)
+        el4 = timed_leg(fs4, k4, dist, dev, finish=fin4)
+        v4 = {"views_per_rank_per_exchange": 4, "steps": k4, "ms_per_step": el4 / k4 * 1e3, "ms_per_view": el4 / k4 / 4 * 1e3,
+              "value": world * 4 * P * k4 / el4,
+              "exchange_ms": (sum(a.elapsed_time(b) for a, b in ev4) / len(ev4)) if ev4 else 0.0,
+              "note": "four views per rank (fwd+bwd, gradients accumulated in the flat bucket) behind one exchange"}
+    # third leg, rank-0 single-GPU runs only: the same workload with the stock 3-sigma tile rule, i.e. upstream's instance list
     aabb = None
     if world == 1 and V == 1 and args.tile_bounds == "opacity" and not args.no_aabb_leg:
-        fns_a, _ = make_views("aabb")
+        fns_a, _ = make_views([cam0], "aabb")
         for _ in range(max(3, min(60, args.settle_steps))):   # the setup above left the device idle: settle again
             fns_a[0](True)
         el = timed_leg(lambda: fns_a[0](True), args.steps, None, dev)
@@ -349,12 +435,19 @@ def main():
             "offsets_scan": P * 16,
         }
         b_alg = G * 850 + (P - G) * 28 + I * 168 + HWp * 40
-        cfg_n = "2" if args.fixed_pose else "3"
+        if (P, W, H) == (500_000, 1920, 1080):
+            cfg_name = "BASELINE config " + ("2" if args.fixed_pose else "3")
+        elif (P, W, H) == (2_000_000, 1920, 1080):
+            cfg_name = "BASELINE config 4 shape (one view of it per step)"
+        elif (P, W, H) == (5_000_000, 3840, 2160):
+            cfg_name = "BASELINE config 5 shape (one view of it per step, distortion parameters at zero)"
+        else:
+            cfg_name = "custom size (not a BASELINE configuration)"
         out = {
             "metric": "composited Gaussians/s (fwd+bwd) @1080p", "value": value, "unit": "Gaussians/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE config {cfg_n}: synth({P}, seed 0, sm {args.sm}), "
+            "config": {"workload": f"{cfg_name}: synth({P}, seed 0, sm {args.sm}), "
                                    f"{V} camera{'s' if V > 1 else ''}/rank/step @{W}x{H}, SH deg 3, fwd+bwd"
                                    f"{'' if args.fixed_pose else ' incl. pose/intrinsic gradients'}",
                        "P": P, "visible_G": G, "instances_I": I, "tile_bounds": args.tile_bounds, "binning": args.binning, "width": W, "height": H,
@@ -365,11 +458,14 @@ def main():
                                                                   if world > 1 else "")},
             "instances_per_s": world * V * I * args.steps / elapsed,
             "ms_per_view": ms_step / V,
+            "ms_per_step_cold": cold / args.steps * 1e3,    # W warm-up + K timed steps from an idle device: no settle steps
             "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0,
             "exchange_ms": exchange_ms,                    # per step, hipEvents around the collective on the launch stream (rank 0)
             "compute_ms": ms_step - exchange_ms,
-            "exchange_bytes": (reducer or pipe.exchanges[0]).bucket.numel * 4 if (reducer or pipe) else 0,
+            "exchange_bytes": ((exch.exchanges[0] if args.overlap else exch).bucket.numel * 4) if exch is not None else 0,
         }
+        if v4 is not None:
+            out["v4"] = v4
         if aabb is not None:
             out["config"]["aabb"] = aabb
         if stages:
@@ -428,6 +524,10 @@ def main():
             out["stage_ms"] = {k: round(v, 4) for k, v in stages.items()}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(P, W, H, args.sm)
+            try:                                               # BASELINE.json metric, second half
+                out["pose_grad_rel_err"] = pose_grad_rel_err(P, W, H, args.sm)
+            except Exception as e:                             # never a reason to lose the throughput line
+                out["pose_grad_rel_err"] = {"error": repr(e)[:300]}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -174,15 +174,31 @@ def save_checkpoint(pc: GaussianBag, iteration: int, path: str, optimizer_state:
     torch.save((capture(pc, optimizer_state, spatial_lr_scale), iteration), path)
 
 
+def _numpy_scalar_globals():
+    """What the safe unpickler must accept for the reference's own files: ``capture()`` stores ``spatial_lr_scale`` =
+    ``scene.cameras_extent`` = ``nerf_normalization['radius']``, a ``numpy.float64`` (scene/dataset_readers.py:100,
+    scene/__init__.py:115), which pickles as ``numpy.core.multiarray.scalar(dtype('f8'), bytes)``."""
+    import numpy as np
+    out = [np.dtype, np.float64, np.float32, np.int64, np.int32, type(np.dtype(np.float64)), type(np.dtype(np.float32)),
+           type(np.dtype(np.int64)), type(np.dtype(np.int32))]
+    try:
+        from numpy._core.multiarray import scalar as _scalar        # numpy >= 2
+    except ImportError:                                              # numpy 1.x
+        from numpy.core.multiarray import scalar as _scalar
+    out.append(_scalar)
+    return out
+
+
 def load_checkpoint(path: str, sh_degree: int, device=None, trust_pickle: bool = False) -> Tuple[GaussianBag, dict, float, int]:
     """Inverse of ``save_checkpoint`` and of the reference's own checkpoints (train.py:132-135 restores them the same way).
 
-    The tuple holds tensors, numbers and an optimizer state dict only, so it is read with ``weights_only=True`` (no code from
-    the file is executed).  A checkpoint that needs the full unpickler (the reference writes ``nn.Parameter`` objects, which
+    The tuple holds tensors, numbers (incl. the numpy scalar the reference stores as ``spatial_lr_scale``) and an optimizer
+    state dict only, so it is read with ``weights_only=True`` (no code from the file is executed).  A checkpoint that needs the full unpickler (the reference writes ``nn.Parameter`` objects, which
     the safe loader accepts; anything else does not) is only read with ``trust_pickle=True`` -- the reference's own behaviour,
     to be used on files you wrote yourself.  A view-sharded run must call ``DensificationSync.rebase()`` after restoring."""
     try:
-        model_args, iteration = torch.load(path, map_location=device, weights_only=True)
+        with torch.serialization.safe_globals(_numpy_scalar_globals()):
+            model_args, iteration = torch.load(path, map_location=device, weights_only=True)
     except Exception:
         if not trust_pickle:
             raise

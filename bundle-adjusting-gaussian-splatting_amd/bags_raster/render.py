@@ -6,7 +6,8 @@ arguments, same choice of covariance path (``pipe.compute_cov3D_python``) and co
 
   * tensors are created on the device of ``pc.get_xyz`` instead of a hard-coded ``"cuda"``;
   * the camera chain (three calls in the reference, :57,58,61) is evaluated once per tensor, not once per use;
-  * ``global_alignment`` may be ``None`` (the reference always passes a pair, ``train.py:250``).
+  * ``global_alignment`` may be ``None`` (the reference always passes a pair, ``train.py:250``);
+  * ``shift_factors`` may be ``None`` (= zeros(3)); one extra keyword, ``depth_key`` (decision D6 of DESIGN.md).
 """
 from __future__ import annotations
 
@@ -46,9 +47,12 @@ def _python_colors(pc, xyz, feats, campos: torch.Tensor, mlp_color) -> torch.Ten
     return rgb + mlp_color
 
 
-def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, mlp_color=0.0, shift_factors: Optional[torch.Tensor] = None,
-           hybrid: bool = False, scaling_modifier: float = 1.0, override_color: Optional[torch.Tensor] = None,
-           iteration: Optional[int] = None, global_alignment=None, depth_key: str = "z"):
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, mlp_color, shift_factors, hybrid: bool = True,
+           scaling_modifier: float = 1.0, override_color: Optional[torch.Tensor] = None, iteration: Optional[int] = None,
+           global_alignment=None, depth_key: str = "z"):
+    """Signature and defaults of gaussian_renderer/__init__.py:30: ``mlp_color`` and ``shift_factors`` are positional and
+    required, ``hybrid`` defaults to True (Python-side SH colours + ``mlp_color``).  ``shift_factors=None`` stands for the
+    zero vector the reference keeps (train.py:125-126: its optimizer is never stepped)."""
     # activations: one fused launch when the container offers it (GaussianBag on a GPU), else the reference's properties
     if hasattr(pc, "activated"):
         xyz, features, opacity, scaling, rotation = pc.activated()

@@ -290,7 +290,9 @@ int bags_forward_finish(const BagsSettings* s, const BagsInputs* in, const BagsS
     GeomView g; carve_geom(align256(stt->geom), in->P, &g);
     BinView b; carve_binning(align256(stt->binning), I, W, H, &b, use_binned(s, in->P));
     ImgView im; carve_image(align256(stt->image), W, H, &im);
-    return enqueue_finish(s, in, g, b, im, out, I, nullptr, st);
+    // the count is compared with I on the device as well: a caller-supplied I below the true count renders the overflowing
+    // lists empty instead of writing past the binning buffer (same guard as the speculative finish)
+    return enqueue_finish(s, in, g, b, im, out, I, in->P > 0 ? g.num_rendered : nullptr, st);
 }
 
 int bags_forward_prepare_async(const BagsSettings* s, const BagsInputs* in, const BagsState* stt, const BagsForwardOut* out,
@@ -494,6 +496,8 @@ static int check_resample(int C, int H, int W, int h, int w, int Hf, int Wf, int
     if (C <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0 || Hf <= 0 || Wf <= 0 || Hc <= 0 || Wc <= 0)
         return fail(BAGS_ERR_ARG, "resample: every extent must be positive");
     if (Hc > Hf || Wc > Wf) return fail(BAGS_ERR_ARG, "resample: crop %dx%d exceeds the flow size %dx%d", Wc, Hc, Wf, Hf);
+    // the backward keeps a 16x16xC accumulator of 64-bit words in LDS (2 KB per channel)
+    if (C > 24) return fail(BAGS_ERR_ARG, "resample: at most 24 channels per call (got %d): split the image along C", C);
     return BAGS_OK;
 }
 

@@ -741,6 +741,12 @@ bool binned_supported(int P, int T)
 hipError_t launch_binned_prepare(const GeomView& g, const ImgView& im, int P, int grid_x, int T, hipStream_t st, u32* host_count)
 {
     const int per = binned_per_block(P), B = cdiv(P, per), T2 = (T + 1) / 2;
+    // the kernel also has 64 B of static LDS (wsum): dynamic + static crosses the default 64 KB limit from T = 32737 tiles on
+    // (4096 x 2048 is exactly 32768), so the launch opts in like ranges_order / emit_binned do
+    if ((size_t)T2 * 4 + 256 > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T2 * 4);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(tile_count_kernel, dim3(B), dim3(BIN_THREADS), (size_t)T2 * 4, st, P, per, grid_x, T2, g.rect, g.tiles_touched,
                        g.keep, im.cnt_rows, g.local_off, g.block_total);
     hipLaunchKernelGGL(tile_prefix_kernel, dim3(cdiv(T2, 64)), dim3(256), 0, st, im.cnt_rows, B, T, T2, im.pre, im.tile_total);

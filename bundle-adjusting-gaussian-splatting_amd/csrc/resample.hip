@@ -203,7 +203,10 @@ resample_gather_kernel(ResampleGeom g, const float* __restrict__ ctrl, const flo
     m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
     // a term is at most m (bilinear weights <= 1) and at most n * 1024 terms meet in one accumulator:
     // quantum = 2^(e - bits), m < 2^e, bits = 62 - ceil(log2(n * 1024))  (>= 47 for listed tiles)
+    // below 2^-100 the scale 2^(24-e) would overflow to +inf (and (int)(v * inf) is undefined): such a tile's terms are
+    // accumulated on the 2^-100 scale instead, where they round to ~0, which is what they are
     int e = 0; (void)frexpf(m, &e);
+    if (e < -100) e = -100;
     int lg = 10; { u32 v = (n > 1 ? n : 1u) - 1u; while (v) { ++lg; v >>= 1; } }
     const int bits = 62 - lg;
     const float up = ldexpf(1.0f, 24 - e);                   // term * up is below 2^24 in magnitude: its integer part fits an int32
@@ -248,8 +251,11 @@ resample_gather_kernel(ResampleGeom g, const float* __restrict__ ctrl, const flo
     const int x = X0 + (threadIdx.x & 15), y = Y0 + (threadIdx.x >> 4);
     if (x < g.W && y < g.H) {
         const double q = ldexp(1.0, e - 24 - 24 - (shift - 24));            // value of one fixed-point unit
+        // a non-finite cotangent anywhere on this source tile's list poisons the tile, as PyTorch's scatter would the taps it hits
+        const bool bad = !isfinite(m);
         for (int ch = 0; ch < g.C; ++ch)
-            grad_image[(size_t)ch * g.H * g.W + (size_t)y * g.W + x] = (float)((double)(long long)acc[ch * 256 + threadIdx.x] * q);
+            grad_image[(size_t)ch * g.H * g.W + (size_t)y * g.W + x] =
+                bad ? __builtin_nanf("") : (float)((double)(long long)acc[ch * 256 + threadIdx.x] * q);
     }
 }
 

@@ -224,11 +224,12 @@ int bags_camera_backward(const BagsCamera* cam, const float* g_viewmatrix, const
  *   mask  = !(out[0] == 0 && out[1] == 0)                                    (may be NULL)
  *   flow_out (crop_H, crop_W, 2): the upsampled flow at the cropped pixels     (may be NULL)
  * Pass h == flow_H, w == flow_W to resample with an already dense flow (the cached flow_apply2_gt_or_img path).
- * Backward: grad_image (C,H,W) is zero-filled and accumulated with float atomics (summation order is not fixed, as in
- * PyTorch's grid_sample backward); grad_ctrl (h,w,2) is gathered per control node in a fixed order and needs a caller-owned
- * workspace of bags_resample_workspace_size(H, W, crop_H, crop_W) bytes (per-tile lists and the dense dL/dflow).  Either gradient
- * may be NULL.  No global float atomics (integer ones only on per-tile list counters); dL/dimage is accumulated in 64-bit fixed
- * point, so both gradients are bitwise reproducible. */
+ * Backward: grad_image (C,H,W) is gathered per 16x16 source tile into a 64-bit fixed-point accumulator in LDS (every
+ * element is written: no memset needed); grad_ctrl (h,w,2) is gathered per control node in a fixed order.  No global float
+ * atomics (integer ones only on per-tile list counters), so both gradients are bitwise reproducible.  Needs a caller-owned
+ * workspace of bags_resample_workspace_size(H, W, crop_H, crop_W) bytes (per-tile lists and the dense dL/dflow).  Either
+ * gradient may be NULL.  C <= 24 per call (2 KB of LDS per channel).  A non-finite grad_out element makes the source tiles
+ * its output tile is listed on NaN; magnitudes below 2^-100 are treated as zero. */
 size_t bags_resample_workspace_size(int32_t H, int32_t W, int32_t crop_H, int32_t crop_W);
 int bags_resample_forward(const float* image, int32_t C, int32_t H, int32_t W, const float* ctrl_flow, int32_t h, int32_t w,
                           int32_t flow_H, int32_t flow_W, int32_t crop_H, int32_t crop_W, float* out, float* mask,

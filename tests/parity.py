@@ -139,7 +139,7 @@ def sample_tiles(W, H, n, seed=0):
     return torch.tensor(sorted(out), dtype=torch.int64)
 
 
-def compare_sampled(scene, cam, deg, tiles, seed=1, check_fp64=False, **kw):
+def compare_sampled(scene, cam, deg, tiles, seed=1, check_fp64=False, return_grads=False, **kw):
     """compare() for sizes at which the CPU oracle cannot blend every tile in seconds (BASELINE configs 4 and 5).
 
     Preprocess, binning and the sort are compared for ALL Gaussians / instances (bit-exact, as in compare()).  Blending
@@ -186,10 +186,13 @@ def compare_sampled(scene, cam, deg, tiles, seed=1, check_fp64=False, **kw):
     rep["weights_bad_frac"] = (w_err > 1e-4).float().mean().item()
     rep["mean2D_max_err"] = (outs[4] - st32.mean2D).abs().max().item()
     rep["grad_rel_fp32"] = {k: rel_err(grads[k], gr32[k]) for k in GRAD_NAMES if grads.get(k) is not None and k in gr32}
+    gr64 = None
     if check_fp64:
         st64, gr64 = O.render_and_grad(inp, s, g, dtype=torch.float64, discrete=O.discrete_of(st32), tiles=tiles)
         rep["grad_rel_fp64"] = {k: rel_err(grads[k], gr64[k]) for k in GRAD_NAMES if grads.get(k) is not None and k in gr64}
         rep["oracle32_vs_64"] = {k: rel_err(gr32[k], gr64[k]) for k in GRAD_NAMES if k in gr32 and k in gr64}
+    if return_grads:
+        return rep, dict(hip=grads, oracle32=gr32, oracle64=gr64)
     return rep
 
 

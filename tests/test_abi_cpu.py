@@ -83,3 +83,15 @@ def test_operator_api_surface_and_argument_errors():
         r(means3D=x, means2D=x, opacities=torch.ones(4, 1), shs=torch.zeros(4, 1, 3), scales=x, rotations=torch.zeros(4, 4))
     with pytest.raises(NotImplementedError):
         dgr.compute_relocation(None, None, None, None, 51)
+
+
+def test_render_signature_is_the_reference_one():
+    """gaussian_renderer/__init__.py:30: render(viewpoint_camera, pc, pipe, bg_color, mlp_color, shift_factors, hybrid=True,
+    scaling_modifier=1.0, override_color=None, iteration=None, global_alignment=None)."""
+    import inspect
+    from bags_raster.render import render
+    ps = list(inspect.signature(render).parameters.values())
+    assert [p.name for p in ps[:11]] == ["viewpoint_camera", "pc", "pipe", "bg_color", "mlp_color", "shift_factors", "hybrid",
+                                         "scaling_modifier", "override_color", "iteration", "global_alignment"]
+    assert all(p.default is inspect.Parameter.empty for p in ps[:6])
+    assert ps[6].default is True and ps[7].default == 1.0 and all(p.default is None for p in ps[8:11])

@@ -83,7 +83,7 @@ def test_render_uses_fused_chain_and_reaches_pose_leaves():
     for wrap in (lambda c: c, Plain):
         c = sphere_views(2, W, H, noise=0.05, device=DEV)[1]
         pc = GaussianBag.from_activated(scene, 3, device=DEV)
-        out = render(wrap(c), pc, PipelineParams(), torch.zeros(3, device=DEV))
+        out = render(wrap(c), pc, PipelineParams(), torch.zeros(3, device=DEV), 0.0, None, hybrid=False)
         out["render"].backward(gimg)
         res.append((out["render"].detach().cpu(), [p.grad.detach().cpu().clone() for p in c.pose_leaves()]))
     assert (res[0][0] - res[1][0]).abs().max().item() < 2e-4

@@ -56,13 +56,13 @@ def test_render_path_raw_leaves_accumulate_in_the_flat_bucket():
     g = torch.randn(3, 128, 160, generator=torch.Generator().manual_seed(3)).to(dev)
     pc = GaussianBag.from_activated(scene, 3, device=dev)
     for c in cams:
-        render(c, pc, PipelineParams(), bg)["render"].backward(g)
+        render(c, pc, PipelineParams(), bg, 0.0, None, hybrid=False)["render"].backward(g)
     ref = [p.grad.clone() for p in pc.leaves()]
     pc2 = GaussianBag.from_activated(scene, 3, device=dev)
     red = GradAllReducer(pc2.leaves())
     red.begin()
     for c in cams:
-        render(c, pc2, PipelineParams(), bg)["render"].backward(g)
+        render(c, pc2, PipelineParams(), bg, 0.0, None, hybrid=False)["render"].backward(g)
     assert red.bucket.bound()
     for p, r in zip(pc2.leaves(), ref):
         assert torch.allclose(p.grad, r, rtol=1e-5, atol=1e-6)

@@ -107,3 +107,30 @@ def test_checkpoint_tuple_matches_capture_and_restores(tmp_path):
     assert torch.equal(back15._features_dc, pc._features_dc) and torch.equal(back15._opacity, pc._opacity)
     with pytest.raises(ValueError):
         restore(t[:5], 2)
+
+
+def test_reference_checkpoint_with_numpy_lr_scale_loads_without_the_full_unpickler(tmp_path):
+    """The reference's capture() stores spatial_lr_scale = scene.cameras_extent, a numpy.float64
+    (scene/dataset_readers.py:100, scene/__init__.py:115): the safe loader must take it (weights_only=True rejects numpy
+    scalars unless their reconstructors are allow-listed) -- and must still refuse arbitrary pickled objects."""
+    pc = _bag(P=5, deg=1)
+    opt = {"state": {}, "param_groups": [{"name": "xyz", "lr": 1e-4}]}
+    t = list(capture(pc, opt, spatial_lr_scale=0.0))
+    t[11] = np.float64(4.25)
+    path = str(tmp_path / "chkpnt7000.pth")
+    torch.save((tuple(t), 7000), path)
+    back, _, scale, it = load_checkpoint(path, 1)
+    assert it == 7000 and scale == 4.25 and isinstance(scale, float)
+    assert torch.equal(back._xyz.detach(), pc._xyz.detach())
+
+    class Evil:                                              # anything outside tensors / numbers / containers
+        pass
+    t[11] = Evil()
+    import pickle
+    bad = str(tmp_path / "bad.pth")
+    try:
+        torch.save((tuple(t), 1), bad)
+    except (pickle.PicklingError, AttributeError):           # a local class may not even pickle: nothing to load then
+        return
+    with pytest.raises(Exception):
+        load_checkpoint(bad, 1)

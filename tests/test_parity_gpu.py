@@ -205,13 +205,34 @@ def test_full_size_config3_against_oracle():
     dump_report("test_full_size_config3_against_oracle", rep)
     # opacity-aware tile bounds (default); the stock 3-sigma rule gives 3 450 308 on this scene (~3.7 M)
     assert rep["num_rendered"][0] == rep["num_rendered"][1] == 2074322
-    assert_report(rep, tol_override={"shift_factors": (2e-3, 2e-2)})
+    assert_report(rep, tol_override={"shift_factors": (1e-3, 1e-2)})     # measured: 3.8e-4 vs fp32, 5.0e-3 vs fp64
     for k, e in rep["grad_rel_fp32"].items():
         if k != "shift_factors":
             assert e <= 1e-4, (k, e)
     # the HIP path must not be further from fp64 than the fp32 oracle itself is (x1.5 slack)
     for k, e in rep["grad_rel_fp64"].items():
         assert e <= 1.5 * rep["oracle32_vs_64"][k] + 1e-5, (k, e, rep["oracle32_vs_64"][k])
+
+
+@pytest.mark.timeout(900)
+def test_full_size_config3_aabb():
+    """BASELINE config 3 at full size on the REFERENCE's instance list: tile_bounds="aabb" is the stock 3-sigma square the
+    CUDA op behind gaussian_renderer/__init__.py:110-121 bins with (the second driver-timed leg of bench.py).  Integers
+    bit-exact for all 500 k Gaussians and all 3 450 308 instances; image, n_contrib and every gradient on 96 sampled tiles
+    (compare_sampled: the cotangent is zero outside them), fp32 oracle and fp64 replay."""
+    import os
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    W, H = 1920, 1080
+    scene, cam = make_case(500_000, W, H, 0.5, 3, seed=0)
+    rep = compare_sampled(scene, cam, 3, sample_tiles(W, H, 96, seed=3), seed=2, check_fp64=True, tile_bounds="aabb")
+    print({n: rep[n] for n in ("num_rendered", "instances_in_sample", "n_contrib_mismatch_frac", "image_max_err",
+                               "image_bad_frac", "grad_rel_fp32", "grad_rel_fp64", "oracle32_vs_64")})
+    from parity import dump_report
+    dump_report("test_full_size_config3_aabb", rep)
+    assert rep["num_rendered"][0] == rep["num_rendered"][1] == 3450308
+    _assert_sampled(rep, skip=("shift_factors",))
+    # shift_factors: identically zero parameter, a near-cancelling sum (see test_full_size_config3_against_oracle)
+    assert min(rep["grad_rel_fp32"]["shift_factors"], rep["grad_rel_fp64"]["shift_factors"]) <= 1e-3
 
 
 def _assert_sampled(rep, grad_tol=1e-4, worst_tol=2e-3, skip=()):
@@ -397,12 +418,14 @@ def test_render_caller_paths_agree_and_match_oracle():
     gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(3)).to(dev)
     bgc = torch.tensor([0.2, 0.1, 0.3], device=dev)
     results = {}
+    # "hybrid": the reference's own default (gaussian_renderer/__init__.py:30, hybrid=True): Python-side SH colours
     for name, pipe in (("default", PipelineParams()), ("sh_python", PipelineParams(convert_SHs_python=True)),
-                       ("cov_python", PipelineParams(compute_cov3D_python=True))):
+                       ("cov_python", PipelineParams(compute_cov3D_python=True)), ("hybrid", PipelineParams())):
         pc = GaussianBag.from_activated(scene, 3, device=dev)
         for p_ in cam.pose_leaves():
             p_.grad = None
-        out = render(cam, pc, pipe, bgc, scaling_modifier=0.9)
+        out = (render(cam, pc, pipe, bgc, 0.0, None, scaling_modifier=0.9) if name == "hybrid" else
+               render(cam, pc, pipe, bgc, 0.0, None, hybrid=False, scaling_modifier=0.9))
         assert set(out) == {"render", "viewspace_points", "viewspace_points_densify", "visibility_filter", "radii", "depth",
                             "weights", "means2D"}
         out["render"].backward(gimg)
@@ -413,7 +436,7 @@ def test_render_caller_paths_agree_and_match_oracle():
                              pose=[t.grad.detach().cpu().clone() for t in cam.pose_leaves()],
                              vp=out["viewspace_points"].grad.detach().cpu(), vpd=out["viewspace_points_densify"].grad.detach().cpu())
     ref = results["default"]
-    for name in ("sh_python", "cov_python"):
+    for name in ("sh_python", "cov_python", "hybrid"):
         r = results[name]
         assert torch.equal(r["radii"], ref["radii"])
         assert (r["img"] - ref["img"]).abs().max().item() < 2e-5, name
@@ -720,6 +743,22 @@ def test_tile_counts_of_every_ranges_order_variant(W, H):
     print({k: rep[k] for k in ("num_rendered", "instances_in_sample", "image_max_err")})
     assert rep["num_rendered"][0] > 20_000
     _assert_sampled(rep, grad_tol=2e-4)
+
+
+@pytest.mark.gpu
+def test_exactly_32768_tiles_stay_on_the_tile_binned_path():
+    """4096x2048 = 32 768 tiles, the largest image the tile-binned path takes: tile_count_kernel then asks for 65 536 B of
+    dynamic LDS next to its 64 B of static LDS, which needs the explicit opt-in above 64 KB (the launch failed with
+    BAGS_ERR_HIP without it).  Lists bit-exact against the oracle AND identical to the radix path's."""
+    W, H = 4096, 2048
+    scene, cam = make_case(4000, W, H, 0.25, 1, seed=5)
+    rep = compare_sampled(scene, cam, 1, sample_tiles(W, H, 32, seed=4))
+    print({k: rep[k] for k in ("num_rendered", "instances_in_sample", "image_max_err", "grad_rel_fp32")})
+    assert rep["num_rendered"][0] > 50_000
+    _assert_sampled(rep, grad_tol=2e-4)
+    _, _, va = run_hip(scene, cam, 1, binning="auto")
+    _, _, vr = run_hip(scene, cam, 1, binning="radix")
+    assert torch.equal(va["point_list"], vr["point_list"]) and torch.equal(va["keys_sorted"], vr["keys_sorted"])
 
 
 @pytest.mark.gpu

@@ -51,7 +51,7 @@ def main():
     def iteration(camera, loss_fn):
         for t in leaves:
             t.grad = None
-        out = render(camera, pc, pipe, bg)
+        out = render(camera, pc, pipe, bg, 0.0, None, hybrid=False)
         loss_fn(out["render"], gt).backward()
 
     def timed(camera, loss_fn):
