@@ -21,7 +21,9 @@ typedef uint64_t u64;
 #define SCAN_BLOCK 256
 #define SCAN_ITEMS 8
 #define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)   // 2048 offsets per workgroup
-#define PART_FLOATS 12                    // one 48-byte partial-gradient record per sorted instance (11 sums), densely packed:
+#ifndef PART_FLOATS
+#define PART_FLOATS 12
+#endif                                    // one 48-byte partial-gradient record per sorted instance (11 sums), densely packed:
                                           // every byte of every line is written, and K8a streams 25 % less than with 64-B slots
 #define POSE_VALS 40                      // pose-gradient slab row (35 used)
 #define KEY_CULLED 0xFFFFFFFFu

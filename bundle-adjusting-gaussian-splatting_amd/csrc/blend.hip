@@ -16,6 +16,7 @@
 // PMC history that led here is in profiles/r01 and DESIGN.md section 5 (the first lane = pixel kernels saturated VALU
 // issue at 96 % with a third of the lanes contributing; they are in the git history).
 #include "bags_common.h"
+#include <type_traits>
 
 #define LOG2E 1.4426950408889634f
 #define ALPHA_MIN (1.0f / 255.0f)
@@ -40,6 +41,17 @@
 #ifndef PRIO_GROUPS
 #define PRIO_GROUPS 0       // ... and in its list-building / scan phase (0/0, 1/0, 3/1 measured: flat)
 #endif
+// round-3 knobs of the backward's row loop (tools/variants.sh A/Bs them with -DKNOB=0)
+#ifndef TF_FOLD
+#define TF_FOLD 1           // the per-pixel carry of prod(1 - alpha) starts at 1 / T_final: T in front of a splat is rcp(carry * A),
+#endif                      // no multiply by T_final, and a pixel pair is 3 float4 of LDS instead of 4
+#ifndef SCALAR_ACC
+#define SCALAR_ACC 1        // sums that only need the ROW total of q (sum q, q dy, q dy^2, q dx, q dx dy) on plain fp32: a packed
+#endif                      // op costs 1.6x a plain one on gfx950 (tools/ubench/issue_rates.hip), so folding first is cheaper
+#ifndef NC_SKIP
+#define NC_SKIP 1           // tiles where no pixel stopped early (flag from the forward) skip the `pos <= n_contrib` test
+#endif
+#define PQ (TF_FOLD ? 3 : 4)                 // float4s per pixel pair in LDS
 
 struct __attribute__((aligned(16))) SplatRec {
     float x, y, ap, bp;       // centre, pre-scaled conic: exp2(ap dx^2 + bp dx dy + cp dy^2) == exp(power)
@@ -142,9 +154,9 @@ struct __attribute__((aligned(16))) ChunkRec {
     float cp, o, r, g;
     float b; u32 pos; u32 mask; u32 e;         // mask: 4x4 blocks reachable (bit by*4+bx); e: emission slot
 };
-// per pixel PAIR (two horizontally adjacent pixels A,B of one block row), 16 floats:
-//   [g0A g0B g1A g1B] [g2A g2B TfA TfB] [ -    -   ncA ncB] [AcA AcB RcA RcB]     (Ac, Rc: carries behind the group)
-struct __attribute__((aligned(16))) PixPair { float4 q0, q1, q2, q3; };
+// per pixel PAIR (two horizontally adjacent pixels A,B of one block row), PQ float4s:
+//   TF_FOLD: [g0A g0B g1A g1B] [g2A g2B ncA ncB] [AcA AcB RcA RcB]                 (Ac starts at 1 / T_final)
+//   else:    [g0A g0B g1A g1B] [g2A g2B TfA TfB] [ -    -   ncA ncB] [AcA AcB RcA RcB]     (Ac, Rc: carries behind the group)
 
 // blocks of the tile a splat can reach with alpha >= 1/255 (conservative; exactness comes from the per-pixel test).
 // Branch-free: one thread evaluates all 16 blocks (the lanes of a wave hold unrelated splats, so early-outs would only
@@ -209,7 +221,7 @@ __device__ __forceinline__ void diag_pairs_flush(int slot, u32 ev, u32 co)
     if ((threadIdx.x & 63) == 0) { atomicAdd(&g_pair_counts[slot], (unsigned long long)ev); atomicAdd(&g_pair_counts[slot + 1], (unsigned long long)co); }
 }
 #endif
-struct TileRef { int tx, ty; u32 rx, n, maxc; };   // wave-uniform: tile coordinates, first instance, instances, deepest contributor
+struct TileRef { int tx, ty; u32 rx, n, maxc; bool early; };   // early: some pixel of the tile stopped before its list ended (or lies outside the image)   // wave-uniform: tile coordinates, first instance, instances, deepest contributor
 
 template <bool ABS>
 __global__ void __launch_bounds__(256, SCAN_WG_PER_CU)
@@ -230,12 +242,13 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     const uint4 desc = tile_desc[dslot];                     // {tile, first instance, instances, deepest contributor}
     if (desc.z == 0) return;                                 // empty tile: no records to write
     TileRef A;
-    A.tx = (int)(desc.x % (u32)grid_x); A.ty = (int)(desc.x / (u32)grid_x); A.rx = desc.y; A.n = desc.z; A.maxc = min(desc.w, desc.z);
+    A.tx = (int)(desc.x % (u32)grid_x); A.ty = (int)(desc.x / (u32)grid_x); A.rx = desc.y; A.n = desc.z;
+    A.maxc = min(desc.w & 0x7FFFFFFFu, desc.z); A.early = (desc.w >> 31) != 0u;
 
     __shared__ ChunkRec recs[BCHUNK];                 // 6 KB
     // 8 pixel pairs (PixPair = 4 x float4) per block + one float4 of padding: the four rows of a wave read four different
     // blocks in one ds_read_b128, and a 512-B block stride would put all four on the same banks
-    __shared__ float4 pixq[16][33];                  //  8.25 KB
+    __shared__ float4 pixq[16][8 * PQ + 1];          //  6.25 KB (8.25 without TF_FOLD)
     __shared__ unsigned char lists[16][BCHUNK];       //  2 KB
     __shared__ u32 masks[BCHUNK];                     //  0.5 KB: block reach masks, compact (the 48-B record stride bank-conflicts)
     __shared__ float acc[4][BCHUNK][12];              // 24 KB, one copy per wave (LDS float atomics on a shared copy were 1.6x slower)
@@ -303,10 +316,15 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
             const float Tf = in ? lT : 1.f;
             const u32 nc = in ? lnc : 0u;
             const float bgg = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;          // what lies behind the deepest splat
-            float* pp = reinterpret_cast<float*>(&pixq[tid >> 4][((tid >> 1) & 7) * 4]);
+            float* pp = reinterpret_cast<float*>(&pixq[tid >> 4][((tid >> 1) & 7) * PQ]);
             const int h = tid & 1;                        // A or B of the pair
+#if TF_FOLD
+            pp[0 + h] = g0; pp[2 + h] = g1; pp[4 + h] = g2; pp[6 + h] = __uint_as_float(nc);
+            pp[8 + h] = 1.0f / Tf; pp[10 + h] = bgg;      // T_final >= 1e-6: a pixel stops before T falls below 1e-4 and alpha <= 0.99
+#else
             pp[0 + h] = g0; pp[2 + h] = g1; pp[4 + h] = g2; pp[6 + h] = Tf;
             pp[8 + h] = 0.f; pp[10 + h] = __uint_as_float(nc); pp[12 + h] = 1.f; pp[14 + h] = bgg;
+#endif
             u32 m = nc;
 #pragma unroll
             for (int d = 8; d >= 1; d >>= 1) m = max(m, (u32)__shfl_xor((int)m, d));   // 16 consecutive threads = one block
@@ -372,14 +390,28 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         // interleave without pipeline bubbles.  `s` is the lane's splat, (bx0, by0) its block origin, pixb its block's
         // pixel pairs, `carry` marks the lane that holds the scan totals (the shallowest of its segment).
         f2 a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10;
-        auto block_rows = [&](const ChunkRec& s, const bool live, const float bx0, const float by0, float4* pixb, const bool carry) {
+#if SCALAR_ACC
+        float sa3, sa4, sa5, sa7, sa8;
+#endif
+        auto block_rows = [&](auto skip_nc_tag, const ChunkRec& s, const bool live, const float bx0, const float by0, float4* pixb, const bool carry) {
+            constexpr bool SKIP_NC = decltype(skip_nc_tag)::value;
             a0 = (f2){0.f, 0.f}; a1 = a0; a2 = a0; a3 = a0; a4 = a0; a5 = a0; a6 = a0; a7 = a0; a8 = a0; a9 = a0; a10 = a0;
+#if SCALAR_ACC
+            sa3 = sa4 = sa5 = sa7 = sa8 = 0.f;
+#endif
 #pragma unroll SCAN_UNROLL
             for (int iy = 0; iy < 4; ++iy) {
-                float4* P0 = pixb + iy * 8;
-                float4* P1 = P0 + 4;
+                float4* P0 = pixb + iy * 2 * PQ;
+                float4* P1 = P0 + PQ;
+#if TF_FOLD
+                const float4 q00 = P0[0], q01 = P0[1], q03 = P0[2];
+                const float4 q10 = P1[0], q11 = P1[1], q13 = P1[2];
+                const u32 nc0 = __float_as_uint(q01.z), nc1 = __float_as_uint(q01.w), nc2 = __float_as_uint(q11.z), nc3 = __float_as_uint(q11.w);
+#else
                 const float4 q00 = P0[0], q01 = P0[1], q02 = P0[2], q03 = P0[3];
                 const float4 q10 = P1[0], q11 = P1[1], q12 = P1[2], q13 = P1[3];
+                const u32 nc0 = __float_as_uint(q02.z), nc1 = __float_as_uint(q02.w), nc2 = __float_as_uint(q12.z), nc3 = __float_as_uint(q12.w);
+#endif
                 const float dy = s.y - (by0 + (float)iy);
                 const float u = __fmul_rn(__fmul_rn(s.cp, dy), dy);
                 const f2 dyy = {dy, dy};
@@ -397,10 +429,12 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                 f2 aua = s.o * Ga, aub = s.o * Gb;
                 // bitwise &, not &&: a short-circuit makes the compiler branch around one pixel's n_contrib read and wait for
                 // every outstanding LDS read (lgkmcnt(0)) in the middle of the row
-                const bool v0 = live & (pa.x <= 0.f) & (aua.x >= ALPHA_MIN) & (s.pos <= __float_as_uint(q02.z));
-                const bool v1 = live & (pa.y <= 0.f) & (aua.y >= ALPHA_MIN) & (s.pos <= __float_as_uint(q02.w));
-                const bool v2 = live & (pb.x <= 0.f) & (aub.x >= ALPHA_MIN) & (s.pos <= __float_as_uint(q12.z));
-                const bool v3 = live & (pb.y <= 0.f) & (aub.y >= ALPHA_MIN) & (s.pos <= __float_as_uint(q12.w));
+                // SKIP_NC: no pixel of the tile stopped early, so a splat behind a pixel's last contributor fails the alpha test
+                // at that pixel anyway (it failed it in the forward): the position test is redundant
+                const bool v0 = live & (pa.x <= 0.f) & (aua.x >= ALPHA_MIN) & (SKIP_NC | (s.pos <= nc0));
+                const bool v1 = live & (pa.y <= 0.f) & (aua.y >= ALPHA_MIN) & (SKIP_NC | (s.pos <= nc1));
+                const bool v2 = live & (pb.x <= 0.f) & (aub.x >= ALPHA_MIN) & (SKIP_NC | (s.pos <= nc2));
+                const bool v3 = live & (pb.y <= 0.f) & (aub.y >= ALPHA_MIN) & (SKIP_NC | (s.pos <= nc3));
                 aua.x = v0 ? aua.x : 0.f; aua.y = v1 ? aua.y : 0.f; aub.x = v2 ? aub.x : 0.f; aub.y = v3 ? aub.y : 0.f;
 #ifdef DIAG_PAIRS
                 dg_eval += live ? 4u : 0u; dg_con += (u32)v0 + (u32)v1 + (u32)v2 + (u32)v3;
@@ -418,8 +452,13 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                 scan_affine16x4(A0, A1, A2, A3, o0, o1, o2, o3);
                 // carries in q*3: .xy = prod (1 - alpha) behind the group, .zw = colour . g seen behind the group
                 const f2 Ba = (f2){A0, A1} * (f2){q03.x, q03.y}, Bb = (f2){A2, A3} * (f2){q13.x, q13.y};
+#if TF_FOLD
+                const f2 Tna = {__builtin_amdgcn_rcpf(Ba.x), __builtin_amdgcn_rcpf(Ba.y)};                   // T in front of i
+                const f2 Tnb = {__builtin_amdgcn_rcpf(Bb.x), __builtin_amdgcn_rcpf(Bb.y)};
+#else
                 const f2 Tna = {q01.z * __builtin_amdgcn_rcpf(Ba.x), q01.w * __builtin_amdgcn_rcpf(Ba.y)};   // T in front of i
                 const f2 Tnb = {q11.z * __builtin_amdgcn_rcpf(Bb.x), q11.w * __builtin_amdgcn_rcpf(Bb.y)};
+#endif
                 const f2 wa = ala * Tna, wb = alb * Tnb;
                 // what is seen at the FRONT face of i; the next deeper lane's value is what lies BEHIND i
                 const f2 Va = __builtin_elementwise_fma((f2){A0, A1}, (f2){q03.z, q03.w}, (f2){o0, o1});
@@ -427,8 +466,8 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                 float R0 = q03.z, R1 = q03.w, R2 = q13.z, R3 = q13.w;
                 shift_up16x4(R0, R1, R2, R3, Va.x, Va.y, Vb.x, Vb.y);
                 if (carry) {                                            // carries for the next (shallower) group
-                    P0[3] = make_float4(Ba.x, Ba.y, Va.x, Va.y);
-                    P1[3] = make_float4(Bb.x, Bb.y, Vb.x, Vb.y);
+                    P0[PQ - 1] = make_float4(Ba.x, Ba.y, Va.x, Va.y);
+                    P1[PQ - 1] = make_float4(Bb.x, Bb.y, Vb.x, Vb.y);
                 }
                 const f2 dLa = Tna * (sda - (f2){R0, R1});
                 const f2 dLb = Tnb * (sdb - (f2){R2, R3});
@@ -440,12 +479,20 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                 const f2 qva = aua * dLa, qvb = aub * dLb;
                 const f2 qdxa = qva * dxa, qdxb = qvb * dxb;
                 const f2 rq = qva + qvb, rqdx = qdxa + qdxb;
-                a3 = a3 + rq; a4 = a4 + rqdx;
                 a6 = __builtin_elementwise_fma(qdxa, dxa, a6); a6 = __builtin_elementwise_fma(qdxb, dxb, a6);
+#if SCALAR_ACC
+                const float rqs = rq.x + rq.y, rqdxs = rqdx.x + rqdx.y;
+                const float rqdys = rqs * dy;
+                sa3 += rqs; sa4 += rqdxs; sa5 += rqdys;
+                sa7 = __fmaf_rn(rqdxs, dy, sa7);
+                sa8 = __fmaf_rn(rqdys, dy, sa8);
+#else
+                a3 = a3 + rq; a4 = a4 + rqdx;
                 const f2 rqdy = rq * dyy;
                 a5 = a5 + rqdy;
                 a7 = __builtin_elementwise_fma(rqdx, dyy, a7);
                 a8 = __builtin_elementwise_fma(rqdy, dyy, a8);
+#endif
                 if (ABS) {                                              // sum |q d power / d centre| per pixel
                     const f2 bp2 = {s.bp, s.bp};
                     const f2 hxa = ta + apdxa, hxb = tb + apdxb;                              // 2 ap dx + bp dy
@@ -466,9 +513,15 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         // phase is issued for the whole wave although only one 16-lane row takes part in it
         float4 h0, h1, h2;
         auto fold_pairs = [&]() {
+#if SCALAR_ACC
+            h0 = make_float4(a0.x + a0.y, a1.x + a1.y, a2.x + a2.y, sa3);
+            h1 = make_float4(sa4, sa5, a6.x + a6.y, sa7);
+            h2 = make_float4(sa8, a9.x + a9.y, a10.x + a10.y, 0.f);
+#else
             h0 = make_float4(a0.x + a0.y, a1.x + a1.y, a2.x + a2.y, a3.x + a3.y);
             h1 = make_float4(a4.x + a4.y, a5.x + a5.y, a6.x + a6.y, a7.x + a7.y);
             h2 = make_float4(a8.x + a8.y, a9.x + a9.y, a10.x + a10.y, 0.f);
+#endif
         };
         auto add_to_copy = [&](const int slot) {      // plain read-modify-write of the wave's own copy
             float4* d4 = reinterpret_cast<float4*>(&acc[wave][slot][0]);
@@ -516,7 +569,8 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
 #ifdef DIAG_PAIRS
             const u32 dg_before = dg_con;
 #endif
-            block_rows(s, live, bx0, by0, pixb, (li == 15) && (gend > 0));
+            if (NC_SKIP && !A.early) block_rows(std::true_type{}, s, live, bx0, by0, pixb, (li == 15) && (gend > 0));
+            else block_rows(std::false_type{}, s, live, bx0, by0, pixb, (li == 15) && (gend > 0));
 #ifdef DIAG_PAIRS
             dg_ent += live ? 1u : 0u; dg_ent0 += (live && dg_con == dg_before) ? 1u : 0u; dg_steps += (lane == 0) ? 1u : 0u;
 #endif
@@ -736,6 +790,7 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
             }
         }
     }
+    const bool stopped = Tq < 0.f;                           // stopped early (T would fall below 1e-4) or outside the image
     Tq = fabsf(Tq);
     if (inside) {
         const size_t HW = (size_t)W * H, pix = (size_t)py * W + px;
@@ -752,10 +807,15 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
     u32 m = last;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (u32)__shfl_xor((int)m, d));
+    const u32 early = (__ballot(stopped) != 0ull) ? 0x80000000u : 0u;
     __syncthreads();                                         // s_live is free again
-    if (lane == 0) s_live[wave] = (int)m;
+    if (lane == 0) s_live[wave] = (int)(m | early);
     __syncthreads();
-    if (tid == 0) tile_desc[dslot].w = (u32)max(max(s_live[0], s_live[1]), max(s_live[2], s_live[3]));
+    // bit 31: some pixel of the tile did not walk its whole list (the backward then needs its `pos <= n_contrib` test)
+    if (tid == 0) {
+        const u32 w0 = (u32)s_live[0], w1 = (u32)s_live[1], w2 = (u32)s_live[2], w3 = (u32)s_live[3];
+        tile_desc[dslot].w = max(max(w0 & 0x7FFFFFFFu, w1 & 0x7FFFFFFFu), max(w2 & 0x7FFFFFFFu, w3 & 0x7FFFFFFFu)) | ((w0 | w1 | w2 | w3) & 0x80000000u);
+    }
 #ifdef DIAG_PAIRS
     diag_pairs_flush(2, dg_eval, dg_con);
 #endif
