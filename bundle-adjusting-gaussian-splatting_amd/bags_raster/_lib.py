@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbags_raster.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 TILES_AABB, TILES_OPACITY = 0, 1
 DEPTH_Z, DEPTH_DISTANCE = 0, 1
 BINNING_AUTO, BINNING_RADIX = 0, 1
@@ -45,7 +45,8 @@ class BagsBackwardArgs(C.Structure):
                 ("grad_means3D", c_fp), ("grad_means2D", c_fp), ("grad_means2D_densify", c_fp), ("grad_shs", c_fp),
                 ("grad_colors_precomp", c_fp), ("grad_opacities", c_fp), ("grad_scales", c_fp), ("grad_rotations", c_fp),
                 ("grad_cov3D_precomp", c_fp), ("grad_viewmatrix", c_fp), ("grad_projmatrix", c_fp),
-                ("grad_intrinsic", c_fp), ("grad_campos", c_fp), ("grad_shift_factors", c_fp)]
+                ("grad_intrinsic", c_fp), ("grad_campos", c_fp), ("grad_shift_factors", c_fp),
+                ("binning_capacity", C.c_int64)]
 
 
 class BagsDebugViews(C.Structure):

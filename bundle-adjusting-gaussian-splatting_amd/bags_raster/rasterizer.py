@@ -19,6 +19,7 @@ from typing import NamedTuple, Optional
 
 import math
 import threading
+import weakref
 
 import torch
 
@@ -147,19 +148,38 @@ def _bytes(n: int, device) -> torch.Tensor:
     return torch.empty(int(n), dtype=torch.uint8, device=device)
 
 
-LAST_NUM_RENDERED = 0      # instance count of the most recent forward (bench/diagnostics)
+LAST_NUM_RENDERED = 0      # instance count of the most recent forward whose count has been read (bench/diagnostics)
 
 
 class _Forwarded:
     """Everything backward (and the parity tests) need from one forward call."""
-    __slots__ = ("packed", "geom", "binning", "image", "num_rendered", "capacity", "H", "W")
+    __slots__ = ("packed", "geom", "binning", "image", "num_rendered", "capacity", "H", "W", "pending", "outs", "stream",
+                 "key", "__weakref__")
 
 
-# Speculative forward (bags_forward_speculative): the instance count of the previous call with the same problem shape
-# is the capacity guess for the next one, so the steady state has no host round trip in the middle of the forward.
+# Speculative forward (bags_forward_prepare_async + bags_forward_finish_speculative): the instance counts of earlier calls
+# with the same problem shape give the capacity guess for the next one, so the steady state has no host round trip in the
+# middle of the forward.
 SPECULATE = True
-_capacity_hint = {}          # (device index, P, W, H) -> last instance count (a hint only: a stale value costs one redo)
+# When the host reads the asynchronous instance count of a speculative forward:
+#   "lazy"     (default) a forward that will be differentiated returns WITHOUT waiting; the count is read at the entry of
+#              its backward (by then it arrived long ago).  Nothing in the forward blocks the host, so the views of a batch
+#              can be enqueued back to back, also on several streams (utils/cubemap_utils.py:229,263-265 renders five per
+#              iteration).  The buffer is sized CAPACITY_HEADROOM x the largest count seen for the shape; should a count
+#              still exceed it, the image of THAT forward had every tile rendered empty: the check at backward entry then
+#              redoes the second phase exactly (the gradients are those of the true render for the cotangent that was
+#              passed in) and raises a RuntimeWarning.  Forwards that nobody differentiates always wait.
+#   "forward"  every forward waits for its count before it returns and redoes an overflowing second phase at once
+#              (exact results always; the behaviour of rounds 1-2).
+HOST_WAIT = "lazy"
+CAPACITY_HEADROOM = 4.0
+_capacity_hint = {}          # (device index, P, W, H) -> slowly decaying maximum of the instance counts seen (a hint only)
 _hint_lock = threading.Lock()
+
+
+def _note_count(key, n: int) -> None:
+    with _hint_lock:
+        _capacity_hint[key] = max(int(n), int(_capacity_hint.get(key, 0) * 0.98))
 
 
 class _PinnedSlots:
@@ -184,10 +204,53 @@ class _PinnedSlots:
 _pinned = _PinnedSlots()
 
 
-def _run_forward(lib, pk: _Packed, H: int, W: int, speculate: bool = True):
+def _abandon(pinned, ev, key):
+    """Finalizer of a lazy forward nobody differentiated: the count is still read (hint, slot reuse only after the kernel
+    that writes the word has run)."""
+    try:
+        ev.synchronize()
+        _note_count(key, int(pinned[0].item()) & 0xFFFFFFFF)
+        _pinned.give(pinned)
+    except Exception:                                        # interpreter shutdown
+        pass
+
+
+def _resolve(lib, fw: "_Forwarded") -> None:
+    """Read the asynchronous instance count of a lazy forward (no-op otherwise); redo its second phase if the speculative
+    buffer turned out too small."""
+    global LAST_NUM_RENDERED
+    if fw.pending is None:
+        return
+    pinned, ev, fin = fw.pending
+    fw.pending = None
+    fin.detach()
+    ev.synchronize()
+    n = int(pinned[0].item()) & 0xFFFFFFFF
+    _pinned.give(pinned)
+    _note_count(fw.key, n)
+    fw.num_rendered = LAST_NUM_RENDERED = n
+    if n <= fw.capacity:
+        return
+    import warnings
+    warnings.warn(f"bags_raster: {n} (tile, Gaussian) instances exceeded the speculative capacity {fw.capacity} "
+                  f"({CAPACITY_HEADROOM} x the largest count seen for this shape): the image returned by that forward had every "
+                  f"tile rendered empty.  The state is recomputed exactly for this backward; set "
+                  f"bags_raster.rasterizer.HOST_WAIT = 'forward' if counts jump like this regularly.", RuntimeWarning)
+    pk, dev = fw.packed, fw.packed.device
+    color, radii, depth, weights, mean2D = fw.outs
+    out = L.BagsForwardOut(color.data_ptr(), radii.data_ptr(), depth.data_ptr(), weights.data_ptr(), mean2D.data_ptr())
+    with torch.cuda.device(dev), torch.cuda.stream(fw.stream):
+        fw.binning = _bytes(lib.bags_binning_size(n, fw.W, fw.H), dev)
+        state = _state_of(fw)
+        L.check(lib.bags_forward_finish(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(out), n,
+                                        fw.stream.cuda_stream), "bags_forward_finish")
+    fw.capacity = n
+
+
+def _run_forward(lib, pk: _Packed, H: int, W: int, speculate: bool = True, lazy: bool = False):
     dev, P = pk.device, pk.P
     fw = _Forwarded()
-    fw.packed, fw.H, fw.W = pk, H, W
+    fw.packed, fw.H, fw.W, fw.pending, fw.outs = pk, H, W, None, None
     fw.geom = _bytes(lib.bags_geom_size(P), dev)
     fw.image = _bytes(lib.bags_image_size(W, H), dev)
     color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
@@ -196,31 +259,37 @@ def _run_forward(lib, pk: _Packed, H: int, W: int, speculate: bool = True):
     radii = torch.empty(P, dtype=torch.int32, device=dev)
     mean2D = torch.empty(P, 2, dtype=torch.float32, device=dev)
     out = L.BagsForwardOut(color.data_ptr(), radii.data_ptr(), depth.data_ptr(), weights.data_ptr(), mean2D.data_ptr())
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    fw.stream = torch.cuda.current_stream(dev)
+    stream = fw.stream.cuda_stream
     state = L.BagsState(fw.geom.data_ptr(), fw.geom.numel(), None, 0, fw.image.data_ptr(), fw.image.numel())
     global LAST_NUM_RENDERED
-    key = (dev.index, P, W, H)
+    fw.key = key = (dev.index, P, W, H)
     with _hint_lock:
         hint = _capacity_hint.get(key) if (SPECULATE and speculate and not pk.settings.debug) else None
+    lazy = lazy and HOST_WAIT == "lazy"
     if hint is not None:
-        cap = int(hint * 1.2) + 8192
+        cap = int(hint * (CAPACITY_HEADROOM if lazy else 1.2)) + 8192
         fw.binning = _bytes(lib.bags_binning_size(cap, W, H), dev)
         state.binning, state.binning_bytes = fw.binning.data_ptr(), fw.binning.numel()
         pinned = _pinned.take()
         L.check(lib.bags_forward_prepare_async(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(out),
                                                pinned.data_ptr(), stream), "bags_forward_prepare_async")
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))
+        ev.record(fw.stream)
         L.check(lib.bags_forward_finish_speculative(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(out),
                                                     cap, stream), "bags_forward_finish_speculative")
+        fw.capacity = cap
+        if lazy:                              # the count is read at backward entry (_resolve)
+            fw.num_rendered = None
+            fw.outs = (color, radii, depth, weights, mean2D)
+            fw.pending = (pinned, ev, weakref.finalize(fw, _abandon, pinned, ev, key))
+            return fw, fw.outs
         ev.synchronize()                      # phase 2 is already queued behind the count: the GPU does not wait for us
         n = int(pinned[0].item()) & 0xFFFFFFFF
         _pinned.give(pinned)
-        with _hint_lock:
-            _capacity_hint[key] = n
+        _note_count(key, n)
         fw.num_rendered = LAST_NUM_RENDERED = n
         if n <= cap:
-            fw.capacity = cap
             return fw, (color, radii, depth, weights, mean2D)
         # guess too small (scene changed abruptly): redo the second phase on an exact buffer; phase 1 results stay valid
         fw.binning = _bytes(lib.bags_binning_size(n, W, H), dev)
@@ -234,8 +303,7 @@ def _run_forward(lib, pk: _Packed, H: int, W: int, speculate: bool = True):
                                      C.byref(n), stream), "bags_forward_prepare")
     fw.num_rendered = fw.capacity = int(n.value)
     LAST_NUM_RENDERED = fw.num_rendered
-    with _hint_lock:
-        _capacity_hint[key] = fw.num_rendered
+    _note_count(key, fw.num_rendered)
     fw.binning = _bytes(lib.bags_binning_size(fw.num_rendered, W, H), dev)
     state.binning, state.binning_bytes = fw.binning.data_ptr(), fw.binning.numel()
     L.check(lib.bags_forward_finish(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(out),
@@ -257,7 +325,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         with torch.cuda.device(means3D.device):
             pk = _Packed(raster_settings, means3D, means2D, shift_factors, sh, colors_precomp, opacities, scales,
                          rotations, cov3Ds_precomp, viewmatrix, projmatrix, intrinsic, campos)
-            fw, outs = _run_forward(lib, pk, int(raster_settings.image_height), int(raster_settings.image_width))
+            fw, outs = _run_forward(lib, pk, int(raster_settings.image_height), int(raster_settings.image_width),
+                                    lazy=any(ctx.needs_input_grad))
         ctx.fw = fw
         ctx.shapes = dict(sh=None if sh is None else sh.shape, opac=opacities.shape, campos=campos.shape)
         color, radii, depth, weights, mean2D = outs
@@ -273,6 +342,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         need = ctx.needs_input_grad
         if grad_color is None:
             return (None,) * 15
+        _resolve(lib, fw)                     # a lazy forward's instance count: read here, not inside the forward
         with torch.cuda.device(dev):
             gc = grad_color.detach()
             if gc.dtype != torch.float32 or not gc.is_contiguous():
@@ -308,11 +378,11 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_proj = new((4, 4), need[11])
             g_intr = new((4, 4), need[12])
             g_campos = new((3,), need[13])
-            ws = _bytes(lib.bags_backward_workspace_size(P, fw.capacity), dev)
-            args = L.BagsBackwardArgs(gc.data_ptr(), fw.capacity, ws.data_ptr(), ws.numel(), _ptr(g_means3D),
+            ws = _bytes(lib.bags_backward_workspace_size(P, fw.num_rendered), dev)     # records: the TRUE count, not the capacity
+            args = L.BagsBackwardArgs(gc.data_ptr(), fw.num_rendered, ws.data_ptr(), ws.numel(), _ptr(g_means3D),
                                       _ptr(g_means2D), _ptr(g_densify), _ptr(g_sh), _ptr(g_col), _ptr(g_opac),
                                       _ptr(g_scales), _ptr(g_rot), _ptr(g_cov), _ptr(g_view), _ptr(g_proj),
-                                      _ptr(g_intr), _ptr(g_campos), _ptr(g_shift))
+                                      _ptr(g_intr), _ptr(g_campos), _ptr(g_shift), fw.capacity)
             state = _state_of(fw)
             stream = torch.cuda.current_stream(dev).cuda_stream
             L.check(lib.bags_backward(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(args), stream),

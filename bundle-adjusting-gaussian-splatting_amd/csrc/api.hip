@@ -346,11 +346,13 @@ int bags_backward(const BagsSettings* s, const BagsInputs* in, const BagsState* 
     const int W = s->image_width, H = s->image_height;
     const int64_t I = a->num_rendered;
     if (I < 0) return fail(BAGS_ERR_ARG, "num_rendered < 0");
-    if (!stt->binning || stt->binning_bytes < bags_binning_size(I, W, H)) return fail(BAGS_ERR_SIZE, "binning buffer too small");
+    const int64_t cap = a->binning_capacity > 0 ? a->binning_capacity : I;     // what the forward carved the binning buffer for
+    if (cap < I) return fail(BAGS_ERR_ARG, "binning_capacity %lld < num_rendered %lld", (long long)cap, (long long)I);
+    if (!stt->binning || stt->binning_bytes < bags_binning_size(cap, W, H)) return fail(BAGS_ERR_SIZE, "binning buffer too small");
     if (!a->workspace || a->workspace_bytes < bags_backward_workspace_size(in->P, I)) return fail(BAGS_ERR_SIZE, "backward workspace too small");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     GeomView g; carve_geom(align256(stt->geom), in->P, &g);
-    BinView b; carve_binning(align256(stt->binning), I, W, H, &b, use_binned(s, in->P));
+    BinView b; carve_binning(align256(stt->binning), cap, W, H, &b, use_binned(s, in->P));
     ImgView im; carve_image(align256(stt->image), W, H, &im);
     char* ws = reinterpret_cast<char*>(align256(a->workspace));
     float* partials = reinterpret_cast<float*>(ws);

@@ -622,6 +622,9 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
             }
             float4* dst = reinterpret_cast<float4*>(partials + (size_t)cur.e * PART_FLOATS);
             dst[0] = r0; dst[1] = r1; dst[2] = r2;
+#if PART_FLOATS == 16 && defined(REC_FULL_LINE)
+            dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);              // experiment: the whole 64-byte line in one go
+#endif
         }
         PH_MARK(6);    // record sums + stores
         // no barrier here: the next chunk's first barrier orders these LDS accesses before any reuse

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BAGS_ABI_VERSION 3
+#define BAGS_ABI_VERSION 4
 #define BAGS_TILE 16
 
 enum { BAGS_OK = 0, BAGS_ERR_ARG = -1, BAGS_ERR_HIP = -2, BAGS_ERR_SIZE = -3, BAGS_ERR_DEVICE = -4 };
@@ -118,6 +118,10 @@ typedef struct BagsBackwardArgs {
     float* grad_intrinsic;           /* (4,4)   */
     float* grad_campos;              /* (3)     */
     float* grad_shift_factors;       /* (3)     */
+    /* capacity the forward's binning buffer was carved for when that was a speculative finish (state.binning then holds
+     * bags_binning_size(binning_capacity, W, H) bytes and num_rendered is the TRUE count, which sizes the workspace);
+     * 0 = the buffer was sized for num_rendered itself (bags_forward_finish) */
+    int64_t binning_capacity;
 } BagsBackwardArgs;
 
 /* integer artefacts for bit-exact parity checks (all device pointers, any may be NULL) */
@@ -156,10 +160,12 @@ int bags_forward_finish(const BagsSettings*, const BagsInputs*, const BagsState*
  *   2. bags_forward_finish_speculative: phase 2 enqueued immediately, sized for a caller-guessed upper bound `capacity`
  *      (e.g. 1.2 x the previous frame's count; state.binning holds bags_binning_size(capacity, W, H) bytes); the
  *      kernels read the true count on the device and clamp it to `capacity`.
- *   3. The caller waits for the event of step 1 (the GPU is already busy with step 2) and compares: if
- *      *host_num_rendered > capacity the outputs are invalid and phase 2 must be redone with bags_forward_finish on a
- *      larger buffer (phase 1 results in state.geom stay valid).  When it fits, `capacity` plays the role of
- *      num_rendered for bags_backward / bags_backward_workspace_size buffer sizing. */
+ *   3. The caller waits for the event of step 1 -- right away (the GPU is already busy with step 2) or as late as the
+ *      entry of bags_backward (no host wait inside the forward at all: what lets the views of a batch be enqueued on
+ *      several streams back to back) -- and compares: if *host_num_rendered > capacity the outputs are invalid (every tile
+ *      was rendered empty) and phase 2 must be redone with bags_forward_finish on a larger buffer (phase 1 results in
+ *      state.geom stay valid).  When it fits, bags_backward takes the true count as num_rendered and `capacity` as
+ *      binning_capacity. */
 int bags_forward_prepare_async(const BagsSettings*, const BagsInputs*, const BagsState*, const BagsForwardOut*,
                                uint32_t* host_num_rendered, void* stream);
 int bags_forward_finish_speculative(const BagsSettings*, const BagsInputs*, const BagsState*, const BagsForwardOut*,

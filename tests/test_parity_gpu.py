@@ -158,30 +158,49 @@ def test_cpu_tensors_fail_loudly():
 
 def test_speculative_forward_matches_exact_and_recovers_from_overflow():
     """Second and later calls of a problem shape skip the mid-forward host round trip by guessing the instance
-    capacity from the previous call; a too-small guess must transparently redo phase 2."""
+    capacity from earlier calls.  HOST_WAIT = "forward": the count is read before the forward returns and a too-small
+    guess transparently redoes phase 2 (exact image and gradients).  HOST_WAIT = "lazy" (default): nothing in a training
+    forward waits; results are identical whenever the guess holds, and a guess that does not hold is caught at backward
+    entry (RuntimeWarning, state recomputed: the gradients are the exact ones for the cotangent passed in)."""
+    import warnings
     from bags_raster import rasterizer as R
     scene, cam = make_case(3000, 160, 128, 1.0, 2, seed=31)
     g = torch.randn(3, 128, 160, generator=torch.Generator().manual_seed(5))
-    R._capacity_hint.clear()
-    o_exact, g_exact, v1 = run_hip(scene, cam, 2, g)                 # no hint yet: exact two-phase path
-    assert R._capacity_hint, "hint not recorded"
-    o_spec, g_spec, _ = run_hip(scene, cam, 2, g)                    # hint present: speculative path
-    for a, b in zip(o_exact, o_spec):
-        assert torch.equal(a, b)
-    for k in g_exact:
-        if g_exact[k] is not None:
-            assert torch.equal(g_exact[k], g_spec[k]), k
-    # same shape, 3x larger splats => several times more instances than the hint allows
-    big = dict(scene); big["scales"] = scene["scales"] * 3.0
-    o_big, g_big, v_big = run_hip(big, cam, 2, g)
-    assert v_big["num_rendered"] > 1.5 * v1["num_rendered"]
-    R._capacity_hint.clear()
-    o_ref, g_ref, _ = run_hip(big, cam, 2, g)
-    for a, b in zip(o_big, o_ref):
-        assert torch.equal(a, b)
-    for k in g_ref:
-        if g_ref[k] is not None:
-            assert torch.equal(g_big[k], g_ref[k]), k
+    big = dict(scene); big["scales"] = scene["scales"] * 6.0     # same shape, several times more instances than any guess
+    saved = R.HOST_WAIT
+    try:
+        ref = {}
+        for mode in ("forward", "lazy"):
+            R.HOST_WAIT = mode
+            R._capacity_hint.clear()
+            o_exact, g_exact, v1 = run_hip(scene, cam, 2, g)             # no hint yet: exact two-phase path
+            assert R._capacity_hint, "hint not recorded"
+            o_spec, g_spec, _ = run_hip(scene, cam, 2, g)                # hint present: speculative path
+            for a, b in zip(o_exact, o_spec):
+                assert torch.equal(a, b)
+            for k in g_exact:
+                if g_exact[k] is not None:
+                    assert torch.equal(g_exact[k], g_spec[k]), (mode, k)
+            with warnings.catch_warnings(record=True) as wlist:
+                warnings.simplefilter("always")
+                o_big, g_big, v_big = run_hip(big, cam, 2, g)
+            assert v_big["num_rendered"] > R.CAPACITY_HEADROOM * v1["num_rendered"] + 8192, (v_big["num_rendered"], v1["num_rendered"])
+            overflowed = [w for w in wlist if issubclass(w.category, RuntimeWarning) and "speculative capacity" in str(w.message)]
+            if mode == "forward":
+                assert not overflowed
+                R._capacity_hint.clear()
+                o_ref, g_ref, _ = run_hip(big, cam, 2, g)                # exact path
+                ref = dict(o=o_ref, g=g_ref)
+                for a, b in zip(o_big, o_ref):
+                    assert torch.equal(a, b)
+            else:
+                assert len(overflowed) == 1                              # caught at backward entry
+                assert torch.equal(o_big[1], ref["o"][1])               # radii come from phase 1: always right
+            for k in ref["g"]:                                           # gradients: exact in both modes
+                if ref["g"][k] is not None:
+                    assert torch.equal(g_big[k], ref["g"][k]), (mode, k)
+    finally:
+        R.HOST_WAIT = saved
 
 
 @pytest.mark.timeout(900)
