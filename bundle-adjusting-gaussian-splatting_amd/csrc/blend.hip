@@ -27,7 +27,8 @@
 #define CHUNK 256           // splats staged per step (LDS: 48 B record + 4 x 48 B accumulator copies + 16 list bytes each)
 #endif
 #ifndef BCHUNK
-#define BCHUNK 128          // the backward's chunk: 4 x 48 B x BCHUNK of accumulator copies dominate its LDS (41 KB at 128)
+#define BCHUNK 176          // the backward's chunk: 4 x 48 B x BCHUNK of accumulator copies dominate its LDS (33 of 51 KB at 176: the
+                            // largest chunk that leaves room for 3 workgroups per CU; 128 / 144 / 160 / 176 measured 0.385 / 0.385 / 0.376 / 0.371 ms)
 #endif
 #ifndef SCAN_WG_PER_CU
 #define SCAN_WG_PER_CU 3    // backward workgroups per CU: 3 x 41 KB of LDS, 168 VGPRs (measured: 128/3 beats 256/2 by 3 %)
@@ -245,13 +246,13 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     A.tx = (int)(desc.x % (u32)grid_x); A.ty = (int)(desc.x / (u32)grid_x); A.rx = desc.y; A.n = desc.z;
     A.maxc = min(desc.w & 0x7FFFFFFFu, desc.z); A.early = (desc.w >> 31) != 0u;
 
-    __shared__ ChunkRec recs[BCHUNK];                 // 6 KB
+    __shared__ ChunkRec recs[BCHUNK];                 // 8.25 KB
     // 8 pixel pairs (PixPair = 4 x float4) per block + one float4 of padding: the four rows of a wave read four different
     // blocks in one ds_read_b128, and a 512-B block stride would put all four on the same banks
     __shared__ float4 pixq[16][8 * PQ + 1];          //  6.25 KB (8.25 without TF_FOLD)
-    __shared__ unsigned char lists[16][BCHUNK];       //  2 KB
+    __shared__ unsigned char lists[16][BCHUNK];       //  2.75 KB
     __shared__ u32 masks[BCHUNK];                     //  0.5 KB: block reach masks, compact (the 48-B record stride bank-conflicts)
-    __shared__ float acc[4][BCHUNK][12];              // 24 KB, one copy per wave (LDS float atomics on a shared copy were 1.6x slower)
+    __shared__ float acc[4][BCHUNK][12];              // 33 KB, one copy per wave (LDS float atomics on a shared copy were 1.6x slower)
     __shared__ u32 blk_maxc[16];                     // last contributor over the 16 pixels of each block
 #ifdef LDS_PAD                                       // experiment knob: extra LDS per workgroup lowers the occupancy without touching the code
     __shared__ u32 lds_pad[LDS_PAD / 4];
