@@ -108,6 +108,7 @@ size_t carve_binning(void* base, long long I, int W, int H, BinView* v, bool bin
         take(p, b.words, n); take(p, b.scratch, n); take(p, b.point_list, n);
         b.keys_a = b.keys_b = b.vals_a = b.vals_b = nullptr; b.ranges = nullptr; b.radix_hist = b.digit_totals = nullptr;
         b.tile_sorted = nullptr;
+        b.reach_mask = reinterpret_cast<unsigned short*>(b.words);       // the unsorted words are dead after the per-tile sorts
     } else {
         take(p, b.keys_a, n); take(p, b.vals_a, n); take(p, b.keys_b, n); take(p, b.vals_b, n);
         take(p, b.ranges, (size_t)(T > 0 ? T : 1));
@@ -116,6 +117,7 @@ size_t carve_binning(void* base, long long I, int W, int H, BinView* v, bool bin
         // emission writes the *_b half; pass 0: b -> a, pass 1: a -> b, ...
         b.point_list = (b.passes & 1) ? b.vals_a : b.vals_b;
         b.tile_sorted = (b.passes & 1) ? b.keys_a : b.keys_b;
+        b.reach_mask = reinterpret_cast<unsigned short*>((b.passes & 1) ? b.keys_b : b.keys_a);   // the ping-pong half the last pass read
     }
     if (v) *v = b;
     return (size_t)(p - reinterpret_cast<char*>(base));

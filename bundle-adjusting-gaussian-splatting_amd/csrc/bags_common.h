@@ -114,6 +114,10 @@ struct BinView {
     u32*    tile_sorted;     // keys after the last pass (radix path only)
     u64*    words;           // tile-binned path: (depth key << 32 | Gaussian id) per instance, grouped by tile, unsorted inside a tile
     u64*    scratch;         // tile-binned path: scratch of the two-level / global-memory sorts (lists of > 4096 entries only)
+    // [I] 16-bit reach mask of the 4x4-pixel blocks per sorted instance: written by blend_fwd when it stages the instance,
+    // read back by blend_bwd instead of evaluating block_mask16 again.  Lives in memory that is dead once the lists are
+    // sorted (`words` / the radix path's spare key buffer).
+    unsigned short* reach_mask;
 };
 struct ImgView {
     float* final_T;          // [H*W]

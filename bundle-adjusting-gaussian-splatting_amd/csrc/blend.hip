@@ -227,7 +227,8 @@ struct TileRef { int tx, ty; u32 rx, n, maxc; bool early; };   // early: some pi
 template <bool ABS>
 __global__ void __launch_bounds__(256, SCAN_WG_PER_CU)
 blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__ tile_desc,
-                      const u32* __restrict__ point_list, const float4* __restrict__ g2d, const u32* __restrict__ inst_off,
+                      const u32* __restrict__ point_list, const unsigned short* __restrict__ reach_mask,
+                      const float4* __restrict__ g2d, const u32* __restrict__ inst_off,
                       const float* __restrict__ bg, const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
                       const float* __restrict__ grad_color, float* __restrict__ partials)
 {
@@ -266,9 +267,12 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
 #endif
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     struct Raw { float4 q0, q1, q2; u32 io; u64 kp; };      // conic+opacity | x y r g | b z rect | inst_offset | tile mask
-    auto fetch_id = [&](u32 rx_, u32 hi_) -> u32 {   // id of this thread's slot in the chunk of a tile's list that ends at hi_
+    // id (x) and 4x4-block reach mask (y, as the forward staged it) of this thread's slot in the chunk of a tile's list that ends at hi_
+    auto fetch_id = [&](u32 rx_, u32 hi_) -> uint2 {
         const u32 c_ = min(hi_, (u32)BCHUNK);
-        return ((u32)tid < c_) ? point_list[rx_ + (hi_ - c_) + tid] : 0xFFFFFFFFu;
+        if ((u32)tid >= c_) return make_uint2(0xFFFFFFFFu, 0u);
+        const u32 at = rx_ + (hi_ - c_) + tid;
+        return make_uint2(point_list[at], (u32)reach_mask[at]);
     };
     auto fetch = [&](u32 g) {
         Raw r; r.q0 = make_float4(0.f, 0.f, 0.f, 0.f); r.q1 = r.q0; r.q2 = r.q0; r.io = 0u; r.kp = 0ull;
@@ -286,7 +290,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         const int minx = (int)(rc.x & 0xFFFF), miny = (int)(rc.x >> 16);
         return io + rect_tile_rank(kp, (int)(rc.y & 0xFFFF) - minx, (int)(rc.y >> 16) - miny, tx - minx, ty - miny);
     };
-    auto make_rec = [&](const Raw& rw, const TileRef& t, u32 lo_, u32 cnt_) {
+    auto make_rec = [&](const Raw& rw, const u32 mask_, const TileRef& t, u32 lo_, u32 cnt_) {
         ChunkRec rec; rec.mask = 0; rec.e = 0;
         rec.x = rec.y = rec.ap = rec.bp = rec.cp = rec.o = rec.r = rec.g = rec.b = 0.f; rec.pos = 0;
         if ((u32)tid < cnt_) {
@@ -297,7 +301,11 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
             rec.ap = -0.5f * LOG2E * co.x; rec.bp = -LOG2E * co.y; rec.cp = -0.5f * LOG2E * co.z; rec.o = co.w;
             rec.r = cz.x; rec.g = cz.y; rec.b = cz.z;
             rec.pos = lo_ + tid + 1;
+#ifdef BWD_OWN_MASKS
             rec.mask = block_mask16(c2.x, c2.y, co.x, co.y, co.z, co.w, (float)(t.tx * BAGS_TILE), (float)(t.ty * BAGS_TILE));
+#else
+            rec.mask = mask_;                 // block_mask16 of this (tile, splat), evaluated once: by the forward
+#endif
         }
         return rec;
     };
@@ -345,8 +353,8 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     // The tile's descriptor carries its deepest contributor (from the forward), so the ids of the first two chunks are
     // requested before anything else and the pixel loads of tile_begin overlap them: the per-tile dependent chain is
     // descriptor -> ids -> gathers.
-    const u32 gid0 = fetch_id(A.rx, A.maxc);
-    u32 gid1 = (A.maxc > BCHUNK) ? fetch_id(A.rx, A.maxc - BCHUNK) : 0xFFFFFFFFu;      // ids of chunk 1, in flight with chunk 0's
+    const uint2 gid0 = fetch_id(A.rx, A.maxc);
+    uint2 gid1 = (A.maxc > BCHUNK) ? fetch_id(A.rx, A.maxc - BCHUNK) : make_uint2(0xFFFFFFFFu, 0u);      // ids of chunk 1, in flight with chunk 0's
     tile_begin(A);
     if (A.maxc == 0) return;                                 // nothing contributed anywhere in the tile: all records are zero
     if (tid < BCHUNK) {
@@ -364,8 +372,8 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     //   then     issue the gathers of chunk k+1 (ids known) and the id load of chunk k+2
     //   ...      lists + groups of chunk k            <- the loads land underneath
     //   barrier  consume gathers -> rec(k+1), ids(k+2); only then store the records of chunk k
-    ChunkRec rec = make_rec(fetch(gid0), A, A.maxc - min(A.maxc, (u32)BCHUNK), min(A.maxc, (u32)BCHUNK));
-    asm volatile("" :: "v"(gid1));    // complete before the loop: a pending load on the entry edge costs a vmcnt(0) at every loop top
+    ChunkRec rec = make_rec(fetch(gid0.x), gid0.y, A, A.maxc - min(A.maxc, (u32)BCHUNK), min(A.maxc, (u32)BCHUNK));
+    asm volatile("" :: "v"(gid1.x), "v"(gid1.y));    // complete before the loop: a pending load on the entry edge costs a vmcnt(0) at every loop top
 
     const int row = lane >> 4, li = lane & 15;
     const int qx = (wave & 1) * 2, qy = (wave >> 1) * 2;
@@ -384,8 +392,8 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         PH_MARK(2);    // barrier 1
         __builtin_amdgcn_s_setprio(PRIO_GROUPS);
         const u32 nx_cnt = min(lo, (u32)BCHUNK), nx_lo = lo - nx_cnt;                  // chunk k+1 = [nx_lo, lo)
-        Raw raw_n = fetch(lo > 0 ? gid1 : 0xFFFFFFFFu);                             // gathers of chunk k+1
-        const u32 gid2 = (nx_lo > 0) ? fetch_id(A.rx, nx_lo) : 0xFFFFFFFFu;          // ids of chunk k+2
+        Raw raw_n = fetch(lo > 0 ? gid1.x : 0xFFFFFFFFu);                           // gathers of chunk k+1
+        const uint2 gid2 = (nx_lo > 0) ? fetch_id(A.rx, nx_lo) : make_uint2(0xFFFFFFFFu, 0u);   // ids of chunk k+2
 
         // The per-(splat, block) work: one block row (4 pixels = two packed pairs) per step; four independent scan chains
         // interleave without pipeline bubbles.  `s` is the lane's splat, (bx0, by0) its block origin, pixb its block's
@@ -600,8 +608,8 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         // and exposes the whole gather latency once per chunk (seen in the ISA; 20 % of the wave time).  Touching gid2
         // here also retires the id load before this chunk's record stores are issued, so the top of the next chunk
         // does not have to drain the stores to be sure the id has arrived.
-        asm volatile("" :: "v"(raw_n.q2.y), "v"(gid2));
-        if (lo > 0) rec = make_rec(raw_n, A, nx_lo, nx_cnt);
+        asm volatile("" :: "v"(raw_n.q2.y), "v"(gid2.x), "v"(gid2.y));
+        if (lo > 0) rec = make_rec(raw_n, gid1.y, A, nx_lo, nx_cnt);
         gid1 = gid2;
         PH_MARK(1);
         // ---- one record per staged instance: the four wave copies added in fixed order
@@ -654,11 +662,11 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     const int grid = cdiv(T, TILE_RUN) * TILE_RUN;
     if (want_abs)
         hipLaunchKernelGGL(blend_bwd_scan_kernel<true>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
-                           im.tile_desc, b.point_list, g.g2d, g.inst_off, s.bg,
+                           im.tile_desc, b.point_list, b.reach_mask, g.g2d, g.inst_off, s.bg,
                            im.final_T, im.n_contrib, grad_color, partials);
     else
         hipLaunchKernelGGL(blend_bwd_scan_kernel<false>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
-                           im.tile_desc, b.point_list, g.g2d, g.inst_off, s.bg,
+                           im.tile_desc, b.point_list, b.reach_mask, g.g2d, g.inst_off, s.bg,
                            im.final_T, im.n_contrib, grad_color, partials);
     return hipGetLastError();
 }
@@ -683,7 +691,7 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
 template <int DUMMY>
 __global__ void __launch_bounds__(256, FWD_WG_PER_CU)
 blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_desc, const u32* __restrict__ point_list,
-                      const float4* __restrict__ g2d, const float* __restrict__ bg, float* __restrict__ out_color,
+                      unsigned short* __restrict__ reach_mask, const float4* __restrict__ g2d, const float* __restrict__ bg, float* __restrict__ out_color,
                       float* __restrict__ out_depth, float* __restrict__ out_weights, float* __restrict__ final_T,
                       u32* __restrict__ n_contrib, const u32* __restrict__ n_dev, u32 capacity)
 {
@@ -739,6 +747,7 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
             rec.r = cz.x; rec.g = cz.y; rec.b = cz.z; rec.z = cz.w;
             rec.pos = base + tid + 1;
             rec.mask = block_mask16(c2.x, c2.y, co.x, co.y, co.z, co.w, X0, Y0);
+            reach_mask[range.x + base + tid] = (unsigned short)rec.mask;      // the backward stages the same instance: it reads this
         }
         if (tid < CHUNK) { recs[tid] = rec; masks[tid] = rec.mask; }
         __syncthreads();
@@ -833,7 +842,7 @@ hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinV
     if (T == 0) return hipSuccess;
     const int grid = cdiv(T, TILE_RUN) * TILE_RUN;
     hipLaunchKernelGGL(blend_fwd_rows_kernel<0>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
-                       im.tile_desc, b.point_list, g.g2d, s.bg, out.color, out.depth, out.weights,
+                       im.tile_desc, b.point_list, b.reach_mask, g.g2d, s.bg, out.color, out.depth, out.weights,
                        im.final_T, im.n_contrib, n_dev, capacity);
     return hipGetLastError();
 }

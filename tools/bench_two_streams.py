@@ -43,8 +43,12 @@ def fwd(v):
 
 red = GradAllReducer(leaves)
 res = {}
-for mode in ("forward", "lazy"):
-    R.HOST_WAIT = mode
+import os
+MODES = os.environ.get("MODES", "forward,lazy").split(",")
+for mode in MODES:
+    R.HOST_WAIT = mode.split(":")[0]
+    if ":" in mode:
+        R.CAPACITY_HEADROOM = float(mode.split(":")[1])
     for order in ("per_view", "batched"):
         for nstreams in (1, 2, 3):
             streams = [torch.cuda.Stream() for _ in range(nstreams)]
@@ -68,12 +72,14 @@ for mode in ("forward", "lazy"):
                 for s in streams: cur.wait_stream(s)
             for _ in range(40): step()
             torch.cuda.synchronize()
+            seg0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
             t0 = time.perf_counter()
             K = 40
             for _ in range(K): step()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / K
             res[f"{mode}/{order}/{nstreams}"] = {"ms_per_view": round(dt * 1e3 / V, 4), "gaussians_per_s": round(V * P / dt / 1e6, 1),
+                                                 "device_allocs_in_timed_region": torch.cuda.memory_stats().get("num_device_alloc", 0) - seg0,
                                                  "grad_checksum": float(leaves[0].grad.double().abs().sum())}
             print(f"{mode}/{order}/{nstreams}", res[f"{mode}/{order}/{nstreams}"], flush=True)
 print(json.dumps(res))
