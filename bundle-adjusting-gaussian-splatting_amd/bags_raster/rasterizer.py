@@ -19,6 +19,7 @@ from typing import NamedTuple, Optional
 
 import math
 import threading
+import time
 import weakref
 
 import torch
@@ -224,12 +225,32 @@ class _PinnedSlots:
 _pinned = _PinnedSlots()
 
 
-def _abandon(pinned, ev, key):
+_NO_COUNT = 0xFFFFFFFF        # what a lazy forward's pinned word holds until the device has written the instance count
+
+
+def _await_count(pinned: torch.Tensor, stream) -> int:
+    """The asynchronous instance count of a lazy forward.  No event is recorded for it (an event between the two phases of the
+    forward costs ~6 us of idle device per frame, tools/trace_gaps.sh): the word starts as _NO_COUNT and is written by the
+    counting kernel itself (system-scope store into pinned memory) or by the copy behind it, so the host simply looks at it;
+    by the time a backward starts it has almost always arrived."""
+    for spin in range(2000):
+        n = int(pinned[0].item()) & 0xFFFFFFFF
+        if n != _NO_COUNT:
+            return n
+        if spin > 50:
+            time.sleep(20e-6)
+    stream.synchronize()                                     # the forward is done: the word must be there
+    n = int(pinned[0].item()) & 0xFFFFFFFF
+    if n == _NO_COUNT:
+        raise RuntimeError("bags_raster: the forward finished without delivering its instance count")
+    return n
+
+
+def _abandon(pinned, stream, key):
     """Finalizer of a lazy forward nobody differentiated: the count is still read (hint, slot reuse only after the kernel
     that writes the word has run)."""
     try:
-        ev.synchronize()
-        _note_count(key, int(pinned[0].item()) & 0xFFFFFFFF)
+        _note_count(key, _await_count(pinned, stream))
         _pinned.give(pinned)
     except Exception:                                        # interpreter shutdown
         pass
@@ -241,11 +262,10 @@ def _resolve(lib, fw: "_Forwarded") -> None:
     global LAST_NUM_RENDERED
     if fw.pending is None:
         return
-    pinned, ev, fin = fw.pending
+    pinned, fin = fw.pending
     fw.pending = None
     fin.detach()
-    ev.synchronize()
-    n = int(pinned[0].item()) & 0xFFFFFFFF
+    n = _await_count(pinned, fw.stream)
     _pinned.give(pinned)
     _note_count(fw.key, n)
     fw.num_rendered = LAST_NUM_RENDERED = n
@@ -294,10 +314,13 @@ def _run_forward(lib, pk: _Packed, H: int, W: int, speculate: bool = True, lazy:
         fw.binning = _bytes(lib.bags_binning_size(cap, W, H), dev)
         state.binning, state.binning_bytes = fw.binning.data_ptr(), fw.binning.numel()
         pinned = _pinned.take()
+        if lazy:
+            pinned[0] = -1                    # _NO_COUNT (the previous user of the slot has read its value)
         L.check(lib.bags_forward_prepare_async(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(out),
                                                pinned.data_ptr(), stream), "bags_forward_prepare_async")
-        ev = torch.cuda.Event()
-        ev.record(fw.stream)
+        if not lazy:
+            ev = torch.cuda.Event()
+            ev.record(fw.stream)
         L.check(lib.bags_forward_finish_speculative(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(out),
                                                     cap, stream), "bags_forward_finish_speculative")
         fw.capacity = cap
@@ -307,7 +330,7 @@ def _run_forward(lib, pk: _Packed, H: int, W: int, speculate: bool = True, lazy:
             # cycle that only the cyclic GC breaks, and until then ~250 MB of state per forward stay allocated (measured: the
             # caching allocator then goes to hipMalloc dozens of times per 40 steps)
             fw.outs = tuple(t.detach() for t in (color, radii, depth, weights, mean2D))
-            fw.pending = (pinned, ev, weakref.finalize(fw, _abandon, pinned, ev, key))
+            fw.pending = (pinned, weakref.finalize(fw, _abandon, pinned, fw.stream, key))
             return fw, (color, radii, depth, weights, mean2D)
         ev.synchronize()                      # phase 2 is already queued behind the count: the GPU does not wait for us
         n = int(pinned[0].item()) & 0xFFFFFFFF

@@ -459,19 +459,15 @@ __device__ __forceinline__ void wave_sort_words(const u64 (&e)[PER], u32 n, u32 
     }
 }
 
-// One WAVE per tile for lists of up to TSORT_WAVE entries: 8160 independent waves, no workgroup barriers.
+// One WAVE per tile for lists of up to TSORT_WAVE entries: independent waves, no workgroup barriers (role of the
+// workgroups behind the long-list ones in tile_sort_kernel: four tiles per 256-thread workgroup, one per wave, each with
+// its own quarter of the workgroup's LDS; neighbouring descriptors hold lists of similar length).
 #define TS_PER (TSORT_WAVE / 64)
-__global__ void __launch_bounds__(64)
-tile_sort_wave_kernel(const uint4* __restrict__ tile_desc, const u64* __restrict__ words_in, u32* __restrict__ point_list,
-                      u32 capacity, const u32* __restrict__ n_dev)
+__device__ __forceinline__ void sort_wave_role(const uint4 desc, const u64* __restrict__ words_in, u32* __restrict__ point_list, u64* t, u32* cnt)
 {
-    __shared__ u64 t[TSORT_WAVE];
-    __shared__ u32 cnt[TSORT_WAVE / 2];
-    if (n_dev && *n_dev > capacity) return;
-    const uint4 desc = tile_desc[blockIdx.x];
     const u32 n = desc.z, start = desc.y;
     if (n == 0 || n > TSORT_WAVE) return;
-    const u32 lane = threadIdx.x;
+    const u32 lane = threadIdx.x & 63;
     if (n == 1) { if (lane == 0) point_list[start] = (u32)words_in[start]; return; }
     // the list's (depth key, id) words in one batch of coalesced loads (clamped indices, no branches)
     u64 e[TS_PER];
@@ -578,18 +574,26 @@ __device__ __forceinline__ void block_sort_words(const u64 (&e)[PER], u32 n, u32
 #define TSORT_BLOCK 4096
 #define TSORT_LARGE 16384
 #define TS_SLABS_MAX 64
+// ONE launch for every list (round 3; the long-list kernel used to be a launch of its own: ~5 us of stream time even when no
+// list is long, every frame): workgroups [0, n_large_wg) take the long lists, the ones behind them four short lists each.
 __global__ void __launch_bounds__(256)
-tile_sort_large_kernel(const uint4* __restrict__ tile_desc, const u32* __restrict__ n_active, const u64* __restrict__ words_in,
-                       u64* __restrict__ scratch, u32* __restrict__ point_list, u32 capacity, const u32* __restrict__ n_dev)
+tile_sort_kernel(const uint4* __restrict__ tile_desc, const u32* __restrict__ n_active, const u64* __restrict__ words_in,
+                 u64* __restrict__ scratch, u32* __restrict__ point_list, u32 capacity, const u32* __restrict__ n_dev, int T,
+                 u32 n_large_wg)
 {
-    __shared__ u64 t_all[TSORT_BLOCK];                       // one list of <= 4096 words, or four waves x 1024 (slab sort)
+    __shared__ u64 t_all[TSORT_BLOCK];                       // one list of <= 4096 words, or four waves x 1024 (slab sort / short lists)
     __shared__ u32 cnt_all[TSORT_BLOCK / 2];                 // packed 16-bit counters
     __shared__ u32 s_red[8];
     __shared__ u32 slab_cnt[TS_SLABS_MAX + 1], slab_start[TS_SLABS_MAX + 1], s_next, s_bad;
     if (n_dev && *n_dev > capacity) return;
-    const u32 n_long = n_active[1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (u32 d = blockIdx.x; d < n_long; d += gridDim.x) {
+    if (blockIdx.x >= n_large_wg) {                          // short lists: a wave per tile
+        const u32 d = (blockIdx.x - n_large_wg) * 4u + (u32)wave;
+        if (d < (u32)T) sort_wave_role(tile_desc[d], words_in, point_list, t_all + wave * TSORT_WAVE, cnt_all + wave * (TSORT_WAVE / 2));
+        return;
+    }
+    const u32 n_long = n_active[1];
+    for (u32 d = blockIdx.x; d < n_long; d += n_large_wg) {
         const uint4 desc = tile_desc[d];
         const u32 n = desc.z, start = desc.y;
         if (n <= TSORT_WAVE) continue;                        // uniform over the workgroup
@@ -774,10 +778,10 @@ hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int
     }
     hipLaunchKernelGGL(emit_binned_kernel, dim3(B), dim3(BIN_THREADS), cursors, st, P, per, grid_x, T, g.rect, g.tiles_touched,
                        g.keep, im.pre, im.ranges, g.local_off, g.block_base, g.inst_off, g.depth_key, words, capacity, n_dev);
-    // long lists first: their few workgroups run beside the many short sorts of the second launch
-    hipLaunchKernelGGL(tile_sort_large_kernel, dim3(T < 768 ? T : 768), dim3(256), 0, st, im.tile_desc, im.n_active, words, scratch,
-                       point_list, capacity, n_dev);
-    hipLaunchKernelGGL(tile_sort_wave_kernel, dim3(T), dim3(64), 0, st, im.tile_desc, words, point_list, capacity, n_dev);
+    // long lists first (lowest workgroup ids): their few workgroups run beside the many short sorts
+    const u32 n_large_wg = (u32)(T < 768 ? T : 768);
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(n_large_wg + (u32)cdiv(T, 4)), dim3(256), 0, st, im.tile_desc, im.n_active, words, scratch,
+                       point_list, capacity, n_dev, T, n_large_wg);
     return hipGetLastError();
 }
 

@@ -408,6 +408,8 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
 #if SCALAR_ACC
             sa3 = sa4 = sa5 = sa7 = sa8 = 0.f;
 #endif
+            float pyf = by0;                                // the row's pixel y: integers, so the += 1 below is exact and dy is
+                                                            // the forward's s.y - (float)py bit for bit
 #pragma unroll SCAN_UNROLL
             for (int iy = 0; iy < 4; ++iy) {
                 float4* P0 = pixb + iy * 2 * PQ;
@@ -421,7 +423,8 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                 const float4 q10 = P1[0], q11 = P1[1], q12 = P1[2], q13 = P1[3];
                 const u32 nc0 = __float_as_uint(q02.z), nc1 = __float_as_uint(q02.w), nc2 = __float_as_uint(q12.z), nc3 = __float_as_uint(q12.w);
 #endif
-                const float dy = s.y - (by0 + (float)iy);
+                const float dy = s.y - pyf;
+                pyf += 1.0f;
                 const float u = __fmul_rn(__fmul_rn(s.cp, dy), dy);
                 const f2 dyy = {dy, dy};
                 // ---- part 1: alpha of the four pixels (same arithmetic as pair_power2 on d = centre - pixel)
