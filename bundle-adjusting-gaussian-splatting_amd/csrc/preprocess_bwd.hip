@@ -97,6 +97,7 @@ sum_partials_kernel(int P, const float4* __restrict__ g2d, const u32* __restrict
 #ifndef PRE_BWD_WAVES
 #define PRE_BWD_WAVES 1
 #endif
+template <bool COV3D>        // the Gaussians carry precomputed 3D covariances instead of scales + rotations (uniform: no branch at the top)
 __global__ void __launch_bounds__(256, PRE_BWD_WAVES)
 preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod,
                       const float* __restrict__ means3D, const float* __restrict__ shift_factors,
@@ -111,20 +112,19 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                       float* __restrict__ g_shs, float* __restrict__ g_colors, float* __restrict__ g_opac,
                       float* __restrict__ g_scales, float* __restrict__ g_rot, float* __restrict__ g_cov3D)
 {
-    __shared__ CamConstB cam;
+    // A wave's life in this kernel is a handful of memory round trips, not arithmetic (55 % of the wave cycles were spent
+    // waiting): round 2 had SEVEN of them in series at the top -- three for the camera constants (vector loads -> LDS ->
+    // barrier), one for the SH rows (12 loads -> wait -> ds_write), one for the word that says whether the Gaussian is
+    // visible, two for its inputs.  Now everything is requested at once: the camera constants are read with wave-uniform
+    // indices from the kernel's own pointers (scalar loads, no LDS, no barrier), the SH rows go to LDS by LDS-DMA (no
+    // registers, no wait here), the visibility word and every input row are requested unconditionally (clamped index; a
+    // culled Gaussian's 104 bytes are read for nothing), and there is ONE wait in front of the arithmetic.
     __shared__ float wpose[4][POSE_VALS];
-    if (threadIdx.x < 16) {
-        cam.v[threadIdx.x] = viewmatrix[threadIdx.x];
-        cam.m[threadIdx.x] = projmatrix[threadIdx.x];
-        cam.k[threadIdx.x] = intrinsic[threadIdx.x];
-    }
-    if (threadIdx.x < 3) {
-        cam.campos[threadIdx.x] = campos_p[threadIdx.x];
-        cam.sf[threadIdx.x] = shift_factors ? shift_factors[threadIdx.x] : 0.0f;
-    }
-    __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const float* v = cam.v; const float* m = cam.m; const float* k = cam.k;
+    const float* v = viewmatrix; const float* m = projmatrix; const float* k = intrinsic;
+    const float sf0 = shift_factors ? shift_factors[0] : 0.0f, sf1 = shift_factors ? shift_factors[1] : 0.0f,
+                sf2 = shift_factors ? shift_factors[2] : 0.0f;
+    const float cpx = campos_p[0], cpy = campos_p[1], cpz = campos_p[2];
 #if SH_STAGE
     // The SH rows (and later the SH-gradient rows) of the workgroup's 256 Gaussians are ONE contiguous 48 KB span.  A
     // thread reading or writing its own 192-byte row 16 bytes at a time puts 64 separate requests per instruction on the
@@ -135,15 +135,16 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     const bool stage = (M == 16) && (colors_precomp == nullptr) && (shs != nullptr);      // uniform
     const size_t base4 = (size_t)blockIdx.x * (256 * 12), lim4 = (size_t)P * 12;
     if (stage) {
+        // global -> LDS without registers (global_load_lds_dwordx4: the wave's 64 x 16 bytes land contiguously at the
+        // wave-uniform LDS address, which is exactly srow[t * 256 + wave * 64 + lane]).  Rows past P are read from the last
+        // valid float4 instead (never used, never written back).
         const float4* s4g = reinterpret_cast<const float4*>(shs);
-        float4 tmp[12];
 #pragma unroll
         for (int t = 0; t < 12; ++t) {
             const size_t e = base4 + (size_t)t * 256 + threadIdx.x;
-            tmp[t] = (e < lim4) ? s4g[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s4g + (e < lim4 ? e : lim4 - 1)),
+                                             (__attribute__((address_space(3))) void*)(&srow[t * 256 + (threadIdx.x & ~63)]), 16, 0, 0);
         }
-#pragma unroll
-        for (int t = 0; t < 12; ++t) srow[t * 256 + threadIdx.x] = tmp[t];
     }
 #endif
 
@@ -155,38 +156,41 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     float gs0 = 0.f, gs1 = 0.f, gs2 = 0.f, gqr = 0.f, gqx = 0.f, gqy = 0.f, gqz = 0.f;
     float gc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float drgb[3] = {0.f, 0.f, 0.f};
-    const float4 q3 = (i < P) ? g2d[4 * (size_t)i + 3] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // Every input row of the Gaussian in one batch, before anything is looked at (index clamped: P > 0 here)
+    const size_t ic = (size_t)(i < P ? i : P - 1);
+    const float4 q3 = g2d[4 * ic + 3];
+    const float4 co = g2d[4 * ic];
+    float x = means3D[3 * ic + 0], y = means3D[3 * ic + 1], z = means3D[3 * ic + 2];
+    float in_s0 = 0.f, in_s1 = 0.f, in_s2 = 0.f;
+    float4 in_q = make_float4(0.f, 0.f, 0.f, 0.f);
+    float in_c[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (COV3D) {
+        const float* c = cov3D_precomp + 6 * ic;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) in_c[t] = c[t];
+    } else {
+        in_s0 = scales[3 * ic + 0]; in_s1 = scales[3 * ic + 1]; in_s2 = scales[3 * ic + 2];
+        in_q = reinterpret_cast<const float4*>(rotations)[ic];
+    }
+    const float4* sm = reinterpret_cast<const float4*>(partials) + 3 * ic;                  // K8a's per-Gaussian sums
+    const float4 sm_a = sm[0], sm_b = sm[1], sm_c = sm[2];
+    // every one of those loads is IN FLIGHT before the first of them is waited for (the compiler otherwise sinks the ones only
+    // the visible branch needs behind the visibility test: one more round trip per group)
+    asm volatile("" :: "v"(q3.y), "v"(co.x), "v"(x), "v"(y), "v"(z), "v"(in_s0), "v"(in_s1), "v"(in_s2), "v"(in_q.x), "v"(in_c[0]),
+                 "v"(in_c[3]), "v"(sm_a.x), "v"(sm_b.x), "v"(sm_c.x));
     const bool live = (i < P) && (__float_as_uint(q3.y) > 0);
 
-    float x = 0.f, y = 0.f, z = 0.f;
     if (live) {
-        // Every input row of the Gaussian is requested here, in one batch: loads issued
-        // further down, behind values that depend on earlier loads, each cost a full memory round trip of their own
-        // (a wave's life in this kernel is a handful of round trips, not arithmetic).
-        x = means3D[3 * i + 0]; y = means3D[3 * i + 1]; z = means3D[3 * i + 2];
-        float in_s0 = 0.f, in_s1 = 0.f, in_s2 = 0.f;
-        float4 in_q = make_float4(0.f, 0.f, 0.f, 0.f);
-        float in_c[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (cov3D_precomp) {
-            const float* c = cov3D_precomp + 6 * (size_t)i;
-#pragma unroll
-            for (int t = 0; t < 6; ++t) in_c[t] = c[t];
-        } else {
-            in_s0 = scales[3 * i + 0]; in_s1 = scales[3 * i + 1]; in_s2 = scales[3 * i + 2];
-            in_q = reinterpret_cast<const float4*>(rotations)[i];
-        }
-        // ---- 1. sum the per-instance records
+        // ---- 1. the per-Gaussian sums of the per-instance records
         float s[12];
         {
-            const float4* sm = reinterpret_cast<const float4*>(partials) + 3 * (size_t)i;   // K8a's per-Gaussian sums
-            const float4 a = sm[0], b = sm[1], c = sm[2];
+            const float4 a = sm_a, b = sm_b, c = sm_c;
             s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
             s[8] = c.x; s[9] = c.y; s[10] = c.z; s[11] = 0.f;
         }
         drgb[0] = s[0]; drgb[1] = s[1]; drgb[2] = s[2];
         gop = s[3];
         const float Mx = s[4], My = s[5], Mxx = s[6], Mxy = s[7], Myy = s[8];
-        const float4 co = g2d[4 * (size_t)i];
         // ---- 2. moments -> screen-space gradients
         const float dpx = -(co.x * Mx + co.y * My);         // dL/d centre (pixel units)
         const float dpy = -(co.z * My + co.y * Mx);
@@ -202,7 +206,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         const float rho = sqrtf(tx * tx + ty * ty + 1e-20f);
         const float theta = det_atan2_pos(rho, tz);
         const float th2 = theta * theta, th3 = th2 * theta;
-        const float shift = cam.sf[0] * th3 + cam.sf[1] * (th3 * th2) + cam.sf[2] * (th3 * th2 * th2);
+        const float shift = sf0 * th3 + sf1 * (th3 * th2) + sf2 * (th3 * th2 * th2);
         const float tzs = tz + shift;
         const float hx = x * m[0] + y * m[4] + z * m[8] + m[12] + shift * k[8];
         const float hy = x * m[1] + y * m[5] + z * m[9] + m[13] + shift * k[9];
@@ -212,7 +216,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         float c0, c1, c2, c3, c4, c5;
         float s0 = 0, s1 = 0, s2 = 0, qr = 0, qx = 0, qy = 0, qz = 0;
         float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
-        if (cov3D_precomp) {
+        if (COV3D) {
             c0 = in_c[0]; c1 = in_c[1]; c2 = in_c[2]; c3 = in_c[3]; c4 = in_c[4]; c5 = in_c[5];
         } else {
             s0 = in_s0 * mod; s1 = in_s1 * mod; s2 = in_s2 * mod;
@@ -303,7 +307,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         dtz += dtzs;
         // shift polynomial in theta = atan2(rho, tz)
         pose[32] = dshift * th3; pose[33] = dshift * th3 * th2; pose[34] = dshift * th3 * th2 * th2;
-        const float dtheta = dshift * (3.f * cam.sf[0] * th2 + 5.f * cam.sf[1] * th2 * th2 + 7.f * cam.sf[2] * th2 * th2 * th2);
+        const float dtheta = dshift * (3.f * sf0 * th2 + 5.f * sf1 * th2 * th2 + 7.f * sf2 * th2 * th2 * th2);
         const float ir2 = 1.0f / (rho * rho + tz * tz);
         const float drho = dtheta * tz * ir2;
         dtz -= dtheta * rho * ir2;
@@ -318,7 +322,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         pose[9] = dtx; pose[10] = dty; pose[11] = dtz;                    // v[12], v[13], v[14]
 
         // ---- Sigma -> scales, rotation
-        if (!cov3D_precomp) {
+        if (!COV3D) {
             const float S00 = 2.f * gc[0], S01 = gc[1], S02 = gc[2], S11 = 2.f * gc[3], S12 = gc[4], S22 = 2.f * gc[5];
             const float l00 = r00 * s0, l01 = r01 * s1, l02 = r02 * s2;
             const float l10 = r10 * s0, l11 = r11 * s1, l12 = r12 * s2;
@@ -350,7 +354,10 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     }
     float cp0 = 0.f, cp1 = 0.f, cp2 = 0.f;            // dL/dcampos of this Gaussian
 #if SH_STAGE
-    if (stage) __syncthreads();                      // every thread's staged float4s are in LDS
+    if (stage) {                                     // every wave's LDS-DMA pieces have landed, then the workgroup meets
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
 #endif
     if (live) {
         // ---- colour
@@ -359,7 +366,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
             if (cl & 1u) drgb[0] = 0.f;
             if (cl & 2u) drgb[1] = 0.f;
             if (cl & 4u) drgb[2] = 0.f;
-            const float ex = x - cam.campos[0], ey = y - cam.campos[1], ez = z - cam.campos[2];
+            const float ex = x - cpx, ey = y - cpy, ez = z - cpz;
             const float il = 1.0f / sqrtf(ex * ex + ey * ey + ez * ez);
             const float ux_ = ex * il, uy_ = ey * il, uz_ = ez * il;
             float bs[16], bx[16], by[16], bz[16];
@@ -537,12 +544,14 @@ hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, co
     hipLaunchKernelGGL(sum_partials_kernel, dim3(nb), dim3(256), 0, st, P, g.g2d, g.inst_off, partials_records,
                        reinterpret_cast<float4*>(sums));
     const float* partials = sums;
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nb), dim3(256), 0, st, P, s.sh_coeffs, s.sh_degree, s.image_width,
-                       s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, in.means3D, in.shift_factors, in.shs,
-                       in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, s.viewmatrix, s.projmatrix,
-                       s.intrinsic, s.campos, g.g2d, partials,
-                       pose_slab, a.grad_means3D, a.grad_means2D, a.grad_means2D_densify, a.grad_shs,
+#define PRE_BWD_LAUNCH(COV)     hipLaunchKernelGGL(preprocess_bwd_kernel<COV>, dim3(nb), dim3(256), 0, st, P, s.sh_coeffs, s.sh_degree, s.image_width, \
+                       s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, in.means3D, in.shift_factors, in.shs, \
+                       in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, s.viewmatrix, s.projmatrix, \
+                       s.intrinsic, s.campos, g.g2d, partials, \
+                       pose_slab, a.grad_means3D, a.grad_means2D, a.grad_means2D_densify, a.grad_shs, \
                        a.grad_colors_precomp, a.grad_opacities, a.grad_scales, a.grad_rotations, a.grad_cov3D_precomp);
+    if (in.cov3D_precomp) { PRE_BWD_LAUNCH(true) } else { PRE_BWD_LAUNCH(false) }
+#undef PRE_BWD_LAUNCH
     return hipGetLastError();
 }
 

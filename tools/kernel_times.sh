@@ -4,7 +4,7 @@ TAG=${1:-kt}; shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p $ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$TAG -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-profile --no-aabb-leg "$@" > $ROOT/gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$TAG -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-profile --no-aabb-leg --no-v4-leg "$@" > $ROOT/gpurun_out/prof_$TAG.log 2>&1
 f=$(find $ROOT/gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
 [ -z "$f" ] && { echo "no stats"; tail -5 $ROOT/gpurun_out/prof_$TAG.log; exit 1; }
 cp "$f" $ROOT/gpurun_out/${TAG}_kernel_stats.csv

@@ -6,7 +6,7 @@ ROOT=$PWD
 OUT=$ROOT/gpurun_out/pmc_$$
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $1 --output-format csv -d $OUT -- python3 $ROOT/bench.py --no-cpu-baseline --no-profile --no-aabb-leg --steps 3 --warmup 1 > /dev/null 2> $OUT/err.log
+rocprofv3 --pmc $1 --output-format csv -d $OUT -- python3 $ROOT/bench.py --no-cpu-baseline --no-profile --no-aabb-leg --no-v4-leg --steps 3 --warmup 1 --settle-steps 20 > /dev/null 2> $OUT/err.log
 python3 - "$OUT" "${2:-blend}" <<'PY'
 import csv, glob, sys, collections
 out, pat = sys.argv[1], sys.argv[2]

@@ -13,7 +13,7 @@ mkdir -p $OUT
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || { echo "bench failed"; tail -5 $OUT/bench.err; exit 1; }
 echo "bench done: $(cut -c1-200 $OUT/bench.json)"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-profile --no-aabb-leg > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-profile --no-aabb-leg --no-v4-leg > $OUT/trace.log 2>&1
 f=$(find $OUT/trace -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp "$f" $OUT/kernel_stats.csv && echo "kernel stats: $(head -3 $OUT/kernel_stats.csv | cut -c1-160)"
 rm -rf $OUT/trace
