@@ -262,8 +262,9 @@ def main():
                     help="views every rank renders (fwd+bwd, gradients accumulated locally) behind ONE exchange; 0 = 1 view at "
                          "every --gpus N (a second leg with 4 views is timed in the same run and reported as 'v4')")
     ap.add_argument("--no-v4-leg", action="store_true", help="skip the second timed leg with 4 views per rank per exchange")
-    ap.add_argument("--exchange", default="all_reduce", choices=("all_reduce", "reduce_scatter"),
-                    help="one ncclAllReduce of the flat gradient bucket, or ncclReduceScatter + ncclAllGather")
+    ap.add_argument("--exchange", default="all_reduce", choices=("all_reduce", "reduce_scatter", "sparse"),
+                    help="one ncclAllReduce of the flat gradient bucket, ncclReduceScatter + ncclAllGather, or only the rows some "
+                         "rank touched (falls back to the dense all-reduce when more than 70 %% of the rows were)")
     ap.add_argument("--overlap", action="store_true",
                     help="pipelined exchange: the collective of step k runs on RCCL's stream while step k+1 renders into a "
                          "second bucket (gradients arrive one step late)")

@@ -19,6 +19,13 @@ collectives and as many views as possible behind each of them):
   * ``mode="all_reduce"``: one ``ncclAllReduce`` of the bucket.  ``mode="reduce_scatter"``: ``ncclReduceScatter`` ->
     optional per-shard hook (a sharded optimizer / clipping step sees only its 1/N of the rows) -> ``ncclAllGather``;
     same bytes on the links, and the hook's work is divided by N.
+  * ``mode="sparse"`` (SURVEY.md 8e "scaling risk"): only the rows some rank touched cross the links.  A Gaussian no view of
+    the batch sees has an all-zero gradient row on every rank, so leaving it out changes nothing: the ranks max-reduce a
+    P-byte "row touched" mask, gather the touched rows of every parameter into one compact buffer, sum-all-reduce that
+    (|U| x 59 floats instead of P x 59) and scatter the sums back.  Three collectives instead of one (the mask, the compact
+    rows; the row count needs one host read), so it only pays when a batch sees a fraction of the scene: above
+    ``dense_above`` (default 0.7 of the rows touched) the exchange falls back to the dense all-reduce.  The synthetic bench
+    scenes are seen whole from every view and always fall back.
   * ``PipelinedExchange``: two buckets; the collective of batch k runs on RCCL's stream while batch k+1 renders into
     the other bucket (forward AND backward: nothing of batch k+1 depends on it unless the caller says so by waiting).
     Gradients arrive one batch late: a caller that steps its optimizer with them trades one step of staleness for an
@@ -92,10 +99,16 @@ class GradExchange:
     pair) of the same length on every rank."""
 
     def __init__(self, bucket: FlatGradBucket, group=None, mode: str = "all_reduce",
-                 shard_hook: Optional[Callable[[torch.Tensor, int, int], None]] = None):
-        if mode not in ("all_reduce", "reduce_scatter"):
-            raise ValueError("mode must be 'all_reduce' or 'reduce_scatter'")
+                 shard_hook: Optional[Callable[[torch.Tensor, int, int], None]] = None, dense_above: float = 0.7):
+        if mode not in ("all_reduce", "reduce_scatter", "sparse"):
+            raise ValueError("mode must be 'all_reduce', 'reduce_scatter' or 'sparse'")
         self.bucket, self.group, self.mode, self.shard_hook = bucket, group, mode, shard_hook
+        self.dense_above = dense_above
+        self.last_rows_exchanged: Optional[int] = None     # sparse mode: rows that crossed the links in the last exchange (P = dense fallback)
+        if mode == "sparse":
+            rows = {p.shape[0] for p in bucket.params}
+            if len(rows) != 1 or any(p.dim() < 1 for p in bucket.params):
+                raise ValueError("mode='sparse' needs parameters that all have one row per Gaussian (same first dimension)")
         self._pending: List[object] = []
         self._shard: Optional[torch.Tensor] = None
         self.collectives_issued = 0            # diagnostics / tests: collectives started so far
@@ -107,7 +120,9 @@ class GradExchange:
                 self.shard_hook(self.bucket.flat, 0, self.bucket.numel)
             return
         flat = self.bucket.flat
-        if self.mode == "all_reduce":
+        if self.mode == "sparse" and self._start_sparse():
+            return
+        if self.mode in ("all_reduce", "sparse"):
             self._pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.collectives_issued += 1
             return
@@ -128,6 +143,37 @@ class GradExchange:
         self._pending.append(dist.all_gather_into_tensor(flat, shard, group=self.group, async_op=True))
         self.collectives_issued += 1
 
+    def _start_sparse(self) -> bool:
+        """Exchange only the rows touched on some rank.  Returns False when the dense all-reduce should run instead."""
+        views = self.bucket.views
+        P = views[0].shape[0]
+        touched = torch.zeros(P, dtype=torch.uint8, device=views[0].device)
+        for v in views:                                       # a row is touched if any parameter's gradient row is non-zero
+            touched |= (v.reshape(P, -1) != 0).any(dim=1).to(torch.uint8)
+        dist.all_reduce(touched, op=dist.ReduceOp.MAX, group=self.group)
+        self.collectives_issued += 1
+        idx = touched.nonzero(as_tuple=False).squeeze(1)      # the one host read: the compact collective's length
+        n = int(idx.numel())
+        if n > self.dense_above * P:
+            self.last_rows_exchanged = P
+            return False
+        self.last_rows_exchanged = n
+        if n == 0:
+            return True                                       # nobody saw anything: every row is zero everywhere
+        widths = [v[0].numel() for v in views]
+        compact = torch.empty(n, sum(widths), dtype=views[0].dtype, device=views[0].device)
+        off = 0
+        for v, w in zip(views, widths):
+            compact[:, off:off + w] = v.reshape(P, w).index_select(0, idx)
+            off += w
+        dist.all_reduce(compact, op=dist.ReduceOp.SUM, group=self.group)
+        self.collectives_issued += 1
+        off = 0
+        for v, w in zip(views, widths):
+            v.reshape(P, w).index_copy_(0, idx, compact[:, off:off + w])
+            off += w
+        return True
+
     def wait(self) -> None:
         for w in self._pending:
             w.wait()
@@ -145,11 +191,12 @@ class GradAllReducer:
     ``all_reduce()`` (or ``start()`` ... ``wait()``).  ``all_reduce()`` without a preceding ``begin()`` still works:
     gradients autograd put elsewhere are absorbed into the bucket first (one extra copy)."""
 
-    def __init__(self, params: Sequence[torch.Tensor], group=None, mode: str = "all_reduce", shard_hook=None):
+    def __init__(self, params: Sequence[torch.Tensor], group=None, mode: str = "all_reduce", shard_hook=None,
+                 dense_above: float = 0.7):
         self.params = list(params)
         self.group = group
         self.bucket = FlatGradBucket(self.params, _world(group))
-        self.exchange = GradExchange(self.bucket, group, mode, shard_hook)
+        self.exchange = GradExchange(self.bucket, group, mode, shard_hook, dense_above)
 
     def begin(self) -> None:
         self.bucket.zero_()

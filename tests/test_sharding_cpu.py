@@ -81,7 +81,7 @@ def _worker(rank, world, port, out, n_views, mode):
         res = r.step(cams)
     assert res["views"] == shard_views(len(cams), rank, world)
     # ONE exchange per step whatever this rank rendered (no view at all included): 1 all-reduce, or 1 reduce-scatter + 1 all-gather
-    assert r.reducer.exchange.collectives_issued == 2 * (1 if mode == "all_reduce" else 2)
+    assert r.reducer.exchange.collectives_issued == 2 * (1 if mode == "all_reduce" else 2)      # sparse: mask + rows (or dense)
     assert r.reducer.bucket.bound(), "p.grad is no longer a view of the flat bucket"
     if rank == 0:
         torch.save({"grads": [p.grad.clone() for p in params], "loss": res["loss_sum"]}, out)
@@ -113,6 +113,7 @@ def _single_process_reference(n_views):
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("n_views,mode", [(5, "all_reduce"),        # V = 3 and 2 views behind one exchange (uneven split)
                                           (5, "reduce_scatter"),    # the same through reduce-scatter + all-gather
+                                          (5, "sparse"),            # only the rows some rank touched (here: all -> dense fallback)
                                           (1, "all_reduce")])       # fewer views than ranks: rank 1 renders nothing
 def test_two_rank_sum_equals_single_process(tmp_path, n_views, mode):
     out = str(tmp_path / "rank0.pt")
@@ -288,3 +289,50 @@ def test_densification_stats_match_single_process(tmp_path):
     assert torch.allclose(got["accum"], pc.xyz_gradient_accum, rtol=1e-6, atol=1e-6)
     assert torch.equal(got["denom"], pc.denom) and torch.equal(got["radii"], pc.max_radii2D)
 
+
+
+def _sparse_worker(rank, world, port, out):
+    """mode="sparse": rows no rank touched stay home.  Rank 0 touches rows 0..39 and 100..119, rank 1 rows 30..59: the union
+    (80 of 320 rows) is what crosses the links, the result equals the dense sum bit for bit (same two addends per element);
+    with dense_above = 0.2 the same gradients take the dense all-reduce instead."""
+    _setup(rank, world, port)
+    from bags_raster.sharding import GradAllReducer
+    g = torch.Generator().manual_seed(11 + rank)
+    P = 320
+    shapes = [(P, 3), (P, 3), (P, 4), (P, 1), (P, 4, 3)]
+    rows = torch.zeros(P, dtype=torch.bool)
+    if rank == 0:
+        rows[0:40] = True; rows[100:120] = True
+    else:
+        rows[30:60] = True
+    results = {}
+    for tag, dense_above in (("sparse", 0.7), ("fallback", 0.2)):
+        params = [torch.zeros(s, requires_grad=True) for s in shapes]
+        red = GradAllReducer(params, mode="sparse", dense_above=dense_above)
+        red.begin()
+        local = []
+        for p in params:
+            gr = torch.randn(p.shape, generator=torch.Generator().manual_seed(5 + rank + p.dim())) * rows.view(-1, *([1] * (p.dim() - 1)))
+            p.grad.add_(gr)
+            local.append(gr)
+        red.all_reduce()
+        results[tag] = dict(grads=[p.grad.clone() for p in params], rows=red.exchange.last_rows_exchanged,
+                            collectives=red.exchange.collectives_issued)
+        # reference: plain dense sum of both ranks' local gradients
+        for p, gr in zip(params, local):
+            ref = gr.clone()
+            dist.all_reduce(ref)
+            assert torch.equal(ref, p.grad), tag
+    assert results["sparse"]["rows"] == 80 and results["sparse"]["collectives"] == 2       # mask + compact rows
+    assert results["fallback"]["rows"] == P and results["fallback"]["collectives"] == 2     # mask + dense bucket
+    if rank == 0:
+        torch.save({k: v["rows"] for k, v in results.items()}, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sparse_exchange_moves_only_touched_rows(tmp_path):
+    out = str(tmp_path / "sparse.pt")
+    port = 29500 + ((os.getpid() + 401) % 500)
+    mp.spawn(_sparse_worker, args=(2, port, out), nprocs=2, join=True)
+    assert torch.load(out) == {"sparse": 80, "fallback": 320}
