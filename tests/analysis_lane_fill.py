@@ -5,7 +5,7 @@ walks that block's list 16 splats per step; a wave runs max over its four rows o
 This script rebuilds the per-(tile, chunk, block) list lengths from the oracle's sorted lists and the kernel's reach-mask
 rule and prints how many of the issued lane slots hold a live (block, splat) pair under a few assignment policies.
 
-usage: python tests/analysis_lane_fill.py [P] [W] [H] [sm]
+usage: python tests/analysis_lane_fill.py [--ring] [P] [W] [H] [sm]
 """
 import os
 import sys
@@ -70,6 +70,9 @@ def main():
     X0, Y0 = (tile % gx) * 16.0, (tile // gx) * 16.0
     m = reach_masks(xy[pl, 0], xy[pl, 1], conic[pl, 0], conic[pl, 1], conic[pl, 2], op[pl], X0, Y0)
     print(f"P={P} {W}x{H} sm={sm}: I={I}, instances/tile mean {n_t.mean():.0f}, blocks reached per instance {m.sum(1).mean():.2f}")
+    if globals().get("_RING"):
+        ring_policies((m * (1 << np.arange(16))).sum(1).astype(np.uint16), ranges)
+        return
     for chunk in (128, 256):
         ck = (n_t[tile] - 1 - pos) // chunk                    # chunks are cut from the back of the list
         nck = int(ck.max()) + 1
@@ -95,5 +98,50 @@ def main():
                   f"length-ranked rows {live / issued_sorted:.3f} (slowest / mean {skew_sorted:.2f})")
 
 
+def ring_policies(bits, ranges):
+    """--ring: what carrying a block's partial 16-lane group over into the next chunk would buy (round 3, asked for by the
+    round-2 review).  Ring of R staged slots; the last D of them stay staged into the next round ("tail zone"); a block
+    walks its entries in the body and takes entries from the tail zone only to complete a group of 16.  D = 0 is the
+    kernel's scheme (R = BCHUNK).  Prints wave steps (max over a wave's four rows per round), rounds and lane fill."""
+    quad = [[qy * 8 + qx * 2, qy * 8 + qx * 2 + 1, qy * 8 + qx * 2 + 4, qy * 8 + qx * 2 + 5] for qy in range(2) for qx in range(2)]
+
+    def sim(R, D):
+        steps = rounds = live = 0
+        for t in range(ranges.shape[0]):
+            lo, hi = ranges[t]
+            n = hi - lo
+            if n == 0:
+                continue
+            mk = bits[lo:hi][::-1]                              # walk order: deepest first
+            mb = ((mk[:, None] >> np.arange(16)) & 1).astype(bool)
+            cum = np.concatenate([np.zeros((1, 16), np.int64), np.cumsum(mb, 0)])
+            c = np.zeros(16, np.int64)                          # entries processed so far, per block
+            F = 0
+            while True:
+                E = min(n, F + R)
+                last = E == n
+                body = E if last else E - D
+                avail_body = np.maximum(cum[body] - c, 0)
+                avail_all = cum[E] - c
+                take = avail_all if last else np.where(cum[body] - c < 0, 0, avail_body + np.minimum((-avail_body) % 16, avail_all - avail_body))
+                g = -(-take // 16)
+                steps += sum(int(g[q].max()) for q in quad)
+                live += int(take.sum())
+                c = c + take
+                rounds += 1
+                if last:
+                    break
+                F = body
+        return steps, rounds, live
+    for R, D in ((128, 0), (128, 16), (128, 32), (128, 48), (128, 64), (64, 0), (96, 0), (160, 0), (176, 0), (256, 0), (10 ** 9, 0)):
+        st, r, l = sim(R, D)
+        print(f"  ring R={R if R < 10 ** 9 else 'whole tile'} D={D}: wave steps {st}, rounds {r}, lane fill {l / (st * 64):.3f}")
+
+
 if __name__ == "__main__":
+    if "--ring" in sys.argv:
+        sys.argv.remove("--ring")
+        _RING = True
+    else:
+        _RING = False
     main()
