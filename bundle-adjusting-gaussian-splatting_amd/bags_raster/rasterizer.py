@@ -233,12 +233,17 @@ def _await_count(pinned: torch.Tensor, stream) -> int:
     forward costs ~6 us of idle device per frame, tools/trace_gaps.sh): the word starts as _NO_COUNT and is written by the
     counting kernel itself (system-scope store into pinned memory) or by the copy behind it, so the host simply looks at it;
     by the time a backward starts it has almost always arrived."""
-    for spin in range(2000):
+    # busy polling, no sleep: the word normally arrives within ~0.1 ms of the forward starting to execute, and a sleep of
+    # "20 us" comes back after 60 us .. 1 ms -- long enough for the device to run dry behind it (25 us of idle in front of every
+    # blend_bwd in one of two otherwise identical traces, tools/trace_gaps.sh).  A queue so deep that the count is still
+    # missing after ~5 ms of polling is waited for with a stream synchronise instead.
+    t_end = time.perf_counter() + 5e-3
+    while True:
         n = int(pinned[0].item()) & 0xFFFFFFFF
         if n != _NO_COUNT:
             return n
-        if spin > 50:
-            time.sleep(20e-6)
+        if time.perf_counter() > t_end:
+            break
     stream.synchronize()                                     # the forward is done: the word must be there
     n = int(pinned[0].item()) & 0xFFFFFFFF
     if n == _NO_COUNT:

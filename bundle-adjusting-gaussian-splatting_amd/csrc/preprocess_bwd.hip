@@ -106,7 +106,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                       const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
                       const float* __restrict__ projmatrix, const float* __restrict__ intrinsic,
                       const float* __restrict__ campos_p,
-                      const float4* __restrict__ g2d,
+                      const float4* __restrict__ g2d, const float* __restrict__ shjac,
                       const float* __restrict__ partials, float* __restrict__ pose_slab,
                       float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_densify,
                       float* __restrict__ g_shs, float* __restrict__ g_colors, float* __restrict__ g_opac,
@@ -126,26 +126,17 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                 sf2 = shift_factors ? shift_factors[2] : 0.0f;
     const float cpx = campos_p[0], cpy = campos_p[1], cpz = campos_p[2];
 #if SH_STAGE
-    // The SH rows (and later the SH-gradient rows) of the workgroup's 256 Gaussians are ONE contiguous 48 KB span.  A
-    // thread reading or writing its own 192-byte row 16 bytes at a time puts 64 separate requests per instruction on the
-    // L2 channels (24 such instructions per Gaussian); here the span crosses the memory system as whole lines -- thread
-    // t moves float4 number k*256 + t -- and the per-row access happens in LDS.  The loads are issued now, next to the
-    // geometry inputs, and wait in LDS (no registers) until the colour section.
-    __shared__ float4 srow[256 * 12];
-    const bool stage = (M == 16) && (colors_precomp == nullptr) && (shs != nullptr);      // uniform
+    // The SH-GRADIENT rows of the workgroup's 256 Gaussians are ONE contiguous 48 KB span of dL/dshs.  A thread writing its
+    // own 192-byte row 16 bytes at a time puts 64 separate requests per instruction on the L2 channels (12 such instructions
+    // per Gaussian), so the span leaves as whole lines: thread t stores float4 number k * 256 + t of it.  A gradient row is an
+    // outer product, dL/dsh[t][c] = basis_t x dL/dcolour_c, so what the storing thread needs of ANOTHER thread's Gaussian is
+    // 16 + 3 floats, not 48: 20 KB of LDS per workgroup instead of 48 (round 2 staged the finished rows; and up to round 2
+    // the SH rows themselves came IN through the same 48 KB -- since round 3 the forward leaves d(colour)/d(direction) behind,
+    // 48 bytes per Gaussian, and the backward does not read the 192-byte row a second time).  With 108 VGPRs that makes four
+    // workgroups per CU (three before, both by registers and by LDS).
+    __shared__ float srow[256][20];                     // basis[16] (zero beyond the active degree), dL/dcolour[3], pad
+    const bool stage = (M == 16) && (colors_precomp == nullptr) && (shs != nullptr) && (g_shs != nullptr);      // uniform
     const size_t base4 = (size_t)blockIdx.x * (256 * 12), lim4 = (size_t)P * 12;
-    if (stage) {
-        // global -> LDS without registers (global_load_lds_dwordx4: the wave's 64 x 16 bytes land contiguously at the
-        // wave-uniform LDS address, which is exactly srow[t * 256 + wave * 64 + lane]).  Rows past P are read from the last
-        // valid float4 instead (never used, never written back).
-        const float4* s4g = reinterpret_cast<const float4*>(shs);
-#pragma unroll
-        for (int t = 0; t < 12; ++t) {
-            const size_t e = base4 + (size_t)t * 256 + threadIdx.x;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s4g + (e < lim4 ? e : lim4 - 1)),
-                                             (__attribute__((address_space(3))) void*)(&srow[t * 256 + (threadIdx.x & ~63)]), 16, 0, 0);
-        }
-    }
 #endif
 
     float pose[POSE_VALS];
@@ -172,12 +163,15 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         in_s0 = scales[3 * ic + 0]; in_s1 = scales[3 * ic + 1]; in_s2 = scales[3 * ic + 2];
         in_q = reinterpret_cast<const float4*>(rotations)[ic];
     }
+    float mj[9];                                                                            // K1's d(colour)/d(direction) (SH path)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) mj[t] = shjac[9 * ic + t];
     const float4* sm = reinterpret_cast<const float4*>(partials) + 3 * ic;                  // K8a's per-Gaussian sums
     const float4 sm_a = sm[0], sm_b = sm[1], sm_c = sm[2];
     // every one of those loads is IN FLIGHT before the first of them is waited for (the compiler otherwise sinks the ones only
     // the visible branch needs behind the visibility test: one more round trip per group)
     asm volatile("" :: "v"(q3.y), "v"(co.x), "v"(x), "v"(y), "v"(z), "v"(in_s0), "v"(in_s1), "v"(in_s2), "v"(in_q.x), "v"(in_c[0]),
-                 "v"(in_c[3]), "v"(sm_a.x), "v"(sm_b.x), "v"(sm_c.x));
+                 "v"(in_c[3]), "v"(sm_a.x), "v"(sm_b.x), "v"(sm_c.x), "v"(mj[0]), "v"(mj[3]), "v"(mj[6]));
     const bool live = (i < P) && (__float_as_uint(q3.y) > 0);
 
     if (live) {
@@ -353,12 +347,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         if (lane == 0) wpose[wave][t] = r;
     }
     float cp0 = 0.f, cp1 = 0.f, cp2 = 0.f;            // dL/dcampos of this Gaussian
-#if SH_STAGE
-    if (stage) {                                     // every wave's LDS-DMA pieces have landed, then the workgroup meets
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-#endif
+
     if (live) {
         // ---- colour
         if (!colors_precomp) {
@@ -369,89 +358,92 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
             const float ex = x - cpx, ey = y - cpy, ez = z - cpz;
             const float il = 1.0f / sqrtf(ex * ex + ey * ey + ez * ez);
             const float ux_ = ex * il, uy_ = ey * il, uz_ = ez * il;
-            float bs[16], bx[16], by[16], bz[16];
+            float bs[16];
             sh_basis(deg, ux_, uy_, uz_, bs);
-            sh_basis_grad(deg, ux_, uy_, uz_, bx, by, bz);
             const int nb = (deg + 1) * (deg + 1);
-            const float* sh = shs + (size_t)i * M * 3;
             float* gsh = g_shs ? g_shs + (size_t)i * M * 3 : nullptr;
-            float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+            // dL/d(direction) = M^T dL/dcolour, M from the forward (clamped channels carry a zero dL/dcolour)
+            const float ddx = mj[0] * drgb[0] + mj[1] * drgb[1] + mj[2] * drgb[2];
+            const float ddy = mj[3] * drgb[0] + mj[4] * drgb[1] + mj[5] * drgb[2];
+            const float ddz = mj[6] * drgb[0] + mj[7] * drgb[1] + mj[8] * drgb[2];
+            // dL/dsh[t][c] = basis_t dL/dcolour_c: no input row needed
             if (M == 16) {
-                // 192-byte rows, 16-byte aligned: four coefficients (12 floats) per step as 3 dwordx4 loads / stores
 #if SH_STAGE
-                const float4* s4 = &srow[threadIdx.x * 12];          // staged above; published by the barrier in 5a
-                float4* g4 = &srow[threadIdx.x * 12];                // the gradient row replaces it (each element is read first)
+                if (stage) {
+                    float4* d4 = reinterpret_cast<float4*>(&srow[threadIdx.x][0]);
+                    d4[0] = make_float4(bs[0], nb > 1 ? bs[1] : 0.f, nb > 1 ? bs[2] : 0.f, nb > 1 ? bs[3] : 0.f);
+                    d4[1] = make_float4(nb > 4 ? bs[4] : 0.f, nb > 4 ? bs[5] : 0.f, nb > 4 ? bs[6] : 0.f, nb > 4 ? bs[7] : 0.f);
+                    d4[2] = make_float4(nb > 4 ? bs[8] : 0.f, nb > 9 ? bs[9] : 0.f, nb > 9 ? bs[10] : 0.f, nb > 9 ? bs[11] : 0.f);
+                    d4[3] = make_float4(nb > 9 ? bs[12] : 0.f, nb > 9 ? bs[13] : 0.f, nb > 9 ? bs[14] : 0.f, nb > 9 ? bs[15] : 0.f);
+                    d4[4] = make_float4(drgb[0], drgb[1], drgb[2], 0.f);
+                }
 #else
-                const float4* s4 = reinterpret_cast<const float4*>(sh);
                 float4* g4 = reinterpret_cast<float4*>(gsh);
-#endif
-                // the whole row is requested before the first coefficient is touched: with a load -> compute -> store
-                // step per block of four coefficients every step waited for its loads AND (vmcnt counts stores on this
-                // part) for the previous step's stores, four serial round trips per Gaussian
-                float4 wrow[12];
+                if (g_shs) {
 #pragma unroll
-                for (int t = 0; t < 12; ++t) wrow[t] = (4 * (t / 3) < nb) ? s4[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int tb = 0; tb < 4; ++tb) {
+                        float o[12];
 #pragma unroll
-                for (int tb = 0; tb < 4; ++tb) {
-                    float c[12], o[12];
-                    if (tb * 4 < nb) {
-                        const float4 w0 = wrow[3 * tb], w1 = wrow[3 * tb + 1], w2 = wrow[3 * tb + 2];
-                        c[0] = w0.x; c[1] = w0.y; c[2] = w0.z; c[3] = w0.w; c[4] = w1.x; c[5] = w1.y; c[6] = w1.z; c[7] = w1.w;
-                        c[8] = w2.x; c[9] = w2.y; c[10] = w2.z; c[11] = w2.w;
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < 12; ++u) c[u] = 0.f;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int t = tb * 4 + u;
-                        const bool on = t < nb;
-                        const float w = c[3 * u] * drgb[0] + c[3 * u + 1] * drgb[1] + c[3 * u + 2] * drgb[2];
-                        if (on) { ddx += bx[t] * w; ddy += by[t] * w; ddz += bz[t] * w; }
-                        o[3 * u] = on ? bs[t] * drgb[0] : 0.f; o[3 * u + 1] = on ? bs[t] * drgb[1] : 0.f; o[3 * u + 2] = on ? bs[t] * drgb[2] : 0.f;
-                    }
-                    if (g4) {
+                        for (int u = 0; u < 4; ++u) {
+                            const int t = tb * 4 + u;
+                            const bool on = t < nb;
+                            o[3 * u] = on ? bs[t] * drgb[0] : 0.f; o[3 * u + 1] = on ? bs[t] * drgb[1] : 0.f; o[3 * u + 2] = on ? bs[t] * drgb[2] : 0.f;
+                        }
                         g4[3 * tb] = make_float4(o[0], o[1], o[2], o[3]);
                         g4[3 * tb + 1] = make_float4(o[4], o[5], o[6], o[7]);
                         g4[3 * tb + 2] = make_float4(o[8], o[9], o[10], o[11]);
                     }
                 }
-            } else
+#endif
+            } else if (gsh)
             for (int t = 0; t < M; ++t) {
-                float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-                if (t < nb) {
-                    const float w = sh[3 * t] * drgb[0] + sh[3 * t + 1] * drgb[1] + sh[3 * t + 2] * drgb[2];
-                    ddx += bx[t] * w; ddy += by[t] * w; ddz += bz[t] * w;
-                    o0 = bs[t] * drgb[0]; o1 = bs[t] * drgb[1]; o2 = bs[t] * drgb[2];
-                }
-                if (gsh) { gsh[3 * t] = o0; gsh[3 * t + 1] = o1; gsh[3 * t + 2] = o2; }
+                const bool on = t < nb;
+                gsh[3 * t] = on ? bs[t] * drgb[0] : 0.f; gsh[3 * t + 1] = on ? bs[t] * drgb[1] : 0.f; gsh[3 * t + 2] = on ? bs[t] * drgb[2] : 0.f;
             }
             const float dot = ux_ * ddx + uy_ * ddy + uz_ * ddz;
             const float px_ = (ddx - ux_ * dot) * il, py_ = (ddy - uy_ * dot) * il, pz_ = (ddz - uz_ * dot) * il;
             dmx += px_; dmy += py_; dmz += pz_;
             cp0 = -px_; cp1 = -py_; cp2 = -pz_;
         }
-    } else if (i < P && g_shs && !colors_precomp) {
+    } else if (i < P && g_shs && !colors_precomp) {       // a culled Gaussian: its gradient row is zero
         float* gsh = g_shs + (size_t)i * M * 3;
         if (M == 16) {
 #if SH_STAGE
-            float4* g4 = &srow[threadIdx.x * 12];
+            if (stage) {
+                float4* d4 = reinterpret_cast<float4*>(&srow[threadIdx.x][0]);
+#pragma unroll
+                for (int t = 0; t < 5; ++t) d4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #else
             float4* g4 = reinterpret_cast<float4*>(gsh);
-#endif
 #pragma unroll
             for (int t = 0; t < 12; ++t) g4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
         } else
             for (int t = 0; t < 3 * M; ++t) gsh[t] = 0.f;
     }
 #if SH_STAGE
-    if (stage && g_shs) {                            // the workgroup's gradient rows leave as whole lines
+    if (stage) {                                     // the workgroup's gradient rows leave as whole lines
         __syncthreads();
         float4* g4g = reinterpret_cast<float4*>(g_shs);
 #pragma unroll
-        for (int t = 0; t < 12; ++t) {
-            const size_t e = base4 + (size_t)t * 256 + threadIdx.x;
-            if (e < lim4) g4g[e] = srow[t * 256 + threadIdx.x];
+        for (int k = 0; k < 12; ++k) {
+            const u32 el = (u32)k * 256u + threadIdx.x;          // float4 number inside the workgroup's span
+            const size_t e = base4 + el;
+            if (e < lim4) {
+                const u32 row = el / 12u, j = el - row * 12u;     // Gaussian of the workgroup, float4 of its row
+                const float* sr = &srow[row][0];
+                // floats 4j .. 4j+3 of the row: float f is coefficient f / 3, channel f % 3 (plain indexed LDS reads: a three-way
+                // select on 4j % 3 came out of the compiler with one branch using the wrong operand)
+                float o4[4];
+#pragma unroll
+                for (u32 u = 0; u < 4; ++u) {
+                    const u32 fl = 4u * j + u, t = fl / 3u, c = fl - 3u * t;
+                    o4[u] = sr[t] * sr[16u + c];
+                }
+                const float4 o = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                g4g[e] = o;
+            }
         }
     }
 #endif
@@ -547,7 +539,7 @@ hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, co
 #define PRE_BWD_LAUNCH(COV)     hipLaunchKernelGGL(preprocess_bwd_kernel<COV>, dim3(nb), dim3(256), 0, st, P, s.sh_coeffs, s.sh_degree, s.image_width, \
                        s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, in.means3D, in.shift_factors, in.shs, \
                        in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, s.viewmatrix, s.projmatrix, \
-                       s.intrinsic, s.campos, g.g2d, partials, \
+                       s.intrinsic, s.campos, g.g2d, g.shjac, partials, \
                        pose_slab, a.grad_means3D, a.grad_means2D, a.grad_means2D_densify, a.grad_shs, \
                        a.grad_colors_precomp, a.grad_opacities, a.grad_scales, a.grad_rotations, a.grad_cov3D_precomp);
     if (in.cov3D_precomp) { PRE_BWD_LAUNCH(true) } else { PRE_BWD_LAUNCH(false) }

@@ -48,7 +48,7 @@ __device__ __forceinline__ u64 tile_reach(float px, float py, float a, float b, 
     return keep;
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 5)     // 5 waves per SIMD (<= 96 VGPRs): this kernel lives on occupancy
 preprocess_fwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod, int depth_mode, int tile_bounds,
                       const float* __restrict__ means3D, const float* __restrict__ means2D,
                       const float* __restrict__ shift_factors, const float* __restrict__ shs,
@@ -57,7 +57,7 @@ preprocess_fwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                       const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
                       const float* __restrict__ projmatrix, const float* __restrict__ intrinsic,
                       const float* __restrict__ campos_p,
-                      u32* __restrict__ depth_key, float4* __restrict__ g2d, uint2* __restrict__ rect_out,
+                      u32* __restrict__ depth_key, float4* __restrict__ g2d, float* __restrict__ shjac, uint2* __restrict__ rect_out,
                       u32* __restrict__ tiles_touched, u64* __restrict__ keep_out, int32_t* __restrict__ radii,
                       float* __restrict__ mean2D_out)
 {
@@ -224,12 +224,44 @@ preprocess_fwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                     } else {
                         const float dx = x - cam.campos[0], dy = y - cam.campos[1], dz = z - cam.campos[2];
                         const float dl = sqrtf(dx * dx + dy * dy + dz * dz);
-                        float basis[16];
-                        sh_basis(deg, dx / dl, dy / dl, dz / dl, basis);
+                        const float ux = dx / dl, uy = dy / dl, uz = dz / dl;
                         const int nb = (deg + 1) * (deg + 1);
                         const float* sh = shs + (size_t)i * M * 3;
                         r = 0.f; g = 0.f; b = 0.f;
-                        if (M == 16) {             // 192 B per Gaussian, 16-byte aligned: 12 dwordx4 loads
+                        // d(colour)/d(direction): the backward multiplies it with dL/dcolour and never reads the SH row again
+                        float mxr = 0.f, mxg = 0.f, mxb = 0.f, myr = 0.f, myg = 0.f, myb = 0.f, mzr = 0.f, mzg = 0.f, mzb = 0.f;
+                        // one coefficient at a time, its basis value and the three derivatives formed right where they are used
+                        // (as arrays for all 16 coefficients they were 64 more live registers: 140 VGPRs, 3 waves per SIMD for 5)
+#define SH_TERM(t, B, GX, GY, GZ)                                                                                      \
+                        if ((t) < nb) {                                                                               \
+                            const float k0 = CO(3 * (t)), k1 = CO(3 * (t) + 1), k2 = CO(3 * (t) + 2);                  \
+                            const float bv = (B), gx_ = (GX), gy_ = (GY), gz_ = (GZ);                                  \
+                            r += bv * k0; g += bv * k1; b += bv * k2;                                                  \
+                            mxr += gx_ * k0; mxg += gx_ * k1; mxb += gx_ * k2;                                         \
+                            myr += gy_ * k0; myg += gy_ * k1; myb += gy_ * k2;                                         \
+                            mzr += gz_ * k0; mzg += gz_ * k1; mzb += gz_ * k2;                                         \
+                        }
+#define SH_ALL()                                                                                                       \
+                        {                                                                                             \
+                            const float xx = ux * ux, yy = uy * uy, zz = uz * uz, xy = ux * uy, yz = uy * uz, xz = ux * uz; \
+                            SH_TERM(0, SH_C0, 0.f, 0.f, 0.f)                                                           \
+                            SH_TERM(1, -SH_C1 * uy, 0.f, -SH_C1, 0.f)                                                  \
+                            SH_TERM(2, SH_C1 * uz, 0.f, 0.f, SH_C1)                                                    \
+                            SH_TERM(3, -SH_C1 * ux, -SH_C1, 0.f, 0.f)                                                  \
+                            SH_TERM(4, SH_C2_0 * xy, SH_C2_0 * uy, SH_C2_0 * ux, 0.f)                                  \
+                            SH_TERM(5, SH_C2_1 * yz, 0.f, SH_C2_1 * uz, SH_C2_1 * uy)                                  \
+                            SH_TERM(6, SH_C2_2 * (2.0f * zz - xx - yy), SH_C2_2 * -2.0f * ux, SH_C2_2 * -2.0f * uy, SH_C2_2 * 4.0f * uz) \
+                            SH_TERM(7, SH_C2_3 * xz, SH_C2_3 * uz, 0.f, SH_C2_3 * ux)                                  \
+                            SH_TERM(8, SH_C2_4 * (xx - yy), SH_C2_4 * 2.0f * ux, SH_C2_4 * -2.0f * uy, 0.f)            \
+                            SH_TERM(9, SH_C3_0 * uy * (3.0f * xx - yy), SH_C3_0 * 6.0f * xy, SH_C3_0 * (3.0f * xx - 3.0f * yy), 0.f) \
+                            SH_TERM(10, SH_C3_1 * xy * uz, SH_C3_1 * yz, SH_C3_1 * xz, SH_C3_1 * xy)                   \
+                            SH_TERM(11, SH_C3_2 * uy * (4.0f * zz - xx - yy), SH_C3_2 * -2.0f * xy, SH_C3_2 * (4.0f * zz - xx - 3.0f * yy), SH_C3_2 * 8.0f * yz) \
+                            SH_TERM(12, SH_C3_3 * uz * (2.0f * zz - 3.0f * xx - 3.0f * yy), SH_C3_3 * -6.0f * xz, SH_C3_3 * -6.0f * yz, SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy)) \
+                            SH_TERM(13, SH_C3_4 * ux * (4.0f * zz - xx - yy), SH_C3_4 * (4.0f * zz - 3.0f * xx - yy), SH_C3_4 * -2.0f * xy, SH_C3_4 * 8.0f * xz) \
+                            SH_TERM(14, SH_C3_5 * uz * (xx - yy), SH_C3_5 * 2.0f * xz, SH_C3_5 * -2.0f * yz, SH_C3_5 * (xx - yy)) \
+                            SH_TERM(15, SH_C3_6 * ux * (xx - 3.0f * yy), SH_C3_6 * (3.0f * xx - 3.0f * yy), SH_C3_6 * -6.0f * xy, 0.f) \
+                        }
+                        if (M == 16) {             // 192 B per Gaussian, 16-byte aligned: 12 dwordx4 loads, all requested at once
                             float c[48];
                             const float4* s4 = reinterpret_cast<const float4*>(sh);
 #pragma unroll
@@ -237,14 +269,19 @@ preprocess_fwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                                 float4 w = s4[t];
                                 c[4 * t] = w.x; c[4 * t + 1] = w.y; c[4 * t + 2] = w.z; c[4 * t + 3] = w.w;
                             }
-#pragma unroll
-                            for (int t = 0; t < 16; ++t)
-                                if (t < nb) { r += basis[t] * c[3 * t]; g += basis[t] * c[3 * t + 1]; b += basis[t] * c[3 * t + 2]; }
+#define CO(k) c[k]
+                            SH_ALL()
+#undef CO
                         } else {
-                            for (int t = 0; t < nb; ++t) {
-                                r += basis[t] * sh[3 * t]; g += basis[t] * sh[3 * t + 1]; b += basis[t] * sh[3 * t + 2];
-                            }
+#define CO(k) sh[k]
+                            SH_ALL()
+#undef CO
                         }
+#undef SH_ALL
+#undef SH_TERM
+                        // 9 floats = 36 bytes per Gaussian, three 12-byte stores
+                        float* mj = shjac + 9 * (size_t)i;
+                        mj[0] = mxr; mj[1] = mxg; mj[2] = mxb; mj[3] = myr; mj[4] = myg; mj[5] = myb; mj[6] = mzr; mj[7] = mzg; mj[8] = mzb;
                         r += 0.5f; g += 0.5f; b += 0.5f;
                         if (r < 0.f) { cl |= 1u; r = 0.f; }
                         if (g < 0.f) { cl |= 2u; g = 0.f; }
@@ -280,6 +317,6 @@ hipError_t launch_preprocess_fwd(const BagsSettings& s, const BagsInputs& in, co
                        s.image_width, s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, s.depth_key, s.tile_bounds,
                        in.means3D, in.means2D, in.shift_factors, in.shs, in.colors_precomp, in.opacities, in.scales,
                        in.rotations, in.cov3D_precomp, s.viewmatrix, s.projmatrix, s.intrinsic, s.campos,
-                       g.depth_key, g.g2d, g.rect, g.tiles_touched, g.keep, radii, mean2D);
+                       g.depth_key, g.g2d, g.shjac, g.rect, g.tiles_touched, g.keep, radii, mean2D);
     return hipGetLastError();
 }
