@@ -261,6 +261,9 @@ def main():
     ap.add_argument("--views-per-exchange", type=int, default=0,
                     help="views every rank renders (fwd+bwd, gradients accumulated locally) behind ONE exchange; 0 = 1 view at "
                          "every --gpus N (a second leg with 4 views is timed in the same run and reported as 'v4')")
+    ap.add_argument("--bucket-always", action="store_true",
+                    help="N > 1, one view per exchange: go through the flat bucket (zero + accumulate) instead of all-reducing the "
+                         "op's own gradient buffer")
     ap.add_argument("--no-v4-leg", action="store_true", help="skip the second timed leg with 4 views per rank per exchange")
     ap.add_argument("--exchange", default="all_reduce", choices=("all_reduce", "reduce_scatter", "sparse"),
                     help="one ncclAllReduce of the flat gradient bucket, ncclReduceScatter + ncclAllGather, or only the rows some "
@@ -331,9 +334,21 @@ def main():
                 red = GradAllReducer(params, mode=args.exchange)
         evs = []
 
+        single = (red is not None and v_per_rank == 1 and args.exchange == "all_reduce" and not args.bucket_always)
+
         def full_step():
             if red is None and pip is None:
                 return fns[0](True)                           # single view, single GPU: autograd hands the gradients over as they are
+            if single:
+                # one view per rank per exchange: the collective runs on the buffer the op's backward carved its gradients
+                # from (no bucket zero / accumulate passes: 85 us per step at 500 k Gaussians)
+                radii_ = fns[0](True)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                red.all_reduce_single_view()
+                e1.record()
+                evs.append((e0, e1))
+                return radii_
             (pip or red).begin()                              # zero the bucket, p.grad = its slices
             for f_ in fns:
                 radii_ = f_(False)                            # gradients of the rank's views accumulate in the bucket
@@ -454,9 +469,12 @@ def main():
                        "P": P, "visible_G": G, "instances_I": I, "tile_bounds": args.tile_bounds, "binning": args.binning, "width": W, "height": H,
                        "views_per_rank_per_exchange": V,
                        "settle_steps": max(0, args.settle_steps) // max(1, V) * max(1, V),   # untimed view renders before the warm-up
-                       "parallelism": f"view-sharded x{world}" + (f", {args.exchange} of the flat Gaussian-gradient bucket"
-                                                                  f"{' (pipelined, one step late)' if args.overlap else ''}"
-                                                                  if world > 1 else "")},
+                       "parallelism": f"view-sharded x{world}" + (
+                           (", all_reduce of the buffer the op's backward carves its Gaussian gradients from (one view per exchange: "
+                            "no bucket zero / accumulate)"
+                            if (V == 1 and args.exchange == "all_reduce" and not args.bucket_always and not args.overlap) else
+                            f", {args.exchange} of the flat Gaussian-gradient bucket"
+                            f"{' (pipelined, one step late)' if args.overlap else ''}") if world > 1 else "")},
             "instances_per_s": world * V * I * args.steps / elapsed,
             "ms_per_view": ms_step / V,
             "ms_per_step_cold": cold / args.steps * 1e3,    # W warm-up + K timed steps from an idle device: no settle steps

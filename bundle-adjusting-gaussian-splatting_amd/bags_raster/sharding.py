@@ -189,7 +189,13 @@ class GradAllReducer:
 
     Usage per iteration: ``begin()`` (zero the bucket, bind ``p.grad``), any number of ``loss.backward()`` calls, then
     ``all_reduce()`` (or ``start()`` ... ``wait()``).  ``all_reduce()`` without a preceding ``begin()`` still works:
-    gradients autograd put elsewhere are absorbed into the bucket first (one extra copy)."""
+    gradients autograd put elsewhere are absorbed into the bucket first (one extra copy).
+
+    ``all_reduce_single_view()`` is the ONE-view-per-rank-per-exchange fast path (BASELINE configs 3-5): the rasterizer's
+    backward already carves its Gaussian gradients out of one buffer, autograd hands those tensors over as ``p.grad`` without
+    a copy, and the collective runs on that buffer as it is -- no bucket to zero (25 us at 500 k Gaussians), no accumulation
+    pass (60 us).  The caller guarantees that EVERY rank differentiated exactly one view through the op with ``p.grad``
+    cleared beforehand (the layout is then identical on all ranks); anything else raises instead of hanging a collective."""
 
     def __init__(self, params: Sequence[torch.Tensor], group=None, mode: str = "all_reduce", shard_hook=None,
                  dense_above: float = 0.7):
@@ -197,6 +203,22 @@ class GradAllReducer:
         self.group = group
         self.bucket = FlatGradBucket(self.params, _world(group))
         self.exchange = GradExchange(self.bucket, group, mode, shard_hook, dense_above)
+        self.single_view_collectives = 0
+
+    def all_reduce_single_view(self) -> None:
+        grads = [p.grad for p in self.params]
+        if any(g is None for g in grads):
+            raise RuntimeError("all_reduce_single_view: a parameter has no gradient (every rank must have rendered one view)")
+        st = grads[0].untyped_storage()
+        for g in grads:
+            if g.untyped_storage().data_ptr() != st.data_ptr() or not g.is_contiguous() or g.dtype != grads[0].dtype:
+                raise RuntimeError("all_reduce_single_view: the gradients are not views of one buffer (they did not come straight "
+                                   "from one rasterizer backward); use begin() ... all_reduce() instead")
+        if _world(self.group) == 1:
+            return
+        flat = torch.empty(0, dtype=grads[0].dtype, device=grads[0].device).set_(st, 0, (st.nbytes() // grads[0].element_size(),))
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.single_view_collectives += 1
 
     def begin(self) -> None:
         self.bucket.zero_()

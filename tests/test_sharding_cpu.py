@@ -336,3 +336,50 @@ def test_sparse_exchange_moves_only_touched_rows(tmp_path):
     port = 29500 + ((os.getpid() + 401) % 500)
     mp.spawn(_sparse_worker, args=(2, port, out), nprocs=2, join=True)
     assert torch.load(out) == {"sparse": 80, "fallback": 320}
+
+
+def _single_view_worker(rank, world, port, out):
+    """One view per rank per exchange without the bucket: the collective runs on the buffer the op's backward carved its
+    gradients from.  Equal to the bucket path bit for bit; a rank whose gradients are separate tensors raises."""
+    _setup(rank, world, port)
+    from bags_raster.sharding import GradAllReducer
+    scene, cams = _views_and_scene()
+    res = {}
+    for tag in ("bucket", "single"):
+        params = _params(scene)
+        render = _make_render_fn(params)
+        red = GradAllReducer(params)
+        if tag == "bucket":
+            red.begin()
+            render(cams[rank]).backward()
+            red.all_reduce()
+        else:
+            render(cams[rank]).backward()                  # p.grad = the op's carved views, handed over without a copy
+            red.all_reduce_single_view()
+            assert red.single_view_collectives == 1 and red.exchange.collectives_issued == 0
+        res[tag] = [p.grad.clone() for p in params]
+    for a, b in zip(res["bucket"], res["single"]):
+        assert torch.equal(a, b)
+    params = _params(scene)
+    for p in params:
+        p.grad = torch.zeros_like(p)                       # unrelated tensors: not one buffer
+    with pytest.raises(RuntimeError, match="not views of one buffer"):
+        GradAllReducer(params).all_reduce_single_view()
+    if rank == 0:
+        torch.save(res["single"], out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_single_view_exchange_runs_on_the_ops_own_gradient_buffer(tmp_path):
+    out = str(tmp_path / "single.pt")
+    port = 29500 + ((os.getpid() + 457) % 500)
+    mp.spawn(_single_view_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    scene, cams = _views_and_scene()
+    params = _params(scene)
+    render = _make_render_fn(params)
+    for c in cams[:2]:
+        render(c).backward()
+    for g2, p in zip(got, params):
+        assert (g2 - p.grad).norm().item() <= 1e-6 * max(p.grad.norm().item(), 1e-12)
