@@ -398,15 +398,19 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         // The per-(splat, block) work: one block row (4 pixels = two packed pairs) per step; four independent scan chains
         // interleave without pipeline bubbles.  `s` is the lane's splat, (bx0, by0) its block origin, pixb its block's
         // pixel pairs, `carry` marks the lane that holds the scan totals (the shallowest of its segment).
-        f2 a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10;
+        f2 a0, a1, a2, a6, a9, a10;
 #if SCALAR_ACC
         float sa3, sa4, sa5, sa7, sa8;
+#else
+        f2 a3, a4, a5, a7, a8;
 #endif
         auto block_rows = [&](auto skip_nc_tag, const ChunkRec& s, const bool live, const float bx0, const float by0, float4* pixb, const bool carry) {
             constexpr bool SKIP_NC = decltype(skip_nc_tag)::value;
-            a0 = (f2){0.f, 0.f}; a1 = a0; a2 = a0; a3 = a0; a4 = a0; a5 = a0; a6 = a0; a7 = a0; a8 = a0; a9 = a0; a10 = a0;
+            a0 = (f2){0.f, 0.f}; a1 = a0; a2 = a0; a6 = a0; a9 = a0; a10 = a0;
 #if SCALAR_ACC
             sa3 = sa4 = sa5 = sa7 = sa8 = 0.f;
+#else
+            a3 = a0; a4 = a0; a5 = a0; a7 = a0; a8 = a0;
 #endif
             float pyf = by0;                                // the row's pixel y: integers, so the += 1 below is exact and dy is
                                                             // the forward's s.y - (float)py bit for bit
