@@ -502,6 +502,7 @@ static int check_resample(int C, int H, int W, int h, int w, int Hf, int Wf, int
     if (Hc > Hf || Wc > Wf) return fail(BAGS_ERR_ARG, "resample: crop %dx%d exceeds the flow size %dx%d", Wc, Hc, Wf, Hf);
     // the backward keeps a 16x16xC accumulator of 64-bit words in LDS (2 KB per channel)
     if (C > 24) return fail(BAGS_ERR_ARG, "resample: at most 24 channels per call (got %d): split the image along C", C);
+    if (H > 32000 || W > 32000) return fail(BAGS_ERR_ARG, "resample: image %dx%d too large (tap coordinates are kept as int16)", W, H);
     return BAGS_OK;
 }
 

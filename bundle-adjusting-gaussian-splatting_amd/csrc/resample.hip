@@ -99,7 +99,7 @@ resample_fwd_kernel(ResampleGeom g, const float* __restrict__ image, const float
 //      id appended to the list of every 16x16 SOURCE tile the box overlaps (integer atomics on a counter: which slot a
 //      tile gets is irrelevant, see 2.).  The flow is smooth, so a box overlaps about four source tiles.
 //   2. resample_gather_kernel, one workgroup per SOURCE tile: for every output tile on its list, thread = output pixel
-//      recomputes its taps and adds those that land in this source tile into a 16x16xC accumulator in LDS -- as 64-bit
+//      reads its taps (left behind by kernel 1) and adds those that land in this source tile into a 16x16xC accumulator in LDS -- as 64-bit
 //      FIXED-POINT integers (LDS integer atomics): integer addition is associative, so the sum does not depend on the
 //      order in which lanes, waves or list entries arrive.  The quantum is a power of two derived from the largest
 //      |dL/dout| on the list and the list length (both order-independent): 2^-47 of that maximum for lists of up to 32
@@ -108,12 +108,16 @@ resample_fwd_kernel(ResampleGeom g, const float* __restrict__ image, const float
 //      sampling one source tile) ignores the list and tests the boxes of all output tiles instead: slow, exact.
 #define RS_TILE 16
 #define RS_CAP 32
-struct RsWork { float2* gflow; int4* bbox; float* tmax; u32* count; u32* list; };
+struct RsWork { float2* gflow; int4* bbox; float* tmax; u32* count; u32* list; float4* taps; };
+// What the pixels kernel leaves for the gather per OUTPUT pixel: the four bilinear taps of its sample, (x0 | y0 << 16 as int16s,
+// fx, fy, 0).  The gather used to re-derive them per listed tile (upsampling taps of the control flow -> four control-node loads
+// -> interpolation -> image taps: two dependent memory round trips per list entry, in a serial loop: 105 us, latency bound --
+// a build without its LDS atomics was no faster); now it is one coalesced 16-byte load, requested four list entries at a time.
 
 __global__ void __launch_bounds__(256)
 resample_bwd_pixels_kernel(ResampleGeom g, const float* __restrict__ image, const float* __restrict__ ctrl, const float* __restrict__ grad_out,
                            float2* __restrict__ gflow /* (Hc,Wc) or NULL */, int4* __restrict__ bbox, float* __restrict__ tmax,
-                           u32* __restrict__ count, u32* __restrict__ list, int src_tiles_x, int src_tiles_y)
+                           u32* __restrict__ count, u32* __restrict__ list, float4* __restrict__ taps, int src_tiles_x, int src_tiles_y)
 {
     __shared__ int s_box[4][4];
     __shared__ float s_max[4];
@@ -128,6 +132,10 @@ resample_bwd_pixels_kernel(ResampleGeom g, const float* __restrict__ image, cons
         const float gx = f.w00 * a.x + f.w01 * b.x + f.w10 * c.x + f.w11 * d.x;
         const float gy = f.w00 * a.y + f.w01 * b.y + f.w10 * c.y + f.w11 * d.y;
         const ImgTap t = img_taps(g, gx, gy);
+        if (bbox) {                                          // dL/dimage requested: the gather reads this instead of recomputing it
+            const u32 xy = ((u32)t.x0 & 0xFFFFu) | ((u32)t.y0 << 16);          // x0, y0 in [-2, 65535): int16 pairs
+            taps[(size_t)yc * g.Wc + xc] = make_float4(__uint_as_float(xy), (t.in00 | t.in01 | t.in10 | t.in11) ? t.fx : 0.f, t.fy, 0.f);
+        }
         const size_t plane = (size_t)g.H * g.W, oplane = (size_t)g.Hc * g.Wc;
         const size_t base = (size_t)t.y0 * g.W + t.x0;
         float dix = 0.f, diy = 0.f;
@@ -177,7 +185,7 @@ resample_bwd_pixels_kernel(ResampleGeom g, const float* __restrict__ image, cons
 __global__ void __launch_bounds__(256)
 resample_gather_kernel(ResampleGeom g, const float* __restrict__ ctrl, const float* __restrict__ grad_out, const int4* __restrict__ bbox,
                        const float* __restrict__ tmax, const u32* __restrict__ count, const u32* __restrict__ list,
-                       float* __restrict__ grad_image, int out_tiles_x, int out_tiles)
+                       const float4* __restrict__ taps, float* __restrict__ grad_image, int out_tiles_x, int out_tiles)
 {
     extern __shared__ unsigned long long acc[];              // [C][256] fixed-point sums
     __shared__ u32 s_list[RS_CAP];
@@ -213,36 +221,86 @@ resample_gather_kernel(ResampleGeom g, const float* __restrict__ ctrl, const flo
     const int shift = bits - 24;                             // fixed point = (term * 2^(24-e)) * 2^shift: exact power-of-two scaling
     const size_t oplane = (size_t)g.Hc * g.Wc;
     if (m > 0.f && isfinite(m)) {
-        for (u32 k = 0; k < n; ++k) {
-            int ot;
-            if (listed) ot = (int)s_list[k];
-            else {
-                ot = (int)k;
-                const int4 bb = bbox[ot];
-                if (!(bb.x <= X0 + RS_TILE - 1 && bb.z >= X0 && bb.y <= Y0 + RS_TILE - 1 && bb.w >= Y0)) continue;   // uniform
-            }
-            const int xc = (ot % out_tiles_x) * RS_TILE + (threadIdx.x & 15), yc = (ot / out_tiles_x) * RS_TILE + (threadIdx.x >> 4);
-            if (xc >= g.Wc || yc >= g.Hc) continue;
-            const FlowTap f = flow_taps(g, g.y0 + yc, g.x0 + xc);
-            const float2* c2 = reinterpret_cast<const float2*>(ctrl);
-            const float2 a = c2[f.i00], b = c2[f.i01], c = c2[f.i10], d = c2[f.i11];
-            const float gx = f.w00 * a.x + f.w01 * b.x + f.w10 * c.x + f.w11 * d.x;
-            const float gy = f.w00 * a.y + f.w01 * b.y + f.w10 * c.y + f.w11 * d.y;
-            const ImgTap t = img_taps(g, gx, gy);
-            const float w[4] = {(1.f - t.fx) * (1.f - t.fy), t.fx * (1.f - t.fy), (1.f - t.fx) * t.fy, t.fx * t.fy};
-            const bool in[4] = {t.in00, t.in01, t.in10, t.in11};
+        // one list entry = one output tile; thread = one of its pixels.  Four entries per batch: their tap records and
+        // cotangents are requested together (one round trip per batch instead of two per entry)
+        auto add_taps = [&](const float4 rec, const float* go) {
+            const u32 xy = __float_as_uint(rec.x);
+            const int tx0 = (int)(short)(xy & 0xFFFFu), ty0 = (int)(short)(xy >> 16);
+            const float fxw = rec.y, fyw = rec.z;
+            const float w[4] = {(1.f - fxw) * (1.f - fyw), fxw * (1.f - fyw), (1.f - fxw) * fyw, fxw * fyw};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int lx = t.x0 + (q & 1) - X0, ly = t.y0 + (q >> 1) - Y0;
-                if (!in[q] || lx < 0 || lx >= RS_TILE || ly < 0 || ly >= RS_TILE) continue;
+                const int sx = tx0 + (q & 1), sy = ty0 + (q >> 1);
+                const int lx = sx - X0, ly = sy - Y0;
+                // in this source tile (and hence inside the image: every source tile is clipped by the write-out below)?
+                if (lx < 0 || lx >= RS_TILE || ly < 0 || ly >= RS_TILE || sx >= g.W || sy >= g.H) continue;
                 for (int ch = 0; ch < g.C; ++ch) {
-                    const float v = w[q] * grad_out[ch * oplane + (size_t)yc * g.Wc + xc];          // the term, as the scatter form had it
+                    const float v = w[q] * go[ch];                                                  // the term, as the scatter form had it
                     const float x = v * up;                                                         // exact (power of two), |x| < 2^24
                     const int hi = (int)x;                                                          // integer part
                     const int lo = (int)((x - (float)hi) * 16777216.0f);                            // 24 more fractional bits, exact
                     const long long fx = shift >= 24 ? (((long long)hi << 24) + (long long)lo) << (shift - 24)
                                                      : (((long long)hi << 24) + (long long)lo) >> (24 - shift);
                     atomicAdd(&acc[ch * 256 + ly * RS_TILE + lx], (unsigned long long)fx);
+                }
+            }
+        };
+        constexpr int RS_BATCH = 4, RS_CMAX = 4;             // channels held in registers per entry (more: loaded inside)
+        if (listed && g.C <= RS_CMAX) {
+            for (u32 k0 = 0; k0 < n; k0 += RS_BATCH) {
+                float4 rec[RS_BATCH]; float go[RS_BATCH][RS_CMAX]; bool on[RS_BATCH];
+#pragma unroll
+                for (int j = 0; j < RS_BATCH; ++j) {
+                    on[j] = false; rec[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int ch = 0; ch < RS_CMAX; ++ch) go[j][ch] = 0.f;
+                    if (k0 + j < n) {
+                        const int ot = (int)s_list[k0 + j];
+                        const int xc = (ot % out_tiles_x) * RS_TILE + (threadIdx.x & 15), yc = (ot / out_tiles_x) * RS_TILE + (threadIdx.x >> 4);
+                        if (xc < g.Wc && yc < g.Hc) {
+                            on[j] = true;
+                            const size_t px = (size_t)yc * g.Wc + xc;
+                            rec[j] = taps[px];
+#pragma unroll
+                            for (int ch = 0; ch < RS_CMAX; ++ch) if (ch < g.C) go[j][ch] = grad_out[ch * oplane + px];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < RS_BATCH; ++j) if (on[j]) add_taps(rec[j], go[j]);
+            }
+        } else {
+            for (u32 k = 0; k < n; ++k) {
+                int ot;
+                if (listed) ot = (int)s_list[k];
+                else {
+                    ot = (int)k;
+                    const int4 bb = bbox[ot];
+                    if (!(bb.x <= X0 + RS_TILE - 1 && bb.z >= X0 && bb.y <= Y0 + RS_TILE - 1 && bb.w >= Y0)) continue;   // uniform
+                }
+                const int xc = (ot % out_tiles_x) * RS_TILE + (threadIdx.x & 15), yc = (ot / out_tiles_x) * RS_TILE + (threadIdx.x >> 4);
+                if (xc >= g.Wc || yc >= g.Hc) continue;
+                const size_t px = (size_t)yc * g.Wc + xc;
+                const float4 rec = taps[px];
+                float go[24];                                 // check_resample caps C at 24
+                for (int ch = 0; ch < g.C; ++ch) go[ch] = grad_out[ch * oplane + px];
+                const u32 xy = __float_as_uint(rec.x);
+                const int tx0 = (int)(short)(xy & 0xFFFFu), ty0 = (int)(short)(xy >> 16);
+                const float fxw = rec.y, fyw = rec.z;
+                const float w[4] = {(1.f - fxw) * (1.f - fyw), fxw * (1.f - fyw), (1.f - fxw) * fyw, fxw * fyw};
+                for (int q = 0; q < 4; ++q) {
+                    const int sx = tx0 + (q & 1), sy = ty0 + (q >> 1);
+                    const int lx = sx - X0, ly = sy - Y0;
+                    if (lx < 0 || lx >= RS_TILE || ly < 0 || ly >= RS_TILE || sx >= g.W || sy >= g.H) continue;
+                    for (int ch = 0; ch < g.C; ++ch) {
+                        const float v = w[q] * go[ch];
+                        const float x = v * up;
+                        const int hi = (int)x;
+                        const int lo = (int)((x - (float)hi) * 16777216.0f);
+                        const long long fx = shift >= 24 ? (((long long)hi << 24) + (long long)lo) << (shift - 24)
+                                                         : (((long long)hi << 24) + (long long)lo) >> (24 - shift);
+                        atomicAdd(&acc[ch * 256 + ly * RS_TILE + lx], (unsigned long long)fx);
+                    }
                 }
             }
         }
@@ -314,6 +372,7 @@ static size_t rs_carve(void* base, int H, int W, int Hc, int Wc, RsWork* w)
     r.tmax = reinterpret_cast<float*>(p); p += align_up(To * sizeof(float), 256);
     r.count = reinterpret_cast<u32*>(p); p += align_up(Ts * sizeof(u32), 256);
     r.list = reinterpret_cast<u32*>(p); p += align_up(Ts * RS_CAP * sizeof(u32), 256);
+    r.taps = reinterpret_cast<float4*>(p); p += align_up((size_t)Hc * Wc * sizeof(float4), 256);
     if (w) *w = r;
     return (size_t)(p - reinterpret_cast<char*>(base));
 }
@@ -328,10 +387,10 @@ hipError_t launch_resample_bwd(const float* image, int C, int H, int W, const fl
     hipError_t e;
     if (grad_image && (e = hipMemsetAsync(wk.count, 0, (size_t)stx * sty * sizeof(u32), st)) != hipSuccess) return e;
     hipLaunchKernelGGL(resample_bwd_pixels_kernel, dim3(otx, oty), dim3(256), 0, st, g, image, ctrl, grad_out,
-                       grad_ctrl ? wk.gflow : (float2*)nullptr, grad_image ? wk.bbox : (int4*)nullptr, wk.tmax, wk.count, wk.list, stx, sty);
+                       grad_ctrl ? wk.gflow : (float2*)nullptr, grad_image ? wk.bbox : (int4*)nullptr, wk.tmax, wk.count, wk.list, wk.taps, stx, sty);
     if (grad_image)
         hipLaunchKernelGGL(resample_gather_kernel, dim3(stx, sty), dim3(256), (size_t)C * 256 * sizeof(unsigned long long), st, g, ctrl, grad_out,
-                           (const int4*)wk.bbox, (const float*)wk.tmax, (const u32*)wk.count, (const u32*)wk.list, grad_image, otx, otx * oty);
+                           (const int4*)wk.bbox, (const float*)wk.tmax, (const u32*)wk.count, (const u32*)wk.list, (const float4*)wk.taps, grad_image, otx, otx * oty);
     if (grad_ctrl)
         hipLaunchKernelGGL(resample_ctrl_gather_kernel, dim3(h * w), dim3(64), 0, st, g, (const float2*)wk.gflow, grad_ctrl);
     return hipGetLastError();
