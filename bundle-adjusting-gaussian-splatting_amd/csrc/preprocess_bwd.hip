@@ -33,16 +33,15 @@ __device__ __forceinline__ float wave_sum(float x)
 #define SUM_COOP 64
 #define RQ (PART_FLOATS / 4)          // float4s per record
 __global__ void __launch_bounds__(256)
-sum_partials_kernel(int P, const float4* __restrict__ g2d, const u32* __restrict__ inst_off, const float* __restrict__ partials,
+sum_partials_kernel(int P, const u32* __restrict__ tiles_touched, const u32* __restrict__ inst_off, const float* __restrict__ partials,
                     float4* __restrict__ sums)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
     u32 nrec = 0, first = 0;
-    if (i < P) {
-        const float4 q3 = g2d[4 * (size_t)i + 3];
-        nrec = __float_as_uint(q3.y); first = inst_off[i];
+    if (i < P) {            // the record count from the compact array (4 coalesced bytes), not from the Gaussian's 64-byte geometry line
+        nrec = tiles_touched[i]; first = inst_off[i];
     }
     if (nrec > 0 && nrec <= SUM_COOP) {
         const float4* rec = reinterpret_cast<const float4*>(partials + (size_t)first * PART_FLOATS);
@@ -533,7 +532,7 @@ hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, co
     const int nb = cdiv(P, 256);
     *nblocks_out = nb;
     if (P == 0) return hipSuccess;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(nb), dim3(256), 0, st, P, g.g2d, g.inst_off, partials_records,
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(nb), dim3(256), 0, st, P, g.tiles_touched, g.inst_off, partials_records,
                        reinterpret_cast<float4*>(sums));
     const float* partials = sums;
 #define PRE_BWD_LAUNCH(COV)     hipLaunchKernelGGL(preprocess_bwd_kernel<COV>, dim3(nb), dim3(256), 0, st, P, s.sh_coeffs, s.sh_degree, s.image_width, \
