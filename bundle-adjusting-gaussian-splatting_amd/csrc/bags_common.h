@@ -87,9 +87,9 @@ struct GeomView {            // per Gaussian, indexed by Gaussian id unless stat
                              // write into every 64-byte line of g2d after the scan cost 6.6 us per frame)
     uint2*  rect;            // (minx | miny<<16, maxx | maxy<<16), max exclusive   (compact copy for emit)
     u32*    tiles_touched;   // instances the Gaussian emits (compact copy for the offsets scan / emit)
-    // [9 * P] d(colour)/d(view direction) of the SH colour path, written by K1 for the visible Gaussians (round 3):
-    //   M[axis][c] = sum_t (d basis_t / d dir_axis) * sh[t][c]   as   Mxr Mxg Mxb  Myr Myg Myb  Mzr Mzg Mzb
-    // so that preprocess_bwd reads 36 bytes per Gaussian instead of the 192-byte SH row a second time
+    // [10 * P] d(colour)/d(view direction) of the SH colour path, written by K1 for the visible Gaussians (round 3):
+    //   M[axis][c] = sum_t (d basis_t / d dir_axis) * sh[t][c]   as   Mxr Mxg Mxb  Myr Myg Myb  Mzr Mzg Mzb, then the clamp bits
+    // so that preprocess_bwd reads 40 bytes per Gaussian instead of the 192-byte SH row a second time (and nothing of g2d)
     float*  shjac;
     u64*    keep;            // tile mask of a rectangle of at most 8 x 8 tiles: bit ry * 8 + rx set = tile (minx + rx, miny + ry)
                              // is emitted (D7: the alpha >= 1/255 ellipse reaches it); larger rectangles emit every tile

@@ -105,7 +105,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                       const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
                       const float* __restrict__ projmatrix, const float* __restrict__ intrinsic,
                       const float* __restrict__ campos_p,
-                      const float4* __restrict__ g2d, const float* __restrict__ shjac,
+                      const u32* __restrict__ tiles_touched, const float* __restrict__ shjac,
                       const float* __restrict__ partials, float* __restrict__ pose_slab,
                       float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_densify,
                       float* __restrict__ g_shs, float* __restrict__ g_colors, float* __restrict__ g_opac,
@@ -148,8 +148,9 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     float drgb[3] = {0.f, 0.f, 0.f};
     // Every input row of the Gaussian in one batch, before anything is looked at (index clamped: P > 0 here)
     const size_t ic = (size_t)(i < P ? i : P - 1);
-    const float4 q3 = g2d[4 * ic + 3];
-    const float4 co = g2d[4 * ic];
+    // (nothing is read from the Gaussian's 64-byte geometry line any more: the conic is re-derived below bit for bit, the
+    // visibility comes from the compact tiles_touched array, the SH clamp bits ride in the tenth word of shjac)
+    const u32 n_inst = tiles_touched[ic];
     float x = means3D[3 * ic + 0], y = means3D[3 * ic + 1], z = means3D[3 * ic + 2];
     float in_s0 = 0.f, in_s1 = 0.f, in_s2 = 0.f;
     float4 in_q = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -162,16 +163,16 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         in_s0 = scales[3 * ic + 0]; in_s1 = scales[3 * ic + 1]; in_s2 = scales[3 * ic + 2];
         in_q = reinterpret_cast<const float4*>(rotations)[ic];
     }
-    float mj[9];                                                                            // K1's d(colour)/d(direction) (SH path)
+    float mj[10];                                                                           // K1's d(colour)/d(direction) + clamp bits (SH path)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) mj[t] = shjac[9 * ic + t];
+    for (int t = 0; t < 10; ++t) mj[t] = shjac[10 * ic + t];
     const float4* sm = reinterpret_cast<const float4*>(partials) + 3 * ic;                  // K8a's per-Gaussian sums
     const float4 sm_a = sm[0], sm_b = sm[1], sm_c = sm[2];
     // every one of those loads is IN FLIGHT before the first of them is waited for (the compiler otherwise sinks the ones only
     // the visible branch needs behind the visibility test: one more round trip per group)
-    asm volatile("" :: "v"(q3.y), "v"(co.x), "v"(x), "v"(y), "v"(z), "v"(in_s0), "v"(in_s1), "v"(in_s2), "v"(in_q.x), "v"(in_c[0]),
+    asm volatile("" :: "v"(n_inst), "v"(mj[9]), "v"(x), "v"(y), "v"(z), "v"(in_s0), "v"(in_s1), "v"(in_s2), "v"(in_q.x), "v"(in_c[0]),
                  "v"(in_c[3]), "v"(sm_a.x), "v"(sm_b.x), "v"(sm_c.x), "v"(mj[0]), "v"(mj[3]), "v"(mj[6]));
-    const bool live = (i < P) && (__float_as_uint(q3.y) > 0);
+    const bool live = (i < P) && (n_inst > 0);
 
     if (live) {
         // ---- 1. the per-Gaussian sums of the per-instance records
@@ -184,12 +185,8 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         drgb[0] = s[0]; drgb[1] = s[1]; drgb[2] = s[2];
         gop = s[3];
         const float Mx = s[4], My = s[5], Mxx = s[6], Mxy = s[7], Myy = s[8];
-        // ---- 2. moments -> screen-space gradients
-        const float dpx = -(co.x * Mx + co.y * My);         // dL/d centre (pixel units)
-        const float dpy = -(co.z * My + co.y * Mx);
+        // ---- 2. moments -> screen-space gradients (the centre's, which needs the conic, follows the covariance below)
         const float gA = -0.5f * Mxx, gB = -Mxy, gC = -0.5f * Myy;   // dL/dconic
-
-        gm2x = dpx * (0.5f * (float)W); gm2y = dpy * (0.5f * (float)H);
         gdx = s[9] * (0.5f * (float)W); gdy = s[10] * (0.5f * (float)H);
 
         // ---- recompute the forward chain
@@ -249,6 +246,12 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         // The file is compiled with -ffp-contract=off so cov2D and det are bit-identical to what preprocess_fwd used.
         const float det = cxx * cyy - cxy * cxy;
         const float di = 1.0f / det, di2 = di * di;
+        {   // K1's conic = (cyy, -cxy, cxx) / det from the same operations (contraction off in both files): bit-identical
+            const float con_a = cyy * di, con_b = -cxy * di, con_c = cxx * di;
+            const float dpx = -(con_a * Mx + con_b * My);     // dL/d centre (pixel units)
+            const float dpy = -(con_c * My + con_b * Mx);
+            gm2x = dpx * (0.5f * (float)W); gm2y = dpy * (0.5f * (float)H);
+        }
         const float ddet = -((gA * cyy - gB * cxy + gC * cxx) * di2);
         const float dcxx = gC * di + ddet * cyy;
         const float dcyy = gA * di + ddet * cxx;
@@ -350,7 +353,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     if (live) {
         // ---- colour
         if (!colors_precomp) {
-            const u32 cl = __float_as_uint(q3.z);
+            const u32 cl = __float_as_uint(mj[9]);
             if (cl & 1u) drgb[0] = 0.f;
             if (cl & 2u) drgb[1] = 0.f;
             if (cl & 4u) drgb[2] = 0.f;
@@ -538,7 +541,7 @@ hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, co
 #define PRE_BWD_LAUNCH(COV)     hipLaunchKernelGGL(preprocess_bwd_kernel<COV>, dim3(nb), dim3(256), 0, st, P, s.sh_coeffs, s.sh_degree, s.image_width, \
                        s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, in.means3D, in.shift_factors, in.shs, \
                        in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, s.viewmatrix, s.projmatrix, \
-                       s.intrinsic, s.campos, g.g2d, g.shjac, partials, \
+                       s.intrinsic, s.campos, g.tiles_touched, g.shjac, partials, \
                        pose_slab, a.grad_means3D, a.grad_means2D, a.grad_means2D_densify, a.grad_shs, \
                        a.grad_colors_precomp, a.grad_opacities, a.grad_scales, a.grad_rotations, a.grad_cov3D_precomp);
     if (in.cov3D_precomp) { PRE_BWD_LAUNCH(true) } else { PRE_BWD_LAUNCH(false) }

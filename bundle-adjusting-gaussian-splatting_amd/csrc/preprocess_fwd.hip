@@ -280,12 +280,13 @@ preprocess_fwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
 #undef SH_ALL
 #undef SH_TERM
                         // 9 floats = 36 bytes per Gaussian, three 12-byte stores
-                        float* mj = shjac + 9 * (size_t)i;
+                        float* mj = shjac + 10 * (size_t)i;           // 9 floats + the clamp bits (written below): 40 bytes per Gaussian
                         mj[0] = mxr; mj[1] = mxg; mj[2] = mxb; mj[3] = myr; mj[4] = myg; mj[5] = myb; mj[6] = mzr; mj[7] = mzg; mj[8] = mzb;
                         r += 0.5f; g += 0.5f; b += 0.5f;
                         if (r < 0.f) { cl |= 1u; r = 0.f; }
                         if (g < 0.f) { cl |= 2u; g = 0.f; }
                         if (b < 0.f) { cl |= 4u; b = 0.f; }
+                        mj[9] = __uint_as_float(cl);
                     }
                     q0 = make_float4(con_a, con_b, con_c, opacities[i]);
                     rgbz_v = make_float4(r, g, b, tzs);
