@@ -54,10 +54,13 @@
 #endif
 #define PQ (TF_FOLD ? 3 : 4)                 // float4s per pixel pair in LDS
 
+#ifndef FWD_PK
+#define FWD_PK 0            // forward: (dx, dy) and (ap dx, cp dy) as two packed fp32 instructions (record order x y ap cp | bp ...):
+#endif                      // 151.2 us against 148.5 -- every v_pk_*_f32 result needs a wait state before its first use
 struct __attribute__((aligned(16))) SplatRec {
-    float x, y, ap, bp;       // centre, pre-scaled conic: exp2(ap dx^2 + bp dx dy + cp dy^2) == exp(power)
-    float cp, o, r, g;
-    float b, z; u32 mask; u32 pos;   // mask: 4x4 blocks reachable (bit by*4+bx); pos: 1-based position in the tile list
+    float x, y, ap, cp;       // centre, pre-scaled conic: exp2(ap dx^2 + bp dx dy + cp dy^2) == exp(power)
+    float bp, o, r, g;
+    float b, z; u32 pos; u32 mask;   // pos: 1-based position in the tile list; mask: 4x4 blocks reachable (bit by*4+bx)
 };
 
 // Workgroup -> tile.  Workgroups are dispatched in blockIdx order, round-robin over the 8 XCDs (b and b+8 share one), and
@@ -693,8 +696,22 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
 // against 0.167 ms.
 // ================================================================================================================
 #ifndef FWD_WG_PER_CU
-#define FWD_WG_PER_CU 8       // forward workgroups per CU (= waves per SIMD): caps VGPRs at 64 (measured best of 5,6,8)
+#define FWD_WG_PER_CU 6       // forward workgroups per CU (= waves per SIMD): 80 VGPRs (8 / 7 / 6: 148.3 / 146.9 / 144.3 us)
 #endif
+#ifdef DIAG_PAIRS             // the pair counters live in the plain C++ form of the step
+#define FWD_ASM 0
+#define FWD_SENTINEL 0
+#endif
+#ifndef FWD_ASM
+#define FWD_ASM 1             // the contribute / stop / composite decision of a walk step as ONE exec-masked block (v_cmpx chain)
+#endif
+#ifndef FWD_SENTINEL
+#define FWD_SENTINEL 1        // slot CHUNK-1 always holds an all-zero record and pads every list: no `i < Lrow` test per step
+#endif
+#if FWD_ASM && !FWD_SENTINEL
+#error "the asm step has no list-length test: it needs the sentinel"
+#endif
+#define FWD_STAGE (FWD_SENTINEL ? CHUNK - 1 : CHUNK)          // splats staged per chunk
 template <int DUMMY>
 __global__ void __launch_bounds__(256, FWD_WG_PER_CU)
 blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_desc, const u32* __restrict__ point_list,
@@ -715,14 +732,17 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
     const uint2 range = make_uint2(desc.y, desc.y + desc.z);
     const u32 n = desc.z;
 
-    __shared__ SplatRec recs[CHUNK];                 // x y ap bp | cp o r g | b z mask pos
-    __shared__ unsigned char lists[16 * CHUNK + 16];        // [16][CHUNK] + padding for the walk's one-ahead read
+    __shared__ SplatRec recs[CHUNK];                 // x y ap cp | bp o r g | b z pos mask
+    typedef unsigned char list_t;
+#define LIST_ENTRY(slot) ((list_t)(slot))
+    __shared__ __attribute__((aligned(16))) list_t lists[16 * CHUNK + 16];   // [16][CHUNK] + padding for the walk's read-ahead
     __shared__ u32 masks[CHUNK];
     __shared__ int s_live[4];
 
     const int bx = (wave & 1) * 2 + (row & 1), by = (wave >> 1) * 2 + (row >> 1), blk = by * 4 + bx;
     const int px = tile_x * BAGS_TILE + bx * 4 + (li & 3), py = tile_y * BAGS_TILE + by * 4 + (li >> 2);
-    const float pxf = (float)px, pyf = (float)py;
+    float pxf = (float)px, pyf = (float)py;
+    asm volatile("" : "+v"(pxf), "+v"(pyf));                 // opaque: otherwise the walk re-converts them from px, py every step
     const bool inside = (px < W) && (py < H);
     // A finished pixel (T would fall below 1e-4, or outside the image) carries its transmittance NEGATED: one VGPR sign
     // instead of a lane mask kept in scalar registers (four scalar instructions per step of a kernel that is as busy on
@@ -736,12 +756,12 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
     // blocks of this wave's rows 0..3
     const int qb = (wave >> 1) * 8 + (wave & 1) * 2;         // block index of row 0; rows: +0, +1, +4, +5
 
-    for (u32 base = 0; base < n; base += CHUNK) {
+    for (u32 base = 0; base < n; base += FWD_STAGE) {
         const u64 live_b = __ballot(Tq > 0.f);
         if (lane == 0) s_live[wave] = (live_b != 0ull);
         __syncthreads();                                     // previous chunk consumed by every wave
         if (!(s_live[0] | s_live[1] | s_live[2] | s_live[3])) break;
-        const u32 cnt = min((u32)CHUNK, n - base);
+        const u32 cnt = min((u32)FWD_STAGE, n - base);
         SplatRec rec; rec.mask = 0; rec.x = rec.y = rec.ap = rec.bp = rec.cp = rec.o = rec.r = rec.g = rec.b = rec.z = 0.f; rec.pos = 0;
         if ((u32)tid < cnt) {
             const u32 g = point_list[range.x + base + tid];
@@ -757,6 +777,18 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
             reach_mask[range.x + base + tid] = (unsigned short)rec.mask;      // the backward stages the same instance: it reads this
         }
         if (tid < CHUNK) { recs[tid] = rec; masks[tid] = rec.mask; }
+#if FWD_SENTINEL
+        // this wave's four lists (rows qb, qb+1 | qb+4, qb+5: two runs of 2 x CHUNK bytes) start out as all-sentinel: a row
+        // past the end of its own list composites the zero record of slot CHUNK-1 (opacity 0: alpha = 0 fails the 1/255 test)
+        {
+            static_assert(CHUNK == 256, "sentinel fill assumes 2 x 256 list bytes = 32 lanes x 16 bytes");
+            const int run = (lane < 32) ? qb : qb + 4;
+            const u32 f = (sizeof(list_t) == 1 ? 0x01010101u : 0x00010001u) * (u32)LIST_ENTRY(CHUNK - 1);
+            uint4* dst = reinterpret_cast<uint4*>(&lists[run * CHUNK]) + (lane & 31) * (int)sizeof(list_t);
+            dst[0] = make_uint4(f, f, f, f);
+            if (sizeof(list_t) == 2) dst[1] = make_uint4(f, f, f, f);
+        }
+#endif
         __syncthreads();
         if (live_b == 0ull) continue;                        // this quadrant is finished; keep pace at the barriers
         // ---- per-row lists (rows whose 16 pixels are all done take nothing)
@@ -769,29 +801,65 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
             const u32 m = masks[slot] >> qb;                 // bits 0,1,4,5 = this wave's rows 0..3
             const bool h0 = r0 && (m & 1u), h1 = r1 && (m & 2u), h2 = r2 && (m & 16u), h3 = r3 && (m & 32u);
             const u64 b0 = __ballot(h0), b1 = __ballot(h1), b2 = __ballot(h2), b3 = __ballot(h3);
-            if (h0) lists[qb * CHUNK + L0 + __popcll(b0 & lt_mask)] = (unsigned char)slot;
-            if (h1) lists[(qb + 1) * CHUNK + L1 + __popcll(b1 & lt_mask)] = (unsigned char)slot;
-            if (h2) lists[(qb + 4) * CHUNK + L2 + __popcll(b2 & lt_mask)] = (unsigned char)slot;
-            if (h3) lists[(qb + 5) * CHUNK + L3 + __popcll(b3 & lt_mask)] = (unsigned char)slot;
+            if (h0) lists[qb * CHUNK + L0 + __popcll(b0 & lt_mask)] = LIST_ENTRY(slot);
+            if (h1) lists[(qb + 1) * CHUNK + L1 + __popcll(b1 & lt_mask)] = LIST_ENTRY(slot);
+            if (h2) lists[(qb + 4) * CHUNK + L2 + __popcll(b2 & lt_mask)] = LIST_ENTRY(slot);
+            if (h3) lists[(qb + 5) * CHUNK + L3 + __popcll(b3 & lt_mask)] = LIST_ENTRY(slot);
             L0 += __popcll(b0); L1 += __popcll(b1); L2 += __popcll(b2); L3 += __popcll(b3);
         }
         const int Lrow = (row == 0) ? L0 : (row == 1) ? L1 : (row == 2) ? L2 : L3;
-        const int Lmax = max(max(L0, L1), max(L2, L3));
+        const int Lmax = __builtin_amdgcn_readfirstlane(max(max(L0, L1), max(L2, L3)));
         __builtin_amdgcn_wave_barrier();
         // ---- every row walks its own list; the next list entry is fetched while the current splat is composited
-        // This kernel is issue bound, so the walk's bookkeeping counts: the next entry is read unconditionally (a row past
-        // the end of its list reads a stale byte, i.e. some valid slot, and `act` discards the result; the array is padded
-        // so that entry Lmax of the last list exists) and the record address is one 24-bit multiply, not v_mul_lo_u32.
-        const unsigned char* mylist = &lists[blk * CHUNK];
-        u32 slot = (u32)mylist[0];
-        for (int i = 0; i < Lmax; ++i) {
-            const bool act = i < Lrow;
-            const SplatRec s = *reinterpret_cast<const SplatRec*>(reinterpret_cast<const char*>(recs) + __umul24(slot, (u32)sizeof(SplatRec)));
-            slot = (u32)mylist[i + 1];
+        // This kernel is issue bound, so the walk's bookkeeping counts: the next entry is read unconditionally (the array is
+        // padded so that entry Lmax of the last list exists), the record address is one 24-bit multiply by an inline constant,
+        // and with the sentinel a row past the end of its list needs no test (it composites the zero record).
+        const list_t* mylist = &lists[blk * CHUNK];
+        static_assert(sizeof(SplatRec) == 48, "record stride is spelled out in the instruction below");
+        auto step = [&](int i, u32 roff) {
+            const bool act = FWD_SENTINEL ? true : (i < Lrow);
+            const SplatRec s = *reinterpret_cast<const SplatRec*>(reinterpret_cast<const char*>(recs) + roff);
+#if FWD_PK
+            // pair_power2 with its two independent first products packed: the same roundings in the same order
+            const f2 d = f2{s.x, s.y} - f2{pxf, pyf};
+            const f2 m = d * f2{s.ap, s.cp};
+            const float p2 = __fmaf_rn(d.x, __fmaf_rn(s.bp, d.y, m.x), __fmul_rn(m.y, d.y));
+#else
             const float dx = s.x - pxf, dy = s.y - pyf;
             const float p2 = pair_power2(dx, dy, s.ap, s.bp, s.cp);
+#endif
             const float G = __builtin_amdgcn_exp2f(p2);
             const float alpha = fminf(0.99f, s.o * G);
+#if FWD_ASM && !defined(DIAG_PAIRS)
+            // contribute (power <= 0, alpha >= 1/255), then stop (T would fall below 1e-4, or the pixel has finished: sign set) or
+            // composite: each v_cmpx narrows EXEC, so there is no mask arithmetic on the scalar unit (the compiler's form of the
+            // same logic is 3 s_and + 3 saveexec + 2 s_or + 2 branches per step, and this kernel is as busy on its scalar unit
+            // as on its vector units).  EXEC is all ones here: 256-thread workgroups, only wave-uniform control flow above.
+            {
+                float t0, t1;
+                asm volatile(
+                    "v_cmpx_ge_f32 vcc, 0, %[p2]\n\t"
+                    "v_cmpx_le_f32 vcc, 0x3b808081, %[al]\n\t"          // 1 / 255
+                    "v_sub_f32 %[t0], 1.0, %[al]\n\t"
+                    "v_mul_f32 %[t1], %[al], %[T]\n\t"
+                    "v_mul_f32 %[t0], %[T], %[t0]\n\t"
+                    "v_cmp_ngt_f32 vcc, 0x38d1b717, %[t0]\n\t"           // !(1e-4 > T (1 - alpha)): composite; else stop
+                    "v_cndmask_b32_e64 %[T], -|%[T]|, %[t0], vcc\n\t"     // (a finished pixel, T < 0, lands here too and stays as it is)
+                    "s_mov_b64 exec, vcc\n\t"                                // (vcc is 0 in inactive lanes; s_and would clobber SCC,
+                                                                              //  which holds the compiler's loop test)
+                    "v_fmac_f32 %[cr], %[t1], %[r]\n\t"
+                    "v_fmac_f32 %[cg], %[t1], %[g]\n\t"
+                    "v_fmac_f32 %[cb], %[t1], %[b]\n\t"
+                    "v_fmac_f32 %[dq], %[t1], %[z]\n\t"
+                    "v_mov_b32 %[last], %[pos]\n\t"
+                    "s_mov_b64 exec, -1"
+                    : [T] "+v"(Tq), [cr] "+v"(Cr), [cg] "+v"(Cg), [cb] "+v"(Cb), [dq] "+v"(Dq), [last] "+v"(last),
+                      [t0] "=&v"(t0), [t1] "=&v"(t1)
+                    : [p2] "v"(p2), [al] "v"(alpha), [r] "v"(s.r), [g] "v"(s.g), [b] "v"(s.b), [z] "v"(s.z), [pos] "v"(s.pos)
+                    : "vcc");
+                (void)act;
+            }
+#else
             const bool contrib = act && (p2 <= 0.f) && (alpha >= ALPHA_MIN) && (Tq > 0.f);
 #ifdef DIAG_PAIRS
             dg_eval += act ? 1u : 0u; dg_con += contrib ? 1u : 0u;
@@ -808,7 +876,33 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
                     last = s.pos;
                 }
             }
+#endif
+        };
+#if FWD_SENTINEL
+        // two steps per trip, no remainder: entry Lmax of every list is the sentinel (at most CHUNK - 1 real entries), and
+        // inline asm is `convergent`, which keeps the compiler from unrolling a loop with a run-time trip count by itself.
+        // The two list bytes of the NEXT trip are one 16-bit read at the top of this one; record address = byte * 48 (SDWA
+        // byte select, the factor in a scalar register).
+        const unsigned short* mypairs = reinterpret_cast<const unsigned short*>(mylist);
+        u32 two = (u32)mypairs[0];
+        for (int i = 0; i < Lmax; i += 2) {
+            u32 ra, rb;
+            asm("v_mul_u32_u24_sdwa %0, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+                "v_mul_u32_u24_sdwa %1, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD"
+                : "=&v"(ra), "=v"(rb) : "v"(two), "s"(48u));
+            u32 nxt = (u32)mypairs[(i >> 1) + 1];
+            step(i, ra); step(i + 1, rb);
+            asm("" : "+v"(nxt));                             // (keeps the zero extension with the load, not behind the loop's phi)
+            two = nxt;
         }
+#else
+        u32 slot = (u32)mylist[0];
+        for (int i = 0; i < Lmax; ++i) {
+            const u32 roff = __umul24(slot, 48u);
+            slot = (u32)mylist[i + 1];
+            step(i, roff);
+        }
+#endif
     }
     const bool stopped = Tq < 0.f;                           // stopped early (T would fall below 1e-4) or outside the image
     Tq = fabsf(Tq);
