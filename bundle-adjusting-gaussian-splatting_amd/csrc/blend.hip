@@ -739,6 +739,9 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
 #if FWD_ASM && !FWD_SENTINEL
 #error "the asm step has no list-length test: it needs the sentinel"
 #endif
+#ifndef FWD_PIPE
+#define FWD_PIPE 1            // record reads issued one step ahead of their use (two register sets)
+#endif
 #define FWD_STAGE (FWD_SENTINEL ? CHUNK - 1 : CHUNK)          // splats staged per chunk
 template <int DUMMY>
 __global__ void __launch_bounds__(256, FWD_WG_PER_CU)
@@ -844,9 +847,9 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
         // and with the sentinel a row past the end of its list needs no test (it composites the zero record).
         const list_t* mylist = &lists[blk * CHUNK];
         static_assert(sizeof(SplatRec) == 48, "record stride is spelled out in the instruction below");
-        auto step = [&](int i, u32 roff) {
+        auto load = [&](u32 roff) { return *reinterpret_cast<const SplatRec*>(reinterpret_cast<const char*>(recs) + roff); };
+        auto step = [&](int i, const SplatRec& s) {
             const bool act = FWD_SENTINEL ? true : (i < Lrow);
-            const SplatRec s = *reinterpret_cast<const SplatRec*>(reinterpret_cast<const char*>(recs) + roff);
 #if FWD_PK
             // pair_power2 with its two independent first products packed: the same roundings in the same order
             const f2 d = f2{s.x, s.y} - f2{pxf, pyf};
@@ -912,23 +915,51 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
         // The two list bytes of the NEXT trip are one 16-bit read at the top of this one; record address = byte * 48 (SDWA
         // byte select, the factor in a scalar register).
         const unsigned short* mypairs = reinterpret_cast<const unsigned short*>(mylist);
-        u32 two = (u32)mypairs[0];
-        for (int i = 0; i < Lmax; i += 2) {
-            u32 ra, rb;
+        auto addr2 = [&](u32 two, u32& ra, u32& rb) {
             asm("v_mul_u32_u24_sdwa %0, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n\t"
                 "v_mul_u32_u24_sdwa %1, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD"
                 : "=&v"(ra), "=v"(rb) : "v"(two), "s"(48u));
+        };
+#if FWD_PIPE
+        // Software pipeline over two register sets, no copies: a record is requested one step before it is composited (its
+        // three LDS reads land behind the other record's arithmetic), its address one trip before that.  Left to itself the
+        // compiler issued a step's third read after its exp and waited for it: two exposed LDS latencies per step, and
+        // dropping that read (timing experiment) bought 9 % -- latency, not bandwidth.  sched_barrier pins the issue points.
+        u32 ra, rb;
+        addr2((u32)mypairs[0], ra, rb);
+        SplatRec S0 = load(ra);
+        u32 two = (u32)mypairs[1];                           // entries 2, 3 (reads run up to 5 entries past Lmax: see the padding)
+        for (int i = 0; i < Lmax; i += 2) {
+            const SplatRec S1 = load(rb);
+            u32 ra2, rb2;
+            addr2(two, ra2, rb2);
+            u32 nxt = (u32)mypairs[(i >> 1) + 2];
+            __builtin_amdgcn_sched_barrier(0);
+            step(i, S0);
+            __builtin_amdgcn_sched_barrier(0);
+            S0 = load(ra2);
+            __builtin_amdgcn_sched_barrier(0);
+            step(i + 1, S1);
+            asm("" : "+v"(nxt));                             // (keeps the zero extension with the load, not behind the loop's phi)
+            two = nxt; rb = rb2;
+        }
+#else
+        u32 two = (u32)mypairs[0];
+        for (int i = 0; i < Lmax; i += 2) {
+            u32 ra, rb;
+            addr2(two, ra, rb);
             u32 nxt = (u32)mypairs[(i >> 1) + 1];
-            step(i, ra); step(i + 1, rb);
+            step(i, load(ra)); step(i + 1, load(rb));
             asm("" : "+v"(nxt));                             // (keeps the zero extension with the load, not behind the loop's phi)
             two = nxt;
         }
+#endif
 #else
         u32 slot = (u32)mylist[0];
         for (int i = 0; i < Lmax; ++i) {
             const u32 roff = __umul24(slot, 48u);
             slot = (u32)mylist[i + 1];
-            step(i, roff);
+            step(i, load(roff));
         }
 #endif
     }
