@@ -195,6 +195,8 @@ hipError_t launch_knn(const float* pts, int P, void* ws, float* out, hipStream_t
 int binned_per_block(int P);
 bool binned_supported(int P, int T);
 hipError_t launch_binned_empty(const GeomView& g, const ImgView& im, int T, hipStream_t st);
+// the tile descriptor list alone (launch_binned_finish builds it beside the emission): for forwards that emit nothing
+hipError_t launch_binned_desc_only(const ImgView& im, int T, hipStream_t st);
 // host_count: device-visible address of a pinned host word that also receives the instance count (may be null)
 hipError_t launch_binned_prepare(const GeomView& g, const ImgView& im, int P, int grid_x, int T, hipStream_t st, u32* host_count = nullptr);
 hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int grid_x, int T, u64* words, u64* scratch, u32* point_list,

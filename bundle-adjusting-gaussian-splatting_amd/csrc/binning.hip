@@ -237,51 +237,60 @@ __device__ __forceinline__ u32 block_excl_scan_1024(u32 v, u32* s_wave /*[17]*/)
 }
 __device__ __forceinline__ void lds_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 #define ORD_PER_MAX 32                                      // tiles per thread: 1024 x 32 = 32768 tiles at most
+__device__ __forceinline__ int ord_pad(int i) { return i + (i >> 5); }
+// thread tid owns the contiguous tiles [ta, tb): their counts stay in registers for every pass.  One CU issues this
+// kernel's every memory request, and a thread reading or writing its own run puts 64 requests per instruction on that CU's
+// path (32 400 tiles: 99 us).  So the wave moves its span of 64 x per tiles in tile order -- 64 consecutive words per
+// instruction -- and the lanes pick their runs out of a padded LDS buffer (stride per + per / 32 words: conflict free).
 template <int ORD_PER>
-__global__ void __launch_bounds__(1024)
-ranges_order_kernel(const u32* __restrict__ tile_total, int T, uint2* __restrict__ ranges, uint4* __restrict__ tile_desc,
-                    u32* __restrict__ n_active, const u32* __restrict__ block_total, int B, u32* __restrict__ block_base,
-                    u32* __restrict__ num_rendered, u32* host_count)
+__device__ __forceinline__ u32 ord_load_counts(const u32* __restrict__ tile_total, int T, int per, u32* tr, u32 (&cntv)[ORD_PER])
 {
-    __shared__ u32 s_cur[ORD_LEVELS * ORD_SUB];
-    __shared__ u32 s_wave[17];
-    extern __shared__ u32 tr_all[];                          // 16 waves x ORD_TRW(ORD_PER) words: wave-local transposes
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // thread tid owns the contiguous tiles [ta, tb): their counts stay in registers for all three passes.  One CU issues
-    // this kernel's every memory request, and a thread reading or writing its own run puts 64 requests per instruction
-    // on that CU's path (32 400 tiles: 99 us).  So the wave moves its span of 64 x per tiles in tile order -- 64
-    // consecutive words per instruction -- and the lanes pick their runs out of a padded LDS buffer (stride per + per / 32
-    // words: conflict free); the range starts go back the same way.
-    const int per = (T + 1023) / 1024;
-    const int ta = min(T, tid * per), tb = min(T, ta + per);
-    u32* tr = tr_all + wave * (64 * ORD_PER + 2 * ORD_PER);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int span0 = wave * 64 * per;
-    auto pad = [](int i) -> int { return i + (i >> 5); };
 #pragma unroll 8
     for (int j = 0; j < ORD_PER; ++j) {                      // load order: tile span0 + j * 64 + lane
         const int t = span0 + j * 64 + lane;
         const u32 v = (j < per && t < T) ? tile_total[t] : 0u;
-        if (j < per) tr[pad(j * 64 + lane)] = v;
+        if (j < per) tr[ord_pad(j * 64 + lane)] = v;
     }
     lds_wave_sync();
-    u32 cntv[ORD_PER];
     u32 sum = 0;
 #pragma unroll
-    for (int i = 0; i < ORD_PER; ++i) { cntv[i] = (i < per) ? tr[pad(lane * per + i)] : 0u; sum += cntv[i]; }
+    for (int i = 0; i < ORD_PER; ++i) { cntv[i] = (i < per) ? tr[ord_pad(lane * per + i)] : 0u; sum += cntv[i]; }
     __builtin_amdgcn_sched_barrier(0);
+    return sum;
+}
+
+// Tile ranges, instance count, block bases.  (The heavy-first descriptor list is built by one extra workgroup of the
+// emission launch, build_tile_desc below: nothing needs it before the per-tile sorts, and its scattered 16-byte stores
+// through ONE CU were half of this kernel's 13.8 us on the path to the instance count.)
+template <int ORD_PER>
+__global__ void __launch_bounds__(1024)
+ranges_order_kernel(const u32* __restrict__ tile_total, int T, uint2* __restrict__ ranges,
+                    const u32* __restrict__ block_total, int B, u32* __restrict__ block_base,
+                    u32* __restrict__ num_rendered, u32* host_count)
+{
+    __shared__ u32 s_wave[17];
+    extern __shared__ u32 tr_all[];                          // 16 waves x ORD_TRW(ORD_PER) words: wave-local transposes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (T + 1023) / 1024;
+    u32* tr = tr_all + wave * (64 * ORD_PER + 2 * ORD_PER);
+    const int span0 = wave * 64 * per;
+    u32 cntv[ORD_PER];
+    const u32 sum = ord_load_counts<ORD_PER>(tile_total, T, per, tr, cntv);
     const u32 first = block_excl_scan_1024(sum, s_wave);     // (its barriers also order the two uses of `tr`)
     {
         u32 run = first;
 #pragma unroll
         for (int i = 0; i < ORD_PER; ++i)
-            if (i < per) { tr[pad(lane * per + i)] = run; run += cntv[i]; }
+            if (i < per) { tr[ord_pad(lane * per + i)] = run; run += cntv[i]; }
         __builtin_amdgcn_sched_barrier(0);
         lds_wave_sync();
 #pragma unroll 8
-        for (int j = 0; j < ORD_PER; ++j) {
+        for (int j = 0; j < ORD_PER; ++j) {                  // the range starts go back the way the counts came
             const int t = span0 + j * 64 + lane;
             // (the count is read again, coalesced, rather than kept: 32 more live registers spill at 1024 threads)
-            if (j < per && t < T) { const u32 s0 = tr[pad(j * 64 + lane)]; ranges[t] = make_uint2(s0, s0 + tile_total[t]); }
+            if (j < per && t < T) { const u32 s0 = tr[ord_pad(j * 64 + lane)]; ranges[t] = make_uint2(s0, s0 + tile_total[t]); }
         }
     }
     __syncthreads();
@@ -297,18 +306,33 @@ ranges_order_kernel(const u32* __restrict__ tile_total, int T, uint2* __restrict
         const u32 ex = block_excl_scan_1024(v, s_wave);
         if (tid < B) block_base[tid] = ex;
     }
-    // ---- heavy-first descriptor list: counting sort of the tiles by instance count (ORD_LEVELS levels, four per octave,
-    // ORD_SUB sub-counters per level picked by the THREAD (tid & 31): the lanes of a wave hit 32 different counters of a
-    // level and a thread's run of neighbouring tiles stays together in the list.  (Picked by tile, (t >> 3) & 31, the 64
-    // lanes of a wave shared 8 counters once a thread held 32 tiles: eight-deep same-address LDS atomics, 99 us at
-    // 32 400 tiles.)  The unrolled loops are cut every 8 tiles so that the compiler keeps 8, not 32, atomics and their
-    // results in flight (124 spilled registers at 32 tiles per thread otherwise).
+}
+
+// The heavy-first descriptor list of the blend launches {tile, first instance, instance count, -} (same ordering rule as
+// tile_order_kernel of sort.hip; see there and blend.hip for why): counting sort of the tiles by instance count, by ONE
+// workgroup of 1024 threads.  ORD_LEVELS levels, four per octave, ORD_SUB sub-counters per level picked by the THREAD
+// (tid & 31): the lanes of a wave hit 32 different counters of a level and a thread's run of neighbouring tiles stays
+// together in the list.  (Picked by tile, (t >> 3) & 31, the 64 lanes of a wave shared 8 counters once a thread held 32
+// tiles: eight-deep same-address LDS atomics, 99 us at 32 400 tiles.)  The unrolled loops are cut every 8 tiles so that
+// the compiler keeps 8, not 32, atomics and their results in flight (124 spilled registers at 32 tiles per thread otherwise).
+template <int ORD_PER>
+__device__ __forceinline__ void build_tile_desc(const u32* __restrict__ tile_total, const uint2* __restrict__ ranges, int T,
+                                                uint4* __restrict__ tile_desc, u32* __restrict__ n_active, u32* tr_all,
+                                                u32* s_cur /*[ORD_LEVELS * ORD_SUB]*/, u32* s_wave /*[17]*/)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (T + 1023) / 1024;
+    const int ta = min(T, tid * per), tb = min(T, ta + per);
+    u32* tr = tr_all + wave * (64 * ORD_PER + 2 * ORD_PER);
+    u32 cntv[ORD_PER];
+    (void)ord_load_counts<ORD_PER>(tile_total, T, per, tr, cntv);
+    const u32 first = (ta < T) ? ranges[ta].x : 0u;          // range start of the thread's first tile
     s_cur[tid] = 0; s_cur[tid + 1024] = 0;
     __syncthreads();
-    auto counter_of = [&](int t, u32 n) -> int { (void)t; return ord_level(n) * ORD_SUB + (tid & (ORD_SUB - 1)); };
+    auto counter_of = [&](u32 n) -> int { return ord_level(n) * ORD_SUB + (tid & (ORD_SUB - 1)); };
 #pragma unroll
     for (int i = 0; i < ORD_PER; ++i) {
-        if (i < per && ta + i < tb) atomicAdd(&s_cur[counter_of(ta + i, cntv[i])], 1u);
+        if (i < per && ta + i < tb) atomicAdd(&s_cur[counter_of(cntv[i])], 1u);
         if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
@@ -336,23 +360,44 @@ ranges_order_kernel(const u32* __restrict__ tile_total, int T, uint2* __restrict
                 u32 c = cntv[i];
                 asm volatile("" : "+v"(c));                 // recompute the level here: carried over from the counting pass it
                                                             // would be 32 more live registers
-                tile_desc[atomicAdd(&s_cur[counter_of(ta + i, c)], 1u)] = make_uint4((u32)(ta + i), run, c, 0u);
+                tile_desc[atomicAdd(&s_cur[counter_of(c)], 1u)] = make_uint4((u32)(ta + i), run, c, 0u);
                 run += c;
             }
             if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
+// the list on its own: when no emission runs (no Gaussians, or none visible)
+template <int ORD_PER>
+__global__ void __launch_bounds__(1024)
+tile_desc_kernel(const u32* __restrict__ tile_total, const uint2* __restrict__ ranges, int T, uint4* __restrict__ tile_desc,
+                 u32* __restrict__ n_active)
+{
+    __shared__ u32 s_cur[ORD_LEVELS * ORD_SUB];
+    __shared__ u32 s_wave[17];
+    extern __shared__ u32 tr_all[];
+    build_tile_desc<ORD_PER>(tile_total, ranges, T, tile_desc, n_active, tr_all, s_cur, s_wave);
+}
 
 // ------------------------------------------------------------------------------------------------ 4. emit_binned
+// The workgroup behind the last block of Gaussians builds the tile descriptor list (build_tile_desc) beside the emission.
+template <int ORD_PER>
 __global__ void __launch_bounds__(BIN_THREADS)
 emit_binned_kernel(int P, int per_block, int grid_x, int T, const uint2* __restrict__ rect,
                    const u32* __restrict__ tiles_touched, const u64* __restrict__ keep, const u32* __restrict__ pre,
                    const uint2* __restrict__ ranges, const u32* __restrict__ local_off, const u32* __restrict__ block_base,
                    u32* __restrict__ inst_off, const u32* __restrict__ depth_key, u64* __restrict__ words, u32 capacity,
-                   const u32* __restrict__ n_dev)
+                   const u32* __restrict__ n_dev, const u32* __restrict__ tile_total, uint4* __restrict__ tile_desc,
+                   u32* __restrict__ n_active)
 {
-    extern __shared__ u32 cur[];                             // T slot cursors
+    static_assert(BIN_THREADS == 1024, "build_tile_desc is written for 1024 threads");
+    extern __shared__ u32 cur[];                             // T slot cursors (the descriptor workgroup: its transposes)
+    if (blockIdx.x == gridDim.x - 1) {
+        __shared__ u32 s_cur[ORD_LEVELS * ORD_SUB];
+        __shared__ u32 s_wave[17];
+        build_tile_desc<ORD_PER>(tile_total, ranges, T, tile_desc, n_active, cur, s_cur, s_wave);
+        return;
+    }
     // the instance offset of a Gaussian's records (blend_bwd's emission slots, preprocess_bwd's record sums): written even
     // when a speculative capacity turns out too small -- the caller then reruns this launch on an exact buffer
     {
@@ -723,18 +768,32 @@ tile_sort_kernel(const uint4* __restrict__ tile_desc, const u32* __restrict__ n_
 
 // ------------------------------------------------------------------------------------------------ launchers
 static size_t ord_tr_bytes(int per) { return (size_t)16 * (64 * per + 2 * per) * 4; }   // 34 / 68 / 135 KB
-static void launch_ranges_order(const ImgView& im, const GeomView& g, int T, int B, hipStream_t st, u32* host_count = nullptr)
+static int ord_per_for(int T) { return T <= 1024 * 8 ? 8 : T <= 1024 * 16 ? 16 : 32; }
+template <typename K>
+static hipError_t big_lds(K kernel, size_t bytes)             // more than 64 KB of dynamic LDS has to be asked for
 {
-#define RO_ARGS(PER) dim3(1), dim3(1024), ord_tr_bytes(PER), st, im.tile_total, T, im.ranges, im.tile_desc, im.n_active, g.block_total, B, g.block_base, g.num_rendered, host_count
-    if (T <= 1024 * 8) hipLaunchKernelGGL(ranges_order_kernel<8>, RO_ARGS(8));
-    else if (T <= 1024 * 16) {                               // more than 64 KB of dynamic LDS has to be asked for
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ranges_order_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ord_tr_bytes(16));
-        hipLaunchKernelGGL(ranges_order_kernel<16>, RO_ARGS(16));
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ranges_order_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ord_tr_bytes(32));
-        hipLaunchKernelGGL(ranges_order_kernel<32>, RO_ARGS(32));
-    }
-#undef RO_ARGS
+    if (bytes <= 65536 - 9 * 1024) return hipSuccess;        // (leaves room for the kernels' static arrays)
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+static hipError_t launch_ranges_order(const ImgView& im, const GeomView& g, int T, int B, hipStream_t st, u32* host_count = nullptr)
+{
+    hipError_t e = hipSuccess;
+#define RO_LAUNCH(PER) { e = big_lds(ranges_order_kernel<PER>, ord_tr_bytes(PER));                                               \
+        if (e == hipSuccess) hipLaunchKernelGGL(ranges_order_kernel<PER>, dim3(1), dim3(1024), ord_tr_bytes(PER), st, im.tile_total, T, \
+                                                im.ranges, g.block_total, B, g.block_base, g.num_rendered, host_count); }
+    switch (ord_per_for(T)) { case 8: RO_LAUNCH(8) break; case 16: RO_LAUNCH(16) break; default: RO_LAUNCH(32) }
+#undef RO_LAUNCH
+    return e;
+}
+hipError_t launch_binned_desc_only(const ImgView& im, int T, hipStream_t st)
+{
+    hipError_t e = hipSuccess;
+#define TD_LAUNCH(PER) { e = big_lds(tile_desc_kernel<PER>, ord_tr_bytes(PER));                                                  \
+        if (e == hipSuccess) hipLaunchKernelGGL(tile_desc_kernel<PER>, dim3(1), dim3(1024), ord_tr_bytes(PER), st, im.tile_total,     \
+                                                im.ranges, T, im.tile_desc, im.n_active); }
+    switch (ord_per_for(T)) { case 8: TD_LAUNCH(8) break; case 16: TD_LAUNCH(16) break; default: TD_LAUNCH(32) }
+#undef TD_LAUNCH
+    return e != hipSuccess ? e : hipGetLastError();
 }
 int binned_per_block(int P)
 {
@@ -759,8 +818,8 @@ hipError_t launch_binned_prepare(const GeomView& g, const ImgView& im, int P, in
     hipLaunchKernelGGL(tile_count_kernel, dim3(B), dim3(BIN_THREADS), (size_t)T2 * 4, st, P, per, grid_x, T2, g.rect, g.tiles_touched,
                        g.keep, im.cnt_rows, g.local_off, g.block_total);
     hipLaunchKernelGGL(tile_prefix_kernel, dim3(cdiv(T2, 64)), dim3(256), 0, st, im.cnt_rows, B, T, T2, im.pre, im.tile_total);
-    launch_ranges_order(im, g, T, B, st, host_count);
-    return hipGetLastError();
+    hipError_t e = launch_ranges_order(im, g, T, B, st, host_count);
+    return e != hipSuccess ? e : hipGetLastError();
 }
 
 // P == 0: no Gaussian block exists; the tile list is all empty tiles
@@ -768,21 +827,25 @@ hipError_t launch_binned_empty(const GeomView& g, const ImgView& im, int T, hipS
 {
     hipError_t e = hipMemsetAsync(im.tile_total, 0, sizeof(u32) * (size_t)T, st);
     if (e != hipSuccess) return e;
-    launch_ranges_order(im, g, T, 0, st);
-    return hipGetLastError();
+    e = launch_ranges_order(im, g, T, 0, st);
+    if (e != hipSuccess) return e;
+    return launch_binned_desc_only(im, T, st);
 }
 
 hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int grid_x, int T, u64* words, u64* scratch, u32* point_list,
                                 u32 capacity, const u32* n_dev, hipStream_t st)
 {
     const int per = binned_per_block(P), B = cdiv(P, per);
-    const size_t cursors = (size_t)T * 4;                     // up to 128 KB of LDS at 32768 tiles: one workgroup per CU
-    if (cursors > 65536) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(emit_binned_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cursors);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(emit_binned_kernel, dim3(B), dim3(BIN_THREADS), cursors, st, P, per, grid_x, T, g.rect, g.tiles_touched,
-                       g.keep, im.pre, im.ranges, g.local_off, g.block_base, g.inst_off, g.depth_key, words, capacity, n_dev);
+    // T slot cursors (up to 128 KB at 32768 tiles: one workgroup per CU); the descriptor workgroup's transposes fit beside
+    hipError_t e = hipSuccess;
+#define EM_LAUNCH(PER) { const size_t lds = (size_t)T * 4 > ord_tr_bytes(PER) ? (size_t)T * 4 : ord_tr_bytes(PER);              \
+        e = big_lds(emit_binned_kernel<PER>, lds);                                                                                \
+        if (e == hipSuccess) hipLaunchKernelGGL(emit_binned_kernel<PER>, dim3(B + 1), dim3(BIN_THREADS), lds, st, P, per, grid_x, T, g.rect, \
+                g.tiles_touched, g.keep, im.pre, im.ranges, g.local_off, g.block_base, g.inst_off, g.depth_key, words, capacity, n_dev,   \
+                im.tile_total, im.tile_desc, im.n_active); }
+    switch (ord_per_for(T)) { case 8: EM_LAUNCH(8) break; case 16: EM_LAUNCH(16) break; default: EM_LAUNCH(32) }
+#undef EM_LAUNCH
+    if (e != hipSuccess) return e;
     // long lists first (lowest workgroup ids): their few workgroups run beside the many short sorts
     const u32 n_large_wg = (u32)(T < 768 ? T : 768);
     hipLaunchKernelGGL(tile_sort_kernel, dim3(n_large_wg + (u32)cdiv(T, 4)), dim3(256), 0, st, im.tile_desc, im.n_active, words, scratch,
