@@ -163,38 +163,41 @@ tile_count_kernel(int P, int per_block, int grid_x, int T2, const uint2* __restr
 }
 
 // ------------------------------------------------------------------------------------------------ 2. tile_prefix
-// lane = packed word (two tiles), wave = a quarter of the blocks; the lane's <= 64 words stay in registers between the
-// summing pass and the writing pass, so the matrix is read once and the prefix written once.
+// thread = (packed word = two tiles, group of 8 blocks); the thread's 8 words stay in registers between the summing pass
+// and the writing pass, so the matrix is read once and the prefix written once.  (First version: 64 words x 4 quarters of
+// 64 blocks per 256-thread workgroup -- 64 workgroups in all, 9.0 us of load latency on a quarter of the CUs.)
 // The blocks are taken in the order (b % 8, b / 8), not 0, 1, 2, ...: emit_binned's workgroup b runs on XCD b % 8, and the
 // eight L2s do not merge partial lines with one another.  With the blocks in id order every 128-byte line of the list
 // collected 8-byte words from all eight XCDs and went to memory up to eight times (PMC: 66 MB written for 18.6 MB of
 // output); now a tile's list is eight stretches, each written through ONE L2.  The order inside a tile's list is free: the
 // per-tile sort follows.
 __device__ __forceinline__ int prefix_block(int seq) { return (seq & 31) * 8 + (seq >> 5); }
-__global__ void __launch_bounds__(256)
+#define PFX_WORDS 32                                        // packed words (64 tiles) per workgroup
+#define PFX_GROUPS 32                                       // groups of 8 blocks: 1024 threads = 32 words x 32 groups
+__global__ void __launch_bounds__(1024)
 tile_prefix_kernel(const u32* __restrict__ cnt_rows, int B, int T, int T2, u32* __restrict__ pre, u32* __restrict__ tile_total)
 {
-    __shared__ u32 qsum[4][64][2];
-    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int w = blockIdx.x * 64 + lane;                    // packed word = tiles 2w, 2w + 1
-    u32 v[64];
+    __shared__ u32 gsum[PFX_GROUPS][PFX_WORDS][2];
+    const int wl = threadIdx.x & (PFX_WORDS - 1), grp = threadIdx.x / PFX_WORDS;
+    const int w = blockIdx.x * PFX_WORDS + wl;               // packed word = tiles 2w, 2w + 1
+    u32 v[8];
     u32 s0 = 0, s1 = 0;
 #pragma unroll
-    for (int i = 0; i < 64; ++i) {
-        const int b = prefix_block(q * 64 + i);
+    for (int i = 0; i < 8; ++i) {
+        const int b = prefix_block(grp * 8 + i);
         v[i] = (w < T2 && b < B) ? cnt_rows[(size_t)b * T2 + w] : 0u;
     }
 #pragma unroll
-    for (int i = 0; i < 64; ++i) { s0 += v[i] & 0xFFFFu; s1 += v[i] >> 16; }
-    qsum[q][lane][0] = s0; qsum[q][lane][1] = s1;
+    for (int i = 0; i < 8; ++i) { s0 += v[i] & 0xFFFFu; s1 += v[i] >> 16; }
+    gsum[grp][wl][0] = s0; gsum[grp][wl][1] = s1;
     __syncthreads();
     u32 r0 = 0, r1 = 0;
-    for (int p = 0; p < q; ++p) { r0 += qsum[p][lane][0]; r1 += qsum[p][lane][1]; }
+    for (int p = 0; p < grp; ++p) { r0 += gsum[p][wl][0]; r1 += gsum[p][wl][1]; }
     const int t0 = 2 * w;
     if (w < T2) {
 #pragma unroll
-        for (int i = 0; i < 64; ++i) {
-            const int b = prefix_block(q * 64 + i);
+        for (int i = 0; i < 8; ++i) {
+            const int b = prefix_block(grp * 8 + i);
             if (b < B) {
                 u32* dst = pre + (size_t)b * T + t0;
                 dst[0] = r0;
@@ -202,7 +205,7 @@ tile_prefix_kernel(const u32* __restrict__ cnt_rows, int B, int T, int T2, u32* 
                 r0 += v[i] & 0xFFFFu; r1 += v[i] >> 16;
             }
         }
-        if (q == 3) {                                        // the last quarter ends on the column totals
+        if (grp == PFX_GROUPS - 1) {                         // the last group ends on the column totals
             tile_total[t0] = r0;
             if (t0 + 1 < T) tile_total[t0 + 1] = r1;
         }
@@ -817,7 +820,7 @@ hipError_t launch_binned_prepare(const GeomView& g, const ImgView& im, int P, in
     }
     hipLaunchKernelGGL(tile_count_kernel, dim3(B), dim3(BIN_THREADS), (size_t)T2 * 4, st, P, per, grid_x, T2, g.rect, g.tiles_touched,
                        g.keep, im.cnt_rows, g.local_off, g.block_total);
-    hipLaunchKernelGGL(tile_prefix_kernel, dim3(cdiv(T2, 64)), dim3(256), 0, st, im.cnt_rows, B, T, T2, im.pre, im.tile_total);
+    hipLaunchKernelGGL(tile_prefix_kernel, dim3(cdiv(T2, PFX_WORDS)), dim3(1024), 0, st, im.cnt_rows, B, T, T2, im.pre, im.tile_total);
     hipError_t e = launch_ranges_order(im, g, T, B, st, host_count);
     return e != hipSuccess ? e : hipGetLastError();
 }
