@@ -395,7 +395,6 @@ class _RasterizeGaussians(torch.autograd.Function):
         need = ctx.needs_input_grad
         if grad_color is None:
             return (None,) * 15
-        _resolve(lib, fw)                     # a lazy forward's instance count: read here, not inside the forward
         with torch.cuda.device(dev):
             gc = grad_color.detach()
             if gc.dtype != torch.float32 or not gc.is_contiguous():
@@ -431,13 +430,22 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_proj = new((4, 4), need[11])
             g_intr = new((4, 4), need[12])
             g_campos = new((3,), need[13])
-            ws = _bytes(lib.bags_backward_workspace_size(P, fw.num_rendered), dev)     # records: the TRUE count, not the capacity
+            # A lazy forward's instance count is read HERE, not inside the forward and not at the top of this function: every
+            # allocation above happens while the device is still busy with the forward, and only the struct fill and the call
+            # itself sit between the count's arrival and the first backward kernel's launch (on a slow host the ~40 us of
+            # Python in between showed up as idle device in front of blend_bwd, tools/trace_gaps.sh).  The workspace is
+            # therefore sized for the speculative capacity (>= the count unless the forward overflowed).
+            ws_for = fw.capacity if fw.pending is not None else fw.num_rendered
+            ws = _bytes(lib.bags_backward_workspace_size(P, ws_for), dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _resolve(lib, fw)
+            if fw.num_rendered > ws_for:                         # overflow: the exact redo found more instances than the capacity
+                ws = _bytes(lib.bags_backward_workspace_size(P, fw.num_rendered), dev)
             args = L.BagsBackwardArgs(gc.data_ptr(), fw.num_rendered, ws.data_ptr(), ws.numel(), _ptr(g_means3D),
                                       _ptr(g_means2D), _ptr(g_densify), _ptr(g_sh), _ptr(g_col), _ptr(g_opac),
                                       _ptr(g_scales), _ptr(g_rot), _ptr(g_cov), _ptr(g_view), _ptr(g_proj),
                                       _ptr(g_intr), _ptr(g_campos), _ptr(g_shift), fw.capacity)
             state = _state_of(fw)
-            stream = torch.cuda.current_stream(dev).cuda_stream
             L.check(lib.bags_backward(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(args), stream),
                     "bags_backward")
         if g_campos is not None:

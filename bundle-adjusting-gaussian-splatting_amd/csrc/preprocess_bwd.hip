@@ -32,17 +32,11 @@ __device__ __forceinline__ float wave_sum(float x)
 // tree), so a splat covering thousands of tiles does not serialise one lane.
 #define SUM_COOP 64
 #define RQ (PART_FLOATS / 4)          // float4s per record
-__global__ void __launch_bounds__(256)
-sum_partials_kernel(int P, const u32* __restrict__ tiles_touched, const u32* __restrict__ inst_off, const float* __restrict__ partials,
-                    float4* __restrict__ sums)
+// The summation itself (whole wave: every lane calls it, lanes without a Gaussian with nrec = 0).
+__device__ __forceinline__ void sum_records(u32 nrec, u32 first, const float* __restrict__ partials, float4& s0, float4& s1, float4& s2)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
-    u32 nrec = 0, first = 0;
-    if (i < P) {            // the record count from the compact array (4 coalesced bytes), not from the Gaussian's 64-byte geometry line
-        nrec = tiles_touched[i]; first = inst_off[i];
-    }
+    s0 = make_float4(0.f, 0.f, 0.f, 0.f); s1 = s0; s2 = s0;
     if (nrec > 0 && nrec <= SUM_COOP) {
         const float4* rec = reinterpret_cast<const float4*>(partials + (size_t)first * PART_FLOATS);
         u32 r = 0;
@@ -87,15 +81,32 @@ sum_partials_kernel(int P, const u32* __restrict__ tiles_touched, const u32* __r
             s2 = make_float4(v[8], v[9], v[10], 0.f);
         }
     }
+}
+__global__ void __launch_bounds__(256)
+sum_partials_kernel(int P, const u32* __restrict__ tiles_touched, const u32* __restrict__ inst_off, const float* __restrict__ partials,
+                    float4* __restrict__ sums)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 nrec = 0, first = 0;
+    if (i < P) {            // the record count from the compact array (4 coalesced bytes), not from the Gaussian's 64-byte geometry line
+        nrec = tiles_touched[i]; first = inst_off[i];
+    }
+    float4 s0, s1, s2;
+    sum_records(nrec, first, partials, s0, s1, s2);
     if (i < P) { sums[3 * (size_t)i] = s0; sums[3 * (size_t)i + 1] = s1; sums[3 * (size_t)i + 2] = s2; }
 }
 
+#ifndef PB_FUSED
+#define PB_FUSED 1           // preprocess_bwd sums the records itself (no sum_partials launch, no sums array written and read back);
+                             // summing before or after the input rows are requested makes no difference (68.4 / 68.8 us)
+#endif
 #ifndef SH_STAGE
 #define SH_STAGE 1
 #endif
 #ifndef PRE_BWD_WAVES
-#define PRE_BWD_WAVES 1
-#endif
+#define PRE_BWD_WAVES (PB_FUSED ? 4 : 1)   // fused: 128 VGPRs (12 spilled) and 4 workgroups per CU: 68.4 us; left free (146, 3 per CU) 76.1;
+#endif                                     // 5 per CU 105.  Separate sum_partials (23.1) + preprocess_bwd (53.1): 76.2
+
 template <bool COV3D>        // the Gaussians carry precomputed 3D covariances instead of scales + rotations (uniform: no branch at the top)
 __global__ void __launch_bounds__(256, PRE_BWD_WAVES)
 preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod,
@@ -105,7 +116,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                       const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
                       const float* __restrict__ projmatrix, const float* __restrict__ intrinsic,
                       const float* __restrict__ campos_p,
-                      const u32* __restrict__ tiles_touched, const float* __restrict__ shjac,
+                      const u32* __restrict__ tiles_touched, const u32* __restrict__ inst_off, const float* __restrict__ shjac,
                       const float* __restrict__ partials, float* __restrict__ pose_slab,
                       float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_densify,
                       float* __restrict__ g_shs, float* __restrict__ g_colors, float* __restrict__ g_opac,
@@ -151,6 +162,9 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     // (nothing is read from the Gaussian's 64-byte geometry line any more: the conic is re-derived below bit for bit, the
     // visibility comes from the compact tiles_touched array, the SH clamp bits ride in the tenth word of shjac)
     const u32 n_inst = tiles_touched[ic];
+#if PB_FUSED
+    const u32 first_rec = inst_off[ic];
+#endif
     float x = means3D[3 * ic + 0], y = means3D[3 * ic + 1], z = means3D[3 * ic + 2];
     float in_s0 = 0.f, in_s1 = 0.f, in_s2 = 0.f;
     float4 in_q = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -166,8 +180,15 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     float mj[10];                                                                           // K1's d(colour)/d(direction) + clamp bits (SH path)
 #pragma unroll
     for (int t = 0; t < 10; ++t) mj[t] = shjac[10 * ic + t];
+#if PB_FUSED
+    // the Gaussian's records (blend_bwd's, `partials` is the record array) summed here, with every other input in flight
+    float4 sm_a, sm_b, sm_c;
+    __builtin_amdgcn_sched_barrier(0);
+    sum_records(i < P ? n_inst : 0u, first_rec, partials, sm_a, sm_b, sm_c);
+#else
     const float4* sm = reinterpret_cast<const float4*>(partials) + 3 * ic;                  // K8a's per-Gaussian sums
     const float4 sm_a = sm[0], sm_b = sm[1], sm_c = sm[2];
+#endif
     // every one of those loads is IN FLIGHT before the first of them is waited for (the compiler otherwise sinks the ones only
     // the visible branch needs behind the visibility test: one more round trip per group)
     asm volatile("" :: "v"(n_inst), "v"(mj[9]), "v"(x), "v"(y), "v"(z), "v"(in_s0), "v"(in_s1), "v"(in_s2), "v"(in_q.x), "v"(in_c[0]),
@@ -535,13 +556,18 @@ hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, co
     const int nb = cdiv(P, 256);
     *nblocks_out = nb;
     if (P == 0) return hipSuccess;
+#if PB_FUSED
+    (void)sums;
+    const float* partials = partials_records;
+#else
     hipLaunchKernelGGL(sum_partials_kernel, dim3(nb), dim3(256), 0, st, P, g.tiles_touched, g.inst_off, partials_records,
                        reinterpret_cast<float4*>(sums));
     const float* partials = sums;
+#endif
 #define PRE_BWD_LAUNCH(COV)     hipLaunchKernelGGL(preprocess_bwd_kernel<COV>, dim3(nb), dim3(256), 0, st, P, s.sh_coeffs, s.sh_degree, s.image_width, \
                        s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, in.means3D, in.shift_factors, in.shs, \
                        in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, s.viewmatrix, s.projmatrix, \
-                       s.intrinsic, s.campos, g.tiles_touched, g.shjac, partials, \
+                       s.intrinsic, s.campos, g.tiles_touched, g.inst_off, g.shjac, partials, \
                        pose_slab, a.grad_means3D, a.grad_means2D, a.grad_means2D_densify, a.grad_shs, \
                        a.grad_colors_precomp, a.grad_opacities, a.grad_scales, a.grad_rotations, a.grad_cov3D_precomp);
     if (in.cov3D_precomp) { PRE_BWD_LAUNCH(true) } else { PRE_BWD_LAUNCH(false) }
