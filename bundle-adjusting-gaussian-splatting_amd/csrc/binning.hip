@@ -13,7 +13,7 @@
 //   4. emit_binned     same workgroups as 1.: instance -> slot from a per-tile cursor in LDS (range start + column prefix,
 //                      bumped by a returning LDS atomic: arbitrary order inside a (block, tile) group), writes the Gaussian id
 //   5. tile_sort       one WAVE per tile sorts its (depth key, id) words in LDS (one-pass bucket sort; bitonic network for
-//                      clustered keys and for lists of more than 1024 entries)
+//                      clustered keys and for lists of more than 512 entries)
 // (depth key, id) is a strict total order, so the sorted list is unique: bit-identical to the stable sort of the 64-bit
 // keys whatever order the atomics of step 4 retired in, and bitwise reproducible.  No global atomics anywhere.
 // Limits: tiles * 2 bytes of LDS (<= 32768 tiles: up to 4K images) and <= 65535 Gaussians per block (P <= 16.7 M);
@@ -215,7 +215,9 @@ tile_prefix_kernel(const u32* __restrict__ cnt_rows, int B, int T, int T2, u32* 
 // ------------------------------------------------------------------------------------------------ 3. ranges_order
 // One workgroup: tile ranges (exclusive scan of the tile totals), instance count, block bases, and the heavy-first tile
 // descriptor list (same ordering rule as tile_order_kernel of sort.hip; see there and blend.hip for why).
-#define TSORT_WAVE 1024                                     // longest list the one-wave-per-tile sort takes
+#ifndef TSORT_WAVE
+#define TSORT_WAVE 512                                      // longest list the one-wave-per-tile sort takes (round 3: 1024 before -- half
+#endif                                                      // the registers and unrolled passes per wave, 20 KB of LDS per workgroup instead of 40)
 #define ORD_LEVELS 64
 #define ORD_SUB 32
 __device__ __forceinline__ int ord_level(u32 n)
@@ -516,34 +518,42 @@ __device__ __forceinline__ void wave_sort_words(const u64 (&e)[PER], u32 n, u32 
 // workgroups behind the long-list ones in tile_sort_kernel: four tiles per 256-thread workgroup, one per wave, each with
 // its own quarter of the workgroup's LDS; neighbouring descriptors hold lists of similar length).
 #define TS_PER (TSORT_WAVE / 64)
-__device__ __forceinline__ void sort_wave_role(const uint4 desc, const u64* __restrict__ words_in, u32* __restrict__ point_list, u64* t, u32* cnt)
+template <int PER>
+__device__ __forceinline__ void sort_wave_list(u32 n, u32 start, const u64* __restrict__ words_in, u32* __restrict__ point_list, u64* t, u32* cnt)
 {
-    const u32 n = desc.z, start = desc.y;
-    if (n == 0 || n > TSORT_WAVE) return;
     const u32 lane = threadIdx.x & 63;
-    if (n == 1) { if (lane == 0) point_list[start] = (u32)words_in[start]; return; }
     // the list's (depth key, id) words in one batch of coalesced loads (clamped indices, no branches)
-    u64 e[TS_PER];
+    u64 e[PER];
     u32 kmin = 0xFFFFFFFFu, kmax = 0u;
 #pragma unroll
-    for (u32 r = 0; r < TS_PER; ++r) {
+    for (u32 r = 0; r < PER; ++r) {
         const u64 w = words_in[start + min(r * 64 + lane, n - 1)];
         const bool valid = r * 64 + lane < n;
         const u32 key = (u32)(w >> 32);
         e[r] = valid ? w : ~0ull;
         kmin = min(kmin, valid ? key : 0xFFFFFFFFu); kmax = max(kmax, valid ? key : 0u);
     }
-    wave_sort_words<TS_PER>(e, n, wave_min(kmin), wave_max(kmax), point_list + start, t, cnt);
+    wave_sort_words<PER>(e, n, wave_min(kmin), wave_max(kmax), point_list + start, t, cnt);
+}
+__device__ __forceinline__ void sort_wave_role(const uint4 desc, const u64* __restrict__ words_in, u32* __restrict__ point_list, u64* t, u32* cnt)
+{
+    const u32 n = desc.z, start = desc.y;
+    if (n == 0 || n > TSORT_WAVE) return;
+    if (n == 1) { if ((threadIdx.x & 63) == 0) point_list[start] = (u32)words_in[start]; return; }
+    // every pass of the sort is unrolled over the entries a lane CAN hold: a list of half the capacity takes the half-size
+    // instance (wave-uniform choice; the median tile of the bench scene holds 254 entries)
+    if (n <= TSORT_WAVE / 2) sort_wave_list<TS_PER / 2>(n, start, words_in, point_list, t, cnt);
+    else sort_wave_list<TS_PER>(n, start, words_in, point_list, t, cnt);
 }
 
-// The same bucket sort run by a whole 256-thread workgroup on n <= 256 * PER words (lists of 1025..4096 entries: the bulk
+// The same bucket sort run by a whole 256-thread workgroup on n <= 256 * PER words (lists of 513..2048 entries: the bulk
 // of the tiles of a dense scene, e.g. 718 instances per tile on average at scale multiplier 1.0).  e[r] = word of entry
 // r * 256 + tid.  s_tmp: 8 words of scratch.
 template <int PER>
 __device__ __forceinline__ void block_sort_words(const u64 (&e)[PER], u32 n, u32 kmin, u32 kmax, u32* __restrict__ out, u64* t, u32* cnt,
                                                  u32* s_tmp)
 {
-    // same scheme as wave_sort_words on 256 threads: packed 16-bit bucket counters (n <= TSORT_BLOCK = 4096), buckets
+    // same scheme as wave_sort_words on 256 threads: packed 16-bit bucket counters (n <= TSORT_BLOCK), buckets
     // recomputed from the key in the ranking pass
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 nb = n, nw = (nb + 1) >> 1;
@@ -624,7 +634,9 @@ __device__ __forceinline__ void block_sort_words(const u64 (&e)[PER], u32 n, u32
 //   * beyond that (tens of thousands of splats over ONE tile: a camera far from the scene, adversarial inputs), or as that
 //     fallback: the bitonic network in global memory, loads and stores at agent scope so that the waves of the workgroup
 //     see each other's exchanges across the barriers.  Slow, correct, never on the path of an ordinary frame.
-#define TSORT_BLOCK 4096
+#ifndef TSORT_BLOCK
+#define TSORT_BLOCK 2048
+#endif
 #define TSORT_LARGE 16384
 #define TS_SLABS_MAX 64
 // ONE launch for every list (round 3; the long-list kernel used to be a launch of its own: ~5 us of stream time even when no
@@ -634,7 +646,7 @@ tile_sort_kernel(const uint4* __restrict__ tile_desc, const u32* __restrict__ n_
                  u64* __restrict__ scratch, u32* __restrict__ point_list, u32 capacity, const u32* __restrict__ n_dev, int T,
                  u32 n_large_wg)
 {
-    __shared__ u64 t_all[TSORT_BLOCK];                       // one list of <= 4096 words, or four waves x 1024 (slab sort / short lists)
+    __shared__ u64 t_all[TSORT_BLOCK];                       // one list of <= TSORT_BLOCK words, or four waves x TSORT_WAVE (slab sort / short lists)
     __shared__ u32 cnt_all[TSORT_BLOCK / 2];                 // packed 16-bit counters
     __shared__ u32 s_red[8];
     __shared__ u32 slab_cnt[TS_SLABS_MAX + 1], slab_start[TS_SLABS_MAX + 1], s_next, s_bad;
@@ -676,7 +688,7 @@ tile_sort_kernel(const uint4* __restrict__ tile_desc, const u32* __restrict__ n_
         bool network = n > TSORT_LARGE;
         if (!network) {
             // ---- level 1: key range, slab of every entry, slab counts
-            const u32 K = min((u32)TS_SLABS_MAX, (n + 511) / 512);
+            const u32 K = min((u32)TS_SLABS_MAX, (n + TSORT_WAVE / 2 - 1) / (TSORT_WAVE / 2));
             u32 kmin = 0xFFFFFFFFu, kmax = 0u;
             for (u32 i = tid; i < n; i += 256) { const u32 key = (u32)(words_in[start + i] >> 32); kmin = min(kmin, key); kmax = max(kmax, key); }
             kmin = wave_min(kmin); kmax = wave_max(kmax);
