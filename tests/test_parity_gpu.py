@@ -670,7 +670,7 @@ def test_binning_paths_agree_on_random_scenes():
 def test_long_and_clustered_tile_lists_take_every_sort_path(P, shrink, flat):
     """The per-tile sort of the tile-binned path (csrc/binning.hip) has four ways through it; each must give the oracle's list:
     thousands of splats over a handful of tiles (a camera far from a compact scene) leave the one-wave bucket sort for the
-    workgroup-wide one (1025..4096 entries: P = 3000), the two-level slab sort (P = 20000) and the global-memory network
+    workgroup-wide one (513..2048 entries) or the two-level slab sort (P = 3000 and 20000) and the global-memory network
     (> 16384 entries: P = 40000); `flat` puts every splat at the SAME depth (identical 32-bit keys: the order is decided by the
     Gaussian id alone), which overflows the buckets / slabs and takes the bitonic fallbacks (in LDS for P = 600 and 2500, in
     global memory for P = 5000)."""
@@ -689,6 +689,33 @@ def test_long_and_clustered_tile_lists_take_every_sort_path(P, shrink, flat):
     else:
         assert longest > {3000: 1024, 20000: 8192, 40000: 16384}[P], longest
     assert_report(rep, grad_tol=3e-4, skip_zero=("campos",))
+
+
+@pytest.mark.parametrize("N", [255, 256, 257, 511, 512, 513, 2047, 2048, 2049])
+def test_tile_sort_size_boundaries(N):
+    """One tile holding exactly N instances, N on either side of every size at which the per-tile sort changes its code path
+    (csrc/binning.hip: half-size one-wave instance <= 256, one wave <= 512, whole workgroup <= 2048, slabs above): the list must
+    be the radix path's, bit for bit (no oracle: fast)."""
+    scene, cam = make_case(N, 48, 48, 1.0, 0, seed=N)
+    gen = torch.Generator().manual_seed(N)
+    xyz = 0.004 * torch.randn(N, 3, generator=gen)          # all of them project into the middle of tile (1, 1)
+    xyz[:, 2] = torch.rand(N, generator=gen) - 0.5          # depths spread out: distinct keys, arbitrary order
+    scene["means3D"] = xyz
+    scene["scales"] = torch.full((N, 3), 0.003)
+    scene["opacities"] = torch.full((N, 1), 0.05)
+    g = torch.randn(3, 48, 48, generator=gen)
+    o_a, g_a, v_a = run_hip(scene, cam, 0, g, binning="auto")
+    o_r, g_r, v_r = run_hip(scene, cam, 0, g, binning="radix")
+    lens = v_r["ranges"][:, 1] - v_r["ranges"][:, 0]
+    assert int(lens.max()) == N and int((lens > 0).sum()) == 1, lens
+    assert v_a["num_rendered"] == v_r["num_rendered"] == N
+    for k in ("point_list", "keys_sorted", "n_contrib"):
+        assert torch.equal(v_a[k], v_r[k]), k
+    for a, b in zip(o_a, o_r):
+        assert torch.equal(a, b)
+    for k in g_a:
+        if g_a[k] is not None:
+            assert torch.equal(g_a[k], g_r[k]), k
 
 
 @pytest.mark.parametrize("W,H,P,sm,shrink,fovy", [
