@@ -691,7 +691,7 @@ def test_long_and_clustered_tile_lists_take_every_sort_path(P, shrink, flat):
     assert_report(rep, grad_tol=3e-4, skip_zero=("campos",))
 
 
-@pytest.mark.parametrize("N", [255, 256, 257, 511, 512, 513, 2047, 2048, 2049])
+@pytest.mark.parametrize("N", [255, 256, 257, 510, 511, 512, 513, 2047, 2048, 2049])
 def test_tile_sort_size_boundaries(N):
     """One tile holding exactly N instances, N on either side of every size at which the per-tile sort changes its code path
     (csrc/binning.hip: half-size one-wave instance <= 256, one wave <= 512, whole workgroup <= 2048, slabs above): the list must
@@ -716,6 +716,10 @@ def test_tile_sort_size_boundaries(N):
     for k in g_a:
         if g_a[k] is not None:
             assert torch.equal(g_a[k], g_r[k]), k
+    if N < 600:     # ... and against the oracle where the forward's chunks end (255 staged splats per chunk: 255 | 256, 510 | 511)
+        rep = compare(scene, cam, 0, check_fp64=False)
+        _report({k: rep[k] for k in ("num_rendered", "image_max_err", "n_contrib_mismatch_frac", "grad_rel_fp32")})
+        assert_report(rep, grad_tol=3e-4, skip_zero=("campos",))
 
 
 @pytest.mark.parametrize("W,H,P,sm,shrink,fovy", [
