@@ -335,6 +335,7 @@ def main():
         evs = []
 
         single = (red is not None and v_per_rank == 1 and args.exchange == "all_reduce" and not args.bucket_always)
+        adopt = (red is not None and v_per_rank > 1 and args.exchange == "all_reduce" and not args.bucket_always)
 
         def full_step():
             if red is None and pip is None:
@@ -346,6 +347,18 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 red.all_reduce_single_view()
+                e1.record()
+                evs.append((e0, e1))
+                return radii_
+            if adopt:
+                # several views per rank: the first view's gradient buffer is adopted as the accumulator (p.grad starts as None,
+                # autograd adds the later views into it in place): no bucket zero pass, no add for the first view
+                radii_ = fns[0](True)
+                for f_ in fns[1:]:
+                    radii_ = f_(False)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                red.all_reduce_adopted()
                 e1.record()
                 evs.append((e0, e1))
                 return radii_
@@ -423,7 +436,7 @@ def main():
         v4 = {"views_per_rank_per_exchange": 4, "steps": k4, "ms_per_step": el4 / k4 * 1e3, "ms_per_view": el4 / k4 / 4 * 1e3,
               "value": world * 4 * P * k4 / el4,
               "exchange_ms": (sum(a.elapsed_time(b) for a, b in ev4) / len(ev4)) if ev4 else 0.0,
-              "note": "four views per rank (fwd+bwd, gradients accumulated in the flat bucket) behind one exchange"}
+              "note": "four views per rank (fwd+bwd; the first view's gradient buffer is adopted as the accumulator, --bucket-always: the flat bucket) behind one exchange"}
     # third leg, rank-0 single-GPU runs only: the same workload with the stock 3-sigma tile rule, i.e. upstream's instance list
     aabb = None
     if world == 1 and V == 1 and args.tile_bounds == "opacity" and not args.no_aabb_leg:

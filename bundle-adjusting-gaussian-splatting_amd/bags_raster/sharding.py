@@ -220,6 +220,12 @@ class GradAllReducer:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         self.single_view_collectives += 1
 
+    def all_reduce_adopted(self) -> None:
+        """The same collective after SEVERAL views of this rank: with every ``p.grad`` None before the first view, the first
+        backward's carved buffer becomes ``p.grad`` (handed over without a copy) and autograd adds the later views into it in
+        place -- the buffer is the accumulator, no bucket zero pass and no add for the first view."""
+        self.all_reduce_single_view()
+
     def begin(self) -> None:
         self.bucket.zero_()
         self.bucket.bind()

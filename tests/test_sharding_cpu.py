@@ -360,6 +360,23 @@ def _single_view_worker(rank, world, port, out):
         res[tag] = [p.grad.clone() for p in params]
     for a, b in zip(res["bucket"], res["single"]):
         assert torch.equal(a, b)
+    # several views per rank: the first backward's buffer is adopted as the accumulator (autograd adds the later views into it
+    # in place), no bucket zero / first-view add passes -- and still bit for bit what the bucket path gives
+    for tag in ("bucket2", "adopt2"):
+        params = _params(scene)
+        render = _make_render_fn(params)
+        red = GradAllReducer(params)
+        if tag == "bucket2":
+            red.begin()
+        for c in (cams[rank], cams[rank + 2]):
+            render(c).backward()
+        if tag == "bucket2":
+            red.all_reduce()
+        else:
+            red.all_reduce_adopted()
+        res[tag] = [p.grad.clone() for p in params]
+    for a, b in zip(res["bucket2"], res["adopt2"]):
+        assert torch.equal(a, b)
     params = _params(scene)
     for p in params:
         p.grad = torch.zeros_like(p)                       # unrelated tensors: not one buffer
