@@ -38,12 +38,30 @@ __device__ __forceinline__ float block_sum_256(float v, float* red)
     return s;
 }
 
-__global__ void __launch_bounds__(256)
+#ifndef LOSS_FWD_WAVES
+#define LOSS_FWD_WAVES 1
+#endif
+#ifndef LOSS_BWD_WAVES
+#define LOSS_BWD_WAVES 1
+#endif
+__global__ void __launch_bounds__(256, LOSS_FWD_WAVES)
 loss_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, int H, int W, int vec, LossWindow win,
                 float* __restrict__ dmu, float* __restrict__ de11, float* __restrict__ de12, float* __restrict__ partials)
 {
-    __shared__ float sa[LEXT][LSTR], sb[LEXT][LSTR];
-    __shared__ float h[5][LEXT][LT + 1];            // row-filtered a, b, aa, bb, ab
+    // LDS: the two staged images (2 x 42 x 49 floats) are dead once the row pass has read them, so three of the five
+    // row-filtered maps (a^2, b^2, ab) are written over them; the row pass keeps its sums in registers across the barrier that
+    // makes this safe.  27.6 KB instead of 44.2 KB: five workgroups per CU instead of three.
+    //   pool[0, 1386)      h3 (b^2), row stride 33      | over sa
+    //   pool[1386, 2730)   h2 (a^2), row stride 32      | over the end of sa and the start of sb
+    //   pool[2730, 4116)   h4 (ab),  row stride 33      | over sb
+    //   pool[4116, 6888)   h0 (a), h1 (b), row stride 33
+    constexpr int HS = LT + 1, HN = LEXT * HS;            // 33, 1386
+    __shared__ float pool[2 * LEXT * LSTR + 2 * HN];
+    static_assert(2 * LEXT * LSTR == 2 * HN + LEXT * LT, "the three aliased maps must fill the two staged images exactly");
+    float (*sa)[LSTR] = reinterpret_cast<float (*)[LSTR]>(pool);
+    float (*sb)[LSTR] = reinterpret_cast<float (*)[LSTR]>(pool + LEXT * LSTR);
+    float* const h3 = pool; float* const h2 = pool + HN; float* const h4 = pool + HN + LEXT * LT;
+    float* const h0 = pool + 2 * LEXT * LSTR; float* const h1 = h0 + HN;
     __shared__ float red[4];
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT, c = blockIdx.z;
@@ -73,33 +91,54 @@ loss_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, int
         }
     }
     __syncthreads();
-    // rows: LEXT x LT outputs, four consecutive columns per work item (14 LDS reads per image feed 4 x 11 taps)
-    for (int i = tid; i < LEXT * (LT / 4); i += 256) {
-        const int ly = i / (LT / 4), lx = (i - ly * (LT / 4)) * 4;
-        float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, s3[4] = {0.f, 0.f, 0.f, 0.f},
-              s4[4] = {0.f, 0.f, 0.f, 0.f};
+    // rows: LEXT x LT outputs, four consecutive columns per work item (14 LDS reads per image feed 4 x 11 taps); a thread's
+    // one or two work items stay in registers until every thread has finished reading the staged images
+    float S[2][5][4];
+    static_assert(LEXT * (LT / 4) <= 2 * 256, "two work items per thread cover the row pass");
 #pragma unroll
-        for (int k = 0; k < 14; ++k) {
-            const float a = sa[ly][lx + k + LOFF], b = sb[ly][lx + k + LOFF];
-            const float aa = a * a, bb = b * b, ab = a * b;
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + 256 * u;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int t = k - j;                       // tap index of output j
-                if (t >= 0 && t < 11) {
-                    const float w = win.w[t];
-                    s0[j] = fmaf(w, a, s0[j]); s1[j] = fmaf(w, b, s1[j]); s2[j] = fmaf(w, aa, s2[j]); s3[j] = fmaf(w, bb, s3[j]);
-                    s4[j] = fmaf(w, ab, s4[j]);
+        for (int q = 0; q < 5; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) S[u][q][j] = 0.f;
+        if (i < LEXT * (LT / 4)) {
+            const int ly = i / (LT / 4), lx = (i - ly * (LT / 4)) * 4;
+#pragma unroll
+            for (int k = 0; k < 14; ++k) {
+                const float a = sa[ly][lx + k + LOFF], b = sb[ly][lx + k + LOFF];
+                const float aa = a * a, bb = b * b, ab = a * b;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = k - j;                       // tap index of output j
+                    if (t >= 0 && t < 11) {
+                        const float w = win.w[t];
+                        S[u][0][j] = fmaf(w, a, S[u][0][j]); S[u][1][j] = fmaf(w, b, S[u][1][j]); S[u][2][j] = fmaf(w, aa, S[u][2][j]);
+                        S[u][3][j] = fmaf(w, bb, S[u][3][j]); S[u][4][j] = fmaf(w, ab, S[u][4][j]);
+                    }
                 }
             }
         }
+    }
+    const int lx = tid & 31, ty = (tid >> 5) * 4;
+    float l1v[4];                                            // |a - b| of the thread's four output pixels, while the images are there
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            h[0][ly][lx + j] = s0[j]; h[1][ly][lx + j] = s1[j]; h[2][ly][lx + j] = s2[j]; h[3][ly][lx + j] = s3[j]; h[4][ly][lx + j] = s4[j];
+    for (int r = 0; r < 4; ++r) l1v[r] = fabsf(sa[ty + r + LHALO][lx + LHALO + LOFF] - sb[ty + r + LHALO][lx + LHALO + LOFF]);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + 256 * u;
+        if (i < LEXT * (LT / 4)) {
+            const int ly = i / (LT / 4), lx4 = (i - ly * (LT / 4)) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                h0[ly * HS + lx4 + j] = S[u][0][j]; h1[ly * HS + lx4 + j] = S[u][1][j]; h2[ly * LT + lx4 + j] = S[u][2][j];
+                h3[ly * HS + lx4 + j] = S[u][3][j]; h4[ly * HS + lx4 + j] = S[u][4][j];
+            }
         }
     }
     __syncthreads();
     // columns + SSIM: one column, four consecutive rows per thread (14 reads per map feed 4 x 11 taps)
-    const int lx = tid & 31, ty = (tid >> 5) * 4;
     float sum_l1 = 0.f, sum_ssim = 0.f;
     float cm[5][4];
 #pragma unroll
@@ -108,9 +147,8 @@ loss_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, int
         for (int j = 0; j < 4; ++j) cm[q][j] = 0.f;
 #pragma unroll
     for (int k = 0; k < 14; ++k) {
-        float v[5];
-#pragma unroll
-        for (int q = 0; q < 5; ++q) v[q] = h[q][ty + k][lx];
+        const float v[5] = {h0[(ty + k) * HS + lx], h1[(ty + k) * HS + lx], h2[(ty + k) * LT + lx], h3[(ty + k) * HS + lx],
+                            h4[(ty + k) * HS + lx]};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int t = k - j;
@@ -140,7 +178,7 @@ loss_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, int
             const size_t o = c * plane + (size_t)gy * W + gx;
             dmu[o] = d_mu; de11[o] = d_e11; de12[o] = d_e12;
             sum_ssim += m;
-            sum_l1 += fabsf(sa[ly + LHALO][lx + LHALO + LOFF] - sb[ly + LHALO][lx + LHALO + LOFF]);
+            sum_l1 += l1v[r];
         }
     }
     const float t_l1 = block_sum_256(sum_l1, red);
@@ -167,15 +205,17 @@ loss_reduce_kernel(const float* __restrict__ partials, int nslots, double inv_co
     if (threadIdx.x == 0) { out_terms[0] = (float)(r0[0] * inv_count); out_terms[1] = (float)(r1[0] * inv_count); }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, LOSS_BWD_WAVES)
 loss_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, int H, int W, int vec, LossWindow win,
                 const float* __restrict__ dmu, const float* __restrict__ de11, const float* __restrict__ de12,
                 const float* __restrict__ grad_terms, float inv_count, float* __restrict__ grad_img)
 {
-    // 42-wide rows, scalar staging: the 48-wide aligned rows of the forward would cost this kernel its fourth resident
-    // workgroup per CU (38 KB -> 41 KB of LDS) and measured 11 % slower
+    // 42-wide rows, scalar staging.  The three row-filtered maps are written over the staged ones (the row pass keeps its sums
+    // in registers across the barrier in between): 21.7 KB of LDS instead of 38.3 KB, seven workgroups per CU instead of four.
     __shared__ float sm[3][LEXT][LEXT + 1];
-    __shared__ float h[3][LEXT][LT + 1];
+    constexpr int HS = LT + 1, HN = LEXT * HS;
+    static_assert(3 * HN <= 3 * LEXT * (LEXT + 1), "the row-filtered maps fit over the staged ones");
+    float* const hp = &sm[0][0][0];
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT, c = blockIdx.z;
     const size_t plane = (size_t)H * W;
@@ -189,23 +229,41 @@ loss_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, int
         sm[0][ly][lx] = in ? M0[o] : 0.f; sm[1][ly][lx] = in ? M1[o] : 0.f; sm[2][ly][lx] = in ? M2[o] : 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < LEXT * (LT / 4); i += 256) {
-        const int ly = i / (LT / 4), lx = (i - ly * (LT / 4)) * 4;
-        float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float S[2][3][4];
 #pragma unroll
-        for (int k = 0; k < 14; ++k) {
-            const float m0 = sm[0][ly][lx + k], m1 = sm[1][ly][lx + k], m2 = sm[2][ly][lx + k];
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + 256 * u;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int t = k - j;
-                if (t >= 0 && t < 11) {
-                    const float w = win.w[t];
-                    s0[j] = fmaf(w, m0, s0[j]); s1[j] = fmaf(w, m1, s1[j]); s2[j] = fmaf(w, m2, s2[j]);
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) S[u][q][j] = 0.f;
+        if (i < LEXT * (LT / 4)) {
+            const int ly = i / (LT / 4), lx = (i - ly * (LT / 4)) * 4;
+#pragma unroll
+            for (int k = 0; k < 14; ++k) {
+                const float m0 = sm[0][ly][lx + k], m1 = sm[1][ly][lx + k], m2 = sm[2][ly][lx + k];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = k - j;
+                    if (t >= 0 && t < 11) {
+                        const float w = win.w[t];
+                        S[u][0][j] = fmaf(w, m0, S[u][0][j]); S[u][1][j] = fmaf(w, m1, S[u][1][j]); S[u][2][j] = fmaf(w, m2, S[u][2][j]);
+                    }
                 }
             }
         }
+    }
+    __syncthreads();                                         // every thread has read the staged maps
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { h[0][ly][lx + j] = s0[j]; h[1][ly][lx + j] = s1[j]; h[2][ly][lx + j] = s2[j]; }
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + 256 * u;
+        if (i < LEXT * (LT / 4)) {
+            const int ly = i / (LT / 4), lx = (i - ly * (LT / 4)) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                hp[ly * HS + lx + j] = S[u][0][j]; hp[HN + ly * HS + lx + j] = S[u][1][j]; hp[2 * HN + ly * HS + lx + j] = S[u][2][j];
+            }
+        }
     }
     __syncthreads();
     const float g_l1 = grad_terms[0] * inv_count, g_ss = grad_terms[1] * inv_count;
@@ -217,7 +275,7 @@ loss_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, int
         for (int j = 0; j < 4; ++j) cf[q][j] = 0.f;
 #pragma unroll
     for (int k = 0; k < 14; ++k) {
-        const float v0 = h[0][ty + k][lx], v1 = h[1][ty + k][lx], v2 = h[2][ty + k][lx];
+        const float v0 = hp[(ty + k) * HS + lx], v1 = hp[HN + (ty + k) * HS + lx], v2 = hp[2 * HN + (ty + k) * HS + lx];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int t = k - j;
