@@ -7,12 +7,15 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbags_raster.so")
+# BAGS_RASTER_LIB: another build of the SAME library (csrc/Makefile `asan`: host-side AddressSanitizer build for the CPU ABI
+# tests).  Not a fallback: a missing file still raises.
+LIB_PATH = os.environ.get("BAGS_RASTER_LIB") or os.path.join(_HERE, "libbags_raster.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 TILES_AABB, TILES_OPACITY = 0, 1
 DEPTH_Z, DEPTH_DISTANCE = 0, 1
 BINNING_AUTO, BINNING_RADIX = 0, 1
+CLAMP_GRAD_STOCK, CLAMP_GRAD_EXACT = 0, 1
 
 c_fp = C.c_void_p  # device pointers travel as integers
 
@@ -21,7 +24,7 @@ class BagsSettings(C.Structure):
     _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
                 ("scale_modifier", C.c_float), ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32),
                 ("depth_key", C.c_int32), ("debug", C.c_int32), ("debug_iter", C.c_int32),
-                ("tile_bounds", C.c_int32), ("binning", C.c_int32),
+                ("tile_bounds", C.c_int32), ("binning", C.c_int32), ("clamp_grad", C.c_int32), ("reserved0", C.c_int32),
                 ("bg", c_fp), ("viewmatrix", c_fp), ("projmatrix", c_fp), ("intrinsic", c_fp), ("campos", c_fp)]
 
 

@@ -177,7 +177,10 @@ def save_checkpoint(pc: GaussianBag, iteration: int, path: str, optimizer_state:
 def _numpy_scalar_globals():
     """What the safe unpickler must accept for the reference's own files: ``capture()`` stores ``spatial_lr_scale`` =
     ``scene.cameras_extent`` = ``nerf_normalization['radius']``, a ``numpy.float64`` (scene/dataset_readers.py:100,
-    scene/__init__.py:115), which pickles as ``numpy.core.multiarray.scalar(dtype('f8'), bytes)``."""
+    scene/__init__.py:115), which pickles as ``<numpy core>.multiarray.scalar(dtype('f8'), bytes)``.  The module path in the
+    file is the WRITER's: ``numpy.core.multiarray`` from the reference's numpy 1.x environment, ``numpy._core.multiarray``
+    from numpy 2 -- both spellings are registered (tuple form: object + the name it is pickled under), whichever numpy
+    reads the file."""
     import numpy as np
     out = [np.dtype, np.float64, np.float32, np.int64, np.int32, type(np.dtype(np.float64)), type(np.dtype(np.float32)),
            type(np.dtype(np.int64)), type(np.dtype(np.int32))]
@@ -185,8 +188,19 @@ def _numpy_scalar_globals():
         from numpy._core.multiarray import scalar as _scalar        # numpy >= 2
     except ImportError:                                              # numpy 1.x
         from numpy.core.multiarray import scalar as _scalar
-    out.append(_scalar)
+    out += [(_scalar, "numpy.core.multiarray.scalar"), (_scalar, "numpy._core.multiarray.scalar")]
     return out
+
+
+def _safe_load(path, device):
+    allow = _numpy_scalar_globals()
+    ser = torch.serialization
+    if hasattr(ser, "safe_globals"):                                 # torch >= 2.5: scoped allow-list
+        with ser.safe_globals(allow):
+            return torch.load(path, map_location=device, weights_only=True)
+    if hasattr(ser, "add_safe_globals"):                             # torch 2.4: process-wide allow-list, no tuple form
+        ser.add_safe_globals([a[0] if isinstance(a, tuple) else a for a in allow])
+    return torch.load(path, map_location=device, weights_only=True)
 
 
 def load_checkpoint(path: str, sh_degree: int, device=None, trust_pickle: bool = False) -> Tuple[GaussianBag, dict, float, int]:
@@ -197,8 +211,7 @@ def load_checkpoint(path: str, sh_degree: int, device=None, trust_pickle: bool =
     the safe loader accepts; anything else does not) is only read with ``trust_pickle=True`` -- the reference's own behaviour,
     to be used on files you wrote yourself.  A view-sharded run must call ``DensificationSync.rebase()`` after restoring."""
     try:
-        with torch.serialization.safe_globals(_numpy_scalar_globals()):
-            model_args, iteration = torch.load(path, map_location=device, weights_only=True)
+        model_args, iteration = _safe_load(path, device)
     except Exception:
         if not trust_pickle:
             raise

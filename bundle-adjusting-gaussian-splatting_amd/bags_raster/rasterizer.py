@@ -17,6 +17,7 @@ from __future__ import annotations
 import ctypes as C
 from typing import NamedTuple, Optional
 
+import collections
 import math
 import threading
 import time
@@ -49,6 +50,9 @@ class GaussianRasterizationSettings(NamedTuple):
     # "auto": per-tile lists from the (block, tile) count matrix + per-tile LDS sort (csrc/binning.hip) when the image has
     # <= 32768 tiles; "radix": depth sort of the Gaussians + stable radix sort of the instances (csrc/sort.hip).  Same lists.
     binning: str = "auto"
+    # gradient of the EWA Jacobian at the 1.3 x FoV clamp: "stock" = upstream diff-gaussian-rasterization's rule (clamped t.x
+    # held constant inside dL/dt.z), which the reference's fork inherits; "exact" differentiates the clamped expression itself
+    clamp_grad: str = "stock"
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -126,6 +130,8 @@ class _Packed:
             raise ValueError("tile_bounds must be 'opacity' or 'aabb'")
         if settings.binning not in ("auto", "radix"):
             raise ValueError("binning must be 'auto' or 'radix'")
+        if settings.clamp_grad not in ("stock", "exact"):
+            raise ValueError("clamp_grad must be 'stock' or 'exact'")
         self.settings = L.BagsSettings(
             int(settings.image_height), int(settings.image_width), float(settings.tanfovx), float(settings.tanfovy),
             float(settings.scale_modifier), int(settings.sh_degree), int(M),
@@ -133,6 +139,7 @@ class _Packed:
             int(settings.debug_iter) if settings.debug_iter is not None else -1,
             L.TILES_OPACITY if settings.tile_bounds == "opacity" else L.TILES_AABB,
             L.BINNING_RADIX if settings.binning == "radix" else L.BINNING_AUTO,
+            L.CLAMP_GRAD_EXACT if settings.clamp_grad == "exact" else L.CLAMP_GRAD_STOCK, 0,
             _ptr(k["bg"]), _ptr(k["viewmatrix"]), _ptr(k["projmatrix"]), _ptr(k["intrinsic"]), _ptr(k["campos"]))
         self.inputs = L.BagsInputs(P, _ptr(k["means3D"]), _ptr(k["means2D"]), _ptr(k["shift_factors"]), _ptr(k["shs"]),
                                    _ptr(k["colors_precomp"]), _ptr(k["opacities"]), _ptr(k["scales"]),
@@ -159,41 +166,58 @@ class _Forwarded:
 
 
 # Speculative forward (bags_forward_prepare_async + bags_forward_finish_speculative): the instance counts of earlier calls
-# with the same problem shape give the capacity guess for the next one, so the steady state has no host round trip in the
-# middle of the forward.
+# with the same problem shape give the capacity guess for the next one, so both phases of the forward are enqueued back to
+# back and the device never waits for the host in the middle of a forward.
 SPECULATE = True
 # When the host reads the asynchronous instance count of a speculative forward:
-#   "lazy"     (default) a forward that will be differentiated returns WITHOUT waiting; the count is read at the entry of
-#              its backward (by then it arrived long ago).  Nothing in the forward blocks the host, so the views of a batch
-#              can be enqueued back to back, also on several streams (utils/cubemap_utils.py:229,263-265 renders five per
-#              iteration).  The buffer is sized CAPACITY_HEADROOM x the largest count seen for the shape; should a count
-#              still exceed it, the image of THAT forward had every tile rendered empty: the check at backward entry then
-#              redoes the second phase exactly (the gradients are those of the true render for the cotangent that was
-#              passed in) and raises a RuntimeWarning.  Forwards that nobody differentiates always wait.
-#   "forward"  every forward waits for its count before it returns and redoes an overflowing second phase at once
-#              (exact results always; the behaviour of rounds 1-2).
-HOST_WAIT = "lazy"
-CAPACITY_HEADROOM = 4.0
-_capacity_hint = {}          # (device index, P, W, H) -> largest instance count seen for the shape (a hint only)
+#   "forward"  (default) every forward reads its count before it returns (the device is meanwhile busy with the second
+#              phase) and redoes an overflowing second phase at once on an exact buffer: the tensors a forward returns are
+#              ALWAYS the true render, as the reference's are (train.py:250-331: render -> loss -> backward).
+#   "lazy"     opt-in.  A forward that will be differentiated returns WITHOUT waiting; the count is read at the entry of
+#              its backward.  Nothing in the forward blocks the host, so the views of a batch can be enqueued back to back,
+#              also on several streams (utils/cubemap_utils.py:229,263-265 renders five per iteration).  The buffer is sized
+#              CAPACITY_HEADROOM x the largest count seen for the shape.  Should a count still exceed it, the image THAT
+#              forward returned had every tile rendered empty and whatever was computed from it (the loss, hence the
+#              cotangent) is wrong: the backward RAISES ``SpeculationOverflow`` so that the caller can redo the step
+#              (the hint has been raised by then, the retry fits).  With LAZY_RECOVER = True it instead redoes the second
+#              phase exactly, writes the true image into the tensors the forward returned, computes the gradients of the
+#              true render for the cotangent that was passed in, and issues a RuntimeWarning.  A lazy forward that is
+#              never differentiated reports an overflow as a RuntimeWarning when its count is collected.
+HOST_WAIT = "forward"
+LAZY_RECOVER = False
+CAPACITY_HEADROOM = 4.0      # lazy forwards only; a waiting forward sizes for 1.2 x the largest count seen and redoes on overflow
+_HINT_KEYS_MAX = 64
+_capacity_hint = {}          # (device index, P, W, H) -> largest instance count seen for the shape (a hint only); insertion order = LRU
 _below_half = {}             # ... -> consecutive calls whose count stayed below half of it
-_hint_lock = threading.Lock()
+_hint_lock = threading.RLock()
+
+
+class SpeculationOverflow(RuntimeError):
+    """A lazy forward (HOST_WAIT = 'lazy') held more instances than its speculative buffer: the image it returned was empty."""
 
 
 def _note_count(key, n: int) -> None:
     """The hint is the MAXIMUM seen (the views of a scene differ by tens of per cent); it only comes down after 256 calls in a
     row below half of it.  It must not drift from call to call: the capacity is a buffer size, and sizes that never repeat
-    defeat torch's caching allocator (measured: 13-71 hipMalloc per 40 steps with a 2 % decay per call, none without)."""
+    defeat torch's caching allocator (measured: 13-71 hipMalloc per 40 steps with a 2 % decay per call, none without).
+    Shapes that have not been rendered for a while are evicted (densification changes P every few hundred iterations)."""
     n = int(n)
     with _hint_lock:
-        old = _capacity_hint.get(key, 0)
+        old = _capacity_hint.pop(key, 0)
         if n >= old:
-            _capacity_hint[key], _below_half[key] = n, 0
+            new, _below_half[key] = n, 0
         elif 2 * n < old:
+            new = old
             _below_half[key] = _below_half.get(key, 0) + 1
             if _below_half[key] >= 256:
-                _capacity_hint[key], _below_half[key] = 2 * n, 0
+                new, _below_half[key] = 2 * n, 0
         else:
-            _below_half[key] = 0
+            new, _below_half[key] = old, 0
+        _capacity_hint[key] = new                              # re-inserted last: most recently used
+        while len(_capacity_hint) > _HINT_KEYS_MAX:
+            oldest = next(iter(_capacity_hint))
+            del _capacity_hint[oldest]
+            _below_half.pop(oldest, None)
 
 
 def _capacity_for(hint: int, headroom: float) -> int:
@@ -225,14 +249,14 @@ class _PinnedSlots:
 _pinned = _PinnedSlots()
 
 
-_NO_COUNT = 0xFFFFFFFF        # what a lazy forward's pinned word holds until the device has written the instance count
+_NO_COUNT = 0xFFFFFFFF        # what a pinned word holds until the device has written the instance count
 
 
 def _await_count(pinned: torch.Tensor, stream) -> int:
-    """The asynchronous instance count of a lazy forward.  No event is recorded for it (an event between the two phases of the
-    forward costs ~6 us of idle device per frame, tools/trace_gaps.sh): the word starts as _NO_COUNT and is written by the
-    counting kernel itself (system-scope store into pinned memory) or by the copy behind it, so the host simply looks at it;
-    by the time a backward starts it has almost always arrived."""
+    """The asynchronous instance count of a speculative forward.  No event is recorded for it (an event between the two
+    phases of the forward costs ~6 us of idle device per frame, tools/trace_gaps.sh): the word starts as _NO_COUNT and is
+    written by the counting kernel itself (system-scope store into pinned memory) or by the copy behind it, so the host simply
+    looks at it."""
     # busy polling, no sleep: the word normally arrives within ~0.1 ms of the forward starting to execute, and a sleep of
     # "20 us" comes back after 60 us .. 1 ms -- long enough for the device to run dry behind it (25 us of idle in front of every
     # blend_bwd in one of two otherwise identical traces, tools/trace_gaps.sh).  A queue so deep that the count is still
@@ -251,19 +275,39 @@ def _await_count(pinned: torch.Tensor, stream) -> int:
     return n
 
 
-def _abandon(pinned, stream, key):
-    """Finalizer of a lazy forward nobody differentiated: the count is still read (hint, slot reuse only after the kernel
-    that writes the word has run)."""
-    try:
-        _note_count(key, _await_count(pinned, stream))
+# Lazy forwards nobody differentiated.  Their finalizer runs wherever the last reference happens to die (inside the cyclic GC,
+# inside another forward, at interpreter shutdown), so it must not block, take locks that may be held, or touch the device: it
+# only parks the pinned word here.  The next forward (or _drain_abandoned()) looks at the parked words, without waiting.
+_abandoned = collections.deque()
+
+
+def _abandon(pinned, key, capacity):
+    _abandoned.append((pinned, key, capacity))               # deque.append is atomic
+
+
+def _drain_abandoned() -> None:
+    for _ in range(len(_abandoned)):
+        try:
+            pinned, key, capacity = _abandoned.popleft()
+        except IndexError:
+            return
+        n = int(pinned[0].item()) & 0xFFFFFFFF
+        if n == _NO_COUNT:                                   # its kernel has not run yet: look again next time
+            _abandoned.append((pinned, key, capacity))
+            continue
         _pinned.give(pinned)
-    except Exception:                                        # interpreter shutdown
-        pass
+        _note_count(key, n)
+        if n > capacity:
+            import warnings
+            warnings.warn(f"bags_raster: a lazy forward that was never differentiated held {n} (tile, Gaussian) instances, more "
+                          f"than its speculative capacity {capacity}: the image it returned had every tile rendered empty.  "
+                          f"Render under torch.no_grad() (such forwards always wait for their count) or leave "
+                          f"bags_raster.rasterizer.HOST_WAIT at 'forward'.", RuntimeWarning)
 
 
 def _resolve(lib, fw: "_Forwarded") -> None:
-    """Read the asynchronous instance count of a lazy forward (no-op otherwise); redo its second phase if the speculative
-    buffer turned out too small."""
+    """Read the asynchronous instance count of a lazy forward (no-op otherwise).  Overflow: raise, or with LAZY_RECOVER redo
+    the second phase on an exact buffer."""
     global LAST_NUM_RENDERED
     if fw.pending is None:
         return
@@ -277,11 +321,16 @@ def _resolve(lib, fw: "_Forwarded") -> None:
     if n <= fw.capacity:
         fw.outs = None
         return
+    msg = (f"bags_raster: {n} (tile, Gaussian) instances exceeded the speculative capacity {fw.capacity} of a lazy forward "
+           f"({CAPACITY_HEADROOM} x the largest count seen for this shape): the image that forward returned had every tile "
+           f"rendered empty, so the loss and the cotangent computed from it are wrong.")
+    if not LAZY_RECOVER or fw.outs is None:
+        fw.outs = None
+        raise SpeculationOverflow(msg + "  Redo the step (the capacity hint has been raised), or use the default "
+                                        "bags_raster.rasterizer.HOST_WAIT = 'forward'.")
     import warnings
-    warnings.warn(f"bags_raster: {n} (tile, Gaussian) instances exceeded the speculative capacity {fw.capacity} "
-                  f"({CAPACITY_HEADROOM} x the largest count seen for this shape): the image returned by that forward had every "
-                  f"tile rendered empty.  The state is recomputed exactly for this backward; set "
-                  f"bags_raster.rasterizer.HOST_WAIT = 'forward' if counts jump like this regularly.", RuntimeWarning)
+    warnings.warn(msg + "  LAZY_RECOVER: the state is recomputed exactly and the gradients are those of the true render for "
+                        "the cotangent that was passed in.", RuntimeWarning)
     pk, dev = fw.packed, fw.packed.device
     color, radii, depth, weights, mean2D = fw.outs
     out = L.BagsForwardOut(color.data_ptr(), radii.data_ptr(), depth.data_ptr(), weights.data_ptr(), mean2D.data_ptr())
@@ -311,6 +360,8 @@ def _run_forward(lib, pk: _Packed, H: int, W: int, speculate: bool = True, lazy:
     state = L.BagsState(fw.geom.data_ptr(), fw.geom.numel(), None, 0, fw.image.data_ptr(), fw.image.numel())
     global LAST_NUM_RENDERED
     fw.key = key = (dev.index, P, W, H)
+    if _abandoned:
+        _drain_abandoned()
     with _hint_lock:
         hint = _capacity_hint.get(key) if (SPECULATE and speculate and not pk.settings.debug) else None
     lazy = lazy and HOST_WAIT == "lazy"
@@ -319,13 +370,9 @@ def _run_forward(lib, pk: _Packed, H: int, W: int, speculate: bool = True, lazy:
         fw.binning = _bytes(lib.bags_binning_size(cap, W, H), dev)
         state.binning, state.binning_bytes = fw.binning.data_ptr(), fw.binning.numel()
         pinned = _pinned.take()
-        if lazy:
-            pinned[0] = -1                    # _NO_COUNT (the previous user of the slot has read its value)
+        pinned[0] = -1                        # _NO_COUNT (the previous user of the slot has read its value)
         L.check(lib.bags_forward_prepare_async(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(out),
                                                pinned.data_ptr(), stream), "bags_forward_prepare_async")
-        if not lazy:
-            ev = torch.cuda.Event()
-            ev.record(fw.stream)
         L.check(lib.bags_forward_finish_speculative(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(out),
                                                     cap, stream), "bags_forward_finish_speculative")
         fw.capacity = cap
@@ -334,11 +381,11 @@ def _run_forward(lib, pk: _Packed, H: int, W: int, speculate: bool = True, lazy:
             # aliases, not the tensors the autograd Function returns: those get a grad_fn that owns ctx, hence fw -- a reference
             # cycle that only the cyclic GC breaks, and until then ~250 MB of state per forward stay allocated (measured: the
             # caching allocator then goes to hipMalloc dozens of times per 40 steps)
-            fw.outs = tuple(t.detach() for t in (color, radii, depth, weights, mean2D))
-            fw.pending = (pinned, weakref.finalize(fw, _abandon, pinned, fw.stream, key))
+            fw.outs = tuple(t.detach() for t in (color, radii, depth, weights, mean2D)) if LAZY_RECOVER else None
+            fw.pending = (pinned, weakref.finalize(fw, _abandon, pinned, key, cap))
             return fw, (color, radii, depth, weights, mean2D)
-        ev.synchronize()                      # phase 2 is already queued behind the count: the GPU does not wait for us
-        n = int(pinned[0].item()) & 0xFFFFFFFF
+        # phase 2 is already queued behind the count: the device does not wait for us while we wait for the word
+        n = _await_count(pinned, fw.stream)
         _pinned.give(pinned)
         _note_count(key, n)
         fw.num_rendered = LAST_NUM_RENDERED = n

@@ -106,8 +106,8 @@ class GradExchange:
         self.dense_above = dense_above
         self.last_rows_exchanged: Optional[int] = None     # sparse mode: rows that crossed the links in the last exchange (P = dense fallback)
         if mode == "sparse":
-            rows = {p.shape[0] for p in bucket.params}
-            if len(rows) != 1 or any(p.dim() < 1 for p in bucket.params):
+            rows = {(p.shape[0] if p.dim() >= 1 else None) for p in bucket.params}
+            if len(rows) != 1 or None in rows:
                 raise ValueError("mode='sparse' needs parameters that all have one row per Gaussian (same first dimension)")
         self._pending: List[object] = []
         self._shard: Optional[torch.Tensor] = None
@@ -147,6 +147,8 @@ class GradExchange:
         """Exchange only the rows touched on some rank.  Returns False when the dense all-reduce should run instead."""
         views = self.bucket.views
         P = views[0].shape[0]
+        if P == 0:
+            return True                                       # nothing to exchange (every rank holds the same empty set)
         touched = torch.zeros(P, dtype=torch.uint8, device=views[0].device)
         for v in views:                                       # a row is touched if any parameter's gradient row is non-zero
             touched |= (v.reshape(P, -1) != 0).any(dim=1).to(torch.uint8)
@@ -210,13 +212,41 @@ class GradAllReducer:
         if any(g is None for g in grads):
             raise RuntimeError("all_reduce_single_view: a parameter has no gradient (every rank must have rendered one view)")
         st = grads[0].untyped_storage()
+        esz = grads[0].element_size()
         for g in grads:
             if g.untyped_storage().data_ptr() != st.data_ptr() or not g.is_contiguous() or g.dtype != grads[0].dtype:
                 raise RuntimeError("all_reduce_single_view: the gradients are not views of one buffer (they did not come straight "
                                    "from one rasterizer backward); use begin() ... all_reduce() instead")
+        # The collective's length and the position of every slice must be the same on all ranks.  The op's backward carves
+        # its Gaussian gradients in a fixed order on 64-float boundaries (rasterizer.py, `want`), so the layout is a function
+        # of the parameter shapes alone -- PROVIDED nothing else sits in the buffer: the slices, taken in buffer order, must
+        # pack exactly like a FlatGradBucket of those shapes.  A rank whose gradients do not (another set of inputs requiring
+        # gradients, tensors from two different backwards) raises here instead of corrupting or hanging the collective.
+        order = sorted(range(len(grads)), key=lambda i: grads[i].storage_offset())
+        base = grads[order[0]].storage_offset()
+        off, gaps = 0, []
+        for i in order:
+            g = grads[i]
+            if g.storage_offset() - base != off or g.numel() != self.params[i].numel():
+                raise RuntimeError("all_reduce_single_view: the gradient buffer is not one 64-float aligned packing of the "
+                                   "parameters' gradients; use begin() ... all_reduce() instead")
+            end = off + g.numel()
+            off = (end + 63) // 64 * 64
+            if i != order[-1]:
+                gaps.append((end, off))
+        if base + end > st.nbytes() // esz:
+            raise RuntimeError("all_reduce_single_view: gradient buffer shorter than its layout")
         if _world(self.group) == 1:
             return
-        flat = torch.empty(0, dtype=grads[0].dtype, device=grads[0].device).set_(st, 0, (st.nbytes() // grads[0].element_size(),))
+        flat = torch.empty(0, dtype=grads[0].dtype, device=grads[0].device).set_(st, base, (end,))
+        # the alignment gaps between the slices come from torch.empty(): zeroed here (one indexed fill, cached index) so that
+        # the collective never reads uninitialised memory -- on this path only, where a 0.6 ms collective follows
+        key = (flat.device, tuple(gaps))
+        if getattr(self, "_gaps", (None, None))[0] != key:
+            idx = [j for a_, b_ in gaps for j in range(a_, b_)]
+            self._gaps = (key, torch.tensor(idx, dtype=torch.int64, device=flat.device) if idx else None)
+        if self._gaps[1] is not None:
+            flat.index_fill_(0, self._gaps[1], 0.0)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         self.single_view_collectives += 1
 

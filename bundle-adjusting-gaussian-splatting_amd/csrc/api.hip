@@ -25,6 +25,40 @@ static int fail(int code, const char* fmt, ...)
          if (e_ != hipSuccess) return fail(BAGS_ERR_HIP, "debug: %s failed at iteration %d: %s", what, (s)->debug_iter, hipGetErrorString(e_)); } \
     } while (0)
 
+// settings.debug also scans what a call produced for NaN / Inf (the reference's debug flag dumps a snapshot
+// when the CUDA op throws; here the op names the first tensor that went non-finite and the iteration it happened in).
+__global__ void __launch_bounds__(256) count_nonfinite_kernel(const float* __restrict__ x, size_t n, u32* __restrict__ counter)
+{
+    u32 bad = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const u32 b = __float_as_uint(x[i]);
+        bad += ((b & 0x7F800000u) == 0x7F800000u) ? 1u : 0u;          // exponent all ones: Inf or NaN
+    }
+    for (int d = 32; d >= 1; d >>= 1) bad += (u32)__shfl_xor((int)bad, d);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(counter, bad);
+}
+struct ScanItem { const char* name; const float* ptr; size_t n; };
+// counters: device words nobody else uses (GeomView::num_rendered[8 ...], 64 words are carved for it); one per item
+static int debug_scan(const BagsSettings* s, hipStream_t st, u32* counters, const ScanItem* items, int n_items, const char* phase,
+                      int (*failfn)(int, const char*, ...))
+{
+    if (!s->debug) return BAGS_OK;
+    if (n_items > 32) n_items = 32;
+    if (hipMemsetAsync(counters, 0, sizeof(u32) * 32, st) != hipSuccess) return failfn(BAGS_ERR_HIP, "debug scan: memset failed");
+    for (int i = 0; i < n_items; ++i) {
+        if (!items[i].ptr || items[i].n == 0) continue;
+        const int grid = (int)((items[i].n + 256 * 16 - 1) / (256 * 16));
+        hipLaunchKernelGGL(count_nonfinite_kernel, dim3(grid < 1 ? 1 : (grid > 4096 ? 4096 : grid)), dim3(256), 0, st, items[i].ptr, items[i].n, counters + i);
+    }
+    u32 host[32];
+    if (hipMemcpyAsync(host, counters, sizeof(u32) * 32, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return failfn(BAGS_ERR_HIP, "debug scan: %s", hipGetErrorString(hipGetLastError()));
+    for (int i = 0; i < n_items; ++i)
+        if (items[i].ptr && host[i])
+            return failfn(BAGS_ERR_DEVICE, "debug: %s produced %u non-finite values in %s at iteration %d", phase, host[i], items[i].name, s->debug_iter);
+    return BAGS_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- stage profiler
 // Opt-in (bags_profile_enable): a start/stop hipEvent pair per stage per call, resolved in bags_profile_read.
 #include <mutex>
@@ -224,6 +258,15 @@ static int enqueue_prepare(const BagsSettings* s, const BagsInputs* in, const Ge
     return BAGS_OK;
 }
 
+static int scan_forward(const BagsSettings* s, const BagsInputs* in, const GeomView& g, const BagsForwardOut* out, hipStream_t st)
+{
+    if (!s->debug) return BAGS_OK;
+    const size_t HW = (size_t)s->image_width * s->image_height;
+    const ScanItem items[] = {{"rendered_image", out->color, 3 * HW}, {"depth", out->depth, HW}, {"weights", out->weights, HW},
+                              {"mean2D", out->mean2D, 2 * (size_t)in->P}};
+    return debug_scan(s, st, g.num_rendered + 8, items, 4, "the forward", fail);
+}
+
 // emission, per-tile ordering, blend.  n_dev != nullptr: the instance count is read on the device and checked against
 // `I` (the capacity the binning buffer was sized for)
 static int enqueue_finish(const BagsSettings* s, const BagsInputs* in, const GeomView& g, const BinView& b, const ImgView& im,
@@ -242,7 +285,7 @@ static int enqueue_finish(const BagsSettings* s, const BagsInputs* in, const Geo
         DEBUG_SYNC(s, st, "emit / tile sort");
         { ProfScope ps(ST_BLEND_FWD, st); HIP_TRY(launch_blend_fwd(*s, g, b, im, *out, st, n_dev, (u32)I)); }
         DEBUG_SYNC(s, st, "blend_fwd");
-        return BAGS_OK;
+        return scan_forward(s, in, g, out, st);
     }
     if (I > 0) {
         { ProfScope ps(ST_EMIT, st); HIP_TRY(launch_emit(g, g.vals_b, in->P, gx, b.keys_b, b.vals_b, (u32)I, st, n_dev, b.ranges, gx * gy)); }
@@ -258,7 +301,7 @@ static int enqueue_finish(const BagsSettings* s, const BagsInputs* in, const Geo
     DEBUG_SYNC(s, st, "tile ranges");
     { ProfScope ps(ST_BLEND_FWD, st); HIP_TRY(launch_blend_fwd(*s, g, b, im, *out, st)); }
     DEBUG_SYNC(s, st, "blend_fwd");
-    return BAGS_OK;
+    return scan_forward(s, in, g, out, st);
 }
 
 int bags_forward_prepare(const BagsSettings* s, const BagsInputs* in, const BagsState* stt, const BagsForwardOut* out,
@@ -372,6 +415,17 @@ int bags_backward(const BagsSettings* s, const BagsInputs* in, const BagsState* 
     DEBUG_SYNC(s, st, "preprocess_bwd");
     { ProfScope ps(ST_POSE_REDUCE, st); HIP_TRY(launch_pose_reduce(slab, nblocks, *a, st)); }
     DEBUG_SYNC(s, st, "pose_reduce");
+    if (s->debug) {
+        const size_t P = (size_t)in->P;
+        const ScanItem items[] = {{"grad_means3D", a->grad_means3D, 3 * P}, {"grad_means2D", a->grad_means2D, 3 * P},
+                                  {"grad_means2D_densify", a->grad_means2D_densify, 3 * P}, {"grad_shs", a->grad_shs, 3 * P * (size_t)s->sh_coeffs},
+                                  {"grad_colors_precomp", a->grad_colors_precomp, 3 * P}, {"grad_opacities", a->grad_opacities, P},
+                                  {"grad_scales", a->grad_scales, 3 * P}, {"grad_rotations", a->grad_rotations, 4 * P},
+                                  {"grad_cov3D_precomp", a->grad_cov3D_precomp, 6 * P}, {"grad_viewmatrix", a->grad_viewmatrix, 16},
+                                  {"grad_projmatrix", a->grad_projmatrix, 16}, {"grad_intrinsic", a->grad_intrinsic, 16},
+                                  {"grad_campos", a->grad_campos, 3}, {"grad_shift_factors", a->grad_shift_factors, 3}};
+        return debug_scan(s, st, g.num_rendered + 8, items, 14, "the backward", fail);
+    }
     return BAGS_OK;
 }
 

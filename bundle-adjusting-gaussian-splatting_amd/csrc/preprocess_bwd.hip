@@ -109,7 +109,7 @@ sum_partials_kernel(int P, const u32* __restrict__ tiles_touched, const u32* __r
 
 template <bool COV3D>        // the Gaussians carry precomputed 3D covariances instead of scales + rotations (uniform: no branch at the top)
 __global__ void __launch_bounds__(256, PRE_BWD_WAVES)
-preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod,
+preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod, int clamp_stock,
                       const float* __restrict__ means3D, const float* __restrict__ shift_factors,
                       const float* __restrict__ shs, const float* __restrict__ colors_precomp,
                       const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -306,8 +306,14 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         const float ditz = dj00 * fx - dj02 * fx * ux + dj11 * fy - dj12 * fy * uy;
         float dtx = 0.f, dty = 0.f, dtz = 0.f;
         float dtzs = -ditz * itz * itz;
+        // Frustum clamp (BagsSettings.clamp_grad).  Upstream's computeCov2DCUDA backward, which the reference's fork inherits
+        // (README.md:126): dL/dt.x = x_grad_mul * (-h_x / t.z^2) dL/dJ02 and dL/dt.z takes (2 h_x t.x / t.z^3) dL/dJ02 with the
+        // CLAMPED t.x (= ux tzs here) as a constant -- i.e. the unclamped formula with t.x replaced.  BAGS_CLAMP_GRAD_EXACT drops
+        // that term for a clamped axis (the clamped t.x is +-1.3 tanfov t.z: J02 = -fx ux / t.z, already in `ditz`).
         if (!clx) { dtx += dux * itz; dtzs -= dux * tx * itz * itz; }
+        else if (clamp_stock) dtzs -= dux * (ux * tzs) * itz * itz;
         if (!cly) { dty += duy * itz; dtzs -= duy * ty * itz * itz; }
+        else if (clamp_stock) dtzs -= duy * (uy * tzs) * itz * itz;
 
         // ---- 4. pixel centre -> homogeneous point
         const float dhx = gm2x * pw, dhy = gm2y * pw;
@@ -565,7 +571,7 @@ hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, co
     const float* partials = sums;
 #endif
 #define PRE_BWD_LAUNCH(COV)     hipLaunchKernelGGL(preprocess_bwd_kernel<COV>, dim3(nb), dim3(256), 0, st, P, s.sh_coeffs, s.sh_degree, s.image_width, \
-                       s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, in.means3D, in.shift_factors, in.shs, \
+                       s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, (s.clamp_grad == BAGS_CLAMP_GRAD_EXACT) ? 0 : 1, in.means3D, in.shift_factors, in.shs, \
                        in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, s.viewmatrix, s.projmatrix, \
                        s.intrinsic, s.campos, g.tiles_touched, g.inst_off, g.shjac, partials, \
                        pose_slab, a.grad_means3D, a.grad_means2D, a.grad_means2D_densify, a.grad_shs, \

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BAGS_ABI_VERSION 4
+#define BAGS_ABI_VERSION 5
 #define BAGS_TILE 16
 
 enum { BAGS_OK = 0, BAGS_ERR_ARG = -1, BAGS_ERR_HIP = -2, BAGS_ERR_SIZE = -3, BAGS_ERR_DEVICE = -4 };
@@ -50,6 +50,12 @@ enum { BAGS_TILES_AABB = 0, BAGS_TILES_OPACITY = 1 };
  * tiles and P <= 16.7 M, else RADIX.  RADIX: depth-sort the Gaussians, emit, stable radix sort by tile (csrc/sort.hip).
  * Both produce the same lists bit for bit. */
 enum { BAGS_BINNING_AUTO = 0, BAGS_BINNING_RADIX = 1 };
+/* Gradient of the EWA Jacobian for a Gaussian whose view-space point lies outside 1.3 x the field of view, where the forward
+ * uses the clamped t.x = +-1.3 tanfovx t.z (same for y).  Forward values do not depend on this switch.
+ * STOCK (default): the rule of upstream diff-gaussian-rasterization's computeCov2DCUDA backward, which the reference's fork
+ * (README.md:126) inherits: dL/dt.x is zeroed (x_grad_mul) and dL/dt.z takes 2 h_x t.x / t.z^3 dL/dJ02 with the clamped t.x
+ * held CONSTANT.  EXACT: differentiates the clamped expression itself (t.x moves with t.z), i.e. half of that one term. */
+enum { BAGS_CLAMP_GRAD_STOCK = 0, BAGS_CLAMP_GRAD_EXACT = 1 };
 
 /* GaussianRasterizationSettings (gaussian_renderer/__init__.py:50-65) */
 typedef struct BagsSettings {
@@ -62,7 +68,9 @@ typedef struct BagsSettings {
     int32_t debug;                   /* !=0: synchronise + check after every kernel */
     int32_t debug_iter;              /* carried for error messages only */
     int32_t tile_bounds;             /* BAGS_TILES_AABB | BAGS_TILES_OPACITY */
-    int32_t binning;                 /* BAGS_BINNING_AUTO | BAGS_BINNING_RADIX (also keeps the pointers 8-byte aligned) */
+    int32_t binning;                 /* BAGS_BINNING_AUTO | BAGS_BINNING_RADIX */
+    int32_t clamp_grad;              /* BAGS_CLAMP_GRAD_STOCK | BAGS_CLAMP_GRAD_EXACT (backward only) */
+    int32_t reserved0;               /* 0 (keeps the pointers 8-byte aligned) */
     const float* bg;                 /* (3)   */
     const float* viewmatrix;         /* (4,4) world->view, transposed (W2C^T) */
     const float* projmatrix;         /* (4,4) viewmatrix * intrinsic */

@@ -41,11 +41,12 @@ Semantics decided here because the fork is unavailable (also listed in DESIGN.md
   D5  extra outputs: depth (1,H,W) = sum w_i z_i, weights (1,H,W) = 1 - T_final, mean2D (P,2) pixel
       centres; depth/weights/mean2D carry no gradient.
   D6  depth key = view-space z (README.md:126 default) or Euclidean distance (``depth_key='distance'``).
-  D8  frustum clamp: for a point outside 1.3 x the field of view the EWA Jacobian uses t.x = +-1.3 tanfovx * t.z.  Here
-      (and in preprocess_bwd.hip) that expression is differentiated EXACTLY: dL/dt.x = 0 and dL/dt.z sees t.x move with
-      t.z.  Upstream 3DGS zeroes dL/dt.x too (x_grad_mul) but keeps the clamped t.x constant inside dL/dt.z, which doubles
-      that one term for clamped points; ``clamp_grad="stock"`` reproduces it so that a test can show the two differ only on
-      clamped Gaussians (tests/test_parity_gpu.py::test_frustum_clamp_gradient_semantic).  Forward values are identical.
+  D8  frustum clamp: for a point outside 1.3 x the field of view the EWA Jacobian uses t.x = +-1.3 tanfovx * t.z.  Default
+      ``clamp_grad="stock"`` (since round 4, here and in preprocess_bwd.hip): upstream 3DGS's rule, which the reference's fork
+      inherits -- dL/dt.x is zeroed (x_grad_mul) and the clamped t.x is a CONSTANT inside dL/dt.z (2 h_x t.x / t.z^3 dL/dJ02).
+      ``clamp_grad="exact"`` differentiates the clamped expression itself (dL/dt.z sees t.x move with t.z: half of that one
+      term).  The two differ on clamped Gaussians only (tests/test_parity_gpu.py::test_frustum_clamp_gradient_semantic);
+      forward values are identical.
 """
 from __future__ import annotations
 
@@ -107,7 +108,7 @@ class OracleSettings:
     debug_iter: Optional[int] = None
     depth_key: str = "z"
     tile_bounds: str = "opacity"      # "aabb": stock 3-sigma square; "opacity": intersected with the alpha >= 1/255 bounds
-    clamp_grad: str = "exact"         # D8; "stock": upstream's x_grad_mul treatment of frustum-clamped points (tests only)
+    clamp_grad: str = "stock"         # D8; "stock": upstream's x_grad_mul treatment of frustum-clamped points; "exact"
 
 
 @dataclass

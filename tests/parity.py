@@ -25,7 +25,8 @@ GRAD_NAMES = ("means3D", "means2D", "means2D_densify", "shift_factors", "shs", "
 
 
 def run_hip(scene, cam, deg, grad_image=None, device="cuda", bg=None, shift=None, colors=None, cov3D=None,
-            scale_modifier=1.0, depth_key="z", debug=False, means2D=None, tile_bounds="opacity", binning="auto"):
+            scale_modifier=1.0, depth_key="z", debug=False, means2D=None, tile_bounds="opacity", binning="auto",
+            clamp_grad="stock"):
     """Forward (+ backward) through the product op.  Returns (outputs, grads dict, views dict)."""
     from bags_raster import GaussianRasterizer, debug_views
     dev = torch.device(device)
@@ -39,7 +40,7 @@ def run_hip(scene, cam, deg, grad_image=None, device="cuda", bg=None, shift=None
     col = None if colors is None else colors.to(dev).clone().requires_grad_(want)
     cov = None if cov3D is None else cov3D.to(dev).clone().requires_grad_(want)
     st = hip_settings(cam, deg, dev, bg=bg, scale_modifier=scale_modifier, depth_key=depth_key, tensors=ct, debug=debug,
-                      tile_bounds=tile_bounds, binning=binning)
+                      tile_bounds=tile_bounds, binning=binning, clamp_grad=clamp_grad)
     rast = GaussianRasterizer(st)
     kw = dict(means3D=t["means3D"], means2D=m2, means2D_densify=m2d, shift_factors=sf,
               shs=None if col is not None else t["shs"], colors_precomp=col, opacities=t["opacities"],
@@ -62,7 +63,7 @@ def run_hip(scene, cam, deg, grad_image=None, device="cuda", bg=None, shift=None
 
 
 def run_oracle(scene, cam, deg, grad_image=None, dtype=torch.float32, bg=None, shift=None, colors=None, cov3D=None,
-               scale_modifier=1.0, depth_key="z", discrete=None, means2D=None, tile_bounds="opacity", clamp_grad="exact",
+               scale_modifier=1.0, depth_key="z", discrete=None, means2D=None, tile_bounds="opacity", clamp_grad="stock",
                binning=None):
     s = oracle_settings(cam, deg, bg=bg, scale_modifier=scale_modifier, depth_key=depth_key, tile_bounds=tile_bounds,
                         clamp_grad=clamp_grad)
@@ -154,7 +155,7 @@ def compare_sampled(scene, cam, deg, tiles, seed=1, check_fp64=False, return_gra
         mask[ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16] = True
     g = torch.randn(3, H, W, generator=torch.Generator().manual_seed(seed)) * mask
     outs, grads, views = run_hip(scene, cam, deg, g, **kw)
-    s = oracle_settings(cam, deg, **{k: v for k, v in kw.items() if k in ("bg", "scale_modifier", "depth_key", "tile_bounds")})
+    s = oracle_settings(cam, deg, **{k: v for k, v in kw.items() if k in ("bg", "scale_modifier", "depth_key", "tile_bounds", "clamp_grad")})
     inp = dict(scene)
     inp["shift_factors"] = kw.get("shift") if kw.get("shift") is not None else torch.zeros(3)
     st32, gr32 = O.render_and_grad(inp, s, g, dtype=torch.float32, tiles=tiles)

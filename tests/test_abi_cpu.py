@@ -41,7 +41,7 @@ def test_buffer_sizes_grow_with_problem(lib):
 
 def test_struct_layout_matches_header(lib):
     # field counts and pointer-size packing of the POD structs (a mismatch would corrupt every call)
-    assert C.sizeof(_lib.BagsSettings) == 12 * 4 + 5 * 8
+    assert C.sizeof(_lib.BagsSettings) == 14 * 4 + 5 * 8     # + clamp_grad, reserved0 (ABI 5)
     assert C.sizeof(_lib.BagsInputs) == 8 + 9 * 8
     assert C.sizeof(_lib.BagsState) == 6 * 8
     assert C.sizeof(_lib.BagsForwardOut) == 5 * 8
@@ -95,3 +95,31 @@ def test_render_signature_is_the_reference_one():
                                          "scaling_modifier", "override_color", "iteration", "global_alignment"]
     assert all(p.default is inspect.Parameter.empty for p in ps[:6])
     assert ps[6].default is True and ps[7].default == 1.0 and all(p.default is None for p in ps[8:11])
+
+
+@pytest.mark.timeout(600)
+def test_host_side_is_clean_under_address_sanitizer():
+    """the host half of the library (argument validation, buffer carving, size queries, error strings,
+    the ctypes struct layout) under AddressSanitizer.  `make asan` instruments HOST code only; the run is CPU-only by
+    construction (this file's tests never launch a kernel) and is never made on a GPU box."""
+    import shutil
+    import subprocess
+    import sys
+    if os.environ.get("BAGS_RASTER_LIB"):
+        pytest.skip("already inside the sanitizer run")
+    if torch.cuda.is_available():
+        pytest.skip("sanitizer builds are not run on a GPU box")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "bundle-adjusting-gaussian-splatting_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "asan", "-j4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rt = subprocess.run([hipcc, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(rt) or not os.path.exists(rt):
+        pytest.skip("no shared ASan runtime in this toolchain")
+    env = dict(os.environ, BAGS_RASTER_LIB=os.path.join(csrc, "build_asan", "libbags_raster_asan.so"), LD_PRELOAD=rt,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=23")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "not address_sanitizer"], capture_output=True, text=True, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "AddressSanitizer" not in r.stderr, r.stdout[-3000:] + r.stderr[-3000:]

@@ -134,3 +134,32 @@ def test_reference_checkpoint_with_numpy_lr_scale_loads_without_the_full_unpickl
         return
     with pytest.raises(Exception):
         load_checkpoint(bad, 1)
+
+
+@pytest.mark.parametrize("writer_numpy", ["numpy.core.multiarray", "numpy._core.multiarray"])
+def test_checkpoint_written_under_either_numpy_major_loads(tmp_path, writer_numpy):
+    """The module path of the pickled numpy scalar is the WRITER's: the reference's environment (numpy 1.x) writes
+    ``numpy.core.multiarray.scalar``, numpy 2 writes ``numpy._core.multiarray.scalar``.  The file is rewritten to carry the
+    given spelling (protocol-2 GLOBAL opcodes are newline-terminated text, so a byte replacement is a valid pickle) and must
+    load with weights_only=True whichever numpy is installed here."""
+    import zipfile
+    pc = _bag(P=4, deg=1)
+    t = list(capture(pc, {"state": {}, "param_groups": []}, spatial_lr_scale=0.0))
+    t[11] = np.float64(2.5)
+    src = str(tmp_path / "src.pth")
+    torch.save((tuple(t), 30000), src)
+    dst = str(tmp_path / "chkpnt30000.pth")
+    seen = False
+    with zipfile.ZipFile(src) as zi, zipfile.ZipFile(dst, "w", zipfile.ZIP_STORED) as zo:
+        for info in zi.infolist():
+            data = zi.read(info.filename)
+            if info.filename.endswith("data.pkl"):
+                for spelling in (b"numpy._core.multiarray", b"numpy.core.multiarray"):
+                    if b"c" + spelling + b"\nscalar\n" in data:
+                        data = data.replace(b"c" + spelling + b"\nscalar\n", b"c" + writer_numpy.encode() + b"\nscalar\n")
+                        seen = True
+                        break
+            zo.writestr(info.filename, data)
+    assert seen, "the checkpoint did not pickle a numpy scalar through a GLOBAL opcode"
+    back, _, scale, it = load_checkpoint(dst, 1)
+    assert it == 30000 and scale == 2.5 and torch.equal(back._xyz.detach(), pc._xyz.detach())

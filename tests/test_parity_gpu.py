@@ -74,30 +74,36 @@ def test_parity_shift_factors_extension():
 
 def test_frustum_clamp_gradient_semantic():
     """Decision D8.  Gaussians outside 1.3x the field of view get the clamped t.x = +-1.3 tanfovx t.z in the EWA Jacobian.
-    The kernels differentiate that expression exactly (as the oracle's autograd does); upstream's backward keeps the
-    clamped t.x constant inside dL/dt.z (oracle option clamp_grad="stock").  The camera sits inside the cloud with huge
-    splats, so >100 clamped Gaussians reach the image: the HIP gradients must match the exact semantic to the ordinary
-    bars, differ from the stock one, and the two semantics may only differ on clamped Gaussians."""
+    DEFAULT (clamp_grad="stock"): upstream diff-gaussian-rasterization's backward, which the reference's fork inherits
+    (README.md:126; op called at gaussian_renderer/__init__.py:110-121): dL/dt.x zeroed, the clamped t.x held constant inside
+    dL/dt.z.  OPTION clamp_grad="exact": the clamped expression differentiated as written.  The camera sits inside the cloud
+    with huge splats, so >100 clamped Gaussians reach the image: HIP must match the oracle of the SAME semantic to the
+    ordinary bars in both modes, the two semantics must differ (on clamped Gaussians only), and forward values must not."""
     import math
     from scenes import camera_tensors
     P, W, H = 1200, 128, 96
     scene, cam = make_case(P, W, H, 5.0, 1, seed=5, dist=1.6)
-    rep = compare(scene, cam, 1)
+    rep = compare(scene, cam, 1)                                   # default = stock, in the op and in the oracle
     _report({k: rep[k] for k in ("num_rendered", "image_max_err", "grad_rel_fp32", "grad_rel_fp64")})
     assert_report(rep, grad_tol=2e-4)
+    rep_e = compare(scene, cam, 1, clamp_grad="exact")
+    assert_report(rep_e, grad_tol=2e-4)
     g = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1))
-    _, grads, _ = run_hip(scene, cam, 1, g)
-    _, g_exact = run_oracle(scene, cam, 1, g)
-    _, g_stock = run_oracle(scene, cam, 1, g, clamp_grad="stock")
+    outs_s, grads_s, _ = run_hip(scene, cam, 1, g)
+    outs_e, grads_e, _ = run_hip(scene, cam, 1, g, clamp_grad="exact")
+    assert all(torch.equal(a, b) for a, b in zip(outs_s, outs_e))   # the switch is a backward-only switch
+    _, g_exact = run_oracle(scene, cam, 1, g, clamp_grad="exact")
+    _, g_stock = run_oracle(scene, cam, 1, g)
     t = torch.cat([scene["means3D"], torch.ones(P, 1)], 1) @ camera_tensors(cam)["viewmatrix"]
     clamped = ((t[:, 0] / t[:, 2]).abs() > 1.3 * math.tan(cam.FoVx / 2)) | ((t[:, 1] / t[:, 2]).abs() > 1.3 * math.tan(cam.FoVy / 2))
     moved = (g_exact["means3D"] - g_stock["means3D"]).abs().sum(1) > 0
     assert int(moved.sum()) > 100 and not bool((moved & ~clamped).any())
     for k in ("means3D", "viewmatrix"):
-        assert rel_err(grads[k], g_exact[k]) < 2e-4, (k, rel_err(grads[k], g_exact[k]))
-        assert rel_err(grads[k], g_stock[k]) > 0.1, (k, rel_err(grads[k], g_stock[k]))
-    # away from the clamp the two semantics are the same function: identical gradients there
-    assert rel_err(grads["means3D"][~clamped], g_stock["means3D"][~clamped]) < 2e-4
+        assert rel_err(grads_s[k], g_stock[k]) < 2e-4, (k, rel_err(grads_s[k], g_stock[k]))
+        assert rel_err(grads_e[k], g_exact[k]) < 2e-4, (k, rel_err(grads_e[k], g_exact[k]))
+        assert rel_err(grads_s[k], g_exact[k]) > 0.1, (k, rel_err(grads_s[k], g_exact[k]))
+    # away from the clamp the two semantics are the same function: bit-identical gradients there
+    assert torch.equal(grads_s["means3D"][~clamped], grads_e["means3D"][~clamped])
 
 
 def test_edge_cases_empty_behind_and_single():
@@ -157,50 +163,104 @@ def test_cpu_tensors_fail_loudly():
 
 
 def test_speculative_forward_matches_exact_and_recovers_from_overflow():
-    """Second and later calls of a problem shape skip the mid-forward host round trip by guessing the instance
-    capacity from earlier calls.  HOST_WAIT = "forward": the count is read before the forward returns and a too-small
-    guess transparently redoes phase 2 (exact image and gradients).  HOST_WAIT = "lazy" (default): nothing in a training
-    forward waits; results are identical whenever the guess holds, and a guess that does not hold is caught at backward
-    entry (RuntimeWarning, state recomputed: the gradients are the exact ones for the cotangent passed in)."""
+    """Second and later calls of a problem shape skip the mid-forward host round trip by guessing the instance capacity from
+    earlier calls.  DEFAULT (HOST_WAIT = "forward"): the count is read before the forward returns and a too-small guess
+    transparently redoes phase 2, so the image a forward returns is always the true render (train.py:250-331 computes its loss
+    from it): a 6x jump of the instance count between two calls of one shape must return the ORACLE's image from forward
+    itself, without any warning.  HOST_WAIT = "lazy" (opt-in): nothing in a training forward waits; results are identical
+    whenever the guess holds; a guess that does not hold RAISES at backward entry (the loss came from an empty image) and the
+    retried step is exact; with LAZY_RECOVER the state is recomputed instead (RuntimeWarning, exact gradients for the
+    cotangent passed in); a lazy forward that is never differentiated reports the overflow when its count is collected."""
+    import gc
     import warnings
     from bags_raster import rasterizer as R
+    assert R.HOST_WAIT == "forward" and not R.LAZY_RECOVER, "the operator must be exact by default"
     scene, cam = make_case(3000, 160, 128, 1.0, 2, seed=31)
     g = torch.randn(3, 128, 160, generator=torch.Generator().manual_seed(5))
     big = dict(scene); big["scales"] = scene["scales"] * 6.0     # same shape, several times more instances than any guess
-    saved = R.HOST_WAIT
+    saved = (R.HOST_WAIT, R.LAZY_RECOVER)
+
+    def overflow_warnings(wlist):
+        return [w for w in wlist if issubclass(w.category, RuntimeWarning) and "speculative capacity" in str(w.message)]
     try:
-        ref = {}
-        for mode in ("forward", "lazy"):
-            R.HOST_WAIT = mode
-            R._capacity_hint.clear()
-            o_exact, g_exact, v1 = run_hip(scene, cam, 2, g)             # no hint yet: exact two-phase path
-            assert R._capacity_hint, "hint not recorded"
-            o_spec, g_spec, _ = run_hip(scene, cam, 2, g)                # hint present: speculative path
-            for a, b in zip(o_exact, o_spec):
-                assert torch.equal(a, b)
-            for k in g_exact:
-                if g_exact[k] is not None:
-                    assert torch.equal(g_exact[k], g_spec[k]), (mode, k)
-            with warnings.catch_warnings(record=True) as wlist:
-                warnings.simplefilter("always")
-                o_big, g_big, v_big = run_hip(big, cam, 2, g)
-            assert v_big["num_rendered"] > R.CAPACITY_HEADROOM * v1["num_rendered"] + 8192, (v_big["num_rendered"], v1["num_rendered"])
-            overflowed = [w for w in wlist if issubclass(w.category, RuntimeWarning) and "speculative capacity" in str(w.message)]
-            if mode == "forward":
-                assert not overflowed
-                R._capacity_hint.clear()
-                o_ref, g_ref, _ = run_hip(big, cam, 2, g)                # exact path
-                ref = dict(o=o_ref, g=g_ref)
-                for a, b in zip(o_big, o_ref):
-                    assert torch.equal(a, b)
-            else:
-                assert len(overflowed) == 1                              # caught at backward entry
-                assert torch.equal(o_big[1], ref["o"][1])               # radii come from phase 1: always right
-            for k in ref["g"]:                                           # gradients: exact in both modes
-                if ref["g"][k] is not None:
-                    assert torch.equal(g_big[k], ref["g"][k]), (mode, k)
+        # ---- default mode
+        R._capacity_hint.clear()
+        o_exact, g_exact, v1 = run_hip(scene, cam, 2, g)             # no hint yet: exact two-phase path
+        assert R._capacity_hint, "hint not recorded"
+        o_spec, g_spec, _ = run_hip(scene, cam, 2, g)                # hint present: speculative path
+        for a, b in zip(o_exact, o_spec):
+            assert torch.equal(a, b)
+        for k in g_exact:
+            if g_exact[k] is not None:
+                assert torch.equal(g_exact[k], g_spec[k]), k
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter("always")
+            o_big, g_big, v_big = run_hip(big, cam, 2, g)            # the count jumps by more than 6x: forward redoes phase 2
+        assert v_big["num_rendered"] > 6 * v1["num_rendered"], (v_big["num_rendered"], v1["num_rendered"])
+        assert not overflow_warnings(wlist)
+        st32, _ = run_oracle(big, cam, 2, None)
+        err = ((o_big[0] - st32.image).abs() / (1.0 + st32.image.abs()))
+        assert float((err > 1e-5).float().mean()) <= 2e-4 and float(err.max()) <= 5e-3, float(err.max())
+        assert torch.equal(o_big[1], st32.radii)
+        R._capacity_hint.clear()
+        o_ref, g_ref, _ = run_hip(big, cam, 2, g)                    # exact path, no speculation
+        for a, b in zip(o_big, o_ref):
+            assert torch.equal(a, b)
+        for k in g_ref:
+            if g_ref[k] is not None:
+                assert torch.equal(g_big[k], g_ref[k]), k
+        # ---- lazy, opt-in: identical when the guess holds; raises on overflow; the retried step is exact
+        R.HOST_WAIT = "lazy"
+        R._capacity_hint.clear()
+        run_hip(scene, cam, 2, g)
+        o_lazy, g_lazy, _ = run_hip(scene, cam, 2, g)
+        for a, b in zip(o_exact, o_lazy):
+            assert torch.equal(a, b)
+        for k in g_exact:
+            if g_exact[k] is not None:
+                assert torch.equal(g_exact[k], g_lazy[k]), k
+        with pytest.raises(R.SpeculationOverflow):
+            run_hip(big, cam, 2, g)
+        o_retry, g_retry, _ = run_hip(big, cam, 2, g)                # the hint has been raised: fits now
+        for a, b in zip(o_retry, o_ref):
+            assert torch.equal(a, b)
+        for k in g_ref:
+            if g_ref[k] is not None:
+                assert torch.equal(g_retry[k], g_ref[k]), k
+        # ---- lazy with recovery
+        R.LAZY_RECOVER = True
+        R._capacity_hint.clear()
+        run_hip(scene, cam, 2, g)
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter("always")
+            o_rec, g_rec, _ = run_hip(big, cam, 2, g)
+        assert len(overflow_warnings(wlist)) == 1
+        for a, b in zip(o_rec, o_ref):                               # the true image was written into the returned tensors
+            assert torch.equal(a, b)
+        for k in g_ref:
+            if g_ref[k] is not None:
+                assert torch.equal(g_rec[k], g_ref[k]), k
+        R.LAZY_RECOVER = False
+        # ---- lazy forward that is never differentiated: the overflow is reported when its count is collected
+        R._capacity_hint.clear()
+        run_hip(scene, cam, 2, g)
+        from bags_raster import GaussianRasterizer
+        from scenes import hip_settings
+        dev = torch.device("cuda")
+        t = {k: v.to(dev).requires_grad_(True) for k, v in big.items()}
+        out = GaussianRasterizer(hip_settings(cam, 2, dev))(means3D=t["means3D"], means2D=torch.zeros(3000, 3, device=dev),
+                                                             shs=t["shs"], opacities=t["opacities"], scales=t["scales"],
+                                                             rotations=t["rotations"])
+        torch.cuda.synchronize()
+        del out
+        gc.collect()
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter("always")
+            R._drain_abandoned()
+        assert len(overflow_warnings(wlist)) == 1 and not R._abandoned
     finally:
-        R.HOST_WAIT = saved
+        R.HOST_WAIT, R.LAZY_RECOVER = saved
+        R._capacity_hint.clear()
 
 
 @pytest.mark.timeout(900)
