@@ -237,9 +237,11 @@ static inline void* align256(void* p) { return reinterpret_cast<void*>(align_up(
 static int enqueue_prepare(const BagsSettings* s, const BagsInputs* in, const GeomView& g, const ImgView& im, const BagsForwardOut* out,
                            hipStream_t st, u32* host_count = nullptr, bool* host_written = nullptr)
 {
-    { ProfScope ps(ST_PRE_FWD, st); HIP_TRY(launch_preprocess_fwd(*s, *in, g, out->radii, out->mean2D, st)); }
+    const bool binned = use_binned(s, in->P);
+    { ProfScope ps(ST_PRE_FWD, st);
+      HIP_TRY(launch_preprocess_fwd(*s, *in, g, out->radii, out->mean2D, st, binned ? &im : nullptr, cdiv(s->image_width, BAGS_TILE))); }
     DEBUG_SYNC(s, st, "preprocess_fwd");
-    if (use_binned(s, in->P)) {
+    if (binned) {
         // (block of Gaussians, tile) count matrix -> column prefixes -> tile ranges, instance count, heavy-first tile list
         const int gx = cdiv(s->image_width, BAGS_TILE), gy = cdiv(s->image_height, BAGS_TILE);
         { ProfScope ps(ST_OFFSETS, st); HIP_TRY(launch_binned_prepare(g, im, in->P, gx, gx * gy, st, host_count)); }
@@ -407,11 +409,11 @@ int bags_backward(const BagsSettings* s, const BagsInputs* in, const BagsState* 
     float* sums = reinterpret_cast<float*>(reinterpret_cast<char*>(slab) +
                                            align_up((size_t)(cdiv(in->P > 0 ? in->P : 1, 256)) * POSE_VALS * sizeof(float), 256));
     if (I > 0) {
-        { ProfScope ps(ST_BLEND_BWD, st); HIP_TRY(launch_blend_bwd(*s, g, b, im, a->grad_color, partials, a->grad_means2D_densify != nullptr, st)); }
+        { ProfScope ps(ST_BLEND_BWD, st); HIP_TRY(launch_blend_bwd(*s, g, b, im, a->grad_color, partials, a->grad_means2D_densify != nullptr, use_binned(s, in->P), st)); }
         DEBUG_SYNC(s, st, "blend_bwd");
     }
     int nblocks = 0;
-    { ProfScope ps(ST_PRE_BWD, st); HIP_TRY(launch_preprocess_bwd(*s, *in, g, nullptr, partials, slab, &nblocks, *a, st, sums)); }
+    { ProfScope ps(ST_PRE_BWD, st); HIP_TRY(launch_preprocess_bwd(*s, *in, g, nullptr, partials, slab, &nblocks, *a, st, sums, use_binned(s, in->P))); }
     DEBUG_SYNC(s, st, "preprocess_bwd");
     { ProfScope ps(ST_POSE_REDUCE, st); HIP_TRY(launch_pose_reduce(slab, nblocks, *a, st)); }
     DEBUG_SYNC(s, st, "pose_reduce");

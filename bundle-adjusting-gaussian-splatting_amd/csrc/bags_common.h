@@ -81,10 +81,11 @@ struct GeomView {            // per Gaussian, indexed by Gaussian id unless stat
     // One 64-byte line per Gaussian with everything the blend kernels gather per (tile, Gaussian) instance, so an
     // instance costs ONE line fetch instead of five partial ones from id-ordered (spatially random) SoA arrays:
     //   q0 = conic a, b, c, opacity      q1 = pixel x, y, colour r, g
-    //   q2 = colour b, view depth z, rect.x, rect.y (bits)      q3 = keep lo, tiles_touched, clamped mask, keep hi (bits)
+    //   q2 = colour b, view depth z, rect.x, rect.y (bits)      q3 = keep lo, block of Gaussians, offset inside the block, keep hi (bits)
     float4* g2d;             // [4 * P]
-    u32*    inst_off;        // [P] first emission slot of the Gaussian's partial-gradient records (an array of its own: a 4-byte
-                             // write into every 64-byte line of g2d after the scan cost 6.6 us per frame)
+    u32*    inst_off;        // [P] first emission slot of the Gaussian's partial-gradient records -- RADIX PATH ONLY since round 4 (an array
+                             // of its own: a 4-byte write into every 64-byte line of g2d after the scan cost 6.6 us per frame).  On the
+                             // tile-binned path the record base is block_base[block] + local_off, both known to K1 (line.q3.y / q3.z)
     uint2*  rect;            // (minx | miny<<16, maxx | maxy<<16), max exclusive   (compact copy for emit)
     u32*    tiles_touched;   // instances the Gaussian emits (compact copy for the offsets scan / emit)
     // [10 * P] d(colour)/d(view direction) of the SH colour path, written by K1 for the visible Gaussians (round 3):
@@ -144,8 +145,10 @@ size_t carve_binning(void* base, long long I, int W, int H, BinView* v, bool bin
 size_t carve_image(void* base, int W, int H, ImgView* v);
 
 // ---- launchers (each enqueues on `st`; returns hipError_t) --------------------------------------------------
+// count_into != nullptr (tile-binned path): K1 also counts the (block of Gaussians, tile) matrix and the block-local instance
+// offsets (step 1 of binning.hip), grid_x = tiles per image row
 hipError_t launch_preprocess_fwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, int32_t* radii,
-                                 float* mean2D, hipStream_t st);
+                                 float* mean2D, hipStream_t st, const ImgView* count_into = nullptr, int grid_x = 0);
 hipError_t launch_radix_sort(const u32* src_k, const u32* src_v, u32* a_k, u32* a_v, u32* b_k, u32* b_v, long long n,
                              int bits, bool iota_vals, u32* hist, u32* totals, int nblocks, hipStream_t st,
                              const u32* n_dev = nullptr);
@@ -157,10 +160,13 @@ hipError_t launch_tile_ranges(const u32* tile_sorted, long long I, uint2* ranges
 hipError_t launch_tile_order(const uint2* ranges, int T, uint4* tile_desc, u32* n_active, hipStream_t st);
 hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
                             const BagsForwardOut& out, hipStream_t st, const u32* n_dev = nullptr, u32 capacity = 0);
+// binned: the record base of a Gaussian is block_base[line.q3.y] + line.q3.z (K1 wrote both into the geometry line); otherwise
+// (radix path) it is gathered from g.inst_off
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
-                            const float* grad_color, float* partials, bool want_abs, hipStream_t st);
+                            const float* grad_color, float* partials, bool want_abs, bool binned, hipStream_t st);
 hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, const int32_t* radii_or_null,
-                                 const float* partials, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a, hipStream_t st, float* sums);
+                                 const float* partials, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a, hipStream_t st, float* sums,
+                                 bool binned);
 hipError_t launch_pose_reduce(const float* pose_slab, int nblocks, const BagsBackwardArgs& a, hipStream_t st);
 // loss.hip: fused L1 + SSIM terms and their image gradient
 size_t loss_workspace_bytes(int C, int H, int W);
@@ -198,6 +204,7 @@ hipError_t launch_binned_empty(const GeomView& g, const ImgView& im, int T, hipS
 // the tile descriptor list alone (launch_binned_finish builds it beside the emission): for forwards that emit nothing
 hipError_t launch_binned_desc_only(const ImgView& im, int T, hipStream_t st);
 // host_count: device-visible address of a pinned host word that also receives the instance count (may be null)
+// (the (block, tile) counts themselves come from launch_preprocess_fwd(count_into = &im))
 hipError_t launch_binned_prepare(const GeomView& g, const ImgView& im, int P, int grid_x, int T, hipStream_t st, u32* host_count = nullptr);
 hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int grid_x, int T, u64* words, u64* scratch, u32* point_list,
                                 u32 capacity, const u32* n_dev, hipStream_t st);

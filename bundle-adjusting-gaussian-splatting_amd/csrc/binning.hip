@@ -19,72 +19,7 @@
 // Limits: tiles * 2 bytes of LDS (<= 32768 tiles: up to 4K images) and <= 65535 Gaussians per block (P <= 16.7 M);
 // beyond them, or on request (BagsSettings.binning), api.hip falls back to the radix path of sort.hip.
 #include "bags_common.h"
-
-// Wave-wide inclusive add scan on DPP (row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast:15 / row_bcast:31 across
-// them): six VALU instructions.  (__shfl_up goes through ds_bpermute: six dependent LDS round trips per scan, which is
-// what a one-wave sort spent most of its time waiting for.)
-__device__ __forceinline__ u32 wave_incl_scan(u32 x)
-{
-    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
-    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
-    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
-    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
-    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
-    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
-    return x;
-}
-// wave-wide max / min on the same DPP pattern (the value of lane 63 of the inclusive scan), broadcast with readlane
-__device__ __forceinline__ u32 wave_max(u32 x)
-{
-    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false));
-    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false));
-    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false));
-    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false));
-    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));
-    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));
-    return (u32)__builtin_amdgcn_readlane((int)x, 63);
-}
-__device__ __forceinline__ u32 wave_min(u32 x) { return ~wave_max(~x); }
-
-#define BIN_COOP 64          // rectangles of more tiles than this are walked by the whole wave
-#define BIN_THREADS 1024     // count / emit workgroup: one block of Gaussians = one workgroup = one row of the count matrix;
-                             // 256 threads left every thread eight Gaussians to walk one after the other (latency bound)
-
-// ------------------------------------------------------------------------------------------------ 1. tile_count
-// Packed counters: tile t lives in the (t & 1) half of word t >> 1.  A half never overflows: a Gaussian covers a tile at
-// most once, so a (block, tile) count is at most the block size (<= 65535 by construction).
-__device__ __forceinline__ u32 lds_count_tile(u32* cnt, u32 t) { return atomicAdd(&cnt[t >> 1], 1u << ((t & 1u) * 16u)); }
-
-// COUNT: packed 16-bit counters.  EMIT: `cnt` holds one 32-bit slot cursor per tile (range start + column prefix of this
-// block, loaded as two coalesced rows); the returning LDS atomic hands the instance its final slot, and the Gaussian id is
-// the only thing written (the per-tile sort fetches the depth key by id: a 4-byte scattered store per instance instead of
-// two scattered loads and an 8-byte store -- the request rate of the L2 channels, not the bytes, bounded this kernel).
-template <bool EMIT>
-__device__ __forceinline__ void walk_rect(u32* cnt, uint2 rc, int grid_x, int lane, bool coop, u64 word, u64* __restrict__ words)
-{
-    const int minx = rc.x & 0xFFFF, miny = rc.x >> 16, w = (int)(rc.y & 0xFFFF) - minx, h = (int)(rc.y >> 16) - miny;
-    const int nt = w * h;
-    for (int k = coop ? lane : 0; k < nt; k += coop ? 64 : 1) {
-        const int dy = k / w, dx = k - dy * w;
-        const u32 t = (u32)((miny + dy) * grid_x + minx + dx);
-        if (EMIT) words[atomicAdd(&cnt[t], 1u)] = word;
-        else (void)lds_count_tile(cnt, t);
-    }
-}
-// A rectangle of at most 8 x 8 tiles: the set bits of its tile mask (GeomView::keep), no division.
-template <bool EMIT>
-__device__ __forceinline__ void walk_mask(u32* cnt, uint2 rc, u64 m, int grid_x, u64 word, u64* __restrict__ words)
-{
-    const int minx = rc.x & 0xFFFF, miny = rc.x >> 16;
-    const u32 t0 = (u32)(miny * grid_x + minx);
-    while (m) {
-        const int bit = __ffsll((long long)m) - 1;
-        m &= m - 1ull;
-        const u32 t = t0 + (u32)((bit >> 3) * grid_x + (bit & 7));
-        if (EMIT) words[atomicAdd(&cnt[t], 1u)] = word;
-        else (void)lds_count_tile(cnt, t);
-    }
-}
+#include "binning_common.h"
 
 // Shared body of tile_count (EMIT = false) and emit_binned (EMIT = true): the block's Gaussians, thread by thread in
 // contiguous runs; small rectangles by their own lane, large ones by the whole wave.
@@ -133,34 +68,9 @@ __device__ __forceinline__ u32 walk_block(u32* cnt, int P, int per_block, int gr
     return mine;
 }
 
-__global__ void __launch_bounds__(BIN_THREADS)
-tile_count_kernel(int P, int per_block, int grid_x, int T2, const uint2* __restrict__ rect, const u32* __restrict__ tiles_touched,
-                  const u64* __restrict__ keep,
-                  u32* __restrict__ cnt_rows, u32* __restrict__ local_off, u32* __restrict__ block_total)
-{
-    extern __shared__ u32 cnt[];                             // T2 packed words
-    __shared__ u32 wsum[BIN_THREADS / 64];
-    for (int i = threadIdx.x; i < T2; i += BIN_THREADS) cnt[i] = 0u;
-    __syncthreads();
-    const u32 mine = walk_block<false>(cnt, P, per_block, grid_x, rect, tiles_touched, keep, nullptr, nullptr);
-    // instance offset of every Gaussian inside its block (id order): exclusive scan of the threads' sums, then a second
-    // walk over the thread's own run
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const u32 incl = wave_incl_scan(mine);
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();                                         // also: every counter of the block is final
-    u32 run = incl - mine;
-    for (int w = 0; w < wave; ++w) run += wsum[w];
-    const int per_thread = per_block / BIN_THREADS;
-    const long long g0 = (long long)blockIdx.x * per_block + (long long)threadIdx.x * per_thread;
-    for (int k = 0; k < per_thread; ++k) {
-        const long long g = g0 + k;
-        if (g < P) { local_off[g] = run; run += tiles_touched[g]; }
-    }
-    if (threadIdx.x == BIN_THREADS - 1) block_total[blockIdx.x] = run;
-    u32* row = cnt_rows + (size_t)blockIdx.x * T2;
-    for (int i = threadIdx.x; i < T2; i += BIN_THREADS) row[i] = cnt[i];
-}
+// (tile_count_kernel, a launch of its own until round 3, is now part of K1: preprocess_fwd_count_kernel in preprocess_fwd.hip
+// runs walk_mask / walk_rect<false> on every Gaussian it has just projected and leaves the same matrix row, block total and
+// block-local offsets behind.)
 
 // ------------------------------------------------------------------------------------------------ 2. tile_prefix
 // thread = (packed word = two tiles, group of 8 blocks); the thread's 8 words stay in registers between the summing pass
@@ -390,8 +300,7 @@ template <int ORD_PER>
 __global__ void __launch_bounds__(BIN_THREADS)
 emit_binned_kernel(int P, int per_block, int grid_x, int T, const uint2* __restrict__ rect,
                    const u32* __restrict__ tiles_touched, const u64* __restrict__ keep, const u32* __restrict__ pre,
-                   const uint2* __restrict__ ranges, const u32* __restrict__ local_off, const u32* __restrict__ block_base,
-                   u32* __restrict__ inst_off, const u32* __restrict__ depth_key, u64* __restrict__ words, u32 capacity,
+                   const uint2* __restrict__ ranges, const u32* __restrict__ depth_key, u64* __restrict__ words, u32 capacity,
                    const u32* __restrict__ n_dev, const u32* __restrict__ tile_total, uint4* __restrict__ tile_desc,
                    u32* __restrict__ n_active)
 {
@@ -402,17 +311,6 @@ emit_binned_kernel(int P, int per_block, int grid_x, int T, const uint2* __restr
         __shared__ u32 s_wave[17];
         build_tile_desc<ORD_PER>(tile_total, ranges, T, tile_desc, n_active, cur, s_cur, s_wave);
         return;
-    }
-    // the instance offset of a Gaussian's records (blend_bwd's emission slots, preprocess_bwd's record sums): written even
-    // when a speculative capacity turns out too small -- the caller then reruns this launch on an exact buffer
-    {
-        const int per_thread = per_block / BIN_THREADS;
-        const long long g0 = (long long)blockIdx.x * per_block + (long long)threadIdx.x * per_thread;
-        const u32 base = block_base[blockIdx.x];
-        for (int k = 0; k < per_thread; ++k) {
-            const long long g = g0 + k;
-            if (g < P) inst_off[g] = base + local_off[g];
-        }
     }
     if (n_dev && *n_dev > capacity) return;
     const u32* prow = pre + (size_t)blockIdx.x * T;
@@ -824,14 +722,7 @@ bool binned_supported(int P, int T)
 hipError_t launch_binned_prepare(const GeomView& g, const ImgView& im, int P, int grid_x, int T, hipStream_t st, u32* host_count)
 {
     const int per = binned_per_block(P), B = cdiv(P, per), T2 = (T + 1) / 2;
-    // the kernel also has 64 B of static LDS (wsum): dynamic + static crosses the default 64 KB limit from T = 32737 tiles on
-    // (4096 x 2048 is exactly 32768), so the launch opts in like ranges_order / emit_binned do
-    if ((size_t)T2 * 4 + 256 > 65536) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T2 * 4);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(tile_count_kernel, dim3(B), dim3(BIN_THREADS), (size_t)T2 * 4, st, P, per, grid_x, T2, g.rect, g.tiles_touched,
-                       g.keep, im.cnt_rows, g.local_off, g.block_total);
+    (void)grid_x;                                             // (the counts came with K1: launch_preprocess_fwd(count_into))
     hipLaunchKernelGGL(tile_prefix_kernel, dim3(cdiv(T2, PFX_WORDS)), dim3(1024), 0, st, im.cnt_rows, B, T, T2, im.pre, im.tile_total);
     hipError_t e = launch_ranges_order(im, g, T, B, st, host_count);
     return e != hipSuccess ? e : hipGetLastError();
@@ -856,7 +747,7 @@ hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int
 #define EM_LAUNCH(PER) { const size_t lds = (size_t)T * 4 > ord_tr_bytes(PER) ? (size_t)T * 4 : ord_tr_bytes(PER);              \
         e = big_lds(emit_binned_kernel<PER>, lds);                                                                                \
         if (e == hipSuccess) hipLaunchKernelGGL(emit_binned_kernel<PER>, dim3(B + 1), dim3(BIN_THREADS), lds, st, P, per, grid_x, T, g.rect, \
-                g.tiles_touched, g.keep, im.pre, im.ranges, g.local_off, g.block_base, g.inst_off, g.depth_key, words, capacity, n_dev,   \
+                g.tiles_touched, g.keep, im.pre, im.ranges, g.depth_key, words, capacity, n_dev,   \
                 im.tile_total, im.tile_desc, im.n_active); }
     switch (ord_per_for(T)) { case 8: EM_LAUNCH(8) break; case 16: EM_LAUNCH(16) break; default: EM_LAUNCH(32) }
 #undef EM_LAUNCH

@@ -1,0 +1,72 @@
+// binning_common.h -- pieces of the tile-binned list construction shared by binning.hip (emit, prefix, sorts) and
+// preprocess_fwd.hip (K1 counts the (block of Gaussians, tile) matrix itself since round 4: one launch fewer on the path to the
+// instance count, and every Gaussian's offset inside its block lands in its 64-byte geometry line).
+#pragma once
+#include "bags_common.h"
+
+// Wave-wide inclusive add scan on DPP (row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast:15 / row_bcast:31 across
+// them): six VALU instructions.  (__shfl_up goes through ds_bpermute: six dependent LDS round trips per scan, which is
+// what a one-wave sort spent most of its time waiting for.)
+__device__ __forceinline__ u32 wave_incl_scan(u32 x)
+{
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+    return x;
+}
+// wave-wide max / min on the same DPP pattern (the value of lane 63 of the inclusive scan), broadcast with readlane
+__device__ __forceinline__ u32 wave_max(u32 x)
+{
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));
+    return (u32)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ __forceinline__ u32 wave_min(u32 x) { return ~wave_max(~x); }
+
+#define BIN_COOP 64          // rectangles of more tiles than this are walked by the whole wave
+#define BIN_THREADS 1024     // count / emit workgroup: one block of Gaussians = one workgroup = one row of the count matrix;
+                             // 256 threads left every thread eight Gaussians to walk one after the other (latency bound)
+
+// ------------------------------------------------------------------------------------------------ 1. tile_count
+// Packed counters: tile t lives in the (t & 1) half of word t >> 1.  A half never overflows: a Gaussian covers a tile at
+// most once, so a (block, tile) count is at most the block size (<= 65535 by construction).
+__device__ __forceinline__ u32 lds_count_tile(u32* cnt, u32 t) { return atomicAdd(&cnt[t >> 1], 1u << ((t & 1u) * 16u)); }
+
+// COUNT: packed 16-bit counters.  EMIT: `cnt` holds one 32-bit slot cursor per tile (range start + column prefix of this
+// block, loaded as two coalesced rows); the returning LDS atomic hands the instance its final slot, and the Gaussian id is
+// the only thing written (the per-tile sort fetches the depth key by id: a 4-byte scattered store per instance instead of
+// two scattered loads and an 8-byte store -- the request rate of the L2 channels, not the bytes, bounded this kernel).
+template <bool EMIT>
+__device__ __forceinline__ void walk_rect(u32* cnt, uint2 rc, int grid_x, int lane, bool coop, u64 word, u64* __restrict__ words)
+{
+    const int minx = rc.x & 0xFFFF, miny = rc.x >> 16, w = (int)(rc.y & 0xFFFF) - minx, h = (int)(rc.y >> 16) - miny;
+    const int nt = w * h;
+    for (int k = coop ? lane : 0; k < nt; k += coop ? 64 : 1) {
+        const int dy = k / w, dx = k - dy * w;
+        const u32 t = (u32)((miny + dy) * grid_x + minx + dx);
+        if (EMIT) words[atomicAdd(&cnt[t], 1u)] = word;
+        else (void)lds_count_tile(cnt, t);
+    }
+}
+// A rectangle of at most 8 x 8 tiles: the set bits of its tile mask (GeomView::keep), no division.
+template <bool EMIT>
+__device__ __forceinline__ void walk_mask(u32* cnt, uint2 rc, u64 m, int grid_x, u64 word, u64* __restrict__ words)
+{
+    const int minx = rc.x & 0xFFFF, miny = rc.x >> 16;
+    const u32 t0 = (u32)(miny * grid_x + minx);
+    while (m) {
+        const int bit = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        const u32 t = t0 + (u32)((bit >> 3) * grid_x + (bit & 7));
+        if (EMIT) words[atomicAdd(&cnt[t], 1u)] = word;
+        else (void)lds_count_tile(cnt, t);
+    }
+}
+

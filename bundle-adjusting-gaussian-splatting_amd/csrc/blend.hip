@@ -53,6 +53,13 @@
 #define NC_SKIP 1           // tiles where no pixel stopped early (flag from the forward) skip the `pos <= n_contrib` test
 #endif
 #define PQ (TF_FOLD ? 3 : 4)                 // float4s per pixel pair in LDS
+// round-4 knobs
+#ifndef BAL_WRITE
+#define BAL_WRITE 1         // the record sums of a chunk (four wave copies -> one 48-B record) spread over all 256 threads, one float4
+#endif                      // each: conflict-free LDS reads, three lanes per record on the way out (was: thread = record, 176 of 256 busy)
+#ifndef ABS_FMA
+#define ABS_FMA 1           // sum |q dpower/dcentre| as v_fma_f32 acc, |q|, |h|, acc (8 per row step instead of 4 packed muls + 8 adds)
+#endif
 
 #ifndef FWD_PK
 #define FWD_PK 0            // forward: (dx, dy) and (ap dx, cp dy) as two packed fp32 instructions (record order x y ap cp | bp ...):
@@ -253,7 +260,7 @@ template <bool ABS>
 __global__ void __launch_bounds__(256, SCAN_WG_PER_CU)
 blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__ tile_desc,
                       const u32* __restrict__ point_list, const unsigned short* __restrict__ reach_mask,
-                      const float4* __restrict__ g2d, const u32* __restrict__ inst_off,
+                      const float4* __restrict__ g2d, const u32* __restrict__ inst_off, const u32* __restrict__ block_base,
                       const float* __restrict__ bg, const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
                       const float* __restrict__ grad_color, float* __restrict__ partials)
 {
@@ -280,6 +287,10 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     __shared__ u32 masks[BCHUNK];                     //  0.5 KB: block reach masks, compact (the 48-B record stride bank-conflicts)
     __shared__ float acc[4][BCHUNK][12];              // 33 KB, one copy per wave (LDS float atomics on a shared copy were 1.6x slower)
     __shared__ u32 blk_maxc[16];                     // last contributor over the 16 pixels of each block
+#if BAL_WRITE
+    __shared__ u32 rec_e[2][BCHUNK];                 // 1.4 KB: emission slots of the staged chunk, two chunks alive (the balanced write-out
+                                                     // of chunk k reads them while faster waves already publish chunk k+1)
+#endif
 #ifdef LDS_PAD                                       // experiment knob: extra LDS per workgroup lowers the occupancy without touching the code
     __shared__ u32 lds_pad[LDS_PAD / 4];
     if (threadIdx.x == 0xFFFF) lds_pad[blockIdx.x & 7] = 1u;
@@ -291,7 +302,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
 #endif
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    struct Raw { float4 q0, q1, q2; u32 io; u64 kp; };      // conic+opacity | x y r g | b z rect | inst_offset | tile mask
+    struct Raw { float4 q0, q1, q2; u32 io, blk; u64 kp; };   // conic+opacity | x y r g | b z rect | record offset (in its block) | block | tile mask
     // id (x) and 4x4-block reach mask (y, as the forward staged it) of this thread's slot in the chunk of a tile's list that ends at hi_
     auto fetch_id = [&](u32 rx_, u32 hi_) -> uint2 {
         const u32 c_ = min(hi_, (u32)BCHUNK);
@@ -300,12 +311,17 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         return make_uint2(point_list[at], (u32)reach_mask[at]);
     };
     auto fetch = [&](u32 g) {
-        Raw r; r.q0 = make_float4(0.f, 0.f, 0.f, 0.f); r.q1 = r.q0; r.q2 = r.q0; r.io = 0u; r.kp = 0ull;
+        Raw r; r.q0 = make_float4(0.f, 0.f, 0.f, 0.f); r.q1 = r.q0; r.q2 = r.q0; r.io = 0u; r.blk = 0u; r.kp = 0ull;
         if (g != 0xFFFFFFFFu) {                       // one 64-byte line
             const float4* rec = g2d + 4 * (size_t)g;
-            r.q0 = rec[0]; r.q1 = rec[1]; r.q2 = rec[2]; r.io = inst_off[g];
+            r.q0 = rec[0]; r.q1 = rec[1]; r.q2 = rec[2];
             const float4 q3 = rec[3];
             r.kp = (u64)__float_as_uint(q3.x) | ((u64)__float_as_uint(q3.w) << 32);
+            // first record of the Gaussian: tile-binned path block_base[q3.y] + q3.z, both in the line since K1 counts the
+            // (block, tile) matrix itself (round 4; the 4-byte gather of inst_off[g] was a second line miss per instance);
+            // radix path: the inst_off array
+            if (inst_off) r.io = inst_off[g];
+            else { r.io = __float_as_uint(q3.z); r.blk = __float_as_uint(q3.y); }
         }
         return r;
     };
@@ -315,13 +331,21 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         const int minx = (int)(rc.x & 0xFFFF), miny = (int)(rc.x >> 16);
         return io + rect_tile_rank(kp, (int)(rc.y & 0xFFFF) - minx, (int)(rc.y >> 16) - miny, tx - minx, ty - miny);
     };
-    auto make_rec = [&](const Raw& rw, const u32 mask_, const TileRef& t, u32 lo_, u32 cnt_) {
+    // emission slot of a fetched line for this tile.  Tile-binned path: the block base comes from a 1 KB table (L1-resident), a
+    // dependent load -- so this is evaluated once the line has landed and long before the slot is needed (after the list
+    // building of the chunk before), and from then on ONE register stands for six (offset, block, rectangle, tile mask).
+    auto slot_of = [&](const Raw& rw, const bool have, const TileRef& t) -> u32 {
+        if (!have) return 0u;
+        const u32 base_ = inst_off ? 0u : block_base[rw.blk];
+        return emission_slot(base_ + rw.io, make_uint2(__float_as_uint(rw.q2.z), __float_as_uint(rw.q2.w)), rw.kp, t.tx, t.ty);
+    };
+    auto make_rec = [&](const Raw& rw, const u32 e_, const u32 mask_, const TileRef& t, u32 lo_, u32 cnt_) {
         ChunkRec rec; rec.mask = 0; rec.e = 0;
         rec.x = rec.y = rec.ap = rec.bp = rec.cp = rec.o = rec.r = rec.g = rec.b = 0.f; rec.pos = 0;
         if ((u32)tid < cnt_) {
             const float2 c2 = make_float2(rw.q1.x, rw.q1.y); const float4 co = rw.q0;
             const float4 cz = make_float4(rw.q1.z, rw.q1.w, rw.q2.x, rw.q2.y);
-            rec.e = emission_slot(rw.io, make_uint2(__float_as_uint(rw.q2.z), __float_as_uint(rw.q2.w)), rw.kp, t.tx, t.ty);
+            rec.e = e_;
             rec.x = c2.x; rec.y = c2.y;
             rec.ap = -0.5f * LOG2E * co.x; rec.bp = -LOG2E * co.y; rec.cp = -0.5f * LOG2E * co.z; rec.o = co.w;
             rec.r = cz.x; rec.g = cz.y; rec.b = cz.z;
@@ -367,7 +391,8 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         for (u32 p = t.maxc + tid; p < t.n; p += 256) {
             const u32 g = point_list[t.rx + p];
             const float4 t2 = g2d[4 * (size_t)g + 2], t3 = g2d[4 * (size_t)g + 3];
-            const u32 e = emission_slot(inst_off[g], make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)),
+            const u32 io = inst_off ? inst_off[g] : block_base[__float_as_uint(t3.y)] + __float_as_uint(t3.z);
+            const u32 e = emission_slot(io, make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)),
                                         (u64)__float_as_uint(t3.x) | ((u64)__float_as_uint(t3.w) << 32), t.tx, t.ty);
             float4* dst = reinterpret_cast<float4*>(partials + (size_t)e * PART_FLOATS);
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -397,7 +422,11 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     //   then     issue the gathers of chunk k+1 (ids known) and the id load of chunk k+2
     //   ...      lists + groups of chunk k            <- the loads land underneath
     //   barrier  consume gathers -> rec(k+1), ids(k+2); only then store the records of chunk k
-    ChunkRec rec = make_rec(fetch(gid0.x), gid0.y, A, A.maxc - min(A.maxc, (u32)BCHUNK), min(A.maxc, (u32)BCHUNK));
+    ChunkRec rec;
+    {
+        const Raw raw0 = fetch(gid0.x);
+        rec = make_rec(raw0, slot_of(raw0, gid0.x != 0xFFFFFFFFu, A), gid0.y, A, A.maxc - min(A.maxc, (u32)BCHUNK), min(A.maxc, (u32)BCHUNK));
+    }
     asm volatile("" :: "v"(gid1.x), "v"(gid1.y));    // complete before the loop: a pending load on the entry edge costs a vmcnt(0) at every loop top
 
     const int row = lane >> 4, li = lane & 15;
@@ -408,11 +437,17 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     u32 dg_eval = 0, dg_con = 0, dg_ent = 0, dg_ent0 = 0, dg_steps = 0, dg_chunks = 0;
 #endif
 
+    u32 par = 0;                                             // chunk parity (rec_e buffer)
     for (u32 hi = A.maxc;;) {
         const u32 cnt = min(hi, (u32)BCHUNK);
         const u32 lo = hi - cnt;
         // ---- publish the staged chunk [lo, hi) of tile A: slot s <-> list position lo + s (front to back)
-        if (tid < BCHUNK) { recs[tid] = rec; masks[tid] = rec.mask; }   // safe without a barrier: after the previous chunk's second barrier nobody reads them
+        if (tid < BCHUNK) {                                  // safe without a barrier: after the previous chunk's second barrier nobody reads them
+            recs[tid] = rec; masks[tid] = rec.mask;
+#if BAL_WRITE
+            rec_e[par][tid] = rec.e;
+#endif
+        }
         lds_barrier();
         PH_MARK(2);    // barrier 1
         __builtin_amdgcn_s_setprio(PRIO_GROUPS);
@@ -546,6 +581,14 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                     const float cdy2 = 2.f * s.cp * dy;
                     const f2 hya = __builtin_elementwise_fma(bp2, dxa, (f2){cdy2, cdy2});       // 2 cp dy + bp dx
                     const f2 hyb = __builtin_elementwise_fma(bp2, dxb, (f2){cdy2, cdy2});
+#if ABS_FMA
+                    // acc += |q| |h| as ONE v_fma_f32 with abs source modifiers (8 per row step; packed fp32 has no modifiers:
+                    // four v_pk_mul + eight v_add with |.| before)
+#define ACC_ABS2(acc, q, h) asm("v_fma_f32 %0, |%1|, |%2|, %0" : "+v"(acc) : "v"(q), "v"(h))
+                    ACC_ABS2(a9.x, qva.x, hxa.x); ACC_ABS2(a9.y, qva.y, hxa.y); ACC_ABS2(a9.x, qvb.x, hxb.x); ACC_ABS2(a9.y, qvb.y, hxb.y);
+                    ACC_ABS2(a10.x, qva.x, hya.x); ACC_ABS2(a10.y, qva.y, hya.y); ACC_ABS2(a10.x, qvb.x, hyb.x); ACC_ABS2(a10.y, qvb.y, hyb.y);
+#undef ACC_ABS2
+#else
                     const f2 mxa = qva * hxa, mxb = qvb * hxb, mya = qva * hya, myb = qvb * hyb;
                     // acc += |v| as ONE v_add_f32 with the abs source modifier (packed fp32 has none: the compiler's
                     // version is two v_and + one v_pk_add per pair)
@@ -553,6 +596,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                     ACC_ABS(a9.x, mxa.x); ACC_ABS(a9.y, mxa.y); ACC_ABS(a9.x, mxb.x); ACC_ABS(a9.y, mxb.y);
                     ACC_ABS(a10.x, mya.x); ACC_ABS(a10.y, mya.y); ACC_ABS(a10.x, myb.x); ACC_ABS(a10.y, myb.y);
 #undef ACC_ABS
+#endif
                 }
             }
         };
@@ -602,6 +646,9 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
 #pragma unroll
         for (int j = 0; j < 4; ++j) Lr[j] = build_list((qy + (j >> 1)) * 4 + qx + (j & 1));
         PH_MARK(3);    // list building
+        // the lines of chunk k+1 have landed by now (a list-building phase is several memory latencies long): their emission
+        // slots are formed here and used after the second barrier
+        const u32 e_n = slot_of(raw_n, lo > 0 && gid1.x != 0xFFFFFFFFu, A);
         const int myL = (row == 0) ? Lr[0] : (row == 1) ? Lr[1] : (row == 2) ? Lr[2] : Lr[3];
         const int nIter = (max(max(Lr[0], Lr[1]), max(Lr[2], Lr[3])) + 15) >> 4;
         const float bx0 = (float)(A.tx * BAGS_TILE) + 4.f * (float)(myblk & 3), by0 = (float)(A.ty * BAGS_TILE) + 4.f * (float)(myblk >> 2);
@@ -639,18 +686,49 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         // the skew is paid at the next barrier.
         __builtin_amdgcn_s_setprio(PRIO_SERIAL);
         // ---- next chunk: its gathers were issued before the groups; turn them into the staged record
+#if !BAL_WRITE
         const ChunkRec cur = rec;
+#endif
         // Keep every loaded register -- also the components nobody reads (q1 z, q3 yzw are not loaded; q2.y, the view
         // depth, is) -- and the id word "in use" up to this point.  Otherwise the register allocator recycles a dead
         // component of an in-flight load as scratch, which needs s_waitcnt vmcnt(0) right after the loads were issued
         // and exposes the whole gather latency once per chunk (seen in the ISA; 20 % of the wave time).  Touching gid2
         // here also retires the id load before this chunk's record stores are issued, so the top of the next chunk
         // does not have to drain the stores to be sure the id has arrived.
-        asm volatile("" :: "v"(raw_n.q2.y), "v"(gid2.x), "v"(gid2.y));
-        if (lo > 0) rec = make_rec(raw_n, gid1.y, A, nx_lo, nx_cnt);
+        asm volatile("" :: "v"(raw_n.q2.y), "v"(gid2.x), "v"(gid2.y), "v"(e_n));
+        if (lo > 0) rec = make_rec(raw_n, e_n, gid1.y, A, nx_lo, nx_cnt);
         gid1 = gid2;
         PH_MARK(1);
-        // ---- one record per staged instance: the four wave copies added in fixed order
+        // ---- one record per staged instance: the four wave copies added in fixed order.  The record holds the raw sums (sum q
+        // rather than sum q / o, the abs sums on the scaled conic): preprocess_bwd applies the per-Gaussian factors once.
+#if BAL_WRITE
+        // float4 number f of the chunk's record array (record f / 3, part f % 3) is float4 number f of every wave copy: thread
+        // tid takes f = tid, tid + 256, tid + 512 -- consecutive lanes read consecutive 16 bytes of LDS (no bank conflicts; thread =
+        // record had a 48-byte lane stride) and three lanes write the 48 contiguous bytes of one record; all four waves take
+        // part (thread = record left 80 of the 256 threads idle in the serial section between the two barriers).
+        {
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4* const acc4 = reinterpret_cast<float4*>(&acc[0][0][0]);
+#pragma unroll
+            for (int j = 0; j < (3 * BCHUNK + 255) / 256; ++j) {
+                const u32 f = (u32)tid + 256u * (u32)j;
+                if (f < 3u * cnt) {
+                    float4 r = z4;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        float4* p = acc4 + (u32)w * (3u * BCHUNK) + f;
+                        const float4 x = *p;
+                        *p = z4;                                        // re-zeroed for the next chunk
+                        r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w;
+                    }
+                    const u32 rcd = (f * 43691u) >> 17;                 // f / 3 (exact below 98304)
+                    const u32 part = f - 3u * rcd;
+                    reinterpret_cast<float4*>(partials + (size_t)rec_e[par][rcd] * PART_FLOATS)[part] = r;
+                }
+            }
+            par ^= 1u;
+        }
+#else
         if ((u32)tid < cnt) {
             float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
             if (cur.mask != 0) {
@@ -664,15 +742,11 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                     r1.x += x1.x; r1.y += x1.y; r1.z += x1.z; r1.w += x1.w;
                     r2.x += x2.x; r2.y += x2.y; r2.z += x2.z;
                 }
-                r2.y *= (1.0f / LOG2E); r2.z *= (1.0f / LOG2E);      // abs sums were taken on the scaled conic
-                r0.w = (cur.o > 0.f) ? r0.w / cur.o : 0.f;           // sum q -> sum G dL/dalpha (a contributing splat has o >= 1/255)
             }
             float4* dst = reinterpret_cast<float4*>(partials + (size_t)cur.e * PART_FLOATS);
             dst[0] = r0; dst[1] = r1; dst[2] = r2;
-#if PART_FLOATS == 16 && defined(REC_FULL_LINE)
-            dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);              // experiment: the whole 64-byte line in one go
-#endif
         }
+#endif
         PH_MARK(6);    // record sums + stores
         // no barrier here: the next chunk's first barrier orders these LDS accesses before any reuse
         if (lo == 0) break;
@@ -692,7 +766,7 @@ extern "C" void bags_diag_phases(unsigned long long* out) { hipMemcpyFromSymbol(
 #endif
 
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
-                            const float* grad_color, float* partials, bool want_abs, hipStream_t st)
+                            const float* grad_color, float* partials, bool want_abs, bool binned, hipStream_t st)
 {
     const int gx = cdiv(s.image_width, BAGS_TILE), gy = cdiv(s.image_height, BAGS_TILE);
     const int T = gx * gy;
@@ -700,11 +774,11 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     const int grid = cdiv(T, TILE_RUN) * TILE_RUN;
     if (want_abs)
         hipLaunchKernelGGL(blend_bwd_scan_kernel<true>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
-                           im.tile_desc, b.point_list, b.reach_mask, g.g2d, g.inst_off, s.bg,
+                           im.tile_desc, b.point_list, b.reach_mask, g.g2d, binned ? nullptr : g.inst_off, g.block_base, s.bg,
                            im.final_T, im.n_contrib, grad_color, partials);
     else
         hipLaunchKernelGGL(blend_bwd_scan_kernel<false>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
-                           im.tile_desc, b.point_list, b.reach_mask, g.g2d, g.inst_off, s.bg,
+                           im.tile_desc, b.point_list, b.reach_mask, g.g2d, binned ? nullptr : g.inst_off, g.block_base, s.bg,
                            im.final_T, im.n_contrib, grad_color, partials);
     return hipGetLastError();
 }

@@ -83,13 +83,14 @@ __device__ __forceinline__ void sum_records(u32 nrec, u32 first, const float* __
     }
 }
 __global__ void __launch_bounds__(256)
-sum_partials_kernel(int P, const u32* __restrict__ tiles_touched, const u32* __restrict__ inst_off, const float* __restrict__ partials,
-                    float4* __restrict__ sums)
+sum_partials_kernel(int P, const u32* __restrict__ tiles_touched, const u32* __restrict__ inst_off, const u32* __restrict__ local_off,
+                    const u32* __restrict__ block_base, int per_block, const float* __restrict__ partials, float4* __restrict__ sums)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     u32 nrec = 0, first = 0;
     if (i < P) {            // the record count from the compact array (4 coalesced bytes), not from the Gaussian's 64-byte geometry line
-        nrec = tiles_touched[i]; first = inst_off[i];
+        nrec = tiles_touched[i];
+        first = inst_off ? inst_off[i] : local_off[i] + block_base[(blockIdx.x * 256u) / (u32)per_block];
     }
     float4 s0, s1, s2;
     sum_records(nrec, first, partials, s0, s1, s2);
@@ -116,7 +117,9 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                       const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
                       const float* __restrict__ projmatrix, const float* __restrict__ intrinsic,
                       const float* __restrict__ campos_p,
-                      const u32* __restrict__ tiles_touched, const u32* __restrict__ inst_off, const float* __restrict__ shjac,
+                      const float* __restrict__ opacities,
+                      const u32* __restrict__ tiles_touched, const u32* __restrict__ inst_off, const u32* __restrict__ local_off,
+                      const u32* __restrict__ block_base, int per_block, const float* __restrict__ shjac,
                       const float* __restrict__ partials, float* __restrict__ pose_slab,
                       float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_densify,
                       float* __restrict__ g_shs, float* __restrict__ g_colors, float* __restrict__ g_opac,
@@ -163,8 +166,12 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     // visibility comes from the compact tiles_touched array, the SH clamp bits ride in the tenth word of shjac)
     const u32 n_inst = tiles_touched[ic];
 #if PB_FUSED
-    const u32 first_rec = inst_off[ic];
+    // first record of the Gaussian: radix path inst_off[i]; tile-binned path block_base[block] + local_off[i], the block being
+    // uniform over the workgroup (per_block is a multiple of 1024)
+    u32 first_rec = inst_off ? inst_off[ic] : local_off[ic];
+    if (!inst_off) first_rec += block_base[(blockIdx.x * 256u) / (u32)per_block];
 #endif
+    const float opac = opacities[ic];
     float x = means3D[3 * ic + 0], y = means3D[3 * ic + 1], z = means3D[3 * ic + 2];
     float in_s0 = 0.f, in_s1 = 0.f, in_s2 = 0.f;
     float4 in_q = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -191,7 +198,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
 #endif
     // every one of those loads is IN FLIGHT before the first of them is waited for (the compiler otherwise sinks the ones only
     // the visible branch needs behind the visibility test: one more round trip per group)
-    asm volatile("" :: "v"(n_inst), "v"(mj[9]), "v"(x), "v"(y), "v"(z), "v"(in_s0), "v"(in_s1), "v"(in_s2), "v"(in_q.x), "v"(in_c[0]),
+    asm volatile("" :: "v"(opac), "v"(n_inst), "v"(mj[9]), "v"(x), "v"(y), "v"(z), "v"(in_s0), "v"(in_s1), "v"(in_s2), "v"(in_q.x), "v"(in_c[0]),
                  "v"(in_c[3]), "v"(sm_a.x), "v"(sm_b.x), "v"(sm_c.x), "v"(mj[0]), "v"(mj[3]), "v"(mj[6]));
     const bool live = (i < P) && (n_inst > 0);
 
@@ -204,11 +211,14 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
             s[8] = c.x; s[9] = c.y; s[10] = c.z; s[11] = 0.f;
         }
         drgb[0] = s[0]; drgb[1] = s[1]; drgb[2] = s[2];
-        gop = s[3];
+        // the records carry sum q = o * sum G dL/dalpha (blend_bwd forms q from the unclamped o G): one division per Gaussian
+        // here instead of one per record there; a Gaussian with a contributing pixel has o >= 1/255
+        gop = (opac > 0.f) ? s[3] / opac : 0.f;
         const float Mx = s[4], My = s[5], Mxx = s[6], Mxy = s[7], Myy = s[8];
         // ---- 2. moments -> screen-space gradients (the centre's, which needs the conic, follows the covariance below)
         const float gA = -0.5f * Mxx, gB = -Mxy, gC = -0.5f * Myy;   // dL/dconic
-        gdx = s[9] * (0.5f * (float)W); gdy = s[10] * (0.5f * (float)H);
+        // (the abs sums were taken on the conic pre-scaled by log2 e)
+        gdx = s[9] * (0.6931471805599453f * 0.5f * (float)W); gdy = s[10] * (0.6931471805599453f * 0.5f * (float)H);
 
         // ---- recompute the forward chain
         const float tx = x * v[0] + y * v[4] + z * v[8] + v[12];
@@ -556,7 +566,7 @@ pose_reduce_kernel(const float* __restrict__ slab, int nblocks, float* __restric
 
 hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, const int32_t*,
                                  const float* partials_records, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a,
-                                 hipStream_t st, float* sums)
+                                 hipStream_t st, float* sums, bool binned)
 {
     const int P = in.P;
     const int nb = cdiv(P, 256);
@@ -566,14 +576,16 @@ hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, co
     (void)sums;
     const float* partials = partials_records;
 #else
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(nb), dim3(256), 0, st, P, g.tiles_touched, g.inst_off, partials_records,
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(nb), dim3(256), 0, st, P, g.tiles_touched, binned ? nullptr : g.inst_off, g.local_off,
+                       g.block_base, binned_per_block(P), partials_records,
                        reinterpret_cast<float4*>(sums));
     const float* partials = sums;
 #endif
 #define PRE_BWD_LAUNCH(COV)     hipLaunchKernelGGL(preprocess_bwd_kernel<COV>, dim3(nb), dim3(256), 0, st, P, s.sh_coeffs, s.sh_degree, s.image_width, \
                        s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, (s.clamp_grad == BAGS_CLAMP_GRAD_EXACT) ? 0 : 1, in.means3D, in.shift_factors, in.shs, \
                        in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, s.viewmatrix, s.projmatrix, \
-                       s.intrinsic, s.campos, g.tiles_touched, g.inst_off, g.shjac, partials, \
+                       s.intrinsic, s.campos, in.opacities, g.tiles_touched, binned ? nullptr : g.inst_off, g.local_off, g.block_base, \
+                       binned_per_block(P), g.shjac, partials, \
                        pose_slab, a.grad_means3D, a.grad_means2D, a.grad_means2D_densify, a.grad_shs, \
                        a.grad_colors_precomp, a.grad_opacities, a.grad_scales, a.grad_rotations, a.grad_cov3D_precomp);
     if (in.cov3D_precomp) { PRE_BWD_LAUNCH(true) } else { PRE_BWD_LAUNCH(false) }

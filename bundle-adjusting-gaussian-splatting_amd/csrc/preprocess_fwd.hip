@@ -7,6 +7,7 @@
 // utils/sh_utils.py:57-112 (SH basis), gaussian_renderer/__init__.py:92-95 (+0.5, clamp at 0).
 #include "bags_common.h"
 #include "sh_basis.h"
+#include "binning_common.h"
 
 struct CamConst {
     float v[16], m[16], k[16];
@@ -48,32 +49,31 @@ __device__ __forceinline__ u64 tile_reach(float px, float py, float a, float b, 
     return keep;
 }
 
-__global__ void __launch_bounds__(256, 5)     // 5 waves per SIMD (<= 96 VGPRs): this kernel lives on occupancy
-preprocess_fwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod, int depth_mode, int tile_bounds,
-                      const float* __restrict__ means3D, const float* __restrict__ means2D,
-                      const float* __restrict__ shift_factors, const float* __restrict__ shs,
-                      const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
-                      const float* __restrict__ scales, const float* __restrict__ rotations,
-                      const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
-                      const float* __restrict__ projmatrix, const float* __restrict__ intrinsic,
-                      const float* __restrict__ campos_p,
-                      u32* __restrict__ depth_key, float4* __restrict__ g2d, float* __restrict__ shjac, uint2* __restrict__ rect_out,
-                      u32* __restrict__ tiles_touched, u64* __restrict__ keep_out, int32_t* __restrict__ radii,
-                      float* __restrict__ mean2D_out)
+// Everything K1 computes for one Gaussian, as values: the two kernels below differ in what happens between the arithmetic and
+// the stores (nothing / the (block, tile) count and the block-local instance offset).
+struct K1Args {
+    int P, M, deg, W, H;
+    float tanfovx, tanfovy, mod;
+    int depth_mode, tile_bounds;
+    const float *means3D, *means2D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+    float* shjac;
+};
+struct K1Result {
+    u32 key, tiles; int radius; uint2 rect; u64 keep; float2 pxy; float4 q0, rgbz_v;
+};
+struct K1Outputs {
+    u32* depth_key; float4* g2d; uint2* rect; u32* tiles_touched; u64* keep; int32_t* radii; float* mean2D;
+};
+
+__device__ __forceinline__ K1Result k1_project(const K1Args& A, const CamConst& cam, const int i)
 {
-    __shared__ CamConst cam;
-    if (threadIdx.x < 16) {
-        cam.v[threadIdx.x] = viewmatrix[threadIdx.x];
-        cam.m[threadIdx.x] = projmatrix[threadIdx.x];
-        cam.k[threadIdx.x] = intrinsic[threadIdx.x];
-    }
-    if (threadIdx.x < 3) {
-        cam.campos[threadIdx.x] = campos_p[threadIdx.x];
-        cam.sf[threadIdx.x] = shift_factors ? shift_factors[threadIdx.x] : 0.0f;
-    }
-    __syncthreads();
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+    const int M = A.M, deg = A.deg, W = A.W, H = A.H, depth_mode = A.depth_mode, tile_bounds = A.tile_bounds;
+    const float tanfovx = A.tanfovx, tanfovy = A.tanfovy, mod = A.mod;
+    const float* __restrict__ means3D = A.means3D; const float* __restrict__ means2D = A.means2D;
+    const float* __restrict__ shs = A.shs; const float* __restrict__ colors_precomp = A.colors_precomp;
+    const float* __restrict__ opacities = A.opacities; const float* __restrict__ scales = A.scales;
+    const float* __restrict__ rotations = A.rotations; const float* __restrict__ cov3D_precomp = A.cov3D_precomp;
+    float* __restrict__ shjac = A.shjac;
     const float* v = cam.v; const float* m = cam.m; const float* k = cam.k;
 
     // defaults for a culled Gaussian
@@ -82,7 +82,6 @@ preprocess_fwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     u64 keep = ~0ull; bool masked = false;
     float2 pxy = make_float2(0.f, 0.f);
     float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), rgbz_v = q0;
-    u32 clamp_bits = 0;
 
     const float x = means3D[3 * i + 0], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
     const float tx = x * v[0] + y * v[4] + z * v[8] + v[12];
@@ -290,34 +289,157 @@ preprocess_fwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                     }
                     q0 = make_float4(con_a, con_b, con_c, opacities[i]);
                     rgbz_v = make_float4(r, g, b, tzs);
-                    clamp_bits = cl;
                 }
             }
         }
     }
-    depth_key[i] = key;
-    tiles_touched[i] = tiles;
-    rect_out[i] = rect;
-    keep_out[i] = keep;
-    float4* rec = g2d + 4 * (size_t)i;            // one full 64-byte line per thread
-    rec[0] = q0;
-    rec[1] = make_float4(pxy.x, pxy.y, rgbz_v.x, rgbz_v.y);
-    rec[2] = make_float4(rgbz_v.z, rgbz_v.w, __uint_as_float(rect.x), __uint_as_float(rect.y));
-    rec[3] = make_float4(__uint_as_float((u32)keep), __uint_as_float(tiles), __uint_as_float(clamp_bits),
-                         __uint_as_float((u32)(keep >> 32)));
-    radii[i] = radius;
-    if (mean2D_out) { mean2D_out[2 * i] = pxy.x; mean2D_out[2 * i + 1] = pxy.y; }
+    K1Result R;
+    R.key = key; R.tiles = tiles; R.radius = radius; R.rect = rect; R.keep = keep; R.pxy = pxy; R.q0 = q0; R.rgbz_v = rgbz_v;
+    return R;
+}
+
+// One full 64-byte line per Gaussian (the blend kernels gather it per instance) plus the compact arrays of the binning kernels.
+//   q3 = (tile mask lo, block of Gaussians, instance offset inside the block, tile mask hi): blend_bwd finds a Gaussian's
+//   first partial-gradient record at block_base[q3.y] + q3.z without a second gather (tile-binned path; zeros on the radix path,
+//   which keeps the inst_off array).
+__device__ __forceinline__ void k1_store(const K1Outputs& O, const int i, const K1Result& R, const u32 blk, const u32 loff)
+{
+    O.depth_key[i] = R.key;
+    O.tiles_touched[i] = R.tiles;
+    O.rect[i] = R.rect;
+    O.keep[i] = R.keep;
+    float4* rec = O.g2d + 4 * (size_t)i;
+    rec[0] = R.q0;
+    rec[1] = make_float4(R.pxy.x, R.pxy.y, R.rgbz_v.x, R.rgbz_v.y);
+    rec[2] = make_float4(R.rgbz_v.z, R.rgbz_v.w, __uint_as_float(R.rect.x), __uint_as_float(R.rect.y));
+    rec[3] = make_float4(__uint_as_float((u32)R.keep), __uint_as_float(blk), __uint_as_float(loff), __uint_as_float((u32)(R.keep >> 32)));
+    O.radii[i] = R.radius;
+    if (O.mean2D) { O.mean2D[2 * i] = R.pxy.x; O.mean2D[2 * i + 1] = R.pxy.y; }
+}
+
+__device__ __forceinline__ void k1_load_camera(CamConst& cam, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
+                                               const float* __restrict__ intrinsic, const float* __restrict__ campos_p,
+                                               const float* __restrict__ shift_factors)
+{
+    if (threadIdx.x < 16) {
+        cam.v[threadIdx.x] = viewmatrix[threadIdx.x];
+        cam.m[threadIdx.x] = projmatrix[threadIdx.x];
+        cam.k[threadIdx.x] = intrinsic[threadIdx.x];
+    }
+    if (threadIdx.x < 3) {
+        cam.campos[threadIdx.x] = campos_p[threadIdx.x];
+        cam.sf[threadIdx.x] = shift_factors ? shift_factors[threadIdx.x] : 0.0f;
+    }
+}
+
+__global__ void __launch_bounds__(256, 5)     // 5 waves per SIMD (<= 96 VGPRs): this kernel lives on occupancy
+preprocess_fwd_kernel(const K1Args A, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
+                      const float* __restrict__ intrinsic, const float* __restrict__ campos_p,
+                      const float* __restrict__ shift_factors, const K1Outputs O)
+{
+    __shared__ CamConst cam;
+    k1_load_camera(cam, viewmatrix, projmatrix, intrinsic, campos_p, shift_factors);
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.P) return;
+    k1_store(O, i, k1_project(A, cam, i), 0u, 0u);
+}
+
+// K1 + step 1 of the tile-binned lists (binning.hip) in one launch (round 4).  One 1024-thread workgroup per block of
+// `per_block` consecutive Gaussians (<= 256 blocks, the row index of the (block, tile) count matrix): pass p handles Gaussian
+// block * per_block + p * 1024 + tid, counts its instances per tile in LDS (packed 16-bit counters, integer LDS atomics: counts
+// do not depend on arrival order), and hands it a range of record slots inside the block (wave scan + one LDS counter) --
+// written into its geometry line and the compact local_off array.  tile_count_kernel was a
+// 9 us launch of its own on the path to the instance count (its work, 2 M LDS atomics, hides behind K1's memory traffic here),
+// and the offset inside the line saves blend_bwd a 4-byte gather per instance.
+__global__ void __launch_bounds__(BIN_THREADS)
+preprocess_fwd_count_kernel(const K1Args A, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
+                            const float* __restrict__ intrinsic, const float* __restrict__ campos_p,
+                            const float* __restrict__ shift_factors, const K1Outputs O, const int per_block, const int grid_x,
+                            const int T2, u32* __restrict__ cnt_rows, u32* __restrict__ local_off, u32* __restrict__ block_total)
+{
+    extern __shared__ u32 cnt[];                             // T2 packed words
+    __shared__ CamConst cam;
+    __shared__ u32 s_run;                                    // instances handed out so far in this block
+    for (int t = threadIdx.x; t < T2; t += BIN_THREADS) cnt[t] = 0u;
+    k1_load_camera(cam, viewmatrix, projmatrix, intrinsic, campos_p, shift_factors);
+    if (threadIdx.x == 0) s_run = 0u;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int passes = per_block / BIN_THREADS;
+    // No barrier inside the loop: the 16 waves drift apart, so the loads of one overlap the arithmetic and the stores of another
+    // (in lockstep -- a block-wide scan per pass -- the 245 workgroups of a 500 k scene all loaded, then all computed, then all
+    // stored: +7 us).  A Gaussian's records only need a range of their own inside the block, not a particular one: each wave
+    // scans its 64 counts and takes the range from an LDS counter.  Which wave gets which range varies from run to run; no
+    // result depends on it (records are summed per Gaussian in tile-list order wherever they lie).
+#pragma unroll 1
+    for (int pass = 0; pass < passes; ++pass) {
+        const long long gi = (long long)blockIdx.x * per_block + (long long)pass * BIN_THREADS + threadIdx.x;
+        const bool valid = gi < (long long)A.P;
+        const int i = (int)(valid ? gi : 0);
+        K1Result R;
+        R.key = KEY_CULLED; R.tiles = 0; R.radius = 0; R.rect = make_uint2(0u, 0u); R.keep = ~0ull; R.pxy = make_float2(0.f, 0.f);
+        R.q0 = make_float4(0.f, 0.f, 0.f, 0.f); R.rgbz_v = R.q0;
+        if (valid) R = k1_project(A, cam, i);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- (block, tile) counts: small rectangles by their tile mask, larger ones tile by tile, huge ones by the whole wave
+        const u32 nt = R.tiles;
+        const uint2 rc = R.rect;
+        const int w = (int)(rc.y & 0xFFFF) - (int)(rc.x & 0xFFFF), h = (int)(rc.y >> 16) - (int)(rc.x >> 16);
+        if (nt > 0) {
+            if (rect_small(w, h)) walk_mask<false>(cnt, rc, R.keep, grid_x, 0ull, nullptr);
+            else if (nt <= BIN_COOP) walk_rect<false>(cnt, rc, grid_x, lane, false, 0ull, nullptr);
+        }
+        u64 big = __ballot(nt > BIN_COOP);                   // never a small rectangle (at most 64 tiles)
+        while (big) {
+            const int src = __ffsll((long long)big) - 1;
+            big &= big - 1;
+            const uint2 brc = make_uint2((u32)__shfl((int)rc.x, src), (u32)__shfl((int)rc.y, src));
+            walk_rect<false>(cnt, brc, grid_x, lane, true, 0ull, nullptr);
+        }
+        // ---- the wave's range of record slots inside the block
+        const u32 incl = wave_incl_scan(nt);
+        u32 base = 0;
+        if (lane == 63) base = atomicAdd(&s_run, incl);
+        base = (u32)__builtin_amdgcn_readlane((int)base, 63);
+        const u32 loff = base + incl - nt;
+        __builtin_amdgcn_sched_barrier(0);
+        if (valid) { k1_store(O, i, R, (u32)blockIdx.x, loff); local_off[i] = loff; }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                                         // every counter of the block is final
+    if (threadIdx.x == 0) block_total[blockIdx.x] = s_run;
+    u32* row = cnt_rows + (size_t)blockIdx.x * T2;
+    for (int t = threadIdx.x; t < T2; t += BIN_THREADS) row[t] = cnt[t];
 }
 
 hipError_t launch_preprocess_fwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, int32_t* radii,
-                                 float* mean2D, hipStream_t st)
+                                 float* mean2D, hipStream_t st, const ImgView* count_into, int grid_x)
 {
     const int P = in.P;
     if (P == 0) return hipSuccess;
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, P, s.sh_coeffs, s.sh_degree,
-                       s.image_width, s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, s.depth_key, s.tile_bounds,
-                       in.means3D, in.means2D, in.shift_factors, in.shs, in.colors_precomp, in.opacities, in.scales,
-                       in.rotations, in.cov3D_precomp, s.viewmatrix, s.projmatrix, s.intrinsic, s.campos,
-                       g.depth_key, g.g2d, g.shjac, g.rect, g.tiles_touched, g.keep, radii, mean2D);
+    K1Args A;
+    A.P = P; A.M = s.sh_coeffs; A.deg = s.sh_degree; A.W = s.image_width; A.H = s.image_height;
+    A.tanfovx = s.tanfovx; A.tanfovy = s.tanfovy; A.mod = s.scale_modifier; A.depth_mode = s.depth_key; A.tile_bounds = s.tile_bounds;
+    A.means3D = in.means3D; A.means2D = in.means2D; A.shs = in.shs; A.colors_precomp = in.colors_precomp; A.opacities = in.opacities;
+    A.scales = in.scales; A.rotations = in.rotations; A.cov3D_precomp = in.cov3D_precomp; A.shjac = g.shjac;
+    K1Outputs O;
+    O.depth_key = g.depth_key; O.g2d = g.g2d; O.rect = g.rect; O.tiles_touched = g.tiles_touched; O.keep = g.keep; O.radii = radii;
+    O.mean2D = mean2D;
+    if (count_into) {                                        // tile-binned path: K1 also counts the (block, tile) matrix
+        const int gy = cdiv(s.image_height, BAGS_TILE), T = grid_x * gy, T2 = (T + 1) / 2;
+        const int per = binned_per_block(P), B = cdiv(P, per);
+        const size_t lds = (size_t)T2 * 4;
+        if (lds + 1024 > 65536) {                            // beyond the default 64 KB of LDS per workgroup the launch has to opt in
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(preprocess_fwd_count_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(preprocess_fwd_count_kernel, dim3(B), dim3(BIN_THREADS), lds, st, A, s.viewmatrix, s.projmatrix, s.intrinsic,
+                           s.campos, in.shift_factors, O, per, grid_x, T2, count_into->cnt_rows, g.local_off, g.block_total);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, A, s.viewmatrix, s.projmatrix, s.intrinsic,
+                       s.campos, in.shift_factors, O);
     return hipGetLastError();
 }
