@@ -57,6 +57,9 @@
 #ifndef BAL_WRITE
 #define BAL_WRITE 1         // the record sums of a chunk (four wave copies -> one 48-B record) spread over all 256 threads, one float4
 #endif                      // each: conflict-free LDS reads, three lanes per record on the way out (was: thread = record, 176 of 256 busy)
+#ifndef P_SKIP
+#define P_SKIP 1            // tiles whose staged splats are all well conditioned (flag from the forward) skip the `power <= 0` test: it cannot fail there
+#endif
 #ifndef ABS_FMA
 #define ABS_FMA 1           // sum |q dpower/dcentre| as v_fma_f32 acc, |q|, |h|, acc (8 per row step instead of 4 packed muls + 8 adds)
 #endif
@@ -254,7 +257,18 @@ __device__ __forceinline__ void diag_pairs_flush(int slot, u32 ev, u32 co)
     if ((threadIdx.x & 63) == 0) { atomicAdd(&g_pair_counts[slot], (unsigned long long)ev); atomicAdd(&g_pair_counts[slot + 1], (unsigned long long)co); }
 }
 #endif
-struct TileRef { int tx, ty; u32 rx, n, maxc; bool early; };   // early: some pixel of the tile stopped before its list ended (or lies outside the image)   // wave-uniform: tile coordinates, first instance, instances, deepest contributor
+// `power <= 0` cannot fail for a splat whose conic is well conditioned.  With Q = [[a, b], [b, c]] the fp32 numbers in the
+// geometry line, the evaluated power is p^ = fma(dx, fma(bp, dy, ap dx), (cp dy) dy) on coefficients that are -K Q rounded
+// (K = log2(e) / 2): |p^ - p| <= ~4 eps K (a dx^2 + 2 |b| |dx dy| + c dy^2) <= 8 eps K (a + c) |d|^2, while -p >= K lambda_min
+// |d|^2 with lambda_min >= det / (a + c).  So det >= 1e-4 (a + c)^2 leaves a factor 200 between the rounding error and the
+// value: p^ < 0 for d != 0, and p^ = 0 for d = 0.  The forward ORs "some staged splat fails that bound" (conic eigenvalue
+// ratio above ~1e4: a needle more than 100 x longer than wide after the 0.3 px dilation) into bit 30 of the tile descriptor.
+__device__ __forceinline__ bool conic_ill_conditioned(float a, float b, float c)
+{
+    const float tr = a + c;
+    return !(a * c - b * b >= 1.0e-4f * (tr * tr));         // also catches NaN and non-positive determinants
+}
+struct TileRef { int tx, ty; u32 rx, n, maxc; bool early, needle; };   // early: some pixel of the tile stopped before its list ended (or lies outside the image)   // wave-uniform: tile coordinates, first instance, instances, deepest contributor
 
 template <bool ABS>
 __global__ void __launch_bounds__(256, SCAN_WG_PER_CU)
@@ -277,7 +291,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     if (desc.z == 0) return;                                 // empty tile: no records to write
     TileRef A;
     A.tx = (int)(desc.x % (u32)grid_x); A.ty = (int)(desc.x / (u32)grid_x); A.rx = desc.y; A.n = desc.z;
-    A.maxc = min(desc.w & 0x7FFFFFFFu, desc.z); A.early = (desc.w >> 31) != 0u;
+    A.maxc = min(desc.w & 0x3FFFFFFFu, desc.z); A.early = (desc.w >> 31) != 0u; A.needle = ((desc.w >> 30) & 1u) != 0u;
 
     __shared__ ChunkRec recs[BCHUNK];                 // 8.25 KB
     // 8 pixel pairs (PixPair = 4 x float4) per block + one float4 of padding: the four rows of a wave read four different
@@ -464,8 +478,9 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
 #else
         f2 a3, a4, a5, a7, a8;
 #endif
-        auto block_rows = [&](auto skip_nc_tag, const ChunkRec& s, const bool live, const float bx0, const float by0, float4* pixb, const bool carry) {
+        auto block_rows = [&](auto skip_nc_tag, auto skip_p_tag, const ChunkRec& s, const bool live, const float bx0, const float by0, float4* pixb, const bool carry) {
             constexpr bool SKIP_NC = decltype(skip_nc_tag)::value;
+            constexpr bool SKIP_P = decltype(skip_p_tag)::value;
             a0 = (f2){0.f, 0.f}; a1 = a0; a2 = a0; a6 = a0; a9 = a0; a10 = a0;
 #if SCALAR_ACC
             sa3 = sa4 = sa5 = sa7 = sa8 = 0.f;
@@ -507,10 +522,10 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                 // every outstanding LDS read (lgkmcnt(0)) in the middle of the row
                 // SKIP_NC: no pixel of the tile stopped early, so a splat behind a pixel's last contributor fails the alpha test
                 // at that pixel anyway (it failed it in the forward): the position test is redundant
-                const bool v0 = live & (pa.x <= 0.f) & (aua.x >= ALPHA_MIN) & (SKIP_NC | (s.pos <= nc0));
-                const bool v1 = live & (pa.y <= 0.f) & (aua.y >= ALPHA_MIN) & (SKIP_NC | (s.pos <= nc1));
-                const bool v2 = live & (pb.x <= 0.f) & (aub.x >= ALPHA_MIN) & (SKIP_NC | (s.pos <= nc2));
-                const bool v3 = live & (pb.y <= 0.f) & (aub.y >= ALPHA_MIN) & (SKIP_NC | (s.pos <= nc3));
+                const bool v0 = live & (SKIP_P | (pa.x <= 0.f)) & (aua.x >= ALPHA_MIN) & (SKIP_NC | (s.pos <= nc0));
+                const bool v1 = live & (SKIP_P | (pa.y <= 0.f)) & (aua.y >= ALPHA_MIN) & (SKIP_NC | (s.pos <= nc1));
+                const bool v2 = live & (SKIP_P | (pb.x <= 0.f)) & (aub.x >= ALPHA_MIN) & (SKIP_NC | (s.pos <= nc2));
+                const bool v3 = live & (SKIP_P | (pb.y <= 0.f)) & (aub.y >= ALPHA_MIN) & (SKIP_NC | (s.pos <= nc3));
                 aua.x = v0 ? aua.x : 0.f; aua.y = v1 ? aua.y : 0.f; aub.x = v2 ? aub.x : 0.f; aub.y = v3 ? aub.y : 0.f;
 #ifdef DIAG_PAIRS
                 dg_eval += live ? 4u : 0u; dg_con += (u32)v0 + (u32)v1 + (u32)v2 + (u32)v3;
@@ -663,8 +678,13 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
 #ifdef DIAG_PAIRS
             const u32 dg_before = dg_con;
 #endif
-            if (NC_SKIP && !A.early) block_rows(std::true_type{}, s, live, bx0, by0, pixb, (li == 15) && (gend > 0));
-            else block_rows(std::false_type{}, s, live, bx0, by0, pixb, (li == 15) && (gend > 0));
+            // three instances of the row loop (wave-uniform choice per tile): the fast one for tiles where no pixel stopped early
+            // and every staged conic is well conditioned; without the position test only; with both tests
+            const bool cry = (li == 15) && (gend > 0);
+            if (NC_SKIP && P_SKIP && !A.early && !A.needle) block_rows(std::true_type{}, std::true_type{}, s, live, bx0, by0, pixb, cry);
+            else if (P_SKIP && !A.needle) block_rows(std::false_type{}, std::true_type{}, s, live, bx0, by0, pixb, cry);
+            else if (NC_SKIP && !A.early) block_rows(std::true_type{}, std::false_type{}, s, live, bx0, by0, pixb, cry);
+            else block_rows(std::false_type{}, std::false_type{}, s, live, bx0, by0, pixb, cry);
 #ifdef DIAG_PAIRS
             dg_ent += live ? 1u : 0u; dg_ent0 += (live && dg_con == dg_before) ? 1u : 0u; dg_steps += (lane == 0) ? 1u : 0u;
 #endif
@@ -854,6 +874,7 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
     // its scalar unit as on its vector units).
     float Tq = inside ? 1.f : -1.f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dq = 0.f;
     u32 last = 0;
+    bool needle = false;                                     // wave-uniform: a thread of this wave staged a splat with an ill-conditioned conic
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #ifdef DIAG_PAIRS
     u32 dg_eval = 0, dg_con = 0;
@@ -868,6 +889,7 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
         if (!(s_live[0] | s_live[1] | s_live[2] | s_live[3])) break;
         const u32 cnt = min((u32)FWD_STAGE, n - base);
         SplatRec rec; rec.mask = 0; rec.x = rec.y = rec.ap = rec.bp = rec.cp = rec.o = rec.r = rec.g = rec.b = rec.z = 0.f; rec.pos = 0;
+        bool ill = false;
         if ((u32)tid < cnt) {
             const u32 g = point_list[range.x + base + tid];
             const float4* grec = g2d + 4 * (size_t)g;             // one 64-byte line per instance
@@ -880,7 +902,9 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
             rec.pos = base + tid + 1;
             rec.mask = block_mask16(c2.x, c2.y, co.x, co.y, co.z, co.w, X0, Y0);
             reach_mask[range.x + base + tid] = (unsigned short)rec.mask;      // the backward stages the same instance: it reads this
+            ill = conic_ill_conditioned(co.x, co.y, co.z);
         }
+        needle |= (__ballot(ill) != 0ull);                   // (a scalar register, not a lane's)
         if (tid < CHUNK) { recs[tid] = rec; masks[tid] = rec.mask; }
 #if FWD_SENTINEL
         // this wave's four lists (rows qb, qb+1 | qb+4, qb+5: two runs of 2 x CHUNK bytes) start out as all-sentinel: a row
@@ -1054,14 +1078,15 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
     u32 m = last;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (u32)__shfl_xor((int)m, d));
-    const u32 early = (__ballot(stopped) != 0ull) ? 0x80000000u : 0u;
+    const u32 early = ((__ballot(stopped) != 0ull) ? 0x80000000u : 0u) | (needle ? 0x40000000u : 0u);
     __syncthreads();                                         // s_live is free again
     if (lane == 0) s_live[wave] = (int)(m | early);
     __syncthreads();
-    // bit 31: some pixel of the tile did not walk its whole list (the backward then needs its `pos <= n_contrib` test)
+    // bit 31: some pixel of the tile did not walk its whole list (the backward then needs its `pos <= n_contrib` test);
+    // bit 30: some staged splat has an ill-conditioned conic (the backward then keeps its `power <= 0` test)
     if (tid == 0) {
         const u32 w0 = (u32)s_live[0], w1 = (u32)s_live[1], w2 = (u32)s_live[2], w3 = (u32)s_live[3];
-        tile_desc[dslot].w = max(max(w0 & 0x7FFFFFFFu, w1 & 0x7FFFFFFFu), max(w2 & 0x7FFFFFFFu, w3 & 0x7FFFFFFFu)) | ((w0 | w1 | w2 | w3) & 0x80000000u);
+        tile_desc[dslot].w = max(max(w0 & 0x3FFFFFFFu, w1 & 0x3FFFFFFFu), max(w2 & 0x3FFFFFFFu, w3 & 0x3FFFFFFFu)) | ((w0 | w1 | w2 | w3) & 0xC0000000u);
     }
 #ifdef DIAG_PAIRS
     diag_pairs_flush(2, dg_eval, dg_con);

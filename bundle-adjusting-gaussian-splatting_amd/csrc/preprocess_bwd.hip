@@ -19,6 +19,15 @@ struct CamConstB {
     float sf[3];
 };
 
+// sum over the 64 lanes on DPP (row_shr 1/2/4/8 inside the 16-lane rows, row_bcast:15 / row_bcast:31 across them: six
+// v_add_f32_dpp); the total is valid in lane 63.  Every lane must be active.
+__device__ __forceinline__ float wave_total_f(float x)
+{
+#define DPP_ADD(ctrl, rmask) x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rmask, 0xf, false))
+    DPP_ADD(0x111, 0xf); DPP_ADD(0x112, 0xf); DPP_ADD(0x114, 0xf); DPP_ADD(0x118, 0xf); DPP_ADD(0x142, 0xa); DPP_ADD(0x143, 0xc);
+#undef DPP_ADD
+    return x;
+}
 __device__ __forceinline__ float wave_sum(float x)
 {
 #pragma unroll
@@ -132,7 +141,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     // indices from the kernel's own pointers (scalar loads, no LDS, no barrier), the SH rows go to LDS by LDS-DMA (no
     // registers, no wait here), the visibility word and every input row are requested unconditionally (clamped index; a
     // culled Gaussian's 104 bytes are read for nothing), and there is ONE wait in front of the arithmetic.
-    __shared__ float wpose[4][POSE_VALS];
+    __shared__ float wpose[4][48];                      // [0..34] the slab row, [35..43] second contribution to [0..8]
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const float* v = viewmatrix; const float* m = projmatrix; const float* k = intrinsic;
     const float sf0 = shift_factors ? shift_factors[0] : 0.0f, sf1 = shift_factors ? shift_factors[1] : 0.0f,
@@ -152,9 +161,6 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     const size_t base4 = (size_t)blockIdx.x * (256 * 12), lim4 = (size_t)P * 12;
 #endif
 
-    float pose[POSE_VALS];
-#pragma unroll
-    for (int t = 0; t < POSE_VALS; ++t) pose[t] = 0.f;
     float dmx = 0.f, dmy = 0.f, dmz = 0.f;           // dL/dmeans3D
     float gm2x = 0.f, gm2y = 0.f, gdx = 0.f, gdy = 0.f, gop = 0.f;
     float gs0 = 0.f, gs1 = 0.f, gs2 = 0.f, gqr = 0.f, gqx = 0.f, gqy = 0.f, gqz = 0.f;
@@ -201,8 +207,18 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     asm volatile("" :: "v"(opac), "v"(n_inst), "v"(mj[9]), "v"(x), "v"(y), "v"(z), "v"(in_s0), "v"(in_s1), "v"(in_s2), "v"(in_q.x), "v"(in_c[0]),
                  "v"(in_c[3]), "v"(sm_a.x), "v"(sm_b.x), "v"(sm_c.x), "v"(mj[0]), "v"(mj[3]), "v"(mj[6]));
     const bool live = (i < P) && (n_inst > 0);
-
-    if (live) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // Pose Jacobians (35 scalars per Gaussian) leave the registers the moment they exist: wave total on DPP (six v_add_f32_dpp,
+    // total in lane 63) -> wpose.  Round 3 formed all 35 inside `if (live)` and reduced them behind it: 35 values live across
+    // the join on top of everything else put the kernel at 140+ registers against the 128 that four workgroups per CU allow
+    // (12-18 spilled: 50-70 MB of scratch traffic per launch).  For that the geometry chain runs in EVERY lane (a culled
+    // Gaussian's lane computes on its real inputs; whatever comes out -- Inf, NaN -- is replaced by 0 in the select below
+    // and never stored), so the DPP rows are complete.  Slots 35..43 take the second contribution to viewmatrix[0..2][0..2].
+    auto red = [&](const int t, const float val) {
+        const float tot = wave_total_f(live ? val : 0.f);
+        if (lane == 63) wpose[wave][t] = tot;
+    };
+    {
         // ---- 1. the per-Gaussian sums of the per-instance records
         float s[12];
         {
@@ -303,15 +319,16 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         const float dj11 = dA10 * v[1] + dA11 * v[5] + dA12 * v[9];
         const float dj12 = dA10 * v[2] + dA11 * v[6] + dA12 * v[10];
         // pose slab: [0..11] viewmatrix (rows 0..3 x cols 0..2), [12..23] projmatrix (rows 0..3 x cols 0,1,3),
-        //            [24] k0 [25] k5 [26] k8 [27] k9 [28] k11, [29..31] campos, [32..34] shift_factors
-        pose[0] = dA00 * j00; pose[1] = dA10 * j11; pose[2] = dA00 * j02 + dA10 * j12;      // v[0], v[1], v[2]
-        pose[3] = dA01 * j00; pose[4] = dA11 * j11; pose[5] = dA01 * j02 + dA11 * j12;      // v[4], v[5], v[6]
-        pose[6] = dA02 * j00; pose[7] = dA12 * j11; pose[8] = dA02 * j02 + dA12 * j12;      // v[8], v[9], v[10]
+        //            [24] k0 [25] k5 [26] k8 [27] k9 [28] k11, [29..31] campos, [32..34] shift_factors;
+        //            [35..43] second contribution to [0..8] (added when the slab row is written)
+        red(0, dA00 * j00); red(1, dA10 * j11); red(2, dA00 * j02 + dA10 * j12);      // v[0], v[1], v[2]
+        red(3, dA01 * j00); red(4, dA11 * j11); red(5, dA01 * j02 + dA11 * j12);      // v[4], v[5], v[6]
+        red(6, dA02 * j00); red(7, dA12 * j11); red(8, dA02 * j02 + dA12 * j12);      // v[8], v[9], v[10]
         // J -> focal lengths, view-space point
         const float dfx = dj00 * itz - dj02 * ux * itz;
         const float dfy = dj11 * itz - dj12 * uy * itz;
-        pose[24] = dfx * (0.5f * (float)W);
-        pose[25] = dfy * (0.5f * (float)H);
+        red(24, dfx * (0.5f * (float)W));
+        red(25, dfy * (0.5f * (float)H));
         const float dux = -dj02 * fx * itz, duy = -dj12 * fy * itz;
         const float ditz = dj00 * fx - dj02 * fx * ux + dj11 * fy - dj12 * fy * uy;
         float dtx = 0.f, dty = 0.f, dtz = 0.f;
@@ -331,15 +348,15 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         dmx = dhx * m[0] + dhy * m[1] + dhw * m[3];
         dmy = dhx * m[4] + dhy * m[5] + dhw * m[7];
         dmz = dhx * m[8] + dhy * m[9] + dhw * m[11];
-        pose[12] = dhx * x; pose[13] = dhy * x; pose[14] = dhw * x;       // m[0], m[1], m[3]
-        pose[15] = dhx * y; pose[16] = dhy * y; pose[17] = dhw * y;       // m[4], m[5], m[7]
-        pose[18] = dhx * z; pose[19] = dhy * z; pose[20] = dhw * z;       // m[8], m[9], m[11]
-        pose[21] = dhx;     pose[22] = dhy;     pose[23] = dhw;           // m[12], m[13], m[15]
-        float dshift = dhx * k[8] + dhy * k[9] + dhw * k[11] + dtzs;
-        pose[26] = dhx * shift; pose[27] = dhy * shift; pose[28] = dhw * shift;
+        red(12, dhx * x); red(13, dhy * x); red(14, dhw * x);       // m[0], m[1], m[3]
+        red(15, dhx * y); red(16, dhy * y); red(17, dhw * y);       // m[4], m[5], m[7]
+        red(18, dhx * z); red(19, dhy * z); red(20, dhw * z);       // m[8], m[9], m[11]
+        red(21, dhx);     red(22, dhy);     red(23, dhw);           // m[12], m[13], m[15]
+        const float dshift = dhx * k[8] + dhy * k[9] + dhw * k[11] + dtzs;
+        red(26, dhx * shift); red(27, dhy * shift); red(28, dhw * shift);
         dtz += dtzs;
         // shift polynomial in theta = atan2(rho, tz)
-        pose[32] = dshift * th3; pose[33] = dshift * th3 * th2; pose[34] = dshift * th3 * th2 * th2;
+        red(32, dshift * th3); red(33, dshift * th3 * th2); red(34, dshift * th3 * th2 * th2);
         const float dtheta = dshift * (3.f * sf0 * th2 + 5.f * sf1 * th2 * th2 + 7.f * sf2 * th2 * th2 * th2);
         const float ir2 = 1.0f / (rho * rho + tz * tz);
         const float drho = dtheta * tz * ir2;
@@ -349,10 +366,10 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         dmx += dtx * v[0] + dty * v[1] + dtz * v[2];
         dmy += dtx * v[4] + dty * v[5] + dtz * v[6];
         dmz += dtx * v[8] + dty * v[9] + dtz * v[10];
-        pose[0] += dtx * x; pose[1] += dty * x; pose[2] += dtz * x;
-        pose[3] += dtx * y; pose[4] += dty * y; pose[5] += dtz * y;
-        pose[6] += dtx * z; pose[7] += dty * z; pose[8] += dtz * z;
-        pose[9] = dtx; pose[10] = dty; pose[11] = dtz;                    // v[12], v[13], v[14]
+        red(35, dtx * x); red(36, dty * x); red(37, dtz * x);
+        red(38, dtx * y); red(39, dty * y); red(40, dtz * y);
+        red(41, dtx * z); red(42, dty * z); red(43, dtz * z);
+        red(9, dtx); red(10, dty); red(11, dtz);                    // v[12], v[13], v[14]
 
         // ---- Sigma -> scales, rotation
         if (!COV3D) {
@@ -374,16 +391,13 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
             gqy = 2.f * (-2.f * qy * d00 + qx * d01 + qr * d02 + qx * d10 + qz * d12 - qr * d20 + qz * d21 - 2.f * qy * d22);
             gqz = 2.f * (-2.f * qz * d00 - qr * d01 + qx * d02 + qr * d10 - 2.f * qz * d11 + qy * d12 + qx * d20 + qy * d21);
         }
-
-    }
-    // ---- 5a. pose Jacobians of the geometry chain: wave -> LDS now, so their 32 registers are free while the SH row
-    // is in flight below (every lane takes part: the sums must not sit inside the divergent branch)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        // a culled Gaussian's lane went through all of the above on its real inputs: none of it is kept
+        if (!live) {
+            dmx = dmy = dmz = 0.f; gm2x = gm2y = gdx = gdy = gop = 0.f; gs0 = gs1 = gs2 = gqr = gqx = gqy = gqz = 0.f;
+            drgb[0] = drgb[1] = drgb[2] = 0.f;
 #pragma unroll
-    for (int t = 0; t < 35; ++t) {
-        if (t >= 29 && t <= 31) continue;
-        const float r = wave_sum(pose[t]);
-        if (lane == 0) wpose[wave][t] = r;
+            for (int t = 0; t < 6; ++t) gc[t] = 0.f;
+        }
     }
     float cp0 = 0.f, cp1 = 0.f, cp2 = 0.f;            // dL/dcampos of this Gaussian
 
@@ -503,14 +517,15 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
 
     // ---- 5b. the view-direction part (campos), then workgroup -> slab row
     {
-        const float r0 = wave_sum(cp0), r1 = wave_sum(cp1), r2 = wave_sum(cp2);
-        if (lane == 0) { wpose[wave][29] = r0; wpose[wave][30] = r1; wpose[wave][31] = r2; }
+        const float r0 = wave_total_f(cp0), r1 = wave_total_f(cp1), r2 = wave_total_f(cp2);
+        if (lane == 63) { wpose[wave][29] = r0; wpose[wave][30] = r1; wpose[wave][31] = r2; }
     }
     __syncthreads();
     if (threadIdx.x < POSE_VALS) {
         const int t = threadIdx.x;
-        pose_slab[(size_t)blockIdx.x * POSE_VALS + t] =
-            (t < 35) ? (wpose[0][t] + wpose[1][t]) + (wpose[2][t] + wpose[3][t]) : 0.f;
+        float r = (t < 35) ? (wpose[0][t] + wpose[1][t]) + (wpose[2][t] + wpose[3][t]) : 0.f;
+        if (t < 9) r += (wpose[0][35 + t] + wpose[1][35 + t]) + (wpose[2][35 + t] + wpose[3][35 + t]);
+        pose_slab[(size_t)blockIdx.x * POSE_VALS + t] = r;
     }
 }
 
