@@ -165,9 +165,10 @@ size_t carve_image(void* base, int W, int H, ImgView* v)
     take(p, im.final_T, n); take(p, im.n_contrib, n);
     const size_t T = (size_t)cdiv(W > 0 ? W : 1, BAGS_TILE) * cdiv(H > 0 ? H : 1, BAGS_TILE);
     take(p, im.tile_desc, T); take(p, im.n_active, 64);
-    im.cnt_rows = im.pre = im.tile_total = nullptr; im.ranges = nullptr;
+    im.cnt_rows = im.pre = im.tile_total = nullptr; im.ranges = nullptr; im.tile_lstart = im.group_total = nullptr;
     if (binned_supported(1, (int)T)) {                        // images the tile-binned path can take (<= 32768 tiles)
         take(p, im.cnt_rows, 256 * ((T + 1) / 2)); take(p, im.pre, 256 * T); take(p, im.tile_total, T); take(p, im.ranges, T);
+        take(p, im.tile_lstart, T); take(p, im.group_total, 512);
     }
     if (v) *v = im;
     return (size_t)(p - reinterpret_cast<char*>(base));
@@ -244,7 +245,9 @@ static int enqueue_prepare(const BagsSettings* s, const BagsInputs* in, const Ge
     if (binned) {
         // (block of Gaussians, tile) count matrix -> column prefixes -> tile ranges, instance count, heavy-first tile list
         const int gx = cdiv(s->image_width, BAGS_TILE), gy = cdiv(s->image_height, BAGS_TILE);
-        { ProfScope ps(ST_OFFSETS, st); HIP_TRY(launch_binned_prepare(g, im, in->P, gx, gx * gy, st, host_count)); }
+        // host_count given (device-visible pinned word, speculative forward): no ranges_order launch -- the emission launch of
+        // the second phase computes the ranges itself and delivers the count there
+        { ProfScope ps(ST_OFFSETS, st); HIP_TRY(launch_binned_prepare(g, im, in->P, gx, gx * gy, st, host_count, host_count == nullptr)); }
         if (host_count && host_written) *host_written = true;
         DEBUG_SYNC(s, st, "tile count / prefix / ranges");
         return BAGS_OK;

@@ -100,7 +100,7 @@ struct GeomView {            // per Gaussian, indexed by Gaussian id unless stat
     u32*    scan_partials;
     u32*    radix_hist;      // [256][nblocks]
     u32*    digit_totals;    // [256]
-    u32*    num_rendered;    // [1] (+ pad)
+    u32*    num_rendered;    // [0] instance count; [2..3] device-visible address of the caller's pinned count word (or 0); [8..] debug counters
     // tile-binned path (binning.hip)
     u32*    local_off;       // [P] instance offset of a Gaussian inside its block of Gaussians (id order)
     u32*    block_total;     // [256] instances per block
@@ -136,6 +136,8 @@ struct ImgView {
     u32*   pre;              // [256][T]
     u32*   tile_total;       // [T]
     uint2* ranges;           // [T]
+    u32*   tile_lstart;      // [T] first instance of a tile relative to its group of 64 tiles (tile_prefix_kernel)
+    u32*   group_total;      // [512] instances per group of 64 tiles
 };
 
 int radix_items_for(long long n);
@@ -205,7 +207,8 @@ hipError_t launch_binned_empty(const GeomView& g, const ImgView& im, int T, hipS
 hipError_t launch_binned_desc_only(const ImgView& im, int T, hipStream_t st);
 // host_count: device-visible address of a pinned host word that also receives the instance count (may be null)
 // (the (block, tile) counts themselves come from launch_preprocess_fwd(count_into = &im))
-hipError_t launch_binned_prepare(const GeomView& g, const ImgView& im, int P, int grid_x, int T, hipStream_t st, u32* host_count = nullptr);
+hipError_t launch_binned_prepare(const GeomView& g, const ImgView& im, int P, int grid_x, int T, hipStream_t st, u32* host_count = nullptr,
+                                 bool count_now = true);
 hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int grid_x, int T, u64* words, u64* scratch, u32* point_list,
                                 u32 capacity, const u32* n_dev, hipStream_t st);
 hipError_t launch_debug_keys_ranges(const uint2* ranges, const u32* point_list, const u32* depth_key, int T, u64* out, hipStream_t st);

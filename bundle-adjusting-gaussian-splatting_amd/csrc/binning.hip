@@ -85,7 +85,8 @@ __device__ __forceinline__ int prefix_block(int seq) { return (seq & 31) * 8 + (
 #define PFX_WORDS 32                                        // packed words (64 tiles) per workgroup
 #define PFX_GROUPS 32                                       // groups of 8 blocks: 1024 threads = 32 words x 32 groups
 __global__ void __launch_bounds__(1024)
-tile_prefix_kernel(const u32* __restrict__ cnt_rows, int B, int T, int T2, u32* __restrict__ pre, u32* __restrict__ tile_total)
+tile_prefix_kernel(const u32* __restrict__ cnt_rows, int B, int T, int T2, u32* __restrict__ pre, u32* __restrict__ tile_total,
+                   u32* __restrict__ tile_lstart, u32* __restrict__ group_total, u32* __restrict__ count_slot, u32* host_count)
 {
     __shared__ u32 gsum[PFX_GROUPS][PFX_WORDS][2];
     const int wl = threadIdx.x & (PFX_WORDS - 1), grp = threadIdx.x / PFX_WORDS;
@@ -120,6 +121,40 @@ tile_prefix_kernel(const u32* __restrict__ cnt_rows, int B, int T, int T2, u32* 
             if (t0 + 1 < T) tile_total[t0 + 1] = r1;
         }
     }
+    // Round 4: the tile ranges without a launch of their own.  The last group (threads 992..1023: lanes 32..63 of wave 15) holds
+    // the totals of this workgroup's 64 tiles: their exclusive prefix INSIDE the workgroup and the workgroup's sum go out here;
+    // whoever needs a range start adds the exclusive scan of the (at most 512) group sums (group_bases below) -- the emission
+    // workgroups do that for themselves, and the descriptor workgroup beside them delivers the instance count.
+    if (threadIdx.x >= 1024 - 64) {                          // wave 15, every lane (the scan needs them all)
+        const bool lastg = grp == PFX_GROUPS - 1;
+        const u32 c0 = lastg ? r0 : 0u, c1 = (lastg && t0 + 1 < T) ? r1 : 0u;   // (w >= T2: every count was read as zero)
+        const u32 v2 = c0 + c1;
+        const u32 incl = wave_incl_scan(v2);
+        const u32 ex = incl - v2;
+        if (lastg && w < T2) { tile_lstart[t0] = ex; if (t0 + 1 < T) tile_lstart[t0 + 1] = ex + c0; }
+        if ((threadIdx.x & 63) == 63) group_total[blockIdx.x] = incl;
+    }
+    // where the asynchronous instance count goes (device-visible address of the caller's pinned word, or null): parked in the
+    // caller's geometry buffer for the kernel that computes the count
+    if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<unsigned long long*>(count_slot) = (unsigned long long)(size_t)host_count;
+}
+
+// Exclusive scan of the group sums of tile_prefix_kernel into LDS: s_gb[g] = first instance of tile group g (64 tiles),
+// s_gb[512] = instance count.  G <= 512.  Every thread of the workgroup calls it (it ends on a barrier).
+__device__ __forceinline__ void group_bases(const u32* __restrict__ group_total, int G, u32* s_gb)
+{
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        u32 v[8], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int idx = lane * 8 + k; v[k] = idx < G ? group_total[idx] : 0u; sum += v[k]; }
+        const u32 incl = wave_incl_scan(sum);
+        u32 run = incl - sum;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int idx = lane * 8 + k; if (idx < G) s_gb[idx] = run; run += v[k]; }
+        if (lane == 63) s_gb[512] = incl;
+    }
+    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------ 3. ranges_order
@@ -233,7 +268,9 @@ ranges_order_kernel(const u32* __restrict__ tile_total, int T, uint2* __restrict
 template <int ORD_PER>
 __device__ __forceinline__ void build_tile_desc(const u32* __restrict__ tile_total, const uint2* __restrict__ ranges, int T,
                                                 uint4* __restrict__ tile_desc, u32* __restrict__ n_active, u32* tr_all,
-                                                u32* s_cur /*[ORD_LEVELS * ORD_SUB]*/, u32* s_wave /*[17]*/)
+                                                u32* s_cur /*[ORD_LEVELS * ORD_SUB]*/, u32* s_wave /*[17]*/,
+                                                const u32* __restrict__ lstart = nullptr, const u32* s_gb = nullptr,
+                                                uint2* __restrict__ ranges_out = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = (T + 1023) / 1024;
@@ -241,7 +278,8 @@ __device__ __forceinline__ void build_tile_desc(const u32* __restrict__ tile_tot
     u32* tr = tr_all + wave * (64 * ORD_PER + 2 * ORD_PER);
     u32 cntv[ORD_PER];
     (void)ord_load_counts<ORD_PER>(tile_total, T, per, tr, cntv);
-    const u32 first = (ta < T) ? ranges[ta].x : 0u;          // range start of the thread's first tile
+    // range start of the thread's first tile: from the ranges array (ranges_order ran) or group base + start inside the group
+    const u32 first = (ta < T) ? (ranges ? ranges[ta].x : s_gb[ta >> 6] + lstart[ta]) : 0u;
     s_cur[tid] = 0; s_cur[tid + 1024] = 0;
     __syncthreads();
     auto counter_of = [&](u32 n) -> int { return ord_level(n) * ORD_SUB + (tid & (ORD_SUB - 1)); };
@@ -276,6 +314,7 @@ __device__ __forceinline__ void build_tile_desc(const u32* __restrict__ tile_tot
                 asm volatile("" : "+v"(c));                 // recompute the level here: carried over from the counting pass it
                                                             // would be 32 more live registers
                 tile_desc[atomicAdd(&s_cur[counter_of(c)], 1u)] = make_uint4((u32)(ta + i), run, c, 0u);
+                if (ranges_out) ranges_out[ta + i] = make_uint2(run, run + c);
                 run += c;
             }
             if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
@@ -300,21 +339,34 @@ template <int ORD_PER>
 __global__ void __launch_bounds__(BIN_THREADS)
 emit_binned_kernel(int P, int per_block, int grid_x, int T, const uint2* __restrict__ rect,
                    const u32* __restrict__ tiles_touched, const u64* __restrict__ keep, const u32* __restrict__ pre,
-                   const uint2* __restrict__ ranges, const u32* __restrict__ depth_key, u64* __restrict__ words, u32 capacity,
-                   const u32* __restrict__ n_dev, const u32* __restrict__ tile_total, uint4* __restrict__ tile_desc,
-                   u32* __restrict__ n_active)
+                   uint2* __restrict__ ranges, const u32* __restrict__ tile_lstart, const u32* __restrict__ group_total,
+                   const u32* __restrict__ depth_key, u64* __restrict__ words, u32 capacity,
+                   const u32* __restrict__ tile_total, uint4* __restrict__ tile_desc, u32* __restrict__ n_active,
+                   u32* __restrict__ num_rendered, const u32* __restrict__ block_total, int B, u32* __restrict__ block_base)
 {
     static_assert(BIN_THREADS == 1024, "build_tile_desc is written for 1024 threads");
     extern __shared__ u32 cur[];                             // T slot cursors (the descriptor workgroup: its transposes)
+    __shared__ u32 s_gb[513];                                // first instance of every group of 64 tiles; [512] = instance count
+    group_bases(group_total, (T + 63) >> 6, s_gb);
     if (blockIdx.x == gridDim.x - 1) {
+        // the workgroup behind the last block of Gaussians: heavy-first descriptor list, the ranges array, the instance count
+        // (device word + the caller's pinned host word), block bases of the record slots
         __shared__ u32 s_cur[ORD_LEVELS * ORD_SUB];
         __shared__ u32 s_wave[17];
-        build_tile_desc<ORD_PER>(tile_total, ranges, T, tile_desc, n_active, cur, s_cur, s_wave);
+        if (threadIdx.x == 0) {
+            num_rendered[0] = s_gb[512];
+            u32* host_count = reinterpret_cast<u32*>((size_t)*reinterpret_cast<const unsigned long long*>(num_rendered + 2));
+            if (host_count) __hip_atomic_store(host_count, s_gb[512], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        build_tile_desc<ORD_PER>(tile_total, nullptr, T, tile_desc, n_active, cur, s_cur, s_wave, tile_lstart, s_gb, ranges);
+        const u32 v = ((int)threadIdx.x < B) ? block_total[threadIdx.x] : 0u;
+        const u32 ex = block_excl_scan_1024(v, s_wave);
+        if ((int)threadIdx.x < B) block_base[threadIdx.x] = ex;
         return;
     }
-    if (n_dev && *n_dev > capacity) return;
+    if (s_gb[512] > capacity) return;                        // the lists do not fit the buffer: nothing is written (the caller reruns)
     const u32* prow = pre + (size_t)blockIdx.x * T;
-    for (int t = threadIdx.x; t < T; t += BIN_THREADS) cur[t] = ranges[t].x + prow[t];
+    for (int t = threadIdx.x; t < T; t += BIN_THREADS) cur[t] = s_gb[t >> 6] + tile_lstart[t] + prow[t];
     __syncthreads();
     (void)walk_block<true>(cur, P, per_block, grid_x, rect, tiles_touched, keep, depth_key, words);
 }
@@ -719,11 +771,16 @@ bool binned_supported(int P, int T)
     return T <= 1024 * ORD_PER_MAX && ((T + 1) / 2) * 4 <= 65536 && binned_per_block(P) <= 65535;
 }
 
-hipError_t launch_binned_prepare(const GeomView& g, const ImgView& im, int P, int grid_x, int T, hipStream_t st, u32* host_count)
+hipError_t launch_binned_prepare(const GeomView& g, const ImgView& im, int P, int grid_x, int T, hipStream_t st, u32* host_count, bool count_now)
 {
     const int per = binned_per_block(P), B = cdiv(P, per), T2 = (T + 1) / 2;
     (void)grid_x;                                             // (the counts came with K1: launch_preprocess_fwd(count_into))
-    hipLaunchKernelGGL(tile_prefix_kernel, dim3(cdiv(T2, PFX_WORDS)), dim3(1024), 0, st, im.cnt_rows, B, T, T2, im.pre, im.tile_total);
+    hipLaunchKernelGGL(tile_prefix_kernel, dim3(cdiv(T2, PFX_WORDS)), dim3(1024), 0, st, im.cnt_rows, B, T, T2, im.pre, im.tile_total,
+                       im.tile_lstart, im.group_total, g.num_rendered + 2, count_now ? nullptr : host_count);
+    // count_now: the caller needs the instance count before the second phase is enqueued (bags_forward_prepare hands it to the
+    // host): tile ranges, count and block bases by ranges_order, one more launch.  Otherwise (speculative forward) the emission
+    // launch computes them itself and its descriptor workgroup writes the count into the caller's pinned word.
+    if (!count_now) return hipGetLastError();
     hipError_t e = launch_ranges_order(im, g, T, B, st, host_count);
     return e != hipSuccess ? e : hipGetLastError();
 }
@@ -747,8 +804,8 @@ hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int
 #define EM_LAUNCH(PER) { const size_t lds = (size_t)T * 4 > ord_tr_bytes(PER) ? (size_t)T * 4 : ord_tr_bytes(PER);              \
         e = big_lds(emit_binned_kernel<PER>, lds);                                                                                \
         if (e == hipSuccess) hipLaunchKernelGGL(emit_binned_kernel<PER>, dim3(B + 1), dim3(BIN_THREADS), lds, st, P, per, grid_x, T, g.rect, \
-                g.tiles_touched, g.keep, im.pre, im.ranges, g.depth_key, words, capacity, n_dev,   \
-                im.tile_total, im.tile_desc, im.n_active); }
+                g.tiles_touched, g.keep, im.pre, im.ranges, im.tile_lstart, im.group_total, g.depth_key, words, capacity,   \
+                im.tile_total, im.tile_desc, im.n_active, g.num_rendered, g.block_total, B, g.block_base); }
     switch (ord_per_for(T)) { case 8: EM_LAUNCH(8) break; case 16: EM_LAUNCH(16) break; default: EM_LAUNCH(32) }
 #undef EM_LAUNCH
     if (e != hipSuccess) return e;
