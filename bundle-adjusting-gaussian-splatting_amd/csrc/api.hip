@@ -283,12 +283,12 @@ static int enqueue_finish(const BagsSettings* s, const BagsInputs* in, const Geo
         if (in->P == 0) HIP_TRY(launch_binned_empty(g, im, gx * gy, st));      // no prepare phase ran: an all-empty tile list
         if (I > 0 && in->P > 0) {
             ProfScope ps(ST_TILE_SORT, st);
-            HIP_TRY(launch_binned_finish(g, im, in->P, gx, gx * gy, b.words, b.scratch, b.point_list, (u32)I, n_dev, st));
+            HIP_TRY(launch_binned_finish(g, im, in->P, gx, gx * gy, b.words, b.scratch, b.point_list, (u32)I, n_dev, st, !blend_fwd_sorts()));
         } else if (in->P > 0) {
             HIP_TRY(launch_binned_desc_only(im, gx * gy, st));                   // nothing to emit: only the (all-empty) tile list
         }
         DEBUG_SYNC(s, st, "emit / tile sort");
-        { ProfScope ps(ST_BLEND_FWD, st); HIP_TRY(launch_blend_fwd(*s, g, b, im, *out, st, n_dev, (u32)I)); }
+        { ProfScope ps(ST_BLEND_FWD, st); HIP_TRY(launch_blend_fwd(*s, g, b, im, *out, st, n_dev, (u32)I, I > 0 && in->P > 0)); }
         DEBUG_SYNC(s, st, "blend_fwd");
         return scan_forward(s, in, g, out, st);
     }

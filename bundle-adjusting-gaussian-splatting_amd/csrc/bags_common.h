@@ -119,9 +119,11 @@ struct BinView {
     u32*    tile_sorted;     // keys after the last pass (radix path only)
     u64*    words;           // tile-binned path: (depth key << 32 | Gaussian id) per instance, grouped by tile, unsorted inside a tile
     u64*    scratch;         // tile-binned path: scratch of the two-level / global-memory sorts (lists of > 4096 entries only)
-    // [I] 16-bit reach mask of the 4x4-pixel blocks per sorted instance: written by blend_fwd when it stages the instance,
-    // read back by blend_bwd instead of evaluating block_mask16 again.  Lives in memory that is dead once the lists are
-    // sorted (`words` / the radix path's spare key buffer).
+    // 16-bit reach mask of the 4x4-pixel blocks per sorted instance: written by blend_fwd when it stages the instance, read
+    // back by blend_bwd instead of evaluating block_mask16 again.  Lives in memory that is dead once the lists are sorted: the
+    // radix path's spare key buffer (u16 per instance), or -- tile-binned path -- the tile's OWN slice of `words` (instance j of
+    // a tile that starts at instance s: byte 8 s + 2 j; blend_fwd sorts its tile's list itself, so other tiles' words may
+    // still be unsorted when it writes).
     unsigned short* reach_mask;
 };
 struct ImgView {
@@ -161,7 +163,8 @@ hipError_t launch_tile_ranges(const u32* tile_sorted, long long I, uint2* ranges
                               const u32* n_dev, bool cleared);
 hipError_t launch_tile_order(const uint2* ranges, int T, uint4* tile_desc, u32* n_active, hipStream_t st);
 hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
-                            const BagsForwardOut& out, hipStream_t st, const u32* n_dev = nullptr, u32 capacity = 0);
+                            const BagsForwardOut& out, hipStream_t st, const u32* n_dev = nullptr, u32 capacity = 0, bool sort_here = false);
+bool blend_fwd_sorts();      // the build's blend_fwd sorts the tile lists of the tile-binned path itself (no tile_sort launch)
 // binned: the record base of a Gaussian is block_base[line.q3.y] + line.q3.z (K1 wrote both into the geometry line); otherwise
 // (radix path) it is gathered from g.inst_off
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
@@ -210,7 +213,7 @@ hipError_t launch_binned_desc_only(const ImgView& im, int T, hipStream_t st);
 hipError_t launch_binned_prepare(const GeomView& g, const ImgView& im, int P, int grid_x, int T, hipStream_t st, u32* host_count = nullptr,
                                  bool count_now = true);
 hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int grid_x, int T, u64* words, u64* scratch, u32* point_list,
-                                u32 capacity, const u32* n_dev, hipStream_t st);
+                                u32 capacity, const u32* n_dev, hipStream_t st, bool sort_lists = true);
 hipError_t launch_debug_keys_ranges(const uint2* ranges, const u32* point_list, const u32* depth_key, int T, u64* out, hipStream_t st);
 hipError_t launch_debug_keys(const u32* tile_sorted, const u32* point_list, const u32* depth_key, long long I, u64* out, hipStream_t st);
 hipError_t launch_unpack_rect(const uint2* rect, int P, u32* out, hipStream_t st);

@@ -16,6 +16,7 @@
 // PMC history that led here is in profiles/r01 and DESIGN.md section 5 (the first lane = pixel kernels saturated VALU
 // issue at 96 % with a third of the lanes contributing; they are in the git history).
 #include "bags_common.h"
+#include "tile_sort.h"
 #include <type_traits>
 
 #define LOG2E 1.4426950408889634f
@@ -55,7 +56,7 @@
 #define PQ (TF_FOLD ? 3 : 4)                 // float4s per pixel pair in LDS
 // round-4 knobs
 #ifndef BAL_WRITE
-#define BAL_WRITE 1         // the record sums of a chunk (four wave copies -> one 48-B record) spread over all 256 threads, one float4
+#define BAL_WRITE 0         // (measured twice on one device: 0.3509 = 0.3509 and 0.3459 -> 0.3420 ms without it; kept as a knob) the record sums of a chunk (four wave copies -> one 48-B record) spread over all 256 threads, one float4
 #endif                      // each: conflict-free LDS reads, three lanes per record on the way out (was: thread = record, 176 of 256 busy)
 #ifndef P_SKIP
 #define P_SKIP 1            // tiles whose staged splats are all well conditioned (flag from the forward) skip the `power <= 0` test: it cannot fail there
@@ -273,7 +274,7 @@ struct TileRef { int tx, ty; u32 rx, n, maxc; bool early, needle; };   // early:
 template <bool ABS>
 __global__ void __launch_bounds__(256, SCAN_WG_PER_CU)
 blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__ tile_desc,
-                      const u32* __restrict__ point_list, const unsigned short* __restrict__ reach_mask,
+                      const u32* __restrict__ point_list, const unsigned char* __restrict__ reach_mask, const u32 rm_stride,
                       const float4* __restrict__ g2d, const u32* __restrict__ inst_off, const u32* __restrict__ block_base,
                       const float* __restrict__ bg, const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
                       const float* __restrict__ grad_color, float* __restrict__ partials)
@@ -322,7 +323,9 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         const u32 c_ = min(hi_, (u32)BCHUNK);
         if ((u32)tid >= c_) return make_uint2(0xFFFFFFFFu, 0u);
         const u32 at = rx_ + (hi_ - c_) + tid;
-        return make_uint2(point_list[at], (u32)reach_mask[at]);
+        // the reach masks of a tile sit at byte rm_stride * (tile's first instance): inside the tile's own slice of the (dead)
+        // unsorted words on the tile-binned path (stride 8), plainly per instance on the radix path (stride 2)
+        return make_uint2(point_list[at], (u32)reinterpret_cast<const unsigned short*>(reach_mask + (size_t)rx_ * rm_stride)[at - rx_]);
     };
     auto fetch = [&](u32 g) {
         Raw r; r.q0 = make_float4(0.f, 0.f, 0.f, 0.f); r.q1 = r.q0; r.q2 = r.q0; r.io = 0u; r.blk = 0u; r.kp = 0ull;
@@ -794,11 +797,11 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     const int grid = cdiv(T, TILE_RUN) * TILE_RUN;
     if (want_abs)
         hipLaunchKernelGGL(blend_bwd_scan_kernel<true>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
-                           im.tile_desc, b.point_list, b.reach_mask, g.g2d, binned ? nullptr : g.inst_off, g.block_base, s.bg,
+                           im.tile_desc, b.point_list, reinterpret_cast<const unsigned char*>(b.reach_mask), binned ? 8u : 2u, g.g2d, binned ? nullptr : g.inst_off, g.block_base, s.bg,
                            im.final_T, im.n_contrib, grad_color, partials);
     else
         hipLaunchKernelGGL(blend_bwd_scan_kernel<false>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
-                           im.tile_desc, b.point_list, b.reach_mask, g.g2d, binned ? nullptr : g.inst_off, g.block_base, s.bg,
+                           im.tile_desc, b.point_list, reinterpret_cast<const unsigned char*>(b.reach_mask), binned ? 8u : 2u, g.g2d, binned ? nullptr : g.inst_off, g.block_base, s.bg,
                            im.final_T, im.n_contrib, grad_color, partials);
     return hipGetLastError();
 }
@@ -837,10 +840,14 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
 #define FWD_PIPE 1            // record reads issued one step ahead of their use (two register sets)
 #endif
 #define FWD_STAGE (FWD_SENTINEL ? CHUNK - 1 : CHUNK)          // splats staged per chunk
+#ifndef FWD_SORT
+#define FWD_SORT 1            // tile-binned path: the tile's workgroup sorts its own (depth key, id) words before it stages them (no
+#endif                        // tile_sort launch: its chains of LDS round trips hide behind the issue-bound walks of the CU's other tiles)
 template <int DUMMY>
 __global__ void __launch_bounds__(256, FWD_WG_PER_CU)
-blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_desc, const u32* __restrict__ point_list,
-                      unsigned short* __restrict__ reach_mask, const float4* __restrict__ g2d, const float* __restrict__ bg, float* __restrict__ out_color,
+blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_desc, u32* __restrict__ point_list,
+                      const u64* __restrict__ words_in, u64* __restrict__ sort_scratch,
+                      unsigned char* __restrict__ reach_mask, const u32 rm_stride, const float4* __restrict__ g2d, const float* __restrict__ bg, float* __restrict__ out_color,
                       float* __restrict__ out_depth, float* __restrict__ out_weights, float* __restrict__ final_T,
                       u32* __restrict__ n_contrib, const u32* __restrict__ n_dev, u32 capacity)
 {
@@ -857,12 +864,41 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
     const uint2 range = make_uint2(desc.y, desc.y + desc.z);
     const u32 n = desc.z;
 
-    __shared__ SplatRec recs[CHUNK];                 // x y ap cp | bp o r g | b z pos mask
     typedef unsigned char list_t;
 #define LIST_ENTRY(slot) ((list_t)(slot))
-    __shared__ __attribute__((aligned(16))) list_t lists[16 * CHUNK + 16];   // [16][CHUNK] + padding for the walk's read-ahead
-    __shared__ u32 masks[CHUNK];
+    // One raw LDS block, used twice: first by the sort of the tile's list (u64 t_all[2048] | u32 cnt_all[1024] | small state:
+    // tile_sort.h), then by the blend (recs x y ap cp | bp o r g | b z pos mask, [16][CHUNK] list bytes + 16 bytes of padding for
+    // the walk's read-ahead, compact masks).  20.6 KB: six workgroups per CU as before.
+    constexpr int LDS_RECS = 0, LDS_LISTS = CHUNK * (int)sizeof(SplatRec), LDS_MASKS = LDS_LISTS + 16 * CHUNK * (int)sizeof(list_t) + 16;
+    constexpr int LDS_BLEND = LDS_MASKS + CHUNK * 4;
+    constexpr int LDS_TS_CNT = TS_LDS_WORDS * 8, LDS_TS_L = LDS_TS_CNT + TS_LDS_WORDS * 2, LDS_SORT = LDS_TS_L + (int)sizeof(TileSortLds);
+    constexpr int LDS_BYTES = FWD_SORT ? (LDS_SORT > LDS_BLEND ? LDS_SORT : LDS_BLEND) : LDS_BLEND;
+    static_assert(LDS_MASKS % 16 == 0 && LDS_TS_L % 8 == 0, "alignment of the carved arrays");
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    SplatRec* const recs = reinterpret_cast<SplatRec*>(lds_raw + LDS_RECS);
+    list_t* const lists = reinterpret_cast<list_t*>(lds_raw + LDS_LISTS);
+    u32* const masks = reinterpret_cast<u32*>(lds_raw + LDS_MASKS);
     __shared__ int s_live[4];
+#if FWD_SORT
+    if (words_in != nullptr && n > 0) {
+        // ---- the tile's list: (depth key, id) words grouped by the emission, unsorted -> ids in depth order in point_list
+        u64* const t_all = reinterpret_cast<u64*>(lds_raw);
+        u32* const cnt_all = reinterpret_cast<u32*>(lds_raw + LDS_TS_CNT);
+#ifndef FWD_SORT_BLOCK
+#define FWD_SORT_BLOCK 0      // short lists by the whole workgroup (block sort: four waves, barriers) instead of by wave 0 alone
+#endif
+        TileSortLds& TL = *reinterpret_cast<TileSortLds*>(lds_raw + LDS_TS_L);
+        if (n == 1) { if (tid == 0) point_list[desc.y] = (u32)words_in[desc.y]; }
+        else if (FWD_SORT_BLOCK && n <= 256) sort_one_block<1>(n, desc.y, words_in, point_list, t_all, cnt_all, TL.s_red);
+        else if (FWD_SORT_BLOCK && n <= 512) sort_one_block<2>(n, desc.y, words_in, point_list, t_all, cnt_all, TL.s_red);
+        else if (n <= TSORT_WAVE) { if (wave == 0) sort_wave_role(desc, words_in, point_list, t_all, cnt_all); }
+        else sort_list_block(desc, words_in, sort_scratch, point_list, t_all, cnt_all, *reinterpret_cast<TileSortLds*>(lds_raw + LDS_TS_L));
+        // the ids were stored by this workgroup and are loaded by it below (at agent scope: a line of the neighbouring tile's
+        // slice may sit in this CU's L1 with our first ids still unsorted in it)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#endif
 
     const int bx = (wave & 1) * 2 + (row & 1), by = (wave >> 1) * 2 + (row >> 1), blk = by * 4 + bx;
     const int px = tile_x * BAGS_TILE + bx * 4 + (li & 3), py = tile_y * BAGS_TILE + by * 4 + (li >> 2);
@@ -891,7 +927,8 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
         SplatRec rec; rec.mask = 0; rec.x = rec.y = rec.ap = rec.bp = rec.cp = rec.o = rec.r = rec.g = rec.b = rec.z = 0.f; rec.pos = 0;
         bool ill = false;
         if ((u32)tid < cnt) {
-            const u32 g = point_list[range.x + base + tid];
+            const u32 g = (FWD_SORT && words_in) ? __hip_atomic_load(&point_list[range.x + base + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                 : point_list[range.x + base + tid];
             const float4* grec = g2d + 4 * (size_t)g;             // one 64-byte line per instance
             const float4 co = grec[0], g1 = grec[1], g2v = grec[2];
             const float2 c2 = make_float2(g1.x, g1.y);
@@ -901,7 +938,9 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
             rec.r = cz.x; rec.g = cz.y; rec.b = cz.z; rec.z = cz.w;
             rec.pos = base + tid + 1;
             rec.mask = block_mask16(c2.x, c2.y, co.x, co.y, co.z, co.w, X0, Y0);
-            reach_mask[range.x + base + tid] = (unsigned short)rec.mask;      // the backward stages the same instance: it reads this
+            // the backward stages the same instance: it reads this (tile-binned path: inside the tile's own slice of the words,
+            // which this workgroup has just finished with)
+            reinterpret_cast<unsigned short*>(reach_mask + (size_t)range.x * rm_stride)[base + tid] = (unsigned short)rec.mask;
             ill = conic_ill_conditioned(co.x, co.y, co.z);
         }
         needle |= (__ballot(ill) != 0ull);                   // (a scalar register, not a lane's)
@@ -1094,14 +1133,17 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
 }
 
 hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
-                            const BagsForwardOut& out, hipStream_t st, const u32* n_dev, u32 capacity)
+                            const BagsForwardOut& out, hipStream_t st, const u32* n_dev, u32 capacity, bool sort_here)
 {
     const int gx = cdiv(s.image_width, BAGS_TILE), gy = cdiv(s.image_height, BAGS_TILE);
     const int T = gx * gy;
     if (T == 0) return hipSuccess;
     const int grid = cdiv(T, TILE_RUN) * TILE_RUN;
     hipLaunchKernelGGL(blend_fwd_rows_kernel<0>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
-                       im.tile_desc, b.point_list, b.reach_mask, g.g2d, s.bg, out.color, out.depth, out.weights,
+                       im.tile_desc, b.point_list, (FWD_SORT && sort_here) ? b.words : nullptr, b.scratch,
+                       reinterpret_cast<unsigned char*>(b.reach_mask), b.words ? 8u : 2u, g.g2d, s.bg, out.color, out.depth, out.weights,
                        im.final_T, im.n_contrib, n_dev, capacity);
     return hipGetLastError();
 }
+
+bool blend_fwd_sorts() { return FWD_SORT != 0; }
