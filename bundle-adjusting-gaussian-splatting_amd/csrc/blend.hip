@@ -454,7 +454,9 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     u32 dg_eval = 0, dg_con = 0, dg_ent = 0, dg_ent0 = 0, dg_steps = 0, dg_chunks = 0;
 #endif
 
+#if BAL_WRITE
     u32 par = 0;                                             // chunk parity (rec_e buffer)
+#endif
     for (u32 hi = A.maxc;;) {
         const u32 cnt = min(hi, (u32)BCHUNK);
         const u32 lo = hi - cnt;
