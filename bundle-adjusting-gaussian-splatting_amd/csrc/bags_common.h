@@ -168,10 +168,13 @@ bool blend_fwd_sorts();      // the build's blend_fwd sorts the tile lists of th
 // binned: the record base of a Gaussian is block_base[line.q3.y] + line.q3.z (K1 wrote both into the geometry line); otherwise
 // (radix path) it is gathered from g.inst_off
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
-                            const float* grad_color, float* partials, bool want_abs, bool binned, hipStream_t st);
+                            const float* grad_color, float* partials, bool want_abs, bool binned, hipStream_t st,
+                            u32* zero_words = nullptr, int n_zero = 0);   // words the launch clears for the kernel behind it (pose tickets)
 hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, const int32_t* radii_or_null,
                                  const float* partials, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a, hipStream_t st, float* sums,
-                                 bool binned);
+                                 bool binned, u32* fold_tickets, unsigned long long* fold_rows);
+int pose_group_size(int nblocks);            // preprocess workgroups per group of the folded pose reduction
+bool pose_fold_enabled();                    // the build's preprocess_bwd sums the pose slab itself (no pose_reduce launch)
 hipError_t launch_pose_reduce(const float* pose_slab, int nblocks, const BagsBackwardArgs& a, hipStream_t st);
 // loss.hip: fused L1 + SSIM terms and their image gradient
 size_t loss_workspace_bytes(int C, int H, int W);

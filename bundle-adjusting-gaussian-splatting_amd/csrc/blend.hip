@@ -277,7 +277,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                       const u32* __restrict__ point_list, const unsigned char* __restrict__ reach_mask, const u32 rm_stride,
                       const float4* __restrict__ g2d, const u32* __restrict__ inst_off, const u32* __restrict__ block_base,
                       const float* __restrict__ bg, const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
-                      const float* __restrict__ grad_color, float* __restrict__ partials)
+                      const float* __restrict__ grad_color, float* __restrict__ partials, u32* __restrict__ zero_words, const int n_zero)
 {
     // One workgroup per tile that holds at least one instance, heavy tiles first (slot_of_vblock).  Tried and dropped:
     // persistent workgroups that run the chunk pipeline over the flattened (tile, chunk) sequence, with the next tile's
@@ -286,6 +286,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     // the wave timeline: the hardware dispatcher refills a CU as soon as any workgroup leaves, while a persistent
     // workgroup keeps its four waves coupled at two barriers per chunk for the whole launch.
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (blockIdx.x == 0) for (int i = tid; i < n_zero; i += 256) zero_words[i] = 0u;   // tickets of preprocess_bwd's folded pose reduction
     const int dslot = slot_of_vblock((int)blockIdx.x);
     if (dslot >= T) return;
     const uint4 desc = tile_desc[dslot];                     // {tile, first instance, instances, deepest contributor}
@@ -791,7 +792,7 @@ extern "C" void bags_diag_phases(unsigned long long* out) { hipMemcpyFromSymbol(
 #endif
 
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
-                            const float* grad_color, float* partials, bool want_abs, bool binned, hipStream_t st)
+                            const float* grad_color, float* partials, bool want_abs, bool binned, hipStream_t st, u32* zero_words, int n_zero)
 {
     const int gx = cdiv(s.image_width, BAGS_TILE), gy = cdiv(s.image_height, BAGS_TILE);
     const int T = gx * gy;
@@ -800,11 +801,11 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     if (want_abs)
         hipLaunchKernelGGL(blend_bwd_scan_kernel<true>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
                            im.tile_desc, b.point_list, reinterpret_cast<const unsigned char*>(b.reach_mask), binned ? 8u : 2u, g.g2d, binned ? nullptr : g.inst_off, g.block_base, s.bg,
-                           im.final_T, im.n_contrib, grad_color, partials);
+                           im.final_T, im.n_contrib, grad_color, partials, zero_words, n_zero);
     else
         hipLaunchKernelGGL(blend_bwd_scan_kernel<false>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
                            im.tile_desc, b.point_list, reinterpret_cast<const unsigned char*>(b.reach_mask), binned ? 8u : 2u, g.g2d, binned ? nullptr : g.inst_off, g.block_base, s.bg,
-                           im.final_T, im.n_contrib, grad_color, partials);
+                           im.final_T, im.n_contrib, grad_color, partials, zero_words, n_zero);
     return hipGetLastError();
 }
 

@@ -113,9 +113,42 @@ sum_partials_kernel(int P, const u32* __restrict__ tiles_touched, const u32* __r
 #ifndef SH_STAGE
 #define SH_STAGE 1
 #endif
+#ifndef POSE_FOLD
+#define POSE_FOLD 0          // 1: the last workgroups to finish sum the pose slab themselves (no pose_reduce launch).  Correct, deterministic,
+                             // and no faster: every workgroup pays a write-through store + a memory-side ticket at its end (preprocess_bwd
+                             // 60.4 -> 69.4 us for the 8.8 us launch it removes; profiles/r04/ab_pose_fold.txt)
+#endif
 #ifndef PRE_BWD_WAVES
 #define PRE_BWD_WAVES (PB_FUSED ? 4 : 1)   // fused: 128 VGPRs (12 spilled) and 4 workgroups per CU: 68.4 us; left free (146, 3 per CU) 76.1;
 #endif                                     // 5 per CU 105.  Separate sum_partials (23.1) + preprocess_bwd (53.1): 76.2
+
+// Slab column t (summed over all Gaussians) -> its place in the five pose tensors.
+// slab layout: [0..11] viewmatrix rows 0..3 x cols 0..2, [12..23] projmatrix rows 0..3 x cols 0,1,3,
+//              [24] k0 [25] k5 [26] k8 [27] k9 [28] k11, [29..31] campos, [32..34] shift_factors.
+// The entries of the 4x4 outputs no Gaussian contributes to are written as zeros by the column next to them.
+__device__ __forceinline__ void pose_write_out(const int t, const float val, float* __restrict__ g_view, float* __restrict__ g_proj,
+                                               float* __restrict__ g_intr, float* __restrict__ g_campos, float* __restrict__ g_shift)
+{
+    if (t < 12) {
+        if (g_view) { g_view[(t / 3) * 4 + t % 3] = val; if (t % 3 == 2) g_view[(t / 3) * 4 + 3] = 0.f; }
+    } else if (t < 24) {
+        const int u = t - 12, r = u / 3, k = u % 3;
+        if (g_proj) { g_proj[r * 4 + (k == 2 ? 3 : k)] = val; if (k == 2) g_proj[r * 4 + 2] = 0.f; }
+    } else if (t < 29) {
+        const int at[5] = {0, 5, 8, 9, 11};
+        if (g_intr) {
+            g_intr[at[t - 24]] = val;
+            if (t == 24) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) if (i != 0 && i != 5 && i != 8 && i != 9 && i != 11) g_intr[i] = 0.f;
+            }
+        }
+    } else if (t < 32) {
+        if (g_campos) g_campos[t - 29] = val;
+    } else if (t < 35) {
+        if (g_shift) g_shift[t - 32] = val;
+    }
+}
 
 template <bool COV3D>        // the Gaussians carry precomputed 3D covariances instead of scales + rotations (uniform: no branch at the top)
 __global__ void __launch_bounds__(256, PRE_BWD_WAVES)
@@ -132,7 +165,10 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                       const float* __restrict__ partials, float* __restrict__ pose_slab,
                       float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_densify,
                       float* __restrict__ g_shs, float* __restrict__ g_colors, float* __restrict__ g_opac,
-                      float* __restrict__ g_scales, float* __restrict__ g_rot, float* __restrict__ g_cov3D)
+                      float* __restrict__ g_scales, float* __restrict__ g_rot, float* __restrict__ g_cov3D,
+                      u32* __restrict__ tickets, unsigned long long* __restrict__ group_rows, int group_size, int nblocks,
+                      float* __restrict__ g_view, float* __restrict__ g_proj, float* __restrict__ g_intr,
+                      float* __restrict__ g_campos, float* __restrict__ g_shift)
 {
     // A wave's life in this kernel is a handful of memory round trips, not arithmetic (55 % of the wave cycles were spent
     // waiting): round 2 had SEVEN of them in series at the top -- three for the camera constants (vector loads -> LDS ->
@@ -525,8 +561,66 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         const int t = threadIdx.x;
         float r = (t < 35) ? (wpose[0][t] + wpose[1][t]) + (wpose[2][t] + wpose[3][t]) : 0.f;
         if (t < 9) r += (wpose[0][35 + t] + wpose[1][35 + t]) + (wpose[2][35 + t] + wpose[3][35 + t]);
+#if POSE_FOLD
+        // agent-scope store: written through to where every XCD sees it (the row is read by a workgroup of another CU)
+        __hip_atomic_store(&pose_slab[(size_t)blockIdx.x * POSE_VALS + t], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
         pose_slab[(size_t)blockIdx.x * POSE_VALS + t] = r;
+#endif
     }
+#if POSE_FOLD
+    // ---- 6. slab rows -> the five pose tensors without another launch (pose_reduce_kernel was 6-8 us of launch floor behind this
+    // kernel).  Two levels of "the last one to arrive does the sum": workgroup b belongs to group b / group_size; whoever draws
+    // the group's last ticket adds the group's rows IN ROW ORDER (fp64) into one group row and draws a ticket of the top
+    // counter; the last of those adds the group rows in group order and writes the outputs.  Who does a sum varies from run to
+    // run, what is summed in which order does not: deterministic.  Rows and tickets cross CUs and XCDs: rows are stored and
+    // loaded with agent-scope atomics (write-through / cache-bypassing), a row's stores are complete (s_waitcnt vmcnt(0), same
+    // wave) before its ticket is drawn, and a reader only looks after it has seen the last ticket -- no L2 write-back fence
+    // (buffer_wbl2) in a kernel that streams 130 MB of gradients through the L2.  The tickets were zeroed by blend_bwd.
+    __shared__ u32 s_role;
+    __shared__ double s_part[6][POSE_VALS];
+    const u32 grp = blockIdx.x / (u32)group_size;
+    const u32 gsz = min((u32)group_size, (u32)nblocks - grp * (u32)group_size);
+    const u32 ngroups = ((u32)nblocks + (u32)group_size - 1) / (u32)group_size;
+    if (threadIdx.x < 64) {                                  // wave 0 stored the row
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0)
+            s_role = (__hip_atomic_fetch_add(&tickets[1 + grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gsz) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_role == 0u) return;
+    const int pc = threadIdx.x % POSE_VALS, ps = threadIdx.x / POSE_VALS;     // column, row slice (6 slices; threads 240.. idle)
+    if (ps < 6) {
+        double acc = 0.0;
+        const float* rows = pose_slab + (size_t)grp * group_size * POSE_VALS + pc;
+        for (u32 r = (u32)ps; r < gsz; r += 6u) acc += (double)__hip_atomic_load(rows + (size_t)r * POSE_VALS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_part[ps][pc] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < POSE_VALS) {
+        const double tot = ((((s_part[0][pc] + s_part[1][pc]) + s_part[2][pc]) + s_part[3][pc]) + s_part[4][pc]) + s_part[5][pc];
+        __hip_atomic_store(&group_rows[(size_t)grp * POSE_VALS + pc], (unsigned long long)__double_as_longlong(tot), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x < 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0)
+            s_role = (__hip_atomic_fetch_add(&tickets[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == ngroups) ? 2u : 0u;
+    }
+    __syncthreads();                                         // (also: s_part is free again)
+    if (s_role != 2u) return;
+    if (ps < 6) {
+        double acc = 0.0;
+        for (u32 r = (u32)ps; r < ngroups; r += 6u)
+            acc += __longlong_as_double((long long)__hip_atomic_load(&group_rows[(size_t)r * POSE_VALS + pc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        s_part[ps][pc] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 35) {
+        const double tot = ((((s_part[0][pc] + s_part[1][pc]) + s_part[2][pc]) + s_part[3][pc]) + s_part[4][pc]) + s_part[5][pc];
+        pose_write_out(pc, (float)tot, g_view, g_proj, g_intr, g_campos, g_shift);
+    }
+#endif
 }
 
 // rows -> the five pose tensors, summed in fp64.  One workgroup per slab column (35 used): thread t adds rows t, t + 256, ...
@@ -555,33 +649,12 @@ pose_reduce_kernel(const float* __restrict__ slab, int nblocks, float* __restric
     __syncthreads();
     if (threadIdx.x != 0) return;
     const float val = (float)(((wsum[0] + wsum[1]) + wsum[2]) + wsum[3]);
-    // slab layout: [0..11] viewmatrix rows 0..3 x cols 0..2, [12..23] projmatrix rows 0..3 x cols 0,1,3,
-    //              [24] k0 [25] k5 [26] k8 [27] k9 [28] k11, [29..31] campos, [32..34] shift_factors.
-    // The entries of the 4x4 outputs no Gaussian contributes to are written as zeros by the column next to them.
-    if (t < 12) {
-        if (g_view) { g_view[(t / 3) * 4 + t % 3] = val; if (t % 3 == 2) g_view[(t / 3) * 4 + 3] = 0.f; }
-    } else if (t < 24) {
-        const int u = t - 12, r = u / 3, k = u % 3;
-        if (g_proj) { g_proj[r * 4 + (k == 2 ? 3 : k)] = val; if (k == 2) g_proj[r * 4 + 2] = 0.f; }
-    } else if (t < 29) {
-        const int at[5] = {0, 5, 8, 9, 11};
-        if (g_intr) {
-            g_intr[at[t - 24]] = val;
-            if (t == 24) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) if (i != 0 && i != 5 && i != 8 && i != 9 && i != 11) g_intr[i] = 0.f;
-            }
-        }
-    } else if (t < 32) {
-        if (g_campos) g_campos[t - 29] = val;
-    } else if (t < 35) {
-        if (g_shift) g_shift[t - 32] = val;
-    }
+    pose_write_out(t, val, g_view, g_proj, g_intr, g_campos, g_shift);
 }
 
 hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, const int32_t*,
                                  const float* partials_records, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a,
-                                 hipStream_t st, float* sums, bool binned)
+                                 hipStream_t st, float* sums, bool binned, u32* fold_tickets, unsigned long long* fold_rows)
 {
     const int P = in.P;
     const int nb = cdiv(P, 256);
@@ -602,7 +675,9 @@ hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, co
                        s.intrinsic, s.campos, in.opacities, g.tiles_touched, binned ? nullptr : g.inst_off, g.local_off, g.block_base, \
                        binned_per_block(P), g.shjac, partials, \
                        pose_slab, a.grad_means3D, a.grad_means2D, a.grad_means2D_densify, a.grad_shs, \
-                       a.grad_colors_precomp, a.grad_opacities, a.grad_scales, a.grad_rotations, a.grad_cov3D_precomp);
+                       a.grad_colors_precomp, a.grad_opacities, a.grad_scales, a.grad_rotations, a.grad_cov3D_precomp, \
+                       fold_tickets, fold_rows, pose_group_size(nb), nb, a.grad_viewmatrix, a.grad_projmatrix, a.grad_intrinsic, \
+                       a.grad_campos, a.grad_shift_factors);
     if (in.cov3D_precomp) { PRE_BWD_LAUNCH(true) } else { PRE_BWD_LAUNCH(false) }
 #undef PRE_BWD_LAUNCH
     return hipGetLastError();
@@ -614,3 +689,7 @@ hipError_t launch_pose_reduce(const float* pose_slab, int nblocks, const BagsBac
                        a.grad_projmatrix, a.grad_intrinsic, a.grad_campos, a.grad_shift_factors);
     return hipGetLastError();
 }
+
+// pose slab rows summed per group by the last workgroup of the group (POSE_FOLD)
+int pose_group_size(int nblocks) { return nblocks <= 4096 ? 32 : 128; }
+bool pose_fold_enabled() { return POSE_FOLD != 0; }
