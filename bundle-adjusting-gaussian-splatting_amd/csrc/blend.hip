@@ -875,13 +875,18 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
     constexpr int LDS_RECS = 0, LDS_LISTS = CHUNK * (int)sizeof(SplatRec), LDS_MASKS = LDS_LISTS + 16 * CHUNK * (int)sizeof(list_t) + 16;
     constexpr int LDS_BLEND = LDS_MASKS + CHUNK * 4;
     constexpr int LDS_TS_CNT = TS_LDS_WORDS * 8, LDS_TS_L = LDS_TS_CNT + TS_LDS_WORDS * 2, LDS_SORT = LDS_TS_L + (int)sizeof(TileSortLds);
-    constexpr int LDS_BYTES = FWD_SORT ? (LDS_SORT > LDS_BLEND ? LDS_SORT : LDS_BLEND) : LDS_BLEND;
-    static_assert(LDS_MASKS % 16 == 0 && LDS_TS_L % 8 == 0, "alignment of the carved arrays");
+#ifndef FWD_SORT_MIRROR
+#define FWD_SORT_MIRROR 0     // (1: measured 0.5 us, nothing; 2 KB of LDS) lists of up to TSORT_WAVE entries: the sorted ids also stay in LDS (2 KB behind everything else), so the
+#endif                        // staging below neither waits for the stores to point_list nor loads them back from the L2
+    constexpr int LDS_IDS = (LDS_SORT > LDS_BLEND ? LDS_SORT : LDS_BLEND);                 // u32 ids[TSORT_WAVE]
+    constexpr int LDS_BYTES = FWD_SORT ? LDS_IDS + (FWD_SORT_MIRROR ? TSORT_WAVE * 4 : 0) : LDS_BLEND;
+    static_assert(LDS_MASKS % 16 == 0 && LDS_TS_L % 8 == 0 && LDS_IDS % 4 == 0, "alignment of the carved arrays");
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
     SplatRec* const recs = reinterpret_cast<SplatRec*>(lds_raw + LDS_RECS);
     list_t* const lists = reinterpret_cast<list_t*>(lds_raw + LDS_LISTS);
     u32* const masks = reinterpret_cast<u32*>(lds_raw + LDS_MASKS);
     __shared__ int s_live[4];
+    const u32* ids_lds = nullptr;                            // sorted ids of the whole list in LDS (short lists sorted here)
 #if FWD_SORT
     if (words_in != nullptr && n > 0) {
         // ---- the tile's list: (depth key, id) words grouped by the emission, unsorted -> ids in depth order in point_list
@@ -894,11 +899,15 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
         if (n == 1) { if (tid == 0) point_list[desc.y] = (u32)words_in[desc.y]; }
         else if (FWD_SORT_BLOCK && n <= 256) sort_one_block<1>(n, desc.y, words_in, point_list, t_all, cnt_all, TL.s_red);
         else if (FWD_SORT_BLOCK && n <= 512) sort_one_block<2>(n, desc.y, words_in, point_list, t_all, cnt_all, TL.s_red);
-        else if (n <= TSORT_WAVE) { if (wave == 0) sort_wave_role(desc, words_in, point_list, t_all, cnt_all); }
+        else if (n <= TSORT_WAVE) {
+            u32* const mirror = FWD_SORT_MIRROR ? reinterpret_cast<u32*>(lds_raw + LDS_IDS) : nullptr;
+            if (wave == 0) sort_wave_role(desc, words_in, point_list, t_all, cnt_all, mirror);
+            if (FWD_SORT_MIRROR && !(FWD_SORT_BLOCK)) ids_lds = mirror;
+        }
         else sort_list_block(desc, words_in, sort_scratch, point_list, t_all, cnt_all, *reinterpret_cast<TileSortLds*>(lds_raw + LDS_TS_L));
-        // the ids were stored by this workgroup and are loaded by it below (at agent scope: a line of the neighbouring tile's
-        // slice may sit in this CU's L1 with our first ids still unsorted in it)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // without the LDS copy: the ids were stored by this workgroup and are loaded by it below (at agent scope: a line of the
+        // neighbouring tile's slice may sit in this CU's L1 with our first ids still unsorted in it)
+        if (ids_lds == nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 #endif
@@ -930,7 +939,8 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
         SplatRec rec; rec.mask = 0; rec.x = rec.y = rec.ap = rec.bp = rec.cp = rec.o = rec.r = rec.g = rec.b = rec.z = 0.f; rec.pos = 0;
         bool ill = false;
         if ((u32)tid < cnt) {
-            const u32 g = (FWD_SORT && words_in) ? __hip_atomic_load(&point_list[range.x + base + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+            const u32 g = ids_lds ? ids_lds[base + tid]
+                        : (FWD_SORT && words_in) ? __hip_atomic_load(&point_list[range.x + base + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                                  : point_list[range.x + base + tid];
             const float4* grec = g2d + 4 * (size_t)g;             // one 64-byte line per instance
             const float4 co = grec[0], g1 = grec[1], g2v = grec[2];

@@ -26,7 +26,8 @@ __device__ __forceinline__ void lds_wave_sync() { __builtin_amdgcn_fence(__ATOMI
 #define TS_BUCKET_MAX 24
 
 template <int PER>
-__device__ __forceinline__ void wave_sort_words(const u64 (&e)[PER], u32 n, u32 kmin, u32 kmax, u32* __restrict__ out, u64* t, u32* cnt)
+__device__ __forceinline__ void wave_sort_words(const u64 (&e)[PER], u32 n, u32 kmin, u32 kmax, u32* __restrict__ out, u64* t, u32* cnt,
+                                                u32* mirror = nullptr /* LDS copy of the sorted ids (outside t / cnt), or null */)
 {
     // LDS per list: the words (8 B per entry) and the bucket counters, two 16-bit counters per word (a count or an offset
     // is at most n <= 64 * PER <= 65535); an entry's bucket is recomputed from its key where it is needed again instead
@@ -84,7 +85,7 @@ __device__ __forceinline__ void wave_sort_words(const u64 (&e)[PER], u32 n, u32 
                 lds_wave_sync();
             }
         }
-        for (u32 i = lane; i < n; i += 64) out[i] = (u32)t[i];
+        for (u32 i = lane; i < n; i += 64) { out[i] = (u32)t[i]; if (mirror) mirror[i] = (u32)t[i]; }
         return;
     }
     // entries grouped by bucket (order inside a bucket = the order the atomics retired in: irrelevant, see above)
@@ -99,6 +100,7 @@ __device__ __forceinline__ void wave_sort_words(const u64 (&e)[PER], u32 n, u32 
         u32 rank = 0;
         for (u32 q = bs; q < be; ++q) rank += (t[q] < x) ? 1u : 0u;
         out[bs + rank] = (u32)x;
+        if (mirror) mirror[bs + rank] = (u32)x;
     }
 }
 
@@ -107,7 +109,8 @@ __device__ __forceinline__ void wave_sort_words(const u64 (&e)[PER], u32 n, u32 
 // its own quarter of the workgroup's LDS; neighbouring descriptors hold lists of similar length).
 #define TS_PER (TSORT_WAVE / 64)
 template <int PER>
-__device__ __forceinline__ void sort_wave_list(u32 n, u32 start, const u64* __restrict__ words_in, u32* __restrict__ point_list, u64* t, u32* cnt)
+__device__ __forceinline__ void sort_wave_list(u32 n, u32 start, const u64* __restrict__ words_in, u32* __restrict__ point_list, u64* t, u32* cnt,
+                                               u32* mirror = nullptr)
 {
     const u32 lane = threadIdx.x & 63;
     // the list's (depth key, id) words in one batch of coalesced loads (clamped indices, no branches)
@@ -121,17 +124,18 @@ __device__ __forceinline__ void sort_wave_list(u32 n, u32 start, const u64* __re
         e[r] = valid ? w : ~0ull;
         kmin = min(kmin, valid ? key : 0xFFFFFFFFu); kmax = max(kmax, valid ? key : 0u);
     }
-    wave_sort_words<PER>(e, n, wave_min(kmin), wave_max(kmax), point_list + start, t, cnt);
+    wave_sort_words<PER>(e, n, wave_min(kmin), wave_max(kmax), point_list + start, t, cnt, mirror);
 }
-__device__ __forceinline__ void sort_wave_role(const uint4 desc, const u64* __restrict__ words_in, u32* __restrict__ point_list, u64* t, u32* cnt)
+__device__ __forceinline__ void sort_wave_role(const uint4 desc, const u64* __restrict__ words_in, u32* __restrict__ point_list, u64* t, u32* cnt,
+                                               u32* mirror = nullptr)
 {
     const u32 n = desc.z, start = desc.y;
     if (n == 0 || n > TSORT_WAVE) return;
     if (n == 1) { if ((threadIdx.x & 63) == 0) point_list[start] = (u32)words_in[start]; return; }
     // every pass of the sort is unrolled over the entries a lane CAN hold: a list of half the capacity takes the half-size
     // instance (wave-uniform choice; the median tile of the bench scene holds 254 entries)
-    if (n <= TSORT_WAVE / 2) sort_wave_list<TS_PER / 2>(n, start, words_in, point_list, t, cnt);
-    else sort_wave_list<TS_PER>(n, start, words_in, point_list, t, cnt);
+    if (n <= TSORT_WAVE / 2) sort_wave_list<TS_PER / 2>(n, start, words_in, point_list, t, cnt, mirror);
+    else sort_wave_list<TS_PER>(n, start, words_in, point_list, t, cnt, mirror);
 }
 
 // The same bucket sort run by a whole 256-thread workgroup on n <= 256 * PER words (lists of 513..2048 entries: the bulk
