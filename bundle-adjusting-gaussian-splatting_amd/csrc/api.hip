@@ -280,7 +280,7 @@ static int scan_forward(const BagsSettings* s, const BagsInputs* in, const GeomV
 // emission, per-tile ordering, blend.  n_dev != nullptr: the instance count is read on the device and checked against
 // `I` (the capacity the binning buffer was sized for)
 static int enqueue_finish(const BagsSettings* s, const BagsInputs* in, const GeomView& g, const BinView& b, const ImgView& im,
-                          const BagsForwardOut* out, int64_t I, const u32* n_dev, hipStream_t st)
+                          const BagsForwardOut* out, int64_t I, const u32* n_dev, hipStream_t st, bool speculative = false)
 {
     const int W = s->image_width, H = s->image_height;
     const int gx = cdiv(W, BAGS_TILE), gy = cdiv(H, BAGS_TILE);
@@ -288,7 +288,7 @@ static int enqueue_finish(const BagsSettings* s, const BagsInputs* in, const Geo
         if (in->P == 0) HIP_TRY(launch_binned_empty(g, im, gx * gy, st));      // no prepare phase ran: an all-empty tile list
         if (I > 0 && in->P > 0) {
             ProfScope ps(ST_TILE_SORT, st);
-            HIP_TRY(launch_binned_finish(g, im, in->P, gx, gx * gy, b.words, b.scratch, b.point_list, (u32)I, n_dev, st, !blend_fwd_sorts()));
+            HIP_TRY(launch_binned_finish(g, im, in->P, gx, gx * gy, b.words, b.scratch, b.point_list, (u32)I, n_dev, st, !blend_fwd_sorts(), speculative));
         } else if (in->P > 0) {
             HIP_TRY(launch_binned_desc_only(im, gx * gy, st));                   // nothing to emit: only the (all-empty) tile list
         }
@@ -392,7 +392,7 @@ int bags_forward_finish_speculative(const BagsSettings* s, const BagsInputs* in,
     GeomView g; carve_geom(align256(stt->geom), in->P, &g);
     BinView b; carve_binning(align256(stt->binning), capacity, W, H, &b, use_binned(s, in->P));
     ImgView im; carve_image(align256(stt->image), W, H, &im);
-    return enqueue_finish(s, in, g, b, im, out, capacity, g.num_rendered, st);
+    return enqueue_finish(s, in, g, b, im, out, capacity, g.num_rendered, st, true);
 }
 
 int bags_backward(const BagsSettings* s, const BagsInputs* in, const BagsState* stt, const BagsBackwardArgs* a, void* stream)

@@ -216,7 +216,7 @@ hipError_t launch_binned_desc_only(const ImgView& im, int T, hipStream_t st);
 hipError_t launch_binned_prepare(const GeomView& g, const ImgView& im, int P, int grid_x, int T, hipStream_t st, u32* host_count = nullptr,
                                  bool count_now = true);
 hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int grid_x, int T, u64* words, u64* scratch, u32* point_list,
-                                u32 capacity, const u32* n_dev, hipStream_t st, bool sort_lists = true);
+                                u32 capacity, const u32* n_dev, hipStream_t st, bool sort_lists = true, bool deliver_count = false);
 hipError_t launch_debug_keys_ranges(const uint2* ranges, const u32* point_list, const u32* depth_key, int T, u64* out, hipStream_t st);
 hipError_t launch_debug_keys(const u32* tile_sorted, const u32* point_list, const u32* depth_key, long long I, u64* out, hipStream_t st);
 hipError_t launch_unpack_rect(const uint2* rect, int P, u32* out, hipStream_t st);

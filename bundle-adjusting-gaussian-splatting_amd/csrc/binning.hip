@@ -339,7 +339,8 @@ emit_binned_kernel(int P, int per_block, int grid_x, int T, const uint2* __restr
                    uint2* __restrict__ ranges, const u32* __restrict__ tile_lstart, const u32* __restrict__ group_total,
                    const u32* __restrict__ depth_key, u64* __restrict__ words, u32 capacity,
                    const u32* __restrict__ tile_total, uint4* __restrict__ tile_desc, u32* __restrict__ n_active,
-                   u32* __restrict__ num_rendered, const u32* __restrict__ block_total, int B, u32* __restrict__ block_base)
+                   u32* __restrict__ num_rendered, const u32* __restrict__ block_total, int B, u32* __restrict__ block_base,
+                   const int deliver_count)
 {
     static_assert(BIN_THREADS == 1024, "build_tile_desc is written for 1024 threads");
     extern __shared__ u32 cur[];                             // T slot cursors (the descriptor workgroup: its transposes)
@@ -353,7 +354,9 @@ emit_binned_kernel(int P, int per_block, int grid_x, int T, const uint2* __restr
         if (threadIdx.x == 0) {
             num_rendered[0] = s_gb[512];
             u32* host_count = reinterpret_cast<u32*>((size_t)*reinterpret_cast<const unsigned long long*>(num_rendered + 2));
-            if (host_count) __hip_atomic_store(host_count, s_gb[512], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            // (only the speculative finish delivers: by the time an exact re-run of this phase executes, the caller has read the
+            // word and may have handed it to another forward)
+            if (host_count && deliver_count) __hip_atomic_store(host_count, s_gb[512], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         build_tile_desc<ORD_PER>(tile_total, nullptr, T, tile_desc, n_active, cur, s_cur, s_wave, tile_lstart, s_gb, ranges);
         const u32 v = ((int)threadIdx.x < B) ? block_total[threadIdx.x] : 0u;
@@ -460,7 +463,7 @@ hipError_t launch_binned_empty(const GeomView& g, const ImgView& im, int T, hipS
 }
 
 hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int grid_x, int T, u64* words, u64* scratch, u32* point_list,
-                                u32 capacity, const u32* n_dev, hipStream_t st, bool sort_lists)
+                                u32 capacity, const u32* n_dev, hipStream_t st, bool sort_lists, bool deliver_count)
 {
     const int per = binned_per_block(P), B = cdiv(P, per);
     // T slot cursors (up to 128 KB at 32768 tiles: one workgroup per CU); the descriptor workgroup's transposes fit beside
@@ -469,7 +472,7 @@ hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int
         e = big_lds(emit_binned_kernel<PER>, lds);                                                                                \
         if (e == hipSuccess) hipLaunchKernelGGL(emit_binned_kernel<PER>, dim3(B + 1), dim3(BIN_THREADS), lds, st, P, per, grid_x, T, g.rect, \
                 g.tiles_touched, g.keep, im.pre, im.ranges, im.tile_lstart, im.group_total, g.depth_key, words, capacity,   \
-                im.tile_total, im.tile_desc, im.n_active, g.num_rendered, g.block_total, B, g.block_base); }
+                im.tile_total, im.tile_desc, im.n_active, g.num_rendered, g.block_total, B, g.block_base, deliver_count ? 1 : 0); }
     switch (ord_per_for(T)) { case 8: EM_LAUNCH(8) break; case 16: EM_LAUNCH(16) break; default: EM_LAUNCH(32) }
 #undef EM_LAUNCH
     if (e != hipSuccess) return e;
