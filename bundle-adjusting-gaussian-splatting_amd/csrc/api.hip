@@ -115,7 +115,7 @@ size_t carve_geom(void* base, int P, GeomView* v)
     g.nblocks_sort = radix_blocks_for((long long)n);
     g.nblocks_scan = cdiv((long long)n, SCAN_TILE);
     take(p, g.depth_key, n); take(p, g.g2d, 4 * n); take(p, g.rect, n); take(p, g.tiles_touched, n); take(p, g.inst_off, n);
-    take(p, g.keep, n); take(p, g.shjac, 10 * n);
+    take(p, g.keep, n); take(p, g.shjac, 10 * n); take(p, g.rec_count, n);
     take(p, g.keys_a, n); take(p, g.keys_b, n); take(p, g.vals_a, n); take(p, g.vals_b, n);
     take(p, g.rank_offset, n);
     take(p, g.scan_partials, (size_t)g.nblocks_scan + 1);

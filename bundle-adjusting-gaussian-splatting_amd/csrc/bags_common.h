@@ -88,6 +88,8 @@ struct GeomView {            // per Gaussian, indexed by Gaussian id unless stat
                              // tile-binned path the record base is block_base[block] + local_off, both known to K1 (line.q3.y / q3.z)
     uint2*  rect;            // (minx | miny<<16, maxx | maxy<<16), max exclusive   (compact copy for emit)
     u32*    tiles_touched;   // instances the Gaussian emits (compact copy for the offsets scan / emit)
+    u32*    rec_count;       // partial-gradient records of the Gaussian (= tiles_touched, except on the tile-binned path with the stock tile
+                             // rule: there only the tiles the opacity rule keeps have a record, round 4)
     // [10 * P] d(colour)/d(view direction) of the SH colour path, written by K1 for the visible Gaussians (round 3):
     //   M[axis][c] = sum_t (d basis_t / d dir_axis) * sh[t][c]   as   Mxr Mxg Mxb  Myr Myg Myb  Mzr Mzg Mzb, then the clamp bits
     // so that preprocess_bwd reads 40 bytes per Gaussian instead of the 192-byte SH row a second time (and nothing of g2d)

@@ -269,6 +269,15 @@ __device__ __forceinline__ bool conic_ill_conditioned(float a, float b, float c)
     const float tr = a + c;
     return !(a * c - b * b >= 1.0e-4f * (tr * tr));         // also catches NaN and non-positive determinants
 }
+// Is tile (tx, ty) among the tiles the Gaussian has a partial-gradient record for?  rc / kp: rectangle and tile mask of the
+// geometry line (the RECORDS' tiles: with the stock tile rule on the tile-binned path a subset of the tiles the lists cover).
+__device__ __forceinline__ bool tile_has_record(const u32 rc_x, const u32 rc_y, const u64 kp, const int tx, const int ty)
+{
+    const int minx = (int)(rc_x & 0xFFFF), miny = (int)(rc_x >> 16), rw = (int)(rc_y & 0xFFFF) - minx, rh = (int)(rc_y >> 16) - miny;
+    const int dx = tx - minx, dy = ty - miny;
+    if (!((dx >= 0) && (dy >= 0) && (dx < rw) && (dy < rh))) return false;
+    return rect_small(rw, rh) ? (((kp >> (dy * 8 + dx)) & 1ull) != 0ull) : true;
+}
 struct TileRef { int tx, ty; u32 rx, n, maxc; bool early, needle; };   // early: some pixel of the tile stopped before its list ended (or lies outside the image)   // wave-uniform: tile coordinates, first instance, instances, deepest contributor
 
 template <bool ABS>
@@ -277,7 +286,8 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                       const u32* __restrict__ point_list, const unsigned char* __restrict__ reach_mask, const u32 rm_stride,
                       const float4* __restrict__ g2d, const u32* __restrict__ inst_off, const u32* __restrict__ block_base,
                       const float* __restrict__ bg, const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
-                      const float* __restrict__ grad_color, float* __restrict__ partials, u32* __restrict__ zero_words, const int n_zero)
+                      const float* __restrict__ grad_color, float* __restrict__ partials, u32* __restrict__ zero_words, const int n_zero,
+                      const int test_keep)
 {
     // One workgroup per tile that holds at least one instance, heavy tiles first (slot_of_vblock).  Tried and dropped:
     // persistent workgroups that run the chunk pipeline over the flattened (tile, chunk) sequence, with the next tile's
@@ -326,7 +336,14 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         const u32 at = rx_ + (hi_ - c_) + tid;
         // the reach masks of a tile sit at byte rm_stride * (tile's first instance): inside the tile's own slice of the (dead)
         // unsorted words on the tile-binned path (stride 8), plainly per instance on the radix path (stride 2)
-        return make_uint2(point_list[at], (u32)reinterpret_cast<const unsigned short*>(reach_mask + (size_t)rx_ * rm_stride)[at - rx_]);
+        // Tile-binned path: a 32-bit word per instance -- bits 0..15 the reach mask, bit 16 "this instance has a record" (with
+        // the stock tile rule the lists hold instances whose tile the opacity rule drops: no record, nothing to gather, nothing
+        // to write; they come back as an empty slot).  Radix path: 16-bit masks, every instance has a record.
+        u32 info;
+        if (rm_stride == 8u) info = reinterpret_cast<const u32*>(reach_mask + (size_t)rx_ * 8u)[at - rx_];
+        else info = 0x10000u | (u32)reinterpret_cast<const unsigned short*>(reach_mask + (size_t)rx_ * 2u)[at - rx_];
+        if (!(info & 0x10000u)) return make_uint2(0xFFFFFFFFu, 0u);
+        return make_uint2(point_list[at], info & 0xFFFFu);
     };
     auto fetch = [&](u32 g) {
         Raw r; r.q0 = make_float4(0.f, 0.f, 0.f, 0.f); r.q1 = r.q0; r.q2 = r.q0; r.io = 0u; r.blk = 0u; r.kp = 0ull;
@@ -353,7 +370,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     // dependent load -- so this is evaluated once the line has landed and long before the slot is needed (after the list
     // building of the chunk before), and from then on ONE register stands for six (offset, block, rectangle, tile mask).
     auto slot_of = [&](const Raw& rw, const bool have, const TileRef& t) -> u32 {
-        if (!have) return 0u;
+        if (!have) return 0xFFFFFFFFu;                        // an empty slot of the chunk: no record is written for it
         const u32 base_ = inst_off ? 0u : block_base[rw.blk];
         return emission_slot(base_ + rw.io, make_uint2(__float_as_uint(rw.q2.z), __float_as_uint(rw.q2.w)), rw.kp, t.tx, t.ty);
     };
@@ -407,8 +424,11 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
             if ((tid & 15) == 0) blk_maxc[b] = m;
         }
         for (u32 p = t.maxc + tid; p < t.n; p += 256) {
+            // (the forward stops staging once every pixel of the tile has finished: these instances may have no reach word)
             const u32 g = point_list[t.rx + p];
             const float4 t2 = g2d[4 * (size_t)g + 2], t3 = g2d[4 * (size_t)g + 3];
+            if (test_keep && !tile_has_record(__float_as_uint(t2.z), __float_as_uint(t2.w),
+                                              (u64)__float_as_uint(t3.x) | ((u64)__float_as_uint(t3.w) << 32), t.tx, t.ty)) continue;   // no record
             const u32 io = inst_off ? inst_off[g] : block_base[__float_as_uint(t3.y)] + __float_as_uint(t3.z);
             const u32 e = emission_slot(io, make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)),
                                         (u64)__float_as_uint(t3.x) | ((u64)__float_as_uint(t3.w) << 32), t.tx, t.ty);
@@ -749,7 +769,8 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                     }
                     const u32 rcd = (f * 43691u) >> 17;                 // f / 3 (exact below 98304)
                     const u32 part = f - 3u * rcd;
-                    reinterpret_cast<float4*>(partials + (size_t)rec_e[par][rcd] * PART_FLOATS)[part] = r;
+                    const u32 e_ = rec_e[par][rcd];
+                    if (e_ != 0xFFFFFFFFu) reinterpret_cast<float4*>(partials + (size_t)e_ * PART_FLOATS)[part] = r;
                 }
             }
             par ^= 1u;
@@ -769,8 +790,10 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                     r2.x += x2.x; r2.y += x2.y; r2.z += x2.z;
                 }
             }
-            float4* dst = reinterpret_cast<float4*>(partials + (size_t)cur.e * PART_FLOATS);
-            dst[0] = r0; dst[1] = r1; dst[2] = r2;
+            if (cur.e != 0xFFFFFFFFu) {
+                float4* dst = reinterpret_cast<float4*>(partials + (size_t)cur.e * PART_FLOATS);
+                dst[0] = r0; dst[1] = r1; dst[2] = r2;
+            }
         }
 #endif
         PH_MARK(6);    // record sums + stores
@@ -801,11 +824,11 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     if (want_abs)
         hipLaunchKernelGGL(blend_bwd_scan_kernel<true>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
                            im.tile_desc, b.point_list, reinterpret_cast<const unsigned char*>(b.reach_mask), binned ? 8u : 2u, g.g2d, binned ? nullptr : g.inst_off, g.block_base, s.bg,
-                           im.final_T, im.n_contrib, grad_color, partials, zero_words, n_zero);
+                           im.final_T, im.n_contrib, grad_color, partials, zero_words, n_zero, (binned && s.tile_bounds != BAGS_TILES_OPACITY) ? 1 : 0);
     else
         hipLaunchKernelGGL(blend_bwd_scan_kernel<false>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
                            im.tile_desc, b.point_list, reinterpret_cast<const unsigned char*>(b.reach_mask), binned ? 8u : 2u, g.g2d, binned ? nullptr : g.inst_off, g.block_base, s.bg,
-                           im.final_T, im.n_contrib, grad_color, partials, zero_words, n_zero);
+                           im.final_T, im.n_contrib, grad_color, partials, zero_words, n_zero, (binned && s.tile_bounds != BAGS_TILES_OPACITY) ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -852,7 +875,7 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
                       const u64* __restrict__ words_in, u64* __restrict__ sort_scratch,
                       unsigned char* __restrict__ reach_mask, const u32 rm_stride, const float4* __restrict__ g2d, const float* __restrict__ bg, float* __restrict__ out_color,
                       float* __restrict__ out_depth, float* __restrict__ out_weights, float* __restrict__ final_T,
-                      u32* __restrict__ n_contrib, const u32* __restrict__ n_dev, u32 capacity)
+                      u32* __restrict__ n_contrib, const u32* __restrict__ n_dev, u32 capacity, const int test_keep)
 {
     const int dslot = slot_of_vblock(blockIdx.x);            // heavy tiles first, balanced over the XCDs
     if (dslot >= T) return;
@@ -950,10 +973,20 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
             rec.ap = -0.5f * LOG2E * co.x; rec.bp = -LOG2E * co.y; rec.cp = -0.5f * LOG2E * co.z; rec.o = co.w;
             rec.r = cz.x; rec.g = cz.y; rec.b = cz.z; rec.z = cz.w;
             rec.pos = base + tid + 1;
-            rec.mask = block_mask16(c2.x, c2.y, co.x, co.y, co.z, co.w, X0, Y0);
-            // the backward stages the same instance: it reads this (tile-binned path: inside the tile's own slice of the words,
-            // which this workgroup has just finished with)
-            reinterpret_cast<unsigned short*>(reach_mask + (size_t)range.x * rm_stride)[base + tid] = (unsigned short)rec.mask;
+            // Tile-binned path with the stock tile rule (test_keep): the list holds every tile of the 3-sigma square, the geometry
+            // line the rectangle and tile mask of the opacity rule; an instance whose tile is not among those can reach no pixel
+            // of this tile with alpha >= 1/255 (decision D7) -- it has no gradient record, and neither blend kernel looks at it.
+            bool has_rec = true;
+            if (test_keep) {
+                const float4 q3 = grec[3];
+                has_rec = tile_has_record(__float_as_uint(g2v.z), __float_as_uint(g2v.w),
+                                          (u64)__float_as_uint(q3.x) | ((u64)__float_as_uint(q3.w) << 32), tile_x, tile_y);
+            }
+            rec.mask = has_rec ? block_mask16(c2.x, c2.y, co.x, co.y, co.z, co.w, X0, Y0) : 0u;
+            // the backward stages the same instance: it reads this (tile-binned path: a 32-bit word, mask | has-record << 16,
+            // inside the tile's own slice of the words, which this workgroup has just finished with; radix path: the mask)
+            if (rm_stride == 8u) reinterpret_cast<u32*>(reach_mask + (size_t)range.x * 8u)[base + tid] = rec.mask | (has_rec ? 0x10000u : 0u);
+            else reinterpret_cast<unsigned short*>(reach_mask + (size_t)range.x * 2u)[base + tid] = (unsigned short)rec.mask;
             ill = conic_ill_conditioned(co.x, co.y, co.z);
         }
         needle |= (__ballot(ill) != 0ull);                   // (a scalar register, not a lane's)
@@ -1155,7 +1188,7 @@ hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinV
     hipLaunchKernelGGL(blend_fwd_rows_kernel<0>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
                        im.tile_desc, b.point_list, (FWD_SORT && sort_here) ? b.words : nullptr, b.scratch,
                        reinterpret_cast<unsigned char*>(b.reach_mask), b.words ? 8u : 2u, g.g2d, s.bg, out.color, out.depth, out.weights,
-                       im.final_T, im.n_contrib, n_dev, capacity);
+                       im.final_T, im.n_contrib, n_dev, capacity, (b.words && s.tile_bounds != BAGS_TILES_OPACITY) ? 1 : 0);
     return hipGetLastError();
 }
 

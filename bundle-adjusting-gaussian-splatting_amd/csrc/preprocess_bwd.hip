@@ -664,7 +664,7 @@ hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, co
     (void)sums;
     const float* partials = partials_records;
 #else
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(nb), dim3(256), 0, st, P, g.tiles_touched, binned ? nullptr : g.inst_off, g.local_off,
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(nb), dim3(256), 0, st, P, g.rec_count, binned ? nullptr : g.inst_off, g.local_off,
                        g.block_base, binned_per_block(P), partials_records,
                        reinterpret_cast<float4*>(sums));
     const float* partials = sums;
@@ -672,7 +672,7 @@ hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, co
 #define PRE_BWD_LAUNCH(COV)     hipLaunchKernelGGL(preprocess_bwd_kernel<COV>, dim3(nb), dim3(256), 0, st, P, s.sh_coeffs, s.sh_degree, s.image_width, \
                        s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, (s.clamp_grad == BAGS_CLAMP_GRAD_EXACT) ? 0 : 1, in.means3D, in.shift_factors, in.shs, \
                        in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, s.viewmatrix, s.projmatrix, \
-                       s.intrinsic, s.campos, in.opacities, g.tiles_touched, binned ? nullptr : g.inst_off, g.local_off, g.block_base, \
+                       s.intrinsic, s.campos, in.opacities, g.rec_count, binned ? nullptr : g.inst_off, g.local_off, g.block_base, \
                        binned_per_block(P), g.shjac, partials, \
                        pose_slab, a.grad_means3D, a.grad_means2D, a.grad_means2D_densify, a.grad_shs, \
                        a.grad_colors_precomp, a.grad_opacities, a.grad_scales, a.grad_rotations, a.grad_cov3D_precomp, \

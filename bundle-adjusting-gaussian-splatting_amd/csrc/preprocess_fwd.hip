@@ -55,19 +55,24 @@ struct K1Args {
     int P, M, deg, W, H;
     float tanfovx, tanfovy, mod;
     int depth_mode, tile_bounds;
+    int rec_opacity;         // tile-binned path with the stock tile rule: the LISTS follow the stock 3-sigma square, the partial-gradient
+                             // RECORDS only exist for the tiles the alpha >= 1/255 ellipse reaches (the opacity rule's rectangle + tile mask)
     const float *means3D, *means2D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
     float* shjac;
 };
 struct K1Result {
     u32 key, tiles; int radius; uint2 rect; u64 keep; float2 pxy; float4 q0, rgbz_v;
+    u32 rtiles; uint2 rrect; u64 rkeep;          // the tiles a partial-gradient record exists for (= tiles / rect / keep unless rec_opacity)
 };
 struct K1Outputs {
-    u32* depth_key; float4* g2d; uint2* rect; u32* tiles_touched; u64* keep; int32_t* radii; float* mean2D;
+    u32* depth_key; float4* g2d; uint2* rect; u32* tiles_touched; u64* keep; int32_t* radii; float* mean2D; u32* rec_count;
 };
 
 __device__ __forceinline__ K1Result k1_project(const K1Args& A, const CamConst& cam, const int i)
 {
     const int M = A.M, deg = A.deg, W = A.W, H = A.H, depth_mode = A.depth_mode, tile_bounds = A.tile_bounds;
+    const bool want_opacity = (tile_bounds == BAGS_TILES_OPACITY) || (A.rec_opacity != 0);
+    u32 rtiles = 0; uint2 rrect = make_uint2(0u, 0u); u64 rkeep = ~0ull;
     const float tanfovx = A.tanfovx, tanfovy = A.tanfovy, mod = A.mod;
     const float* __restrict__ means3D = A.means3D; const float* __restrict__ means2D = A.means2D;
     const float* __restrict__ shs = A.shs; const float* __restrict__ colors_precomp = A.colors_precomp;
@@ -179,7 +184,7 @@ __device__ __forceinline__ K1Result k1_project(const K1Args& A, const CamConst& 
                 const int nt = (maxx - minx) * (maxy - miny);
                 if (nt > 0) {                                // "visible" (radii > 0) is decided by the stock rectangle
                     int ex0 = minx, ey0 = miny, ex1 = maxx, ey1 = maxy;      // rectangle the instances are emitted for
-                    if (tile_bounds == BAGS_TILES_OPACITY) {
+                    if (want_opacity) {
                         // alpha = o exp(-d^T Q d / 2) >= 1/255 only inside d^T Q d <= 2 ln(255 o), whose axis-aligned half
                         // extents are sqrt(2 ln(255 o) cov_xx), sqrt(.. cov_yy).  ln is bounded from above with operations
                         // every IEEE implementation rounds identically (the oracle repeats them in torch): 255 o = m 2^e,
@@ -213,6 +218,13 @@ __device__ __forceinline__ K1Result k1_project(const K1Args& A, const CamConst& 
                     tiles = masked ? (u32)__popcll(keep) : (u32)((ex1 - ex0) * (ey1 - ey0));
                     radius = (int)rad_f;
                     rect = make_uint2((u32)ex0 | ((u32)ey0 << 16), (u32)ex1 | ((u32)ey1 << 16));
+                    rtiles = tiles; rrect = rect; rkeep = keep;                 // records: the opacity rule's tiles
+                    if (tile_bounds != BAGS_TILES_OPACITY) {                    // lists: the stock square, every tile of it
+                        keep = rect_full_mask(maxx - minx, maxy - miny);
+                        tiles = (u32)nt;
+                        rect = make_uint2((u32)minx | ((u32)miny << 16), (u32)maxx | ((u32)maxy << 16));
+                        if (!A.rec_opacity) { rtiles = tiles; rrect = rect; rkeep = keep; }
+                    }
                     pxy = make_float2(px, py);
                     const float dsort = (depth_mode == BAGS_DEPTH_DISTANCE) ? sqrtf(tx * tx + ty * ty + tzs * tzs) : tzs;
                     key = __float_as_uint(dsort);
@@ -295,13 +307,16 @@ __device__ __forceinline__ K1Result k1_project(const K1Args& A, const CamConst& 
     }
     K1Result R;
     R.key = key; R.tiles = tiles; R.radius = radius; R.rect = rect; R.keep = keep; R.pxy = pxy; R.q0 = q0; R.rgbz_v = rgbz_v;
+    R.rtiles = rtiles; R.rrect = rrect; R.rkeep = rkeep;
     return R;
 }
 
 // One full 64-byte line per Gaussian (the blend kernels gather it per instance) plus the compact arrays of the binning kernels.
 //   q3 = (tile mask lo, block of Gaussians, instance offset inside the block, tile mask hi): blend_bwd finds a Gaussian's
 //   first partial-gradient record at block_base[q3.y] + q3.z without a second gather (tile-binned path; zeros on the radix path,
-//   which keeps the inst_off array).
+//   which keeps the inst_off array).  Rectangle and tile mask in the line are those of the RECORDS (rrect / rkeep): with the
+//   stock tile rule on the tile-binned path they are the opacity rule's, a subset of the tiles the lists cover -- an instance
+//   whose tile is not among them has no record, and the blend kernels skip it (round 4).
 __device__ __forceinline__ void k1_store(const K1Outputs& O, const int i, const K1Result& R, const u32 blk, const u32 loff)
 {
     O.depth_key[i] = R.key;
@@ -311,8 +326,9 @@ __device__ __forceinline__ void k1_store(const K1Outputs& O, const int i, const 
     float4* rec = O.g2d + 4 * (size_t)i;
     rec[0] = R.q0;
     rec[1] = make_float4(R.pxy.x, R.pxy.y, R.rgbz_v.x, R.rgbz_v.y);
-    rec[2] = make_float4(R.rgbz_v.z, R.rgbz_v.w, __uint_as_float(R.rect.x), __uint_as_float(R.rect.y));
-    rec[3] = make_float4(__uint_as_float((u32)R.keep), __uint_as_float(blk), __uint_as_float(loff), __uint_as_float((u32)(R.keep >> 32)));
+    rec[2] = make_float4(R.rgbz_v.z, R.rgbz_v.w, __uint_as_float(R.rrect.x), __uint_as_float(R.rrect.y));
+    rec[3] = make_float4(__uint_as_float((u32)R.rkeep), __uint_as_float(blk), __uint_as_float(loff), __uint_as_float((u32)(R.rkeep >> 32)));
+    O.rec_count[i] = R.rtiles;
     O.radii[i] = R.radius;
     if (O.mean2D) { O.mean2D[2 * i] = R.pxy.x; O.mean2D[2 * i + 1] = R.pxy.y; }
 }
@@ -379,7 +395,7 @@ preprocess_fwd_count_kernel(const K1Args A, const float* __restrict__ viewmatrix
         const int i = (int)(valid ? gi : 0);
         K1Result R;
         R.key = KEY_CULLED; R.tiles = 0; R.radius = 0; R.rect = make_uint2(0u, 0u); R.keep = ~0ull; R.pxy = make_float2(0.f, 0.f);
-        R.q0 = make_float4(0.f, 0.f, 0.f, 0.f); R.rgbz_v = R.q0;
+        R.q0 = make_float4(0.f, 0.f, 0.f, 0.f); R.rgbz_v = R.q0; R.rtiles = 0; R.rrect = make_uint2(0u, 0u); R.rkeep = ~0ull;
         if (valid) R = k1_project(A, cam, i);
         __builtin_amdgcn_sched_barrier(0);
         // ---- (block, tile) counts: small rectangles by their tile mask, larger ones tile by tile, huge ones by the whole wave
@@ -397,12 +413,13 @@ preprocess_fwd_count_kernel(const K1Args A, const float* __restrict__ viewmatrix
             const uint2 brc = make_uint2((u32)__shfl((int)rc.x, src), (u32)__shfl((int)rc.y, src));
             walk_rect<false>(cnt, brc, grid_x, lane, true, 0ull, nullptr);
         }
-        // ---- the wave's range of record slots inside the block
-        const u32 incl = wave_incl_scan(nt);
+        // ---- the wave's range of record slots inside the block (records, not list instances: see K1Args::rec_opacity)
+        const u32 nrec = R.rtiles;
+        const u32 incl = wave_incl_scan(nrec);
         u32 base = 0;
         if (lane == 63) base = atomicAdd(&s_run, incl);
         base = (u32)__builtin_amdgcn_readlane((int)base, 63);
-        const u32 loff = base + incl - nt;
+        const u32 loff = base + incl - nrec;
         __builtin_amdgcn_sched_barrier(0);
         if (valid) { k1_store(O, i, R, (u32)blockIdx.x, loff); local_off[i] = loff; }
         __builtin_amdgcn_sched_barrier(0);
@@ -421,11 +438,12 @@ hipError_t launch_preprocess_fwd(const BagsSettings& s, const BagsInputs& in, co
     K1Args A;
     A.P = P; A.M = s.sh_coeffs; A.deg = s.sh_degree; A.W = s.image_width; A.H = s.image_height;
     A.tanfovx = s.tanfovx; A.tanfovy = s.tanfovy; A.mod = s.scale_modifier; A.depth_mode = s.depth_key; A.tile_bounds = s.tile_bounds;
+    A.rec_opacity = (count_into != nullptr && s.tile_bounds != BAGS_TILES_OPACITY) ? 1 : 0;
     A.means3D = in.means3D; A.means2D = in.means2D; A.shs = in.shs; A.colors_precomp = in.colors_precomp; A.opacities = in.opacities;
     A.scales = in.scales; A.rotations = in.rotations; A.cov3D_precomp = in.cov3D_precomp; A.shjac = g.shjac;
     K1Outputs O;
     O.depth_key = g.depth_key; O.g2d = g.g2d; O.rect = g.rect; O.tiles_touched = g.tiles_touched; O.keep = g.keep; O.radii = radii;
-    O.mean2D = mean2D;
+    O.mean2D = mean2D; O.rec_count = g.rec_count;
     if (count_into) {                                        // tile-binned path: K1 also counts the (block, tile) matrix
         const int gy = cdiv(s.image_height, BAGS_TILE), T = grid_x * gy, T2 = (T + 1) / 2;
         const int per = binned_per_block(P), B = cdiv(P, per);

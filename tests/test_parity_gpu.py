@@ -729,7 +729,8 @@ def test_binning_paths_give_identical_lists(P, W, H, sm, deg):
 
 def test_binning_paths_agree_on_random_scenes():
     """Randomised cross-check of the two list builders (no oracle: fast): odd image sizes, 1 .. 60 k Gaussians, mixed
-    anisotropy and opacity, both tile rules, both depth keys -- lists, ranges, outputs and gradients must be bit-identical."""
+    anisotropy and opacity, both tile rules, both depth keys -- lists, ranges, outputs and gradients must be bit-identical
+    (gradients with the stock tile rule: to summation order, see below)."""
     rng = torch.Generator().manual_seed(2024)
     for trial in range(14):
         P = int(torch.randint(1, 60000, (1,), generator=rng)) if trial else 1
@@ -754,7 +755,14 @@ def test_binning_paths_agree_on_random_scenes():
             assert torch.equal(a, b), tag
         for k in g_a:
             if g_a[k] is not None:
-                assert torch.equal(g_a[k], g_r[k]), (k, tag)
+                if kw["tile_bounds"] == "opacity":
+                    assert torch.equal(g_a[k], g_r[k]), (k, tag)
+                else:
+                    # stock tile rule: the tile-binned path keeps gradient records only for the tiles the opacity rule reaches
+                    # (the others are exact zeros on the radix path), so a Gaussian with more than 64 records has them dealt to
+                    # the lanes of its wave-cooperative sum differently: equal to summation order, not bit for bit
+                    # (measured: <= 2.2e-6, and 1.5e-4 for dL/dscales of the needle scenes, whose sums cancel by four digits)
+                    assert rel_err(g_a[k], g_r[k]) <= (5e-4 if trial % 3 == 1 else 2e-5), (k, tag, rel_err(g_a[k], g_r[k]))
 
 
 @pytest.mark.parametrize("P,shrink,flat", [(3000, 0.04, False), (20000, 0.02, False), (40000, 0.012, False),
