@@ -126,6 +126,32 @@ def test_edge_cases_empty_behind_and_single():
     assert_report(rep)
 
 
+def test_speculative_forward_of_a_scene_that_left_the_frustum():
+    """Same problem shape, second call: a capacity hint exists, so the forward is speculative -- and this time NOTHING is in
+    front of the camera (instance count 0: the emission launch runs on empty lists, no blend_bwd launch in the backward).
+    Background only, zero gradients, and the next ordinary call is unaffected."""
+    from bags_raster import rasterizer as R
+    from bags_raster.synth import look_at_origin_camera
+    cam = look_at_origin_camera(96, 80)
+    g = torch.randn(3, 80, 96, generator=torch.Generator().manual_seed(3))
+    scene, _ = make_case(400, 96, 80, 1.5, 1, seed=4)
+    R._capacity_hint.clear()
+    o1, g1, v1 = run_hip(scene, cam, 1, g)
+    assert v1["num_rendered"] > 0 and R._capacity_hint
+    gone = dict(scene); gone["means3D"] = scene["means3D"] + torch.tensor([0.0, 0.0, -20.0])
+    bg = torch.tensor([0.1, 0.5, 0.9])
+    o0, g0, v0 = run_hip(gone, cam, 1, g, bg=bg)
+    assert v0["num_rendered"] == 0 and int(o0[1].max()) == 0
+    assert torch.equal(o0[0], bg[:, None, None].expand(3, 80, 96).contiguous())
+    assert all(v is None or float(v.abs().max()) == 0.0 for v in g0.values())
+    o2, g2, _ = run_hip(scene, cam, 1, g)
+    for a, b in zip(o1, o2):
+        assert torch.equal(a, b)
+    for k in g1:
+        if g1[k] is not None:
+            assert torch.equal(g1[k], g2[k]), k
+
+
 def test_saturated_alpha_and_early_termination():
     """Opaque, overlapping splats: exercises alpha clamp 0.99 and the T < 1e-4 stop."""
     scene, cam = make_case(800, 96, 96, 6.0, 1, seed=11)
