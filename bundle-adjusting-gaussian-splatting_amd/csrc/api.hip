@@ -164,7 +164,7 @@ size_t carve_image(void* base, int W, int H, ImgView* v)
     const size_t n = (size_t)W * H > 0 ? (size_t)W * H : 1;
     take(p, im.final_T, n); take(p, im.n_contrib, n);
     const size_t T = (size_t)cdiv(W > 0 ? W : 1, BAGS_TILE) * cdiv(H > 0 ? H : 1, BAGS_TILE);
-    take(p, im.tile_desc, T); take(p, im.n_active, 64);
+    take(p, im.tile_desc, T); take(p, im.n_active, 64); take(p, im.tile_aux, T);
     im.cnt_rows = im.pre = im.tile_total = nullptr; im.ranges = nullptr; im.tile_lstart = im.group_total = nullptr;
     if (binned_supported(1, (int)T)) {                        // images the tile-binned path can take (<= 32768 tiles)
         take(p, im.cnt_rows, 256 * ((T + 1) / 2)); take(p, im.pre, 256 * T); take(p, im.tile_total, T); take(p, im.ranges, T);

@@ -135,6 +135,9 @@ struct ImgView {
     // x,y,z by tile_order_kernel, w by blend_fwd; decides which workgroup of a blend launch takes which tile.
     uint4* tile_desc;
     u32*   n_active;         // [1] tiles that hold at least one instance (they come first in tile_desc)
+    uint4* tile_aux;         // [tiles] by descriptor slot, stock tile rule on the tile-binned path only (blend_fwd -> blend_bwd):
+                             // {record-holding instances in front of the deepest contributor, record-holding instances staged,
+                             //  list positions staged, -}
     // tile-binned path (binning.hip): (block of Gaussians, tile) instance counts and their prefix over the blocks
     u32*   cnt_rows;         // [256][(T+1)/2] packed 16-bit counters
     u32*   pre;              // [256][T]

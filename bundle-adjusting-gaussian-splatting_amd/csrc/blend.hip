@@ -280,14 +280,17 @@ __device__ __forceinline__ bool tile_has_record(const u32 rc_x, const u32 rc_y, 
 }
 struct TileRef { int tx, ty; u32 rx, n, maxc; bool early, needle; };   // early: some pixel of the tile stopped before its list ended (or lies outside the image)   // wave-uniform: tile coordinates, first instance, instances, deepest contributor
 
-template <bool ABS>
+// COMPACT (stock tile rule on the tile-binned path): the chunks are staged from the forward's compacted list of record-holding
+// positions (tile_aux, cpos) instead of from consecutive list positions; everything that needs a list POSITION (the pos <=
+// n_contrib test, the per-block "behind the last contributor" filter) takes it from the compacted entry.
+template <bool ABS, bool COMPACT>
 __global__ void __launch_bounds__(256, SCAN_WG_PER_CU)
 blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__ tile_desc,
                       const u32* __restrict__ point_list, const unsigned char* __restrict__ reach_mask, const u32 rm_stride,
                       const float4* __restrict__ g2d, const u32* __restrict__ inst_off, const u32* __restrict__ block_base,
                       const float* __restrict__ bg, const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
                       const float* __restrict__ grad_color, float* __restrict__ partials, u32* __restrict__ zero_words, const int n_zero,
-                      const int test_keep)
+                      const int test_keep, const uint4* __restrict__ tile_aux)
 {
     // One workgroup per tile that holds at least one instance, heavy tiles first (slot_of_vblock).  Tried and dropped:
     // persistent workgroups that run the chunk pipeline over the flattened (tile, chunk) sequence, with the next tile's
@@ -304,6 +307,11 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     TileRef A;
     A.tx = (int)(desc.x % (u32)grid_x); A.ty = (int)(desc.x / (u32)grid_x); A.rx = desc.y; A.n = desc.z;
     A.maxc = min(desc.w & 0x3FFFFFFFu, desc.z); A.early = (desc.w >> 31) != 0u; A.needle = ((desc.w >> 30) & 1u) != 0u;
+    // where the chunks start (back to front): the deepest contributor's list position, or -- COMPACT -- the number of
+    // record-holding instances in front of it
+    u32 hi0 = A.maxc, n_live = 0, n_staged = A.n;
+    if (COMPACT) { const uint4 ax = tile_aux[dslot]; hi0 = min(ax.x, A.n); n_live = min(ax.y, A.n); n_staged = min(ax.z, A.n); }
+    const u32* const cposp = reinterpret_cast<const u32*>(reach_mask + (size_t)A.rx * 8u) + A.n;   // COMPACT: positions of the record holders
 
     __shared__ ChunkRec recs[BCHUNK];                 // 8.25 KB
     // 8 pixel pairs (PixPair = 4 x float4) per block + one float4 of padding: the four rows of a wave read four different
@@ -313,6 +321,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     __shared__ u32 masks[BCHUNK];                     //  0.5 KB: block reach masks, compact (the 48-B record stride bank-conflicts)
     __shared__ float acc[4][BCHUNK][12];              // 33 KB, one copy per wave (LDS float atomics on a shared copy were 1.6x slower)
     __shared__ u32 blk_maxc[16];                     // last contributor over the 16 pixels of each block
+    __shared__ u32 chunk_pos[COMPACT ? BCHUNK : 1];  // COMPACT: list position of every staged slot (the slots are no longer consecutive positions)
 #if BAL_WRITE
     __shared__ u32 rec_e[2][BCHUNK];                 // 1.4 KB: emission slots of the staged chunk, two chunks alive (the balanced write-out
                                                      // of chunk k reads them while faster waves already publish chunk k+1)
@@ -330,9 +339,15 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     struct Raw { float4 q0, q1, q2; u32 io, blk; u64 kp; };   // conic+opacity | x y r g | b z rect | record offset (in its block) | block | tile mask
     // id (x) and 4x4-block reach mask (y, as the forward staged it) of this thread's slot in the chunk of a tile's list that ends at hi_
-    auto fetch_id = [&](u32 rx_, u32 hi_) -> uint2 {
+    auto fetch_id = [&](u32 rx_, u32 hi_, u32& pos_) -> uint2 {
         const u32 c_ = min(hi_, (u32)BCHUNK);
+        pos_ = 0u;
         if ((u32)tid >= c_) return make_uint2(0xFFFFFFFFu, 0u);
+        if (COMPACT) {                                   // entry (hi_ - c_) + tid of the compacted list -> its position -> id, reach word
+            pos_ = cposp[(hi_ - c_) + tid];
+            const u32 info = reinterpret_cast<const u32*>(reach_mask + (size_t)rx_ * 8u)[pos_];
+            return make_uint2(point_list[rx_ + pos_], info & 0xFFFFu);
+        }
         const u32 at = rx_ + (hi_ - c_) + tid;
         // the reach masks of a tile sit at byte rm_stride * (tile's first instance): inside the tile's own slice of the (dead)
         // unsorted words on the tile-binned path (stride 8), plainly per instance on the radix path (stride 2)
@@ -374,7 +389,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         const u32 base_ = inst_off ? 0u : block_base[rw.blk];
         return emission_slot(base_ + rw.io, make_uint2(__float_as_uint(rw.q2.z), __float_as_uint(rw.q2.w)), rw.kp, t.tx, t.ty);
     };
-    auto make_rec = [&](const Raw& rw, const u32 e_, const u32 mask_, const TileRef& t, u32 lo_, u32 cnt_) {
+    auto make_rec = [&](const Raw& rw, const u32 e_, const u32 mask_, const TileRef& t, u32 lo_, u32 cnt_, const u32 pos_) {
         ChunkRec rec; rec.mask = 0; rec.e = 0;
         rec.x = rec.y = rec.ap = rec.bp = rec.cp = rec.o = rec.r = rec.g = rec.b = 0.f; rec.pos = 0;
         if ((u32)tid < cnt_) {
@@ -384,7 +399,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
             rec.x = c2.x; rec.y = c2.y;
             rec.ap = -0.5f * LOG2E * co.x; rec.bp = -LOG2E * co.y; rec.cp = -0.5f * LOG2E * co.z; rec.o = co.w;
             rec.r = cz.x; rec.g = cz.y; rec.b = cz.z;
-            rec.pos = lo_ + tid + 1;
+            rec.pos = (COMPACT ? pos_ : lo_ + tid) + 1;
 #ifdef BWD_OWN_MASKS
             rec.mask = block_mask16(c2.x, c2.y, co.x, co.y, co.z, co.w, (float)(t.tx * BAGS_TILE), (float)(t.ty * BAGS_TILE));
 #else
@@ -423,7 +438,21 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
             for (int d = 8; d >= 1; d >>= 1) m = max(m, (u32)__shfl_xor((int)m, d));   // 16 consecutive threads = one block
             if ((tid & 15) == 0) blk_maxc[b] = m;
         }
-        for (u32 p = t.maxc + tid; p < t.n; p += 256) {
+        // zero records for the record-holding instances no chunk will visit: those at or behind the deepest contributor.
+        // COMPACT: first the staged ones (compacted entries hi0 .. n_live), then, below, the positions the forward never staged
+        if (COMPACT) {
+            for (u32 k = hi0 + tid; k < n_live; k += 256) {
+                const u32 g = point_list[t.rx + cposp[k]];
+                const float4 t2 = g2d[4 * (size_t)g + 2], t3 = g2d[4 * (size_t)g + 3];
+                const u32 io = block_base[__float_as_uint(t3.y)] + __float_as_uint(t3.z);
+                const u32 e = emission_slot(io, make_uint2(__float_as_uint(t2.z), __float_as_uint(t2.w)),
+                                            (u64)__float_as_uint(t3.x) | ((u64)__float_as_uint(t3.w) << 32), t.tx, t.ty);
+                float4* dst = reinterpret_cast<float4*>(partials + (size_t)e * PART_FLOATS);
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                dst[0] = z4; dst[1] = z4; dst[2] = z4;
+            }
+        }
+        for (u32 p = (COMPACT ? n_staged : t.maxc) + tid; p < t.n; p += 256) {
             // (the forward stops staging once every pixel of the tile has finished: these instances may have no reach word)
             const u32 g = point_list[t.rx + p];
             const float4 t2 = g2d[4 * (size_t)g + 2], t3 = g2d[4 * (size_t)g + 3];
@@ -441,10 +470,11 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     // The tile's descriptor carries its deepest contributor (from the forward), so the ids of the first two chunks are
     // requested before anything else and the pixel loads of tile_begin overlap them: the per-tile dependent chain is
     // descriptor -> ids -> gathers.
-    const uint2 gid0 = fetch_id(A.rx, A.maxc);
-    uint2 gid1 = (A.maxc > BCHUNK) ? fetch_id(A.rx, A.maxc - BCHUNK) : make_uint2(0xFFFFFFFFu, 0u);      // ids of chunk 1, in flight with chunk 0's
+    u32 gid0p, gid1p = 0u;                                   // (COMPACT: list positions of the fetched ids)
+    const uint2 gid0 = fetch_id(A.rx, hi0, gid0p);
+    uint2 gid1 = (hi0 > BCHUNK) ? fetch_id(A.rx, hi0 - BCHUNK, gid1p) : make_uint2(0xFFFFFFFFu, 0u);      // ids of chunk 1, in flight with chunk 0's
     tile_begin(A);
-    if (A.maxc == 0) return;                                 // nothing contributed anywhere in the tile: all records are zero
+    if (hi0 == 0) return;                                    // nothing contributed anywhere in the tile: all records are zero
     if (tid < BCHUNK) {
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -463,9 +493,9 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     ChunkRec rec;
     {
         const Raw raw0 = fetch(gid0.x);
-        rec = make_rec(raw0, slot_of(raw0, gid0.x != 0xFFFFFFFFu, A), gid0.y, A, A.maxc - min(A.maxc, (u32)BCHUNK), min(A.maxc, (u32)BCHUNK));
+        rec = make_rec(raw0, slot_of(raw0, gid0.x != 0xFFFFFFFFu, A), gid0.y, A, hi0 - min(hi0, (u32)BCHUNK), min(hi0, (u32)BCHUNK), gid0p);
     }
-    asm volatile("" :: "v"(gid1.x), "v"(gid1.y));    // complete before the loop: a pending load on the entry edge costs a vmcnt(0) at every loop top
+    asm volatile("" :: "v"(gid1.x), "v"(gid1.y), "v"(gid1p));    // complete before the loop: a pending load on the entry edge costs a vmcnt(0) at every loop top
 
     const int row = lane >> 4, li = lane & 15;
     const int qx = (wave & 1) * 2, qy = (wave >> 1) * 2;
@@ -478,12 +508,13 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
 #if BAL_WRITE
     u32 par = 0;                                             // chunk parity (rec_e buffer)
 #endif
-    for (u32 hi = A.maxc;;) {
+    for (u32 hi = hi0;;) {
         const u32 cnt = min(hi, (u32)BCHUNK);
         const u32 lo = hi - cnt;
         // ---- publish the staged chunk [lo, hi) of tile A: slot s <-> list position lo + s (front to back)
         if (tid < BCHUNK) {                                  // safe without a barrier: after the previous chunk's second barrier nobody reads them
             recs[tid] = rec; masks[tid] = rec.mask;
+            if (COMPACT) chunk_pos[tid] = rec.pos - 1u;
 #if BAL_WRITE
             rec_e[par][tid] = rec.e;
 #endif
@@ -493,7 +524,8 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         __builtin_amdgcn_s_setprio(PRIO_GROUPS);
         const u32 nx_cnt = min(lo, (u32)BCHUNK), nx_lo = lo - nx_cnt;                  // chunk k+1 = [nx_lo, lo)
         Raw raw_n = fetch(lo > 0 ? gid1.x : 0xFFFFFFFFu);                           // gathers of chunk k+1
-        const uint2 gid2 = (nx_lo > 0) ? fetch_id(A.rx, nx_lo) : make_uint2(0xFFFFFFFFu, 0u);   // ids of chunk k+2
+        u32 gid2p = 0u;
+        const uint2 gid2 = (nx_lo > 0) ? fetch_id(A.rx, nx_lo, gid2p) : make_uint2(0xFFFFFFFFu, 0u);   // ids of chunk k+2
 
         // The per-(splat, block) work: one block row (4 pixels = two packed pairs) per step; four independent scan chains
         // interleave without pipeline bubbles.  `s` is the lane's splat, (bx0, by0) its block origin, pixb its block's
@@ -673,7 +705,9 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
 #pragma unroll
             for (int r = 0; r < (BCHUNK + 63) / 64; ++r) {
                 const int slot = r * 64 + lane;
-                const bool hit = ((mreg[r] >> blk) & 1u) && (lo + (u32)slot < bmax);   // pos = lo + slot + 1
+                // pos = lo + slot + 1, or the compacted entry's own position
+                const u32 posv = COMPACT ? (slot < BCHUNK ? chunk_pos[slot] : 0xFFFFFFFFu) : lo + (u32)slot;
+                const bool hit = ((mreg[r] >> blk) & 1u) && (posv < bmax);
                 const u64 bal = __ballot(hit);
                 if (hit) lists[blk][L + __popcll(bal & lt_mask)] = (unsigned char)slot;
                 L += __popcll(bal);
@@ -741,9 +775,9 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         // and exposes the whole gather latency once per chunk (seen in the ISA; 20 % of the wave time).  Touching gid2
         // here also retires the id load before this chunk's record stores are issued, so the top of the next chunk
         // does not have to drain the stores to be sure the id has arrived.
-        asm volatile("" :: "v"(raw_n.q2.y), "v"(gid2.x), "v"(gid2.y), "v"(e_n));
-        if (lo > 0) rec = make_rec(raw_n, e_n, gid1.y, A, nx_lo, nx_cnt);
-        gid1 = gid2;
+        asm volatile("" :: "v"(raw_n.q2.y), "v"(gid2.x), "v"(gid2.y), "v"(e_n), "v"(gid2p));
+        if (lo > 0) rec = make_rec(raw_n, e_n, gid1.y, A, nx_lo, nx_cnt, gid1p);
+        gid1 = gid2; gid1p = gid2p;
         PH_MARK(1);
         // ---- one record per staged instance: the four wave copies added in fixed order.  The record holds the raw sums (sum q
         // rather than sum q / o, the abs sums on the scaled conic): preprocess_bwd applies the per-Gaussian factors once.
@@ -821,14 +855,15 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     const int T = gx * gy;
     if (T == 0) return hipSuccess;
     const int grid = cdiv(T, TILE_RUN) * TILE_RUN;
-    if (want_abs)
-        hipLaunchKernelGGL(blend_bwd_scan_kernel<true>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
-                           im.tile_desc, b.point_list, reinterpret_cast<const unsigned char*>(b.reach_mask), binned ? 8u : 2u, g.g2d, binned ? nullptr : g.inst_off, g.block_base, s.bg,
-                           im.final_T, im.n_contrib, grad_color, partials, zero_words, n_zero, (binned && s.tile_bounds != BAGS_TILES_OPACITY) ? 1 : 0);
-    else
-        hipLaunchKernelGGL(blend_bwd_scan_kernel<false>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
-                           im.tile_desc, b.point_list, reinterpret_cast<const unsigned char*>(b.reach_mask), binned ? 8u : 2u, g.g2d, binned ? nullptr : g.inst_off, g.block_base, s.bg,
-                           im.final_T, im.n_contrib, grad_color, partials, zero_words, n_zero, (binned && s.tile_bounds != BAGS_TILES_OPACITY) ? 1 : 0);
+    const bool compact = binned && s.tile_bounds != BAGS_TILES_OPACITY;
+#define BWD_LAUNCH(ABS_, CMP_)                                                                                                       \
+    hipLaunchKernelGGL((blend_bwd_scan_kernel<ABS_, CMP_>), dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,     \
+                       im.tile_desc, b.point_list, reinterpret_cast<const unsigned char*>(b.reach_mask), binned ? 8u : 2u, g.g2d,    \
+                       binned ? nullptr : g.inst_off, g.block_base, s.bg, im.final_T, im.n_contrib, grad_color, partials, zero_words, \
+                       n_zero, compact ? 1 : 0, im.tile_aux)
+    if (want_abs) { if (compact) BWD_LAUNCH(true, true); else BWD_LAUNCH(true, false); }
+    else          { if (compact) BWD_LAUNCH(false, true); else BWD_LAUNCH(false, false); }
+#undef BWD_LAUNCH
     return hipGetLastError();
 }
 
@@ -875,7 +910,8 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
                       const u64* __restrict__ words_in, u64* __restrict__ sort_scratch,
                       unsigned char* __restrict__ reach_mask, const u32 rm_stride, const float4* __restrict__ g2d, const float* __restrict__ bg, float* __restrict__ out_color,
                       float* __restrict__ out_depth, float* __restrict__ out_weights, float* __restrict__ final_T,
-                      u32* __restrict__ n_contrib, const u32* __restrict__ n_dev, u32 capacity, const int test_keep)
+                      u32* __restrict__ n_contrib, const u32* __restrict__ n_dev, u32 capacity, const int test_keep,
+                      uint4* __restrict__ tile_aux)
 {
     const int dslot = slot_of_vblock(blockIdx.x);            // heavy tiles first, balanced over the XCDs
     if (dslot >= T) return;
@@ -909,6 +945,14 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
     list_t* const lists = reinterpret_cast<list_t*>(lds_raw + LDS_LISTS);
     u32* const masks = reinterpret_cast<u32*>(lds_raw + LDS_MASKS);
     __shared__ int s_live[4];
+    __shared__ u32 s_cnt[4];                                 // stock tile rule: record-holding instances staged by each wave (this chunk)
+    // Stock tile rule on the tile-binned path (test_keep): 40 % of the list positions hold instances without a gradient record.
+    // The backward stages its chunks from a COMPACTED list of the record-holding positions, written here as they are staged
+    // (u32 positions in the upper half of the tile's own slice of the words, behind the n reach words), so that its 176-slot
+    // chunks hold 176 live splats (62 k instead of 93 k wave-chunks on config 3).  tile_aux[slot] = {compact entries in front of
+    // the deepest contributor, compact entries, list positions staged, -}.
+    u32 n_live_run = 0, n_staged = 0;
+    u32* const cpos = reinterpret_cast<u32*>(reach_mask + (size_t)range.x * 8u) + n;
     const u32* ids_lds = nullptr;                            // sorted ids of the whole list in LDS (short lists sorted here)
 #if FWD_SORT
     if (words_in != nullptr && n > 0) {
@@ -960,7 +1004,7 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
         if (!(s_live[0] | s_live[1] | s_live[2] | s_live[3])) break;
         const u32 cnt = min((u32)FWD_STAGE, n - base);
         SplatRec rec; rec.mask = 0; rec.x = rec.y = rec.ap = rec.bp = rec.cp = rec.o = rec.r = rec.g = rec.b = rec.z = 0.f; rec.pos = 0;
-        bool ill = false;
+        bool ill = false, live_rec = false;
         if ((u32)tid < cnt) {
             const u32 g = ids_lds ? ids_lds[base + tid]
                         : (FWD_SORT && words_in) ? __hip_atomic_load(&point_list[range.x + base + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -988,8 +1032,12 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
             if (rm_stride == 8u) reinterpret_cast<u32*>(reach_mask + (size_t)range.x * 8u)[base + tid] = rec.mask | (has_rec ? 0x10000u : 0u);
             else reinterpret_cast<unsigned short*>(reach_mask + (size_t)range.x * 2u)[base + tid] = (unsigned short)rec.mask;
             ill = conic_ill_conditioned(co.x, co.y, co.z);
+            live_rec = has_rec;
         }
         needle |= (__ballot(ill) != 0ull);                   // (a scalar register, not a lane's)
+        const u64 rec_b = __ballot(live_rec);
+        if (test_keep && lane == 0) s_cnt[wave] = (u32)__popcll(rec_b);
+        n_staged = base + cnt;
         if (tid < CHUNK) { recs[tid] = rec; masks[tid] = rec.mask; }
 #if FWD_SENTINEL
         // this wave's four lists (rows qb, qb+1 | qb+4, qb+5: two runs of 2 x CHUNK bytes) start out as all-sentinel: a row
@@ -1004,6 +1052,12 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
         }
 #endif
         __syncthreads();
+        if (test_keep) {                                     // the chunk's record-holding positions, compacted in list order
+            const u32 c0 = s_cnt[0], c1 = s_cnt[1], c2_ = s_cnt[2], c3 = s_cnt[3];
+            const u32 before = (wave > 0 ? c0 : 0u) + (wave > 1 ? c1 : 0u) + (wave > 2 ? c2_ : 0u);
+            if (live_rec) cpos[n_live_run + before + (u32)__popcll(rec_b & lt_mask)] = base + (u32)tid;
+            n_live_run += c0 + c1 + c2_ + c3;
+        }
         if (live_b == 0ull) continue;                        // this quadrant is finished; keep pace at the barriers
         // ---- per-row lists (rows whose 16 pixels are all done take nothing)
         int L0 = 0, L1 = 0, L2 = 0, L3 = 0;
@@ -1169,9 +1223,22 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
     __syncthreads();
     // bit 31: some pixel of the tile did not walk its whole list (the backward then needs its `pos <= n_contrib` test);
     // bit 30: some staged splat has an ill-conditioned conic (the backward then keeps its `power <= 0` test)
-    if (tid == 0) {
-        const u32 w0 = (u32)s_live[0], w1 = (u32)s_live[1], w2 = (u32)s_live[2], w3 = (u32)s_live[3];
-        tile_desc[dslot].w = max(max(w0 & 0x3FFFFFFFu, w1 & 0x3FFFFFFFu), max(w2 & 0x3FFFFFFFu, w3 & 0x3FFFFFFFu)) | ((w0 | w1 | w2 | w3) & 0xC0000000u);
+    const u32 w0 = (u32)s_live[0], w1 = (u32)s_live[1], w2 = (u32)s_live[2], w3 = (u32)s_live[3];
+    const u32 maxc_all = max(max(w0 & 0x3FFFFFFFu, w1 & 0x3FFFFFFFu), max(w2 & 0x3FFFFFFFu, w3 & 0x3FFFFFFFu));
+    if (tid == 0) tile_desc[dslot].w = maxc_all | ((w0 | w1 | w2 | w3) & 0xC0000000u);
+    if (test_keep) {
+        // compact entries in front of the deepest contributor (positions < maxc: the backward's chunks start there); the
+        // positions were stored by this workgroup (waited for below) and are read back at agent scope
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        u32 c = 0;
+        for (u32 k = (u32)tid; k < n_live_run; k += 256u)
+            c += (__hip_atomic_load(&cpos[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < maxc_all) ? 1u : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c += (u32)__shfl_xor((int)c, d);
+        if (lane == 0) s_cnt[wave] = c;
+        __syncthreads();
+        if (tid == 0) tile_aux[dslot] = make_uint4(s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3], n_live_run, n_staged, 0u);
     }
 #ifdef DIAG_PAIRS
     diag_pairs_flush(2, dg_eval, dg_con);
@@ -1188,7 +1255,7 @@ hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinV
     hipLaunchKernelGGL(blend_fwd_rows_kernel<0>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
                        im.tile_desc, b.point_list, (FWD_SORT && sort_here) ? b.words : nullptr, b.scratch,
                        reinterpret_cast<unsigned char*>(b.reach_mask), b.words ? 8u : 2u, g.g2d, s.bg, out.color, out.depth, out.weights,
-                       im.final_T, im.n_contrib, n_dev, capacity, (b.words && s.tile_bounds != BAGS_TILES_OPACITY) ? 1 : 0);
+                       im.final_T, im.n_contrib, n_dev, capacity, (b.words && s.tile_bounds != BAGS_TILES_OPACITY) ? 1 : 0, im.tile_aux);
     return hipGetLastError();
 }
 

@@ -787,8 +787,10 @@ def test_binning_paths_agree_on_random_scenes():
                     # stock tile rule: the tile-binned path keeps gradient records only for the tiles the opacity rule reaches
                     # (the others are exact zeros on the radix path), so a Gaussian with more than 64 records has them dealt to
                     # the lanes of its wave-cooperative sum differently: equal to summation order, not bit for bit
-                    # (measured: <= 2.2e-6, and 1.5e-4 for dL/dscales of the needle scenes, whose sums cancel by four digits)
-                    assert rel_err(g_a[k], g_r[k]) <= (5e-4 if trial % 3 == 1 else 2e-5), (k, tag, rel_err(g_a[k], g_r[k]))
+                    # (and the backward's chunks hold other splats: compacted record holders against consecutive list positions).
+                    # Measured: <= 2.2e-6; 8e-4 for dL/dscales of the needle scenes, whose sums cancel by four digits (fp32 itself
+                    # is good to ~1e-2 there: test_extreme_inputs_match_oracle[needle])
+                    assert rel_err(g_a[k], g_r[k]) <= (3e-3 if trial % 3 == 1 else 2e-5), (k, tag, rel_err(g_a[k], g_r[k]))
 
 
 @pytest.mark.parametrize("P,shrink,flat", [(3000, 0.04, False), (20000, 0.02, False), (40000, 0.012, False),
