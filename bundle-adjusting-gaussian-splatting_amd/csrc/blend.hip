@@ -1084,8 +1084,26 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
         // and with the sentinel a row past the end of its list needs no test (it composites the zero record).
         const list_t* mylist = &lists[blk * CHUNK];
         static_assert(sizeof(SplatRec) == 48, "record stride is spelled out in the instruction below");
+#ifndef FWD_NARROW
+#define FWD_NARROW 1          // the walk reads 40 of a record's 48 bytes (b128 + b128 + b64): the list position of the last contributor
+#endif                        // is derived from the record's byte offset once per chunk instead of being read with every record
+#if FWD_NARROW
+        struct SplatW { float x, y, ap, cp, bp, o, r, g, b, z; u32 pos; };      // pos: the record's byte offset in `recs`
+        auto load = [&](u32 roff) {
+            const char* p = reinterpret_cast<const char*>(recs) + roff;
+            const float4 a = *reinterpret_cast<const float4*>(p), b4 = *reinterpret_cast<const float4*>(p + 16);
+            const float2 c = *reinterpret_cast<const float2*>(p + 32);
+            SplatW w; w.x = a.x; w.y = a.y; w.ap = a.z; w.cp = a.w; w.bp = b4.x; w.o = b4.y; w.r = b4.z; w.g = b4.w; w.b = c.x; w.z = c.y; w.pos = roff;
+            return w;
+        };
+        u32 last_off = 0xFFFFFFFFu;                          // byte offset of the record of this chunk's last contributor (per pixel)
+#define LAST_VAR last_off
+#else
+        typedef SplatRec SplatW;
         auto load = [&](u32 roff) { return *reinterpret_cast<const SplatRec*>(reinterpret_cast<const char*>(recs) + roff); };
-        auto step = [&](int i, const SplatRec& s) {
+#define LAST_VAR last
+#endif
+        auto step = [&](int i, const SplatW& s) {
             const bool act = FWD_SENTINEL ? true : (i < Lrow);
 #if FWD_PK
             // pair_power2 with its two independent first products packed: the same roundings in the same order
@@ -1121,7 +1139,7 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
                     "v_fmac_f32 %[dq], %[t1], %[z]\n\t"
                     "v_mov_b32 %[last], %[pos]\n\t"
                     "s_mov_b64 exec, -1"
-                    : [T] "+v"(Tq), [cr] "+v"(Cr), [cg] "+v"(Cg), [cb] "+v"(Cb), [dq] "+v"(Dq), [last] "+v"(last),
+                    : [T] "+v"(Tq), [cr] "+v"(Cr), [cg] "+v"(Cg), [cb] "+v"(Cb), [dq] "+v"(Dq), [last] "+v"(LAST_VAR),
                       [t0] "=&v"(t0), [t1] "=&v"(t1)
                     : [p2] "v"(p2), [al] "v"(alpha), [r] "v"(s.r), [g] "v"(s.g), [b] "v"(s.b), [z] "v"(s.z), [pos] "v"(s.pos)
                     : "vcc");
@@ -1141,7 +1159,7 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
                     Cr = __fmaf_rn(w, s.r, Cr); Cg = __fmaf_rn(w, s.g, Cg); Cb = __fmaf_rn(w, s.b, Cb);
                     Dq = __fmaf_rn(w, s.z, Dq);
                     Tq = test_T;
-                    last = s.pos;
+                    LAST_VAR = s.pos;
                 }
             }
 #endif
@@ -1164,10 +1182,10 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
         // dropping that read (timing experiment) bought 9 % -- latency, not bandwidth.  sched_barrier pins the issue points.
         u32 ra, rb;
         addr2((u32)mypairs[0], ra, rb);
-        SplatRec S0 = load(ra);
+        SplatW S0 = load(ra);
         u32 two = (u32)mypairs[1];                           // entries 2, 3 (reads run up to 5 entries past Lmax: see the padding)
         for (int i = 0; i < Lmax; i += 2) {
-            const SplatRec S1 = load(rb);
+            const SplatW S1 = load(rb);
             u32 ra2, rb2;
             addr2(two, ra2, rb2);
             u32 nxt = (u32)mypairs[(i >> 1) + 2];
@@ -1199,6 +1217,11 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
             step(i, load(roff));
         }
 #endif
+#if FWD_NARROW
+        // record offset -> slot (/ 48: x 43691 >> 21, exact below 2^17 slots) -> 1-based list position
+        if (last_off != 0xFFFFFFFFu) last = base + ((last_off * 43691u) >> 21) + 1u;
+#endif
+#undef LAST_VAR
     }
     const bool stopped = Tq < 0.f;                           // stopped early (T would fall below 1e-4) or outside the image
     Tq = fabsf(Tq);
