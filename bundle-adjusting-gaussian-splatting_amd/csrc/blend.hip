@@ -54,6 +54,9 @@
 #define NC_SKIP 1           // tiles where no pixel stopped early (flag from the forward) skip the `pos <= n_contrib` test
 #endif
 #define PQ (TF_FOLD ? 3 : 4)                 // float4s per pixel pair in LDS
+#ifndef PIX_NARROW
+#define PIX_NARROW 1        // pixel pair = [g0A g0B g1A g1B] [g2A g2B AcA AcB] [RcA RcB ncA ncB]: the row loop of tiles without an early stop
+#endif                      // does not need nc, so its third read is 8 bytes (80 instead of 96 bytes per lane and row step)
 // round-4 knobs
 #ifndef BAL_WRITE
 #define BAL_WRITE 0         // (measured twice on one device: 0.3509 = 0.3509 and 0.3459 -> 0.3420 ms without it; kept as a knob) the record sums of a chunk (four wave copies -> one 48-B record) spread over all 256 threads, one float4
@@ -193,6 +196,7 @@ struct __attribute__((aligned(16))) ChunkRec {
 };
 // per pixel PAIR (two horizontally adjacent pixels A,B of one block row), PQ float4s:
 //   TF_FOLD: [g0A g0B g1A g1B] [g2A g2B ncA ncB] [AcA AcB RcA RcB]                 (Ac starts at 1 / T_final)
+//   + PIX_NARROW: [g0A g0B g1A g1B] [g2A g2B AcA AcB] [RcA RcB ncA ncB]
 //   else:    [g0A g0B g1A g1B] [g2A g2B TfA TfB] [ -    -   ncA ncB] [AcA AcB RcA RcB]     (Ac, Rc: carries behind the group)
 
 // blocks of the tile a splat can reach with alpha >= 1/255 (conservative; exactness comes from the per-pixel test).
@@ -427,8 +431,13 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
             float* pp = reinterpret_cast<float*>(&pixq[tid >> 4][((tid >> 1) & 7) * PQ]);
             const int h = tid & 1;                        // A or B of the pair
 #if TF_FOLD
+#if PIX_NARROW
+            pp[0 + h] = g0; pp[2 + h] = g1; pp[4 + h] = g2; pp[6 + h] = 1.0f / Tf;   // T_final >= 1e-6: a pixel stops before T falls below 1e-4 and alpha <= 0.99
+            pp[8 + h] = bgg; pp[10 + h] = __uint_as_float(nc);
+#else
             pp[0 + h] = g0; pp[2 + h] = g1; pp[4 + h] = g2; pp[6 + h] = __uint_as_float(nc);
             pp[8 + h] = 1.0f / Tf; pp[10 + h] = bgg;      // T_final >= 1e-6: a pixel stops before T falls below 1e-4 and alpha <= 0.99
+#endif
 #else
             pp[0 + h] = g0; pp[2 + h] = g1; pp[4 + h] = g2; pp[6 + h] = Tf;
             pp[8 + h] = 0.f; pp[10 + h] = __uint_as_float(nc); pp[12 + h] = 1.f; pp[14 + h] = bgg;
@@ -551,7 +560,12 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
             for (int iy = 0; iy < 4; ++iy) {
                 float4* P0 = pixb + iy * 2 * PQ;
                 float4* P1 = P0 + PQ;
-#if TF_FOLD
+#if TF_FOLD && PIX_NARROW
+                const float4 q00 = P0[0], q01 = P0[1], q02 = P0[2];       // q*1.zw: carry of prod (1 - alpha); q*2 = Rc Rc nc nc
+                const float4 q10 = P1[0], q11 = P1[1], q12 = P1[2];
+                const u32 nc0 = __float_as_uint(q02.z), nc1 = __float_as_uint(q02.w), nc2 = __float_as_uint(q12.z), nc3 = __float_as_uint(q12.w);
+                const float4 q03 = make_float4(q01.z, q01.w, q02.x, q02.y), q13 = make_float4(q11.z, q11.w, q12.x, q12.y);   // (Ac Ac Rc Rc)
+#elif TF_FOLD
                 const float4 q00 = P0[0], q01 = P0[1], q03 = P0[2];
                 const float4 q10 = P1[0], q11 = P1[1], q13 = P1[2];
                 const u32 nc0 = __float_as_uint(q01.z), nc1 = __float_as_uint(q01.w), nc2 = __float_as_uint(q11.z), nc3 = __float_as_uint(q11.w);
@@ -621,8 +635,13 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                 float R0 = q03.z, R1 = q03.w, R2 = q13.z, R3 = q13.w;
                 shift_up16x4(R0, R1, R2, R3, Va.x, Va.y, Vb.x, Vb.y);     // (pinned like the scan: same instruction count, same time)
                 if (carry) {                                            // carries for the next (shallower) group
+#if TF_FOLD && PIX_NARROW
+                    reinterpret_cast<float2*>(P0 + 1)[1] = make_float2(Ba.x, Ba.y); reinterpret_cast<float2*>(P0 + 2)[0] = make_float2(Va.x, Va.y);
+                    reinterpret_cast<float2*>(P1 + 1)[1] = make_float2(Bb.x, Bb.y); reinterpret_cast<float2*>(P1 + 2)[0] = make_float2(Vb.x, Vb.y);
+#else
                     P0[PQ - 1] = make_float4(Ba.x, Ba.y, Va.x, Va.y);
                     P1[PQ - 1] = make_float4(Bb.x, Bb.y, Vb.x, Vb.y);
+#endif
                 }
                 const f2 dLa = Tna * (sda - (f2){R0, R1});
                 const f2 dLb = Tnb * (sdb - (f2){R2, R3});
