@@ -161,19 +161,23 @@ int bags_forward_prepare(const BagsSettings*, const BagsInputs*, const BagsState
 int bags_forward_finish(const BagsSettings*, const BagsInputs*, const BagsState*, const BagsForwardOut*,
                         int64_t num_rendered, void* stream);
 /* Forward without a host round trip in the middle (speculative instance capacity).
- *   1. bags_forward_prepare_async: phase 1 as above, but instead of synchronising it delivers the instance count
- *      asynchronously into *host_num_rendered (caller-owned PINNED host word: written by the counting kernel itself when
- *      the word is device-mapped, as hipHostMalloc / torch pinned memory is, otherwise by an enqueued copy).  The caller
- *      records an event here.
+ *   1. bags_forward_prepare_async: phase 1 as above, without the synchronisation.  *host_num_rendered is a caller-owned
+ *      PINNED host word (hipHostMalloc / torch pinned memory: device-mapped) that will receive the instance count; set it to a
+ *      sentinel (e.g. 0xFFFFFFFF) before the call.
  *   2. bags_forward_finish_speculative: phase 2 enqueued immediately, sized for a caller-guessed upper bound `capacity`
  *      (e.g. 1.2 x the previous frame's count; state.binning holds bags_binning_size(capacity, W, H) bytes); the
- *      kernels read the true count on the device and clamp it to `capacity`.
- *   3. The caller waits for the event of step 1 -- right away (the GPU is already busy with step 2) or as late as the
- *      entry of bags_backward (no host wait inside the forward at all: what lets the views of a batch be enqueued on
- *      several streams back to back) -- and compares: if *host_num_rendered > capacity the outputs are invalid (every tile
- *      was rendered empty) and phase 2 must be redone with bags_forward_finish on a larger buffer (phase 1 results in
- *      state.geom stay valid).  When it fits, bags_backward takes the true count as num_rendered and `capacity` as
- *      binning_capacity. */
+ *      kernels read the true count on the device and render every tile empty if it exceeds `capacity`.
+ *      WHEN THE COUNT ARRIVES (ABI 5): on the tile-binned path no launch of phase 1 computes it any more -- the first launch
+ *      of THIS call does (tile ranges, count and block bases are formed inside the emission launch) and stores it into the
+ *      pinned word at system scope, a few tens of microseconds into phase 2.  On the radix path, for P == 0, or when the
+ *      word is not device-mapped, step 1 delivers it by an enqueued copy as before.  Either way: the word holds the count
+ *      no later than the end of step 2; a caller that needs the count BEFORE it enqueues phase 2 uses bags_forward_prepare.
+ *   3. The caller polls the word (or waits for an event recorded behind step 2) -- right away, while the GPU is busy with
+ *      phase 2, or as late as the entry of bags_backward -- and compares: if the count exceeds `capacity` the outputs are
+ *      invalid (every tile was rendered empty) and phase 2 must be redone with bags_forward_finish on a buffer of
+ *      bags_binning_size(count, W, H) bytes (phase 1 results in state.geom stay valid; that exact re-run does not touch the
+ *      pinned word again, so the word may be reused for another call as soon as it has been read).  When it fits,
+ *      bags_backward takes the true count as num_rendered and `capacity` as binning_capacity. */
 int bags_forward_prepare_async(const BagsSettings*, const BagsInputs*, const BagsState*, const BagsForwardOut*,
                                uint32_t* host_num_rendered, void* stream);
 int bags_forward_finish_speculative(const BagsSettings*, const BagsInputs*, const BagsState*, const BagsForwardOut*,
