@@ -437,6 +437,9 @@ def main():
     # "exchange" is the bucket alone), same parameters, same timed-region rules
     v4 = None
     if not args.no_v4_leg and V != 4:
+        # views 2-4 add their Gaussian gradients into the first view's inside the backward kernel (rasterizer.ACCUMULATE_IN_PLACE,
+        # an opt-in of the operator: BagsBackwardArgs.accumulate) instead of through one autograd add pass per tensor and view
+        R.ACCUMULATE_IN_PLACE = not args.bucket_always
         fs4, fin4, exch4, ev4, _ = make_leg(4, leaves=params, overlap=args.overlap)
         for _ in range(max(3, min(20, args.settle_steps // 4))):
             fs4()
@@ -448,7 +451,10 @@ def main():
         v4 = {"views_per_rank_per_exchange": 4, "steps": k4, "ms_per_step": el4 / k4 * 1e3, "ms_per_view": el4 / k4 / 4 * 1e3,
               "value": world * 4 * P * k4 / el4,
               "exchange_ms": (sum(a.elapsed_time(b) for a, b in ev4) / len(ev4)) if ev4 else 0.0,
-              "note": "four views per rank (fwd+bwd; the first view's gradient buffer is adopted as the accumulator, --bucket-always: the flat bucket) behind one exchange"}
+              "accumulate_in_place": bool(R.ACCUMULATE_IN_PLACE),
+              "note": "four views per rank (fwd+bwd; the first view's gradient buffer is adopted as the accumulator and views 2-4 add "
+                      "into it inside the backward kernel; --bucket-always: the flat bucket and autograd's add passes) behind one exchange"}
+        R.ACCUMULATE_IN_PLACE = False
     def settle(fn, n):
         for _ in range(n):
             fn()

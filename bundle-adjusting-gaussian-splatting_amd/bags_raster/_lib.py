@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # tests).  Not a fallback: a missing file still raises.
 LIB_PATH = os.environ.get("BAGS_RASTER_LIB") or os.path.join(_HERE, "libbags_raster.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 TILES_AABB, TILES_OPACITY = 0, 1
 DEPTH_Z, DEPTH_DISTANCE = 0, 1
 BINNING_AUTO, BINNING_RADIX = 0, 1
@@ -49,7 +49,7 @@ class BagsBackwardArgs(C.Structure):
                 ("grad_colors_precomp", c_fp), ("grad_opacities", c_fp), ("grad_scales", c_fp), ("grad_rotations", c_fp),
                 ("grad_cov3D_precomp", c_fp), ("grad_viewmatrix", c_fp), ("grad_projmatrix", c_fp),
                 ("grad_intrinsic", c_fp), ("grad_campos", c_fp), ("grad_shift_factors", c_fp),
-                ("binning_capacity", C.c_int64)]
+                ("binning_capacity", C.c_int64), ("accumulate", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class BagsDebugViews(C.Structure):

@@ -185,6 +185,12 @@ SPECULATE = True
 #              never differentiated reports an overflow as a RuntimeWarning when its count is collected.
 HOST_WAIT = "forward"
 LAZY_RECOVER = False
+# Opt-in for loops that differentiate several views of one step into the same parameters (view sharding, the reference's cubemap
+# step renders five per iteration, utils/cubemap_utils.py:229,263-265): when every Gaussian-parameter input of the op is a leaf
+# that already HOLDS a gradient (contiguous fp32 of its own shape), the backward adds into those tensors itself
+# (BagsBackwardArgs.accumulate) and hands autograd None for them -- no flat buffer, no add pass per tensor and view.  The sums are
+# what autograd's own accumulation gives; tensor hooks on those parameters do not see the per-view gradients.
+ACCUMULATE_IN_PLACE = False
 CAPACITY_HEADROOM = 4.0      # lazy forwards only; a waiting forward sizes for 1.2 x the largest count seen and redoes on overflow
 _HINT_KEYS_MAX = 64
 _capacity_hint = {}          # (device index, P, W, H) -> largest instance count seen for the shape (a hint only); insertion order = LRU
@@ -428,6 +434,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             fw, outs = _run_forward(lib, pk, int(raster_settings.image_height), int(raster_settings.image_width),
                                     lazy=any(ctx.needs_input_grad))
         ctx.fw = fw
+        # (weak: the op must not keep the caller's parameters alive; only used by ACCUMULATE_IN_PLACE)
+        ctx.leaves = tuple(None if t is None else weakref.ref(t) for t in
+                           (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp))
         ctx.shapes = dict(sh=None if sh is None else sh.shape, opac=opacities.shape, campos=campos.shape)
         color, radii, depth, weights, mean2D = outs
         ctx.mark_non_differentiable(radii, depth, weights, mean2D)
@@ -460,14 +469,33 @@ class _RasterizeGaussians(torch.autograd.Function):
                     ("scales", (P, 3), need[7] and k["scales"] is not None),
                     ("rot", (P, 4), need[8] and k["rotations"] is not None),
                     ("cov", (P, 6), need[9] and k["cov3D_precomp"] is not None)]
-            sizes = {n: (math.prod(sh) if f else 0) for n, sh, f in want}
-            total = sum((v + 63) // 64 * 64 for v in sizes.values())
-            flat = torch.empty(total, dtype=torch.float32, device=dev) if total else None
-            carved, off = {}, 0
-            for n, sh, f in want:
-                carved[n] = flat[off:off + sizes[n]].view(sh) if f else None
-                off += (sizes[n] + 63) // 64 * 64
-            del flat
+            # ACCUMULATE_IN_PLACE: every wanted Gaussian gradient has a running sum to be added into
+            in_place = None
+            if ACCUMULATE_IN_PLACE:
+                tgt = {}
+                for (n, sh, f), ref in zip(want, ctx.leaves):
+                    if not f:
+                        continue
+                    t = ref() if ref is not None else None
+                    g = None if t is None else t.grad
+                    if (g is None or not t.is_leaf or g.dtype != torch.float32 or not g.is_contiguous() or g.device != dev
+                            or tuple(g.shape) != tuple(sh)):
+                        tgt = None
+                        break
+                    tgt[n] = g
+                if tgt:
+                    in_place = tgt
+            if in_place is not None:
+                carved = {n: in_place.get(n) for n, _, _ in want}
+            else:
+                sizes = {n: (math.prod(sh) if f else 0) for n, sh, f in want}
+                total = sum((v + 63) // 64 * 64 for v in sizes.values())
+                flat = torch.empty(total, dtype=torch.float32, device=dev) if total else None
+                carved, off = {}, 0
+                for n, sh, f in want:
+                    carved[n] = flat[off:off + sizes[n]].view(sh) if f else None
+                    off += (sizes[n] + 63) // 64 * 64
+                del flat
             g_means3D, g_sh, g_col, g_opac = carved["means3D"], carved["sh"], carved["col"], carved["opac"]
             g_scales, g_rot, g_cov = carved["scales"], carved["rot"], carved["cov"]
             g_means2D = new((P, 3), need[1])
@@ -491,12 +519,14 @@ class _RasterizeGaussians(torch.autograd.Function):
             args = L.BagsBackwardArgs(gc.data_ptr(), fw.num_rendered, ws.data_ptr(), ws.numel(), _ptr(g_means3D),
                                       _ptr(g_means2D), _ptr(g_densify), _ptr(g_sh), _ptr(g_col), _ptr(g_opac),
                                       _ptr(g_scales), _ptr(g_rot), _ptr(g_cov), _ptr(g_view), _ptr(g_proj),
-                                      _ptr(g_intr), _ptr(g_campos), _ptr(g_shift), fw.capacity)
+                                      _ptr(g_intr), _ptr(g_campos), _ptr(g_shift), fw.capacity, 1 if in_place is not None else 0, 0)
             state = _state_of(fw)
             L.check(lib.bags_backward(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(args), stream),
                     "bags_backward")
         if g_campos is not None:
             g_campos = g_campos.reshape(ctx.shapes["campos"])
+        if in_place is not None:                              # already added into the parameters' .grad: nothing for autograd to add
+            g_means3D = g_sh = g_col = g_opac = g_scales = g_rot = g_cov = None
         return (g_means3D, g_means2D, g_densify, g_shift, g_sh, g_col, g_opac, g_scales, g_rot, g_cov, g_view, g_proj,
                 g_intr, g_campos, None)
 

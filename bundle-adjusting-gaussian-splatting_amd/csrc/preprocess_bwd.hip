@@ -150,7 +150,9 @@ __device__ __forceinline__ void pose_write_out(const int t, const float val, flo
     }
 }
 
-template <bool COV3D>        // the Gaussians carry precomputed 3D covariances instead of scales + rotations (uniform: no branch at the top)
+// ACCUM (BagsBackwardArgs.accumulate): the seven Gaussian-parameter gradients are ADDED to what their buffers hold (several
+// views of one step accumulate in place: no separate add pass per view); means2D / densify / pose outputs are overwritten.
+template <bool COV3D, bool ACCUM>   // COV3D: precomputed 3D covariances instead of scales + rotations (uniform: no branch at the top)
 __global__ void __launch_bounds__(256, PRE_BWD_WAVES)
 preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod, int clamp_stock,
                       const float* __restrict__ means3D, const float* __restrict__ shift_factors,
@@ -478,6 +480,10 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                             const bool on = t < nb;
                             o[3 * u] = on ? bs[t] * drgb[0] : 0.f; o[3 * u + 1] = on ? bs[t] * drgb[1] : 0.f; o[3 * u + 2] = on ? bs[t] * drgb[2] : 0.f;
                         }
+                        if (ACCUM) {
+#pragma unroll
+                            for (int q = 0; q < 3; ++q) { const float4 old = g4[3 * tb + q]; o[4 * q] += old.x; o[4 * q + 1] += old.y; o[4 * q + 2] += old.z; o[4 * q + 3] += old.w; }
+                        }
                         g4[3 * tb] = make_float4(o[0], o[1], o[2], o[3]);
                         g4[3 * tb + 1] = make_float4(o[4], o[5], o[6], o[7]);
                         g4[3 * tb + 2] = make_float4(o[8], o[9], o[10], o[11]);
@@ -487,7 +493,9 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
             } else if (gsh)
             for (int t = 0; t < M; ++t) {
                 const bool on = t < nb;
-                gsh[3 * t] = on ? bs[t] * drgb[0] : 0.f; gsh[3 * t + 1] = on ? bs[t] * drgb[1] : 0.f; gsh[3 * t + 2] = on ? bs[t] * drgb[2] : 0.f;
+                const float o0 = on ? bs[t] * drgb[0] : 0.f, o1 = on ? bs[t] * drgb[1] : 0.f, o2 = on ? bs[t] * drgb[2] : 0.f;
+                if (ACCUM) { gsh[3 * t] += o0; gsh[3 * t + 1] += o1; gsh[3 * t + 2] += o2; }
+                else { gsh[3 * t] = o0; gsh[3 * t + 1] = o1; gsh[3 * t + 2] = o2; }
             }
             const float dot = ux_ * ddx + uy_ * ddy + uz_ * ddz;
             const float px_ = (ddx - ux_ * dot) * il, py_ = (ddy - uy_ * dot) * il, pz_ = (ddz - uz_ * dot) * il;
@@ -505,10 +513,12 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
             }
 #else
             float4* g4 = reinterpret_cast<float4*>(gsh);
+            if (!ACCUM) {
 #pragma unroll
-            for (int t = 0; t < 12; ++t) g4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int t = 0; t < 12; ++t) g4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #endif
-        } else
+        } else if (!ACCUM)
             for (int t = 0; t < 3 * M; ++t) gsh[t] = 0.f;
     }
 #if SH_STAGE
@@ -530,7 +540,8 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                     const u32 fl = 4u * j + u, t = fl / 3u, c = fl - 3u * t;
                     o4[u] = sr[t] * sr[16u + c];
                 }
-                const float4 o = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                float4 o = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                if (ACCUM) { const float4 old = g4g[e]; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
                 g4g[e] = o;
             }
         }
@@ -538,6 +549,17 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
 #endif
 
     if (i < P) {
+        if (ACCUM) {                                     // += into the caller's running sums
+            if (g_means3D) { dmx += g_means3D[3 * i]; dmy += g_means3D[3 * i + 1]; dmz += g_means3D[3 * i + 2]; }
+            if (g_opac) gop += g_opac[i];
+            if (g_colors) { drgb[0] += g_colors[3 * i]; drgb[1] += g_colors[3 * i + 1]; drgb[2] += g_colors[3 * i + 2]; }
+            if (g_scales) { gs0 += g_scales[3 * i]; gs1 += g_scales[3 * i + 1]; gs2 += g_scales[3 * i + 2]; }
+            if (g_rot) { const float4 old = reinterpret_cast<const float4*>(g_rot)[i]; gqr += old.x; gqx += old.y; gqy += old.z; gqz += old.w; }
+            if (g_cov3D) {
+#pragma unroll
+                for (int t = 0; t < 6; ++t) gc[t] += g_cov3D[6 * (size_t)i + t];
+            }
+        }
         if (g_means3D) { g_means3D[3 * i] = dmx; g_means3D[3 * i + 1] = dmy; g_means3D[3 * i + 2] = dmz; }
         if (g_means2D) { g_means2D[3 * i] = gm2x; g_means2D[3 * i + 1] = gm2y; g_means2D[3 * i + 2] = 0.f; }
         if (g_densify) { g_densify[3 * i] = gdx; g_densify[3 * i + 1] = gdy; g_densify[3 * i + 2] = 0.f; }
@@ -669,7 +691,7 @@ hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, co
                        reinterpret_cast<float4*>(sums));
     const float* partials = sums;
 #endif
-#define PRE_BWD_LAUNCH(COV)     hipLaunchKernelGGL(preprocess_bwd_kernel<COV>, dim3(nb), dim3(256), 0, st, P, s.sh_coeffs, s.sh_degree, s.image_width, \
+#define PRE_BWD_LAUNCH(COV)     hipLaunchKernelGGL((preprocess_bwd_kernel<COV, ACC_>), dim3(nb), dim3(256), 0, st, P, s.sh_coeffs, s.sh_degree, s.image_width, \
                        s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, (s.clamp_grad == BAGS_CLAMP_GRAD_EXACT) ? 0 : 1, in.means3D, in.shift_factors, in.shs, \
                        in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, s.viewmatrix, s.projmatrix, \
                        s.intrinsic, s.campos, in.opacities, g.rec_count, binned ? nullptr : g.inst_off, g.local_off, g.block_base, \
@@ -678,7 +700,15 @@ hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, co
                        a.grad_colors_precomp, a.grad_opacities, a.grad_scales, a.grad_rotations, a.grad_cov3D_precomp, \
                        fold_tickets, fold_rows, pose_group_size(nb), nb, a.grad_viewmatrix, a.grad_projmatrix, a.grad_intrinsic, \
                        a.grad_campos, a.grad_shift_factors);
-    if (in.cov3D_precomp) { PRE_BWD_LAUNCH(true) } else { PRE_BWD_LAUNCH(false) }
+    if (a.accumulate) {
+#define ACC_ true
+        if (in.cov3D_precomp) { PRE_BWD_LAUNCH(true) } else { PRE_BWD_LAUNCH(false) }
+#undef ACC_
+    } else {
+#define ACC_ false
+        if (in.cov3D_precomp) { PRE_BWD_LAUNCH(true) } else { PRE_BWD_LAUNCH(false) }
+#undef ACC_
+    }
 #undef PRE_BWD_LAUNCH
     return hipGetLastError();
 }

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BAGS_ABI_VERSION 5
+#define BAGS_ABI_VERSION 6
 #define BAGS_TILE 16
 
 enum { BAGS_OK = 0, BAGS_ERR_ARG = -1, BAGS_ERR_HIP = -2, BAGS_ERR_SIZE = -3, BAGS_ERR_DEVICE = -4 };
@@ -111,7 +111,7 @@ typedef struct BagsBackwardArgs {
     const float* grad_color;         /* (3,H,W) dL/dimage */
     int64_t num_rendered;            /* I returned by bags_forward_prepare */
     void* workspace; size_t workspace_bytes;   /* >= bags_backward_workspace_size(P, I) */
-    /* outputs; any may be NULL when not needed.  All are fully overwritten (not accumulated). */
+    /* outputs; any may be NULL when not needed.  All are fully overwritten unless `accumulate` (below) says otherwise. */
     float* grad_means3D;             /* (P,3)   */
     float* grad_means2D;             /* (P,3)   NDC units, z = 0 */
     float* grad_means2D_densify;     /* (P,3)   sum over pixels of |per-pixel NDC gradient|, z = 0 */
@@ -130,6 +130,11 @@ typedef struct BagsBackwardArgs {
      * bags_binning_size(binning_capacity, W, H) bytes and num_rendered is the TRUE count, which sizes the workspace);
      * 0 = the buffer was sized for num_rendered itself (bags_forward_finish) */
     int64_t binning_capacity;
+    /* != 0: the seven Gaussian-parameter gradients (means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp) are
+     * ADDED to what their buffers hold instead of overwriting them -- the views of one optimisation step accumulate in place, as
+     * autograd would do with one add pass per view and tensor; every other output is overwritten as before (ABI 6) */
+    int32_t accumulate;
+    int32_t reserved1;
 } BagsBackwardArgs;
 
 /* integer artefacts for bit-exact parity checks (all device pointers, any may be NULL) */

@@ -45,7 +45,7 @@ def test_struct_layout_matches_header(lib):
     assert C.sizeof(_lib.BagsInputs) == 8 + 9 * 8
     assert C.sizeof(_lib.BagsState) == 6 * 8
     assert C.sizeof(_lib.BagsForwardOut) == 5 * 8
-    assert C.sizeof(_lib.BagsBackwardArgs) == 4 * 8 + 14 * 8 + 8          # + binning_capacity (ABI 4)
+    assert C.sizeof(_lib.BagsBackwardArgs) == 4 * 8 + 14 * 8 + 8 + 8      # + binning_capacity (ABI 4), accumulate + reserved1 (ABI 6)
     assert C.sizeof(_lib.BagsDebugViews) == 8 * 8
 
 

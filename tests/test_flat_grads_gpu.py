@@ -105,3 +105,47 @@ def test_five_views_with_distance_depth_key_accumulate_to_the_oracle_sum():
             want[n] += gr[n]
     for n in names:
         assert rel_err(leaves[n].grad.cpu(), want[n]) < 1e-4, (n, rel_err(leaves[n].grad.cpu(), want[n]))
+
+
+@pytest.mark.gpu
+def test_views_accumulate_in_place_like_autograd():
+    """rasterizer.ACCUMULATE_IN_PLACE (opt-in): with a gradient already in every Gaussian parameter, the backward of the next view
+    adds into those tensors inside the kernel (BagsBackwardArgs.accumulate) and returns None to autograd.  old + new is the same
+    fp32 addition autograd's accumulation performs: bit-identical sums; per-view outputs (pose tensors, means2D) are untouched by
+    the switch; the first view (no gradient yet) takes the ordinary path."""
+    import math
+    from bags_raster import GaussianRasterizationSettings, GaussianRasterizer, rasterizer as R
+    from bags_raster.synth import sphere_views, synth_scene
+    from scenes import camera_tensors
+    dev = torch.device("cuda")
+    P, W, H, deg = 3000, 160, 112, 2
+    scene = synth_scene(P, 7, 1.5, deg)
+    cams = sphere_views(3, W, H, noise=0.05)
+    cots = [torch.randn(3, H, W, generator=torch.Generator().manual_seed(10 + v)).to(dev) for v in range(3)]
+
+    def run(in_place):
+        R.ACCUMULATE_IN_PLACE = in_place
+        try:
+            leaves = {k: v.to(dev).clone().requires_grad_(True) for k, v in scene.items()}
+            per_view = []
+            for cam, cot in zip(cams, cots):
+                ct = {k: v.clone().requires_grad_(True) for k, v in camera_tensors(cam, dev).items()}
+                m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
+                st = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5),
+                                                   tanfovy=math.tan(cam.FoVy * 0.5), bg=torch.zeros(3, device=dev), scale_modifier=1.0,
+                                                   viewmatrix=ct["viewmatrix"], projmatrix=ct["projmatrix"], intrinsic=ct["intrinsic"],
+                                                   sh_degree=deg, campos=ct["campos"])
+                img = GaussianRasterizer(st)(means3D=leaves["means3D"], means2D=m2, shs=leaves["shs"], opacities=leaves["opacities"],
+                                             scales=leaves["scales"], rotations=leaves["rotations"])[0]
+                img.backward(cot)
+                per_view.append({**{k: v.grad.clone() for k, v in ct.items()}, "means2D": m2.grad.clone()})
+            return {k: v.grad.clone() for k, v in leaves.items()}, per_view
+        finally:
+            R.ACCUMULATE_IN_PLACE = False
+    g_ref, pv_ref = run(False)
+    g_acc, pv_acc = run(True)
+    for k in g_ref:
+        assert torch.equal(g_ref[k], g_acc[k]), k
+    for a, b in zip(pv_ref, pv_acc):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
