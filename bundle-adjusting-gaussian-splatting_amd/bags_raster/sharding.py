@@ -336,10 +336,18 @@ class ViewShardedRenderer:
         self.reducer.begin()
         mine = shard_views(len(views), rank, world)
         losses = []
-        for v in mine:
-            loss = self.render_fn(views[v])
-            loss.backward()                      # grads of this rank's views accumulate in the bucket
-            losses.append(loss.detach())
+        # the parameters' .grad are the (zeroed) bucket slices: where the rasterizer is called on the leaves themselves its backward
+        # adds into them inside the kernel (rasterizer.ACCUMULATE_IN_PLACE) instead of through one autograd add pass per tensor and view
+        from . import rasterizer as _R
+        saved = _R.ACCUMULATE_IN_PLACE
+        _R.ACCUMULATE_IN_PLACE = True
+        try:
+            for v in mine:
+                loss = self.render_fn(views[v])
+                loss.backward()                  # grads of this rank's views accumulate in the bucket
+                losses.append(loss.detach())
+        finally:
+            _R.ACCUMULATE_IN_PLACE = saved
         self.reducer.all_reduce()
         total = torch.stack(losses).sum() if losses else torch.zeros((), device=self.params[0].device)
         if world > 1:
