@@ -552,6 +552,10 @@ def main():
         }
         if v4 is not None:
             out["v4"] = v4
+        if world > 1:
+            out["scaling_note"] = ("one view per rank per exchange moves the whole Gaussian-gradient set (59 floats per Gaussian) for one "
+                                   "view of compute: link-bound on xGMI (DESIGN.md section 6 expects ~4x at 8 GPUs); the >= 6x design "
+                                   "point is V >= 4 views per exchange, timed in the same run as 'v4'")
         if median50 is not None:
             out["ms_per_step_median"] = median50["median_ms"]
             out["median_leg"] = median50
