@@ -5,7 +5,9 @@ cd "$(dirname "$0")/.."
 CS=bundle-adjusting-gaussian-splatting_amd/csrc
 for v in "$@"; do
   rm -rf $CS/build
-  make -C $CS -j8 DEFS="$v" > /tmp/build.log 2>&1 || { echo "BUILD FAILED: $v"; tail -5 /tmp/build.log; continue; }
+  # a variant of the form "make: VAR=value VAR=value" passes make variables (per-file flags, no blanks inside a value)
+  if [[ "$v" == make:* ]]; then read -ra MA <<< "${v#make:}"; else MA=("DEFS=$v"); fi
+  make -C $CS -j8 "${MA[@]}" > /tmp/build.log 2>&1 || { echo "BUILD FAILED: $v"; tail -5 /tmp/build.log; continue; }
   echo "== $v"
   timeout 200 python bench.py --no-cpu-baseline --no-aabb-leg --no-v4-leg --no-lazy-leg --no-median-leg --steps ${STEPS:-40} --warmup 5 ${BENCH_ARGS} 2>/dev/null | python -c "
 import json,sys
