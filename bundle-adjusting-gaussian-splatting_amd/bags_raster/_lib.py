@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # tests).  Not a fallback: a missing file still raises.
 LIB_PATH = os.environ.get("BAGS_RASTER_LIB") or os.path.join(_HERE, "libbags_raster.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 TILES_AABB, TILES_OPACITY = 0, 1
 DEPTH_Z, DEPTH_DISTANCE = 0, 1
 BINNING_AUTO, BINNING_RADIX = 0, 1
@@ -31,7 +31,7 @@ class BagsSettings(C.Structure):
 class BagsInputs(C.Structure):
     _fields_ = [("P", C.c_int32), ("means3D", c_fp), ("means2D", c_fp), ("shift_factors", c_fp), ("shs", c_fp),
                 ("colors_precomp", c_fp), ("opacities", c_fp), ("scales", c_fp), ("rotations", c_fp),
-                ("cov3D_precomp", c_fp)]
+                ("cov3D_precomp", c_fp), ("shs_rest", c_fp)]
 
 
 class BagsState(C.Structure):
@@ -49,7 +49,7 @@ class BagsBackwardArgs(C.Structure):
                 ("grad_colors_precomp", c_fp), ("grad_opacities", c_fp), ("grad_scales", c_fp), ("grad_rotations", c_fp),
                 ("grad_cov3D_precomp", c_fp), ("grad_viewmatrix", c_fp), ("grad_projmatrix", c_fp),
                 ("grad_intrinsic", c_fp), ("grad_campos", c_fp), ("grad_shift_factors", c_fp),
-                ("binning_capacity", C.c_int64), ("accumulate", C.c_int32), ("reserved1", C.c_int32)]
+                ("binning_capacity", C.c_int64), ("accumulate", C.c_int32), ("reserved1", C.c_int32), ("grad_shs_rest", c_fp)]
 
 
 class BagsDebugViews(C.Structure):
@@ -96,6 +96,10 @@ SYMBOLS = {
                                     C.c_void_p, C.c_void_p]),
     "bags_loss_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bags_photometric_loss_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
+                                                C.c_float, C.c_void_p, C.c_void_p]),
+    "bags_photometric_loss_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
+                                                 C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bags_camera_forward": (C.c_int, [C.POINTER(BagsCamera), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bags_camera_backward": (C.c_int, [C.POINTER(BagsCamera)] + [C.c_void_p] * 11),
     "bags_resample_forward": (C.c_int, [C.c_void_p] + [C.c_int32] * 3 + [C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p] * 4),

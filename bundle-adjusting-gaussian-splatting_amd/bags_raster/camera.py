@@ -188,7 +188,8 @@ class _FusedCameraChain(torch.autograd.Function):
         c = lambda t: None if t is None else t.to(torch.float32).contiguous()
         gV, gM, gK, gC = c(gV), c(gM), c(gK), c(gC)
         need = ctx.needs_input_grad
-        out = torch.zeros(19, dtype=torch.float32, device=dev)                  # dq 4 | dt 3 | fovx | fovy | grot 9 | gscale
+        out = torch.empty(19, dtype=torch.float32, device=dev)                  # dq 4 | dt 3 | fovx | fovy | grot 9 | gscale (every requested
+        # slice is fully written by the kernel, the others are not returned: no fill launch)
         g_dq, g_dt, g_fx, g_fy, g_gr, g_gs = out[0:4], out[4:7], out[7:8], out[8:9], out[9:18], out[18:19]
         p = lambda t, on=True: None if (t is None or not on) else t.data_ptr()
         lib = L.load()

@@ -161,13 +161,18 @@ class GaussianBag:
     def get_covariance(self, scaling_modifier: float = 1.0):
         return covariance_from_scaling_rotation(self.get_scaling, scaling_modifier, self._rotation)
 
-    def activated(self):
+    def activated(self, features: bool = True):
         """(get_xyz, get_features, get_opacity, get_scaling, get_rotation) in one HIP launch each way on a GPU
-        (bags_activations_forward / _backward, csrc/activations.hip); the same properties evaluated one by one on the host."""
+        (bags_activations_forward / _backward, csrc/activations.hip); the same properties evaluated one by one on the host.
+        ``features=False``: no concatenation (second entry None) -- for the rasterizer's ``shs`` / ``shs_rest`` pair, which
+        takes ``_features_dc`` and ``_features_rest`` as they are (bags_raster.render)."""
         if self._xyz.is_cuda:
+            if not features:
+                _, op, sc, rot = _FusedActivations.apply(None, None, self._opacity, self._scaling, self._rotation)
+                return self._xyz, None, op, sc, rot
             shs, op, sc, rot = fused_activations(self._features_dc, self._features_rest, self._opacity, self._scaling, self._rotation)
             return self._xyz, shs, op, sc, rot
-        return self.get_xyz, self.get_features, self.get_opacity, self.get_scaling, self.get_rotation
+        return self.get_xyz, (self.get_features if features else None), self.get_opacity, self.get_scaling, self.get_rotation
 
     def oneupSHdegree(self):
         if self.active_sh_degree < self.max_sh_degree:
@@ -185,46 +190,56 @@ class GaussianBag:
 
 
 class _FusedActivations(torch.autograd.Function):
+    """``dc`` and ``rest`` may both be None (packed features): no SH concatenation, the first output is None."""
+
     @staticmethod
     def forward(ctx, dc, rest, opacity, scaling, rotation):
         from . import _lib as L
-        ts = [t.detach().to(torch.float32).contiguous() for t in (dc, rest, opacity, scaling, rotation)]
-        if not all(t.is_cuda for t in ts):
+        feats = dc is not None
+        if (dc is None) != (rest is None):
+            raise RuntimeError("fused_activations: features_dc and features_rest are given together or not at all")
+        ts = [None if t is None else t.detach().to(torch.float32).contiguous() for t in (dc, rest, opacity, scaling, rotation)]
+        if not all(t.is_cuda for t in ts if t is not None):
             raise RuntimeError("fused_activations: tensors must live on a GPU (use the GaussianBag properties on the host)")
-        P, K = ts[0].shape[0], 1 + ts[1].shape[1]
-        if ts[0].shape != (P, 1, 3) or ts[1].shape != (P, K - 1, 3) or ts[2].numel() != P or ts[3].shape != (P, 3) or ts[4].shape != (P, 4):
+        P = ts[3].shape[0]
+        K = 1 + ts[1].shape[1] if feats else 1
+        if (feats and (ts[0].shape != (P, 1, 3) or ts[1].shape != (P, K - 1, 3))) or ts[2].numel() != P or ts[3].shape != (P, 3) or ts[4].shape != (P, 4):
             raise RuntimeError("fused_activations: expected features_dc (P,1,3), features_rest (P,K-1,3), opacity (P,1), scaling (P,3), rotation (P,4)")
-        dev = ts[0].device
-        shs = torch.empty(P, K, 3, dtype=torch.float32, device=dev)
+        dev = ts[3].device
+        shs = torch.empty(P, K, 3, dtype=torch.float32, device=dev) if feats else None
         op = torch.empty(P, 1, dtype=torch.float32, device=dev)
         sc = torch.empty(P, 3, dtype=torch.float32, device=dev)
         rot = torch.empty(P, 4, dtype=torch.float32, device=dev)
-        raw = L.BagsRawGaussians(P, K, *[t.data_ptr() for t in ts])
+        raw = L.BagsRawGaussians(P, K, *[None if t is None else t.data_ptr() for t in ts])
         lib = L.load()
         with torch.cuda.device(dev):
-            L.check(lib.bags_activations_forward(raw, shs.data_ptr(), op.data_ptr(), sc.data_ptr(), rot.data_ptr(),
+            L.check(lib.bags_activations_forward(raw, None if shs is None else shs.data_ptr(), op.data_ptr(), sc.data_ptr(), rot.data_ptr(),
                                                  torch.cuda.current_stream().cuda_stream), "bags_activations_forward")
-        ctx.save_for_backward(*ts)
+        ctx.feats = feats
+        ctx.save_for_backward(*[t for t in ts if t is not None])
         ctx.set_materialize_grads(False)          # an unused output arrives as None, not as 96 MB of zeros
         return shs, op, sc, rot
 
     @staticmethod
     def backward(ctx, g_shs, g_op, g_sc, g_rot):
         from . import _lib as L
-        ts = ctx.saved_tensors
-        P, K = ts[0].shape[0], 1 + ts[1].shape[1]
+        ts = list(ctx.saved_tensors)
+        if not ctx.feats:
+            ts = [None, None] + ts
+        P = ts[3].shape[0]
+        K = 1 + ts[1].shape[1] if ctx.feats else 1
         need = ctx.needs_input_grad
         c = lambda g: None if g is None else g.to(torch.float32).contiguous()
         g_shs, g_op, g_sc, g_rot = c(g_shs), c(g_op), c(g_sc), c(g_rot)
-        out = [torch.empty_like(ts[0]) if (need[0] and g_shs is not None) else None,
-               torch.empty_like(ts[1]) if (need[1] and g_shs is not None) else None,
+        out = [torch.empty_like(ts[0]) if (ctx.feats and need[0] and g_shs is not None) else None,
+               torch.empty_like(ts[1]) if (ctx.feats and need[1] and g_shs is not None) else None,
                torch.empty_like(ts[2]) if (need[2] and g_op is not None) else None,
                torch.empty_like(ts[3]) if (need[3] and g_sc is not None) else None,
                torch.empty_like(ts[4]) if (need[4] and g_rot is not None) else None]
         p = lambda t: None if t is None else t.data_ptr()
-        raw = L.BagsRawGaussians(P, K, *[t.data_ptr() for t in ts])
+        raw = L.BagsRawGaussians(P, K, *[p(t) for t in ts])
         lib = L.load()
-        with torch.cuda.device(ts[0].device):
+        with torch.cuda.device(ts[3].device):
             L.check(lib.bags_activations_backward(raw, p(g_shs), p(g_op), p(g_sc), p(g_rot), *[p(o) for o in out],
                                                   torch.cuda.current_stream().cuda_stream), "bags_activations_backward")
         return tuple(out)

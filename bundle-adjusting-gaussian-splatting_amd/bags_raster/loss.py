@@ -99,7 +99,62 @@ def fused_l1_ssim(image: torch.Tensor, gt: torch.Tensor):
     return _FusedL1SSIM.apply(image, gt)
 
 
-def fused_photometric_loss(image: torch.Tensor, gt: torch.Tensor, lambda_dssim: float = 0.2) -> torch.Tensor:
-    """train.py:325: (1 - lambda) L1 + lambda (1 - SSIM)."""
-    l1, s = fused_l1_ssim(image, gt)
-    return (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - s)
+def _check_pair(fn: str, image: torch.Tensor, gt: torch.Tensor) -> None:
+    for name, t in (("image", image), ("gt", gt)):
+        if not t.is_cuda:
+            raise RuntimeError(f"{fn}: {name} must be a GPU tensor (the fused loss has no CPU path; "
+                               f"use bags_raster.loss.l1_loss / ssim on the host)")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"{fn}: {name} must be float32, got {t.dtype}")
+    if image.shape != gt.shape or image.dim() != 3:
+        raise RuntimeError(f"{fn}: expected two (C,H,W) tensors of one shape, got {tuple(image.shape)} and {tuple(gt.shape)}")
+
+
+class _FusedPhotometric(torch.autograd.Function):
+    """(image, gt, lambda) -> (loss, L1 mean, SSIM mean) with train.py:325's combination formed inside the reduce kernel and its
+    backward inside the backward kernel (``bags_photometric_loss_*``): two launches forward, one backward, no one-element
+    PyTorch kernels around them.  Only ``loss`` carries gradient; the two terms are returned for logging."""
+
+    @staticmethod
+    def forward(ctx, image: torch.Tensor, gt: torch.Tensor, lambda_dssim: float):
+        from . import _lib as L
+        _check_pair("fused_photometric_loss", image, gt)
+        lib = L.load()
+        image, gt = image.contiguous(), gt.contiguous()
+        Cn, H, W = image.shape
+        with torch.cuda.device(image.device):
+            nbytes = lib.bags_loss_workspace_size(Cn, H, W)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=image.device)
+            out = torch.empty(3, dtype=torch.float32, device=image.device)
+            stream = torch.cuda.current_stream().cuda_stream
+            L.check(lib.bags_photometric_loss_forward(image.data_ptr(), gt.data_ptr(), Cn, H, W, ws.data_ptr(), nbytes,
+                                                      float(lambda_dssim), out.data_ptr(), stream), "bags_photometric_loss_forward")
+        ctx.save_for_backward(image, gt, ws)
+        ctx.lambda_dssim = float(lambda_dssim)
+        loss, l1, s = out[0], out[1], out[2]
+        ctx.mark_non_differentiable(l1, s)
+        ctx.set_materialize_grads(False)          # no zero-fill launches for the two logging terms' absent gradients
+        return loss, l1, s
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_l1, _g_ssim):
+        from . import _lib as L
+        image, gt, ws = ctx.saved_tensors
+        if not ctx.needs_input_grad[0] or g_loss is None:
+            return None, None, None
+        lib = L.load()
+        Cn, H, W = image.shape
+        g = g_loss.to(torch.float32).contiguous()
+        grad = torch.empty_like(image)
+        with torch.cuda.device(image.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            L.check(lib.bags_photometric_loss_backward(image.data_ptr(), gt.data_ptr(), Cn, H, W, ws.data_ptr(), ws.numel(),
+                                                       ctx.lambda_dssim, g.data_ptr(), grad.data_ptr(), stream),
+                    "bags_photometric_loss_backward")
+        return grad, None, None
+
+
+def fused_photometric_loss(image: torch.Tensor, gt: torch.Tensor, lambda_dssim: float = 0.2, return_terms: bool = False):
+    """train.py:325: (1 - lambda) L1 + lambda (1 - SSIM) as one fused op.  ``return_terms``: also the two means (detached)."""
+    loss, l1, s = _FusedPhotometric.apply(image, gt, lambda_dssim)
+    return (loss, l1, s) if return_terms else loss

@@ -82,7 +82,7 @@ class _Packed:
     """C structs + the tensors that keep their pointers alive."""
 
     def __init__(self, settings: GaussianRasterizationSettings, means3D, means2D, shift_factors, sh, colors_precomp,
-                 opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, intrinsic, campos):
+                 opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, intrinsic, campos, sh_rest=None):
         dev = means3D.device
         if dev.type != "cuda":
             raise RuntimeError("bags_raster runs only on an AMD GPU: tensors must be on a 'cuda' (ROCm) device; "
@@ -95,6 +95,7 @@ class _Packed:
         k["shift_factors"] = _f32c(shift_factors, "shift_factors", dev, (3,)) if shift_factors is not None else None
         e0 = P == 0                          # an empty scene: (0, n) tensors are real arguments, not the "absent" marker
         k["shs"] = _f32c(sh, "shs", dev, empty_ok=e0)
+        k["shs_rest"] = _f32c(sh_rest, "shs_rest", dev, empty_ok=e0)
         k["colors_precomp"] = _f32c(colors_precomp, "colors_precomp", dev, empty_ok=e0)
         k["opacities"] = _f32c(opacities, "opacities", dev, empty_ok=e0)
         k["scales"] = _f32c(scales, "scales", dev, empty_ok=e0)
@@ -110,6 +111,12 @@ class _Packed:
             if k["shs"].dim() != 3 or k["shs"].shape[0] != P or k["shs"].shape[2] != 3:
                 raise ValueError(f"shs must be (P,M,3), got {tuple(k['shs'].shape)}")
             M = k["shs"].shape[1]
+        if k["shs_rest"] is not None:            # the reference's two feature parameters as they are stored: features_dc + features_rest
+            if k["shs"] is None or M != 1:
+                raise ValueError("shs_rest (features_rest, (P,M-1,3)) goes with shs = features_dc of shape (P,1,3)")
+            if k["shs_rest"].dim() != 3 or k["shs_rest"].shape[0] != P or k["shs_rest"].shape[2] != 3 or k["shs_rest"].shape[1] < 1:
+                raise ValueError(f"shs_rest must be (P,M-1,3) with M >= 2, got {tuple(k['shs_rest'].shape)}")
+            M = 1 + k["shs_rest"].shape[1]
         if k["colors_precomp"] is not None and tuple(k["colors_precomp"].shape) != (P, 3):
             raise ValueError("colors_precomp must be (P,3)")
         if k["opacities"] is None or k["opacities"].numel() != P:
@@ -143,7 +150,7 @@ class _Packed:
             _ptr(k["bg"]), _ptr(k["viewmatrix"]), _ptr(k["projmatrix"]), _ptr(k["intrinsic"]), _ptr(k["campos"]))
         self.inputs = L.BagsInputs(P, _ptr(k["means3D"]), _ptr(k["means2D"]), _ptr(k["shift_factors"]), _ptr(k["shs"]),
                                    _ptr(k["colors_precomp"]), _ptr(k["opacities"]), _ptr(k["scales"]),
-                                   _ptr(k["rotations"]), _ptr(k["cov3D_precomp"]))
+                                   _ptr(k["rotations"]), _ptr(k["cov3D_precomp"]), _ptr(k["shs_rest"]))
 
 
 def _require_gpu(t: torch.Tensor) -> None:
@@ -425,19 +432,21 @@ def _state_of(fw: _Forwarded) -> L.BagsState:
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, means2D_densify, shift_factors, sh, colors_precomp, opacities, scales, rotations,
-                cov3Ds_precomp, viewmatrix, projmatrix, intrinsic, campos, raster_settings):
+                cov3Ds_precomp, viewmatrix, projmatrix, intrinsic, campos, raster_settings, sh_rest=None):
         lib = L.load()
         _require_gpu(means3D)
         with torch.cuda.device(means3D.device):
             pk = _Packed(raster_settings, means3D, means2D, shift_factors, sh, colors_precomp, opacities, scales,
-                         rotations, cov3Ds_precomp, viewmatrix, projmatrix, intrinsic, campos)
+                         rotations, cov3Ds_precomp, viewmatrix, projmatrix, intrinsic, campos, sh_rest)
             fw, outs = _run_forward(lib, pk, int(raster_settings.image_height), int(raster_settings.image_width),
                                     lazy=any(ctx.needs_input_grad))
         ctx.fw = fw
         # (weak: the op must not keep the caller's parameters alive; only used by ACCUMULATE_IN_PLACE)
-        ctx.leaves = tuple(None if t is None else weakref.ref(t) for t in
-                           (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp))
-        ctx.shapes = dict(sh=None if sh is None else sh.shape, opac=opacities.shape, campos=campos.shape)
+        ctx.leaves = (tuple(None if t is None else weakref.ref(t) for t in
+                            (means3D, sh, sh_rest, colors_precomp, opacities, scales, rotations, cov3Ds_precomp))
+                      if ACCUMULATE_IN_PLACE else None)
+        ctx.shapes = dict(sh=None if sh is None else sh.shape, sh_rest=None if sh_rest is None else sh_rest.shape,
+                          opac=opacities.shape, campos=campos.shape)
         color, radii, depth, weights, mean2D = outs
         ctx.mark_non_differentiable(radii, depth, weights, mean2D)
         ctx.set_materialize_grads(False)     # no zero-fill kernels for the four outputs nobody differentiates
@@ -450,7 +459,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         pk, dev, P = fw.packed, fw.packed.device, fw.packed.P
         need = ctx.needs_input_grad
         if grad_color is None:
-            return (None,) * 15
+            return (None,) * 16
         with torch.cuda.device(dev):
             gc = grad_color.detach()
             if gc.dtype != torch.float32 or not gc.is_contiguous():
@@ -464,6 +473,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             # (bags_raster/sharding.py finds the common storage); to autograd they are ordinary tensors.
             want = [("means3D", (P, 3), need[0]),
                     ("sh", ctx.shapes["sh"], need[4] and k["shs"] is not None),
+                    ("sh_rest", ctx.shapes["sh_rest"], need[15] and k["shs_rest"] is not None),
                     ("col", (P, 3), need[5] and k["colors_precomp"] is not None),
                     ("opac", ctx.shapes["opac"], need[6]),
                     ("scales", (P, 3), need[7] and k["scales"] is not None),
@@ -471,7 +481,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     ("cov", (P, 6), need[9] and k["cov3D_precomp"] is not None)]
             # ACCUMULATE_IN_PLACE: every wanted Gaussian gradient has a running sum to be added into
             in_place = None
-            if ACCUMULATE_IN_PLACE:
+            if ACCUMULATE_IN_PLACE and ctx.leaves is not None:       # (the flag was already set when this forward ran)
                 tgt = {}
                 for (n, sh, f), ref in zip(want, ctx.leaves):
                     if not f:
@@ -497,6 +507,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                     off += (sizes[n] + 63) // 64 * 64
                 del flat
             g_means3D, g_sh, g_col, g_opac = carved["means3D"], carved["sh"], carved["col"], carved["opac"]
+            g_sh_rest = carved["sh_rest"]
+            if k["shs_rest"] is not None and (g_sh is None) != (g_sh_rest is None):
+                # the library writes the pair or neither (one staged pass over both): the unwanted half goes to a scratch tensor
+                if g_sh is None:
+                    g_sh = torch.zeros(ctx.shapes["sh"], dtype=torch.float32, device=dev)
+                else:
+                    g_sh_rest = torch.zeros(ctx.shapes["sh_rest"], dtype=torch.float32, device=dev)
             g_scales, g_rot, g_cov = carved["scales"], carved["rot"], carved["cov"]
             g_means2D = new((P, 3), need[1])
             g_densify = new((P, 3), need[2])
@@ -519,24 +536,29 @@ class _RasterizeGaussians(torch.autograd.Function):
             args = L.BagsBackwardArgs(gc.data_ptr(), fw.num_rendered, ws.data_ptr(), ws.numel(), _ptr(g_means3D),
                                       _ptr(g_means2D), _ptr(g_densify), _ptr(g_sh), _ptr(g_col), _ptr(g_opac),
                                       _ptr(g_scales), _ptr(g_rot), _ptr(g_cov), _ptr(g_view), _ptr(g_proj),
-                                      _ptr(g_intr), _ptr(g_campos), _ptr(g_shift), fw.capacity, 1 if in_place is not None else 0, 0)
+                                      _ptr(g_intr), _ptr(g_campos), _ptr(g_shift), fw.capacity, 1 if in_place is not None else 0, 0,
+                                      _ptr(g_sh_rest))
             state = _state_of(fw)
             L.check(lib.bags_backward(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(args), stream),
                     "bags_backward")
         if g_campos is not None:
             g_campos = g_campos.reshape(ctx.shapes["campos"])
         if in_place is not None:                              # already added into the parameters' .grad: nothing for autograd to add
-            g_means3D = g_sh = g_col = g_opac = g_scales = g_rot = g_cov = None
+            g_means3D = g_sh = g_sh_rest = g_col = g_opac = g_scales = g_rot = g_cov = None
+        if not need[4]:
+            g_sh = None
+        if not need[15]:
+            g_sh_rest = None
         return (g_means3D, g_means2D, g_densify, g_shift, g_sh, g_col, g_opac, g_scales, g_rot, g_cov, g_view, g_proj,
-                g_intr, g_campos, None)
+                g_intr, g_campos, None, g_sh_rest)
 
 
 def rasterize_gaussians(means3D, means2D, means2D_densify, shift_factors, sh, colors_precomp, opacities, scales,
-                        rotations, cov3Ds_precomp, raster_settings: GaussianRasterizationSettings):
+                        rotations, cov3Ds_precomp, raster_settings: GaussianRasterizationSettings, sh_rest=None):
     return _RasterizeGaussians.apply(means3D, means2D, means2D_densify, shift_factors, sh, colors_precomp, opacities,
                                      scales, rotations, cov3Ds_precomp, raster_settings.viewmatrix,
                                      raster_settings.projmatrix, raster_settings.intrinsic, raster_settings.campos,
-                                     raster_settings)
+                                     raster_settings, sh_rest)
 
 
 class GaussianRasterizer(torch.nn.Module):
@@ -552,15 +574,20 @@ class GaussianRasterizer(torch.nn.Module):
             return z > 0.2
 
     def forward(self, means3D, means2D, opacities, means2D_densify=None, shift_factors=None, shs=None,
-                colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+                colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, shs_rest=None):
+        """The ten keywords of gaussian_renderer/__init__.py:110-121, plus ``shs_rest``: with it, ``shs`` is the reference's
+        ``_features_dc`` (P,1,3) and ``shs_rest`` its ``_features_rest`` (P,M-1,3) -- the two parameters as they are stored,
+        without ``get_features``' torch.cat in front of the op and the split of dL/dshs behind it."""
         rs = self.raster_settings
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        if shs_rest is not None and shs is None:
+            raise Exception('shs_rest (features_rest) goes with shs = features_dc')
         return rasterize_gaussians(means3D, means2D, means2D_densify, shift_factors, shs, colors_precomp, opacities,
-                                   scales, rotations, cov3D_precomp, rs)
+                                   scales, rotations, cov3D_precomp, rs, shs_rest)
 
 
 def debug_views(settings: GaussianRasterizationSettings, means3D, means2D, shift_factors, shs, colors_precomp,

@@ -7,7 +7,8 @@ arguments, same choice of covariance path (``pipe.compute_cov3D_python``) and co
   * tensors are created on the device of ``pc.get_xyz`` instead of a hard-coded ``"cuda"``;
   * the camera chain (three calls in the reference, :57,58,61) is evaluated once per tensor, not once per use;
   * ``global_alignment`` may be ``None`` (the reference always passes a pair, ``train.py:250``);
-  * ``shift_factors`` may be ``None`` (= zeros(3)); one extra keyword, ``depth_key`` (decision D6 of DESIGN.md).
+  * ``shift_factors`` may be ``None`` (= zeros(3)); one extra keyword, ``depth_key`` (decision D6 of DESIGN.md);
+  * the two screen-space gradient sinks are leaf tensors (the reference: ``zeros + 0`` with ``retain_grad()``, :37-44).
 """
 from __future__ import annotations
 
@@ -26,6 +27,9 @@ class PipelineParams(SimpleNamespace):
 
     def __init__(self, convert_SHs_python: bool = False, compute_cov3D_python: bool = False, debug: bool = False):
         super().__init__(convert_SHs_python=convert_SHs_python, compute_cov3D_python=compute_cov3D_python, debug=debug)
+
+
+_ZERO3 = {}        # device -> zeros(3): the `shift_factors=None` stand-in (read-only: one fill launch per device, not per call)
 
 
 def quaternion_multiply(q1: torch.Tensor, q2: torch.Tensor) -> torch.Tensor:
@@ -54,16 +58,23 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, mlp_color, shift_
     required, ``hybrid`` defaults to True (Python-side SH colours + ``mlp_color``).  ``shift_factors=None`` stands for the
     zero vector the reference keeps (train.py:125-126: its optimizer is never stepped)."""
     # activations: one fused launch when the container offers it (GaussianBag on a GPU), else the reference's properties
-    if hasattr(pc, "activated"):
+    # rasterizer-side SH colours: the two feature parameters go to the op as they are stored (shs = features_dc, shs_rest =
+    # features_rest), without get_features' torch.cat; every other colour path needs the (P,K,3) tensor
+    raster_sh = override_color is None and not (hybrid or pipe.convert_SHs_python)
+    split = (raster_sh and hasattr(pc, "activated") and getattr(pc, "_features_rest", None) is not None
+             and pc._features_rest.dim() == 3 and pc._features_rest.shape[1] >= 1 and pc._features_dc.is_cuda)
+    if split:
+        xyz, _, opacity, scaling, rotation = pc.activated(features=False)
+        features = None
+    elif hasattr(pc, "activated"):
         xyz, features, opacity, scaling, rotation = pc.activated()
     else:
         xyz, features, opacity, scaling, rotation = pc.get_xyz, pc.get_features, pc.get_opacity, pc.get_scaling, pc.get_rotation
     # zero tensors whose .grad receives the screen-space gradients (:37-44)
-    screenspace_points = torch.zeros_like(xyz, requires_grad=True) + 0
-    screenspace_points_densify = torch.zeros_like(xyz, requires_grad=True) + 0
-    if screenspace_points.requires_grad:
-        screenspace_points.retain_grad()
-        screenspace_points_densify.retain_grad()
+    # (leaves: `.grad` is populated as with the reference's `zeros + 0` / retain_grad() pair, without the two adds and the two
+    # 6 MB gradient copies that pair costs per call)
+    screenspace_points = torch.zeros_like(xyz, requires_grad=True)
+    screenspace_points_densify = torch.zeros_like(xyz, requires_grad=True)
 
     ga = global_alignment if global_alignment is not None else (None, None)
     if hasattr(viewpoint_camera, "get_matrices"):              # one HIP launch (bags_raster.camera.PoseCamera)
@@ -99,21 +110,25 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, mlp_color, shift_
     else:
         scales, rotations = scaling, rotation
 
-    shs = colors_precomp = None
+    shs = shs_rest = colors_precomp = None
     if override_color is not None:
         colors_precomp = override_color
     elif hybrid or pipe.convert_SHs_python:
         colors_precomp = _python_colors(pc, xyz, features, campos, mlp_color)
+    elif split:
+        shs, shs_rest = pc._features_dc, pc._features_rest
     else:
         shs = features
 
     if shift_factors is None:
-        shift_factors = torch.zeros(3, device=xyz.device)
+        shift_factors = _ZERO3.get(xyz.device)
+        if shift_factors is None:
+            shift_factors = _ZERO3[xyz.device] = torch.zeros(3, device=xyz.device)
 
     rendered_image, radii, depth, weights, mean2D = rasterizer(
         means3D=xyz, means2D=screenspace_points, means2D_densify=screenspace_points_densify,
         shift_factors=shift_factors, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
-        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, **({"shs_rest": shs_rest} if shs_rest is not None else {}))
 
     return {"render": rendered_image,
             "viewspace_points": screenspace_points,

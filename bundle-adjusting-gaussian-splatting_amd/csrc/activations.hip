@@ -82,7 +82,7 @@ hipError_t launch_activations_fwd(int P, int K, const float* dc, const float* re
 {
     if (P <= 0) return hipSuccess;
     const RawView raw{dc, rest, opacity, scaling, rotation};
-    const size_t n = (size_t)P * K * 3;
+    const size_t n = shs ? (size_t)P * K * 3 : (size_t)P;      // without the SH concatenation (packed features): one thread per Gaussian
     hipLaunchKernelGGL(activations_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, K * 3, raw, shs, o_opacity, o_scales, o_rot);
     return hipGetLastError();
 }
@@ -94,7 +94,7 @@ hipError_t launch_activations_bwd(int P, int K, const float* dc, const float* re
 {
     if (P <= 0) return hipSuccess;
     const RawView raw{dc, rest, opacity, scaling, rotation};
-    const size_t n = (size_t)P * K * 3;
+    const size_t n = (g_shs && (g_dc || g_rest)) ? (size_t)P * K * 3 : (size_t)P;
     hipLaunchKernelGGL(activations_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, K * 3, raw, g_shs, g_opacity, g_scales,
                        g_rot, g_dc, g_rest, g_opacity_raw, g_scaling, g_rotation);
     return hipGetLastError();

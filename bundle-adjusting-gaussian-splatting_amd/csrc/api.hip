@@ -192,6 +192,8 @@ static int check_common(const BagsSettings* s, const BagsInputs* in, const BagsS
         const bool sr = in->scales && in->rotations;
         if ((in->scales != nullptr) != (in->rotations != nullptr) || sr == (in->cov3D_precomp != nullptr))
             return fail(BAGS_ERR_ARG, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+        if (in->shs_rest && (!in->shs || s->sh_coeffs < 2))
+            return fail(BAGS_ERR_ARG, "shs_rest (features_rest) needs shs (features_dc) and sh_coeffs >= 2 (got %d)", s->sh_coeffs);
         if (in->shs && (s->sh_degree + 1) * (s->sh_degree + 1) > s->sh_coeffs)
             return fail(BAGS_ERR_ARG, "sh_degree %d needs %d coefficients, shs holds %d", s->sh_degree,
                         (s->sh_degree + 1) * (s->sh_degree + 1), s->sh_coeffs);
@@ -407,6 +409,8 @@ int bags_backward(const BagsSettings* s, const BagsInputs* in, const BagsState* 
     if (cap < I) return fail(BAGS_ERR_ARG, "binning_capacity %lld < num_rendered %lld", (long long)cap, (long long)I);
     if (!stt->binning || stt->binning_bytes < bags_binning_size(cap, W, H)) return fail(BAGS_ERR_SIZE, "binning buffer too small");
     if (!a->workspace || a->workspace_bytes < bags_backward_workspace_size(in->P, I)) return fail(BAGS_ERR_SIZE, "backward workspace too small");
+    if (in->shs_rest ? ((a->grad_shs != nullptr) != (a->grad_shs_rest != nullptr)) : (a->grad_shs_rest != nullptr))
+        return fail(BAGS_ERR_ARG, "grad_shs_rest goes with inputs.shs_rest, and then grad_shs (features_dc) and grad_shs_rest are given together");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     GeomView g; carve_geom(align256(stt->geom), in->P, &g);
     BinView b; carve_binning(align256(stt->binning), cap, W, H, &b, use_binned(s, in->P));
@@ -438,13 +442,14 @@ int bags_backward(const BagsSettings* s, const BagsInputs* in, const BagsState* 
     if (s->debug) {
         const size_t P = (size_t)in->P;
         const ScanItem items[] = {{"grad_means3D", a->grad_means3D, 3 * P}, {"grad_means2D", a->grad_means2D, 3 * P},
-                                  {"grad_means2D_densify", a->grad_means2D_densify, 3 * P}, {"grad_shs", a->grad_shs, 3 * P * (size_t)s->sh_coeffs},
+                                  {"grad_means2D_densify", a->grad_means2D_densify, 3 * P}, {"grad_shs", a->grad_shs, 3 * P * (size_t)(in->shs_rest ? 1 : s->sh_coeffs)},
+                                  {"grad_shs_rest", in->shs_rest ? a->grad_shs_rest : nullptr, 3 * P * (size_t)(s->sh_coeffs - 1)},
                                   {"grad_colors_precomp", a->grad_colors_precomp, 3 * P}, {"grad_opacities", a->grad_opacities, P},
                                   {"grad_scales", a->grad_scales, 3 * P}, {"grad_rotations", a->grad_rotations, 4 * P},
                                   {"grad_cov3D_precomp", a->grad_cov3D_precomp, 6 * P}, {"grad_viewmatrix", a->grad_viewmatrix, 16},
                                   {"grad_projmatrix", a->grad_projmatrix, 16}, {"grad_intrinsic", a->grad_intrinsic, 16},
                                   {"grad_campos", a->grad_campos, 3}, {"grad_shift_factors", a->grad_shift_factors, 3}};
-        return debug_scan(s, st, g.num_rendered + 8, items, 14, "the backward", fail);
+        return debug_scan(s, st, g.num_rendered + 8, items, 15, "the backward", fail);
     }
     return BAGS_OK;
 }
@@ -539,6 +544,30 @@ int bags_loss_backward(const float* image, const float* gt, int32_t C, int32_t H
     return BAGS_OK;
 }
 
+int bags_photometric_loss_forward(const float* image, const float* gt, int32_t C, int32_t H, int32_t W, void* workspace,
+                                  size_t workspace_bytes, float lambda_dssim, float* out_loss_terms, void* stream)
+{
+    if (C <= 0 || H <= 0 || W <= 0) return fail(BAGS_ERR_ARG, "photometric_loss_forward: C, H, W must be positive (got %d, %d, %d)", C, H, W);
+    if (!image || !gt || !workspace || !out_loss_terms) return fail(BAGS_ERR_ARG, "photometric_loss_forward: null pointer");
+    if (!(lambda_dssim >= 0.f && lambda_dssim <= 1.f)) return fail(BAGS_ERR_ARG, "photometric_loss_forward: lambda_dssim %g outside [0, 1]", (double)lambda_dssim);
+    if (workspace_bytes < loss_workspace_bytes(C, H, W))
+        return fail(BAGS_ERR_SIZE, "photometric_loss_forward: workspace %zu bytes < %zu", workspace_bytes, loss_workspace_bytes(C, H, W));
+    HIP_TRY(launch_loss_fwd(image, gt, C, H, W, workspace, out_loss_terms, (hipStream_t)stream, true, lambda_dssim));
+    return BAGS_OK;
+}
+
+int bags_photometric_loss_backward(const float* image, const float* gt, int32_t C, int32_t H, int32_t W, const void* workspace,
+                                   size_t workspace_bytes, float lambda_dssim, const float* grad_loss, float* grad_image, void* stream)
+{
+    if (C <= 0 || H <= 0 || W <= 0) return fail(BAGS_ERR_ARG, "photometric_loss_backward: C, H, W must be positive (got %d, %d, %d)", C, H, W);
+    if (!image || !gt || !workspace || !grad_loss || !grad_image) return fail(BAGS_ERR_ARG, "photometric_loss_backward: null pointer");
+    if (!(lambda_dssim >= 0.f && lambda_dssim <= 1.f)) return fail(BAGS_ERR_ARG, "photometric_loss_backward: lambda_dssim %g outside [0, 1]", (double)lambda_dssim);
+    if (workspace_bytes < loss_workspace_bytes(C, H, W))
+        return fail(BAGS_ERR_SIZE, "photometric_loss_backward: workspace %zu bytes < %zu", workspace_bytes, loss_workspace_bytes(C, H, W));
+    HIP_TRY(launch_loss_bwd(image, gt, C, H, W, workspace, grad_loss, grad_image, (hipStream_t)stream, true, lambda_dssim));
+    return BAGS_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- camera chain
 static int check_camera(const BagsCamera* c)
 {
@@ -612,18 +641,19 @@ int bags_resample_backward(const float* image, int32_t C, int32_t H, int32_t W, 
 }
 
 // ---------------------------------------------------------------------------------------------- activations
-static int check_raw(const BagsRawGaussians* r)
+static int check_raw(const BagsRawGaussians* r, bool features)      // features: the SH concatenation (or its gradient) is asked for
 {
     if (!r) return fail(BAGS_ERR_ARG, "activations: null struct");
     if (r->P < 0 || r->K < 1) return fail(BAGS_ERR_ARG, "activations: need P >= 0 and K >= 1 (got %d, %d)", r->P, r->K);
-    if (r->P > 0 && (!r->features_dc || (r->K > 1 && !r->features_rest) || !r->opacity || !r->scaling || !r->rotation))
-        return fail(BAGS_ERR_ARG, "activations: null parameter pointer");
+    if (r->P > 0 && (!r->opacity || !r->scaling || !r->rotation)) return fail(BAGS_ERR_ARG, "activations: null parameter pointer");
+    if (r->P > 0 && features && (!r->features_dc || (r->K > 1 && !r->features_rest)))
+        return fail(BAGS_ERR_ARG, "activations: null feature pointer (features_dc / features_rest may only be NULL when shs / g_shs is)");
     return BAGS_OK;
 }
 
 int bags_activations_forward(const BagsRawGaussians* r, float* shs, float* opacity, float* scales, float* rotations, void* stream)
 {
-    int rc = check_raw(r);
+    int rc = check_raw(r, shs != nullptr);
     if (rc) return rc;
     HIP_TRY(launch_activations_fwd(r->P, r->K, r->features_dc, r->features_rest, r->opacity, r->scaling, r->rotation, shs, opacity,
                                    scales, rotations, (hipStream_t)stream));
@@ -634,7 +664,7 @@ int bags_activations_backward(const BagsRawGaussians* r, const float* g_shs, con
                               const float* g_rotations, float* g_dc, float* g_rest, float* g_opacity_raw, float* g_scaling,
                               float* g_rotation, void* stream)
 {
-    int rc = check_raw(r);
+    int rc = check_raw(r, g_shs != nullptr && (g_dc != nullptr || g_rest != nullptr));
     if (rc) return rc;
     HIP_TRY(launch_activations_bwd(r->P, r->K, r->features_dc, r->features_rest, r->opacity, r->scaling, r->rotation, g_shs, g_opacity,
                                    g_scales, g_rotations, g_dc, g_rest, g_opacity_raw, g_scaling, g_rotation, (hipStream_t)stream));

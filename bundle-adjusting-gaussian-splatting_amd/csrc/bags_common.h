@@ -183,9 +183,10 @@ bool pose_fold_enabled();                    // the build's preprocess_bwd sums 
 hipError_t launch_pose_reduce(const float* pose_slab, int nblocks, const BagsBackwardArgs& a, hipStream_t st);
 // loss.hip: fused L1 + SSIM terms and their image gradient
 size_t loss_workspace_bytes(int C, int H, int W);
-hipError_t launch_loss_fwd(const float* img, const float* gt, int C, int H, int W, void* ws, float* out_terms, hipStream_t st);
+hipError_t launch_loss_fwd(const float* img, const float* gt, int C, int H, int W, void* ws, float* out_terms, hipStream_t st,
+                           bool combined = false, float lambda_dssim = 0.f);
 hipError_t launch_loss_bwd(const float* img, const float* gt, int C, int H, int W, const void* ws, const float* grad_terms,
-                           float* grad_img, hipStream_t st);
+                           float* grad_img, hipStream_t st, bool combined = false, float lambda_dssim = 0.f);
 // camera.hip: pose leaves -> viewmatrix / projmatrix / intrinsic / campos, and the adjoint
 hipError_t launch_camera_fwd(const float* q0, const float* dq, const float* t0, const float* dt, const float* fovx, const float* fovy,
                              const float* grot, const float* gscale, float znear, float zfar,

@@ -191,7 +191,8 @@ loss_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, int
 
 // one workgroup: fixed-order sum of the per-tile slots in fp64, then the means
 __global__ void __launch_bounds__(256)
-loss_reduce_kernel(const float* __restrict__ partials, int nslots, double inv_count, float* __restrict__ out_terms)
+loss_reduce_kernel(const float* __restrict__ partials, int nslots, double inv_count, float* __restrict__ out_terms,
+                   const int combined, const float lambda_dssim)
 {
     __shared__ double r0[256], r1[256];
     double a = 0.0, b = 0.0;
@@ -202,13 +203,19 @@ loss_reduce_kernel(const float* __restrict__ partials, int nslots, double inv_co
         if ((int)threadIdx.x < d) { r0[threadIdx.x] += r0[threadIdx.x + d]; r1[threadIdx.x] += r1[threadIdx.x + d]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { out_terms[0] = (float)(r0[0] * inv_count); out_terms[1] = (float)(r1[0] * inv_count); }
+    if (threadIdx.x == 0) {
+        const float l1 = (float)(r0[0] * inv_count), ss = (float)(r1[0] * inv_count);
+        if (combined) {     // train.py:325 with the reference's own roundings: (1 - lambda) * L1 + lambda * (1 - SSIM), fp32, left to right
+            out_terms[0] = __fadd_rn(__fmul_rn(1.0f - lambda_dssim, l1), __fmul_rn(lambda_dssim, __fsub_rn(1.0f, ss))); out_terms[1] = l1; out_terms[2] = ss;
+        } else { out_terms[0] = l1; out_terms[1] = ss; }
+    }
 }
 
 __global__ void __launch_bounds__(256, LOSS_BWD_WAVES)
 loss_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, int H, int W, int vec, LossWindow win,
                 const float* __restrict__ dmu, const float* __restrict__ de11, const float* __restrict__ de12,
-                const float* __restrict__ grad_terms, float inv_count, float* __restrict__ grad_img)
+                const float* __restrict__ grad_terms, float inv_count, float* __restrict__ grad_img, const int combined,
+                const float lambda_dssim)
 {
     // 42-wide rows, scalar staging.  The three row-filtered maps are written over the staged ones (the row pass keeps its sums
     // in registers across the barrier in between): 21.7 KB of LDS instead of 38.3 KB, seven workgroups per CU instead of four.
@@ -266,7 +273,9 @@ loss_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, int
         }
     }
     __syncthreads();
-    const float g_l1 = grad_terms[0] * inv_count, g_ss = grad_terms[1] * inv_count;
+    // combined: grad_terms[0] is dL/d(loss) of loss = (1 - lambda) L1 + lambda (1 - SSIM)
+    const float g_l1 = (combined ? grad_terms[0] * (1.0f - lambda_dssim) : grad_terms[0]) * inv_count;
+    const float g_ss = (combined ? -(grad_terms[0] * lambda_dssim) : grad_terms[1]) * inv_count;
     const int lx = tid & 31, ty = (tid >> 5) * 4;
     float cf[3][4];
 #pragma unroll
@@ -323,7 +332,8 @@ static void carve_loss(void* ws, int C, int H, int W, float** dmu, float** de11,
     *partials = reinterpret_cast<float*>(p + 3 * n);
 }
 
-hipError_t launch_loss_fwd(const float* img, const float* gt, int C, int H, int W, void* ws, float* out_terms, hipStream_t st)
+hipError_t launch_loss_fwd(const float* img, const float* gt, int C, int H, int W, void* ws, float* out_terms, hipStream_t st,
+                           bool combined, float lambda_dssim)
 {
     float *dmu, *de11, *de12, *partials;
     carve_loss(ws, C, H, W, &dmu, &de11, &de12, &partials);
@@ -333,12 +343,12 @@ hipError_t launch_loss_fwd(const float* img, const float* gt, int C, int H, int 
     hipLaunchKernelGGL(loss_fwd_kernel, grid, dim3(256), 0, st, img, gt, H, W, vec, win, dmu, de11, de12, partials);
     const int nslots = (int)(grid.x * grid.y * grid.z);
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)partials, nslots,
-                       1.0 / ((double)C * H * W), out_terms);
+                       1.0 / ((double)C * H * W), out_terms, combined ? 1 : 0, lambda_dssim);
     return hipGetLastError();
 }
 
 hipError_t launch_loss_bwd(const float* img, const float* gt, int C, int H, int W, const void* ws, const float* grad_terms,
-                           float* grad_img, hipStream_t st)
+                           float* grad_img, hipStream_t st, bool combined, float lambda_dssim)
 {
     float *dmu, *de11, *de12, *partials;
     carve_loss(const_cast<void*>(ws), C, H, W, &dmu, &de11, &de12, &partials);
@@ -346,6 +356,6 @@ hipError_t launch_loss_bwd(const float* img, const float* gt, int C, int H, int 
     const LossWindow win = make_window();
     const int vec = ((W & 3) == 0) && (((size_t)dmu | (size_t)de11 | (size_t)de12) & 15) == 0;
     hipLaunchKernelGGL(loss_bwd_kernel, grid, dim3(256), 0, st, img, gt, H, W, vec, win, (const float*)dmu, (const float*)de11,
-                       (const float*)de12, grad_terms, (float)(1.0 / ((double)C * H * W)), grad_img);
+                       (const float*)de12, grad_terms, (float)(1.0 / ((double)C * H * W)), grad_img, combined ? 1 : 0, lambda_dssim);
     return hipGetLastError();
 }

@@ -166,7 +166,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                       const u32* __restrict__ block_base, int per_block, const float* __restrict__ shjac,
                       const float* __restrict__ partials, float* __restrict__ pose_slab,
                       float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_densify,
-                      float* __restrict__ g_shs, float* __restrict__ g_colors, float* __restrict__ g_opac,
+                      float* __restrict__ g_shs, float* __restrict__ g_shs_rest, float* __restrict__ g_colors, float* __restrict__ g_opac,
                       float* __restrict__ g_scales, float* __restrict__ g_rot, float* __restrict__ g_cov3D,
                       u32* __restrict__ tickets, unsigned long long* __restrict__ group_rows, int group_size, int nblocks,
                       float* __restrict__ g_view, float* __restrict__ g_proj, float* __restrict__ g_intr,
@@ -452,13 +452,15 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
             float bs[16];
             sh_basis(deg, ux_, uy_, uz_, bs);
             const int nb = (deg + 1) * (deg + 1);
-            float* gsh = g_shs ? g_shs + (size_t)i * M * 3 : nullptr;
+            // gradient rows: one (M,3) row of g_shs, or (BagsInputs.shs_rest) the DC triple in g_shs + an (M-1,3) row of g_shs_rest
+            float* gsh = g_shs ? (g_shs_rest ? g_shs + 3 * (size_t)i : g_shs + (size_t)i * M * 3) : nullptr;
+            float* gsr = g_shs ? (g_shs_rest ? g_shs_rest + (size_t)i * (M - 1) * 3 : gsh + 3) : nullptr;
             // dL/d(direction) = M^T dL/dcolour, M from the forward (clamped channels carry a zero dL/dcolour)
             const float ddx = mj[0] * drgb[0] + mj[1] * drgb[1] + mj[2] * drgb[2];
             const float ddy = mj[3] * drgb[0] + mj[4] * drgb[1] + mj[5] * drgb[2];
             const float ddz = mj[6] * drgb[0] + mj[7] * drgb[1] + mj[8] * drgb[2];
             // dL/dsh[t][c] = basis_t dL/dcolour_c: no input row needed
-            if (M == 16) {
+            if (M == 16 && (SH_STAGE || !g_shs_rest)) {
 #if SH_STAGE
                 if (stage) {
                     float4* d4 = reinterpret_cast<float4*>(&srow[threadIdx.x][0]);
@@ -494,8 +496,9 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
             for (int t = 0; t < M; ++t) {
                 const bool on = t < nb;
                 const float o0 = on ? bs[t] * drgb[0] : 0.f, o1 = on ? bs[t] * drgb[1] : 0.f, o2 = on ? bs[t] * drgb[2] : 0.f;
-                if (ACCUM) { gsh[3 * t] += o0; gsh[3 * t + 1] += o1; gsh[3 * t + 2] += o2; }
-                else { gsh[3 * t] = o0; gsh[3 * t + 1] = o1; gsh[3 * t + 2] = o2; }
+                float* gr = (t == 0) ? gsh : gsr + 3 * (t - 1);
+                if (ACCUM) { gr[0] += o0; gr[1] += o1; gr[2] += o2; }
+                else { gr[0] = o0; gr[1] = o1; gr[2] = o2; }
             }
             const float dot = ux_ * ddx + uy_ * ddy + uz_ * ddz;
             const float px_ = (ddx - ux_ * dot) * il, py_ = (ddy - uy_ * dot) * il, pz_ = (ddz - uz_ * dot) * il;
@@ -503,8 +506,9 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
             cp0 = -px_; cp1 = -py_; cp2 = -pz_;
         }
     } else if (i < P && g_shs && !colors_precomp) {       // a culled Gaussian: its gradient row is zero
-        float* gsh = g_shs + (size_t)i * M * 3;
-        if (M == 16) {
+        float* gsh = g_shs_rest ? g_shs + 3 * (size_t)i : g_shs + (size_t)i * M * 3;
+        float* gsr = g_shs_rest ? g_shs_rest + (size_t)i * (M - 1) * 3 : gsh + 3;
+        if (M == 16 && (SH_STAGE || !g_shs_rest)) {
 #if SH_STAGE
             if (stage) {
                 float4* d4 = reinterpret_cast<float4*>(&srow[threadIdx.x][0]);
@@ -518,11 +522,41 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                 for (int t = 0; t < 12; ++t) g4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #endif
-        } else if (!ACCUM)
-            for (int t = 0; t < 3 * M; ++t) gsh[t] = 0.f;
+        } else if (!ACCUM) {
+            gsh[0] = gsh[1] = gsh[2] = 0.f;
+            for (int t = 0; t < 3 * (M - 1); ++t) gsr[t] = 0.f;
+        }
     }
 #if SH_STAGE
-    if (stage) {                                     // the workgroup's gradient rows leave as whole lines
+    if (stage && g_shs_rest) {                       // ... as two spans: 256 DC triples (3 KB) and 256 rows of 45 floats (45 KB)
+        __syncthreads();
+        auto span = [&](float* __restrict__ out, const u32 R, const u32 t0, const u32 rounds) {      // R floats per row, first coefficient t0
+            const size_t first = (size_t)blockIdx.x * 256u * R, total = (size_t)P * R;
+            for (u32 k = 0; k < rounds; ++k) {
+                const u32 el = k * 256u + threadIdx.x;           // float4 number inside the workgroup's span
+                if (el * 4u >= 256u * R) break;
+                float o4[4]; size_t gi[4];
+#pragma unroll
+                for (u32 u = 0; u < 4; ++u) {
+                    const u32 f = el * 4u + u, row = f / R, r = f - row * R, t = t0 + r / 3u, c = r - 3u * (r / 3u);
+                    o4[u] = srow[row][t] * srow[row][16u + c];
+                    gi[u] = first + f;
+                }
+                if (gi[3] < total) {
+                    float4* d = reinterpret_cast<float4*>(out + gi[0]);
+                    float4 o = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                    if (ACCUM) { const float4 old = *d; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+                    *d = o;
+                } else {
+#pragma unroll
+                    for (u32 u = 0; u < 4; ++u)
+                        if (gi[u] < total) out[gi[u]] = ACCUM ? out[gi[u]] + o4[u] : o4[u];
+                }
+            }
+        };
+        span(g_shs, 3u, 0u, 1u);
+        span(g_shs_rest, 45u, 1u, 12u);
+    } else if (stage) {                              // the workgroup's gradient rows leave as whole lines
         __syncthreads();
         float4* g4g = reinterpret_cast<float4*>(g_shs);
 #pragma unroll
@@ -696,7 +730,7 @@ hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, co
                        in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, s.viewmatrix, s.projmatrix, \
                        s.intrinsic, s.campos, in.opacities, g.rec_count, binned ? nullptr : g.inst_off, g.local_off, g.block_base, \
                        binned_per_block(P), g.shjac, partials, \
-                       pose_slab, a.grad_means3D, a.grad_means2D, a.grad_means2D_densify, a.grad_shs, \
+                       pose_slab, a.grad_means3D, a.grad_means2D, a.grad_means2D_densify, a.grad_shs, in.shs_rest ? a.grad_shs_rest : nullptr, \
                        a.grad_colors_precomp, a.grad_opacities, a.grad_scales, a.grad_rotations, a.grad_cov3D_precomp, \
                        fold_tickets, fold_rows, pose_group_size(nb), nb, a.grad_viewmatrix, a.grad_projmatrix, a.grad_intrinsic, \
                        a.grad_campos, a.grad_shift_factors);

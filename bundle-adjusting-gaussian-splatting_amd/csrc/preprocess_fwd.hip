@@ -58,6 +58,7 @@ struct K1Args {
     int rec_opacity;         // tile-binned path with the stock tile rule: the LISTS follow the stock 3-sigma square, the partial-gradient
                              // RECORDS only exist for the tiles the alpha >= 1/255 ellipse reaches (the opacity rule's rectangle + tile mask)
     const float *means3D, *means2D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+    const float* shs_rest;   // BagsInputs.shs_rest: `shs` is then the (P,1,3) DC tensor and this the (P,M-1,3) rest (no concatenation upstream)
     float* shjac;
 };
 struct K1Result {
@@ -68,7 +69,8 @@ struct K1Outputs {
     u32* depth_key; float4* g2d; uint2* rect; u32* tiles_touched; u64* keep; int32_t* radii; float* mean2D; u32* rec_count;
 };
 
-__device__ __forceinline__ K1Result k1_project(const K1Args& A, const CamConst& cam, const int i)
+template <bool SPLIT>            // SPLIT: BagsInputs.shs_rest given (a template parameter: as a run-time branch around the two ways of
+__device__ __forceinline__ K1Result k1_project(const K1Args& A, const CamConst& cam, const int i)     // filling c[48] it cost 22-50 spilled registers)
 {
     const int M = A.M, deg = A.deg, W = A.W, H = A.H, depth_mode = A.depth_mode, tile_bounds = A.tile_bounds;
     const bool want_opacity = (tile_bounds == BAGS_TILES_OPACITY) || (A.rec_opacity != 0);
@@ -237,7 +239,9 @@ __device__ __forceinline__ K1Result k1_project(const K1Args& A, const CamConst& 
                         const float dl = sqrtf(dx * dx + dy * dy + dz * dz);
                         const float ux = dx / dl, uy = dy / dl, uz = dz / dl;
                         const int nb = (deg + 1) * (deg + 1);
-                        const float* sh = shs + (size_t)i * M * 3;
+                        // a Gaussian's coefficients: one (M,3) row of `shs`, or the DC triple of `shs` + an (M-1,3) row of `shs_rest`
+                        const float* __restrict__ dcp = SPLIT ? shs + 3 * (size_t)i : shs + (size_t)i * M * 3;
+                        const float* __restrict__ rsp = SPLIT ? A.shs_rest + (size_t)i * (M - 1) * 3 : dcp + 3;
                         r = 0.f; g = 0.f; b = 0.f;
                         // d(colour)/d(direction): the backward multiplies it with dL/dcolour and never reads the SH row again
                         float mxr = 0.f, mxg = 0.f, mxb = 0.f, myr = 0.f, myg = 0.f, myb = 0.f, mzr = 0.f, mzg = 0.f, mzb = 0.f;
@@ -274,17 +278,29 @@ __device__ __forceinline__ K1Result k1_project(const K1Args& A, const CamConst& 
                         }
                         if (M == 16) {             // 192 B per Gaussian, 16-byte aligned: 12 dwordx4 loads, all requested at once
                             float c[48];
-                            const float4* s4 = reinterpret_cast<const float4*>(sh);
+                            if (SPLIT) {                  // 12 + 180 bytes, the second row only 4-byte aligned (dwordx4 loads at any dword)
+                                struct __attribute__((packed, aligned(4))) UF4 { float x, y, z, w; };
+                                c[0] = dcp[0]; c[1] = dcp[1]; c[2] = dcp[2];
+                                const UF4* u4 = reinterpret_cast<const UF4*>(rsp);
 #pragma unroll
-                            for (int t = 0; t < 12; ++t) {
-                                float4 w = s4[t];
-                                c[4 * t] = w.x; c[4 * t + 1] = w.y; c[4 * t + 2] = w.z; c[4 * t + 3] = w.w;
+                                for (int t = 0; t < 11; ++t) {
+                                    const UF4 w = u4[t];
+                                    c[3 + 4 * t] = w.x; c[4 + 4 * t] = w.y; c[5 + 4 * t] = w.z; c[6 + 4 * t] = w.w;
+                                }
+                                c[47] = rsp[44];
+                            } else {
+                                const float4* s4 = reinterpret_cast<const float4*>(dcp);
+#pragma unroll
+                                for (int t = 0; t < 12; ++t) {
+                                    float4 w = s4[t];
+                                    c[4 * t] = w.x; c[4 * t + 1] = w.y; c[4 * t + 2] = w.z; c[4 * t + 3] = w.w;
+                                }
                             }
 #define CO(k) c[k]
                             SH_ALL()
 #undef CO
                         } else {
-#define CO(k) sh[k]
+#define CO(k) ((k) < 3 ? dcp[(k)] : rsp[(k) - 3])
                             SH_ALL()
 #undef CO
                         }
@@ -348,6 +364,7 @@ __device__ __forceinline__ void k1_load_camera(CamConst& cam, const float* __res
     }
 }
 
+template <bool SPLIT>
 __global__ void __launch_bounds__(256, 5)     // 5 waves per SIMD (<= 96 VGPRs): this kernel lives on occupancy
 preprocess_fwd_kernel(const K1Args A, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
                       const float* __restrict__ intrinsic, const float* __restrict__ campos_p,
@@ -358,7 +375,7 @@ preprocess_fwd_kernel(const K1Args A, const float* __restrict__ viewmatrix, cons
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.P) return;
-    k1_store(O, i, k1_project(A, cam, i), 0u, 0u);
+    k1_store(O, i, k1_project<SPLIT>(A, cam, i), 0u, 0u);
 }
 
 // K1 + step 1 of the tile-binned lists (binning.hip) in one launch (round 4).  One 1024-thread workgroup per block of
@@ -368,6 +385,7 @@ preprocess_fwd_kernel(const K1Args A, const float* __restrict__ viewmatrix, cons
 // written into its geometry line and the compact local_off array.  tile_count_kernel was a
 // 9 us launch of its own on the path to the instance count (its work, 2 M LDS atomics, hides behind K1's memory traffic here),
 // and the offset inside the line saves blend_bwd a 4-byte gather per instance.
+template <bool SPLIT>
 __global__ void __launch_bounds__(BIN_THREADS)
 preprocess_fwd_count_kernel(const K1Args A, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
                             const float* __restrict__ intrinsic, const float* __restrict__ campos_p,
@@ -396,7 +414,7 @@ preprocess_fwd_count_kernel(const K1Args A, const float* __restrict__ viewmatrix
         K1Result R;
         R.key = KEY_CULLED; R.tiles = 0; R.radius = 0; R.rect = make_uint2(0u, 0u); R.keep = ~0ull; R.pxy = make_float2(0.f, 0.f);
         R.q0 = make_float4(0.f, 0.f, 0.f, 0.f); R.rgbz_v = R.q0; R.rtiles = 0; R.rrect = make_uint2(0u, 0u); R.rkeep = ~0ull;
-        if (valid) R = k1_project(A, cam, i);
+        if (valid) R = k1_project<SPLIT>(A, cam, i);
         __builtin_amdgcn_sched_barrier(0);
         // ---- (block, tile) counts: small rectangles by their tile mask, larger ones tile by tile, huge ones by the whole wave
         const u32 nt = R.tiles;
@@ -440,7 +458,7 @@ hipError_t launch_preprocess_fwd(const BagsSettings& s, const BagsInputs& in, co
     A.tanfovx = s.tanfovx; A.tanfovy = s.tanfovy; A.mod = s.scale_modifier; A.depth_mode = s.depth_key; A.tile_bounds = s.tile_bounds;
     A.rec_opacity = (count_into != nullptr && s.tile_bounds != BAGS_TILES_OPACITY) ? 1 : 0;
     A.means3D = in.means3D; A.means2D = in.means2D; A.shs = in.shs; A.colors_precomp = in.colors_precomp; A.opacities = in.opacities;
-    A.scales = in.scales; A.rotations = in.rotations; A.cov3D_precomp = in.cov3D_precomp; A.shjac = g.shjac;
+    A.scales = in.scales; A.rotations = in.rotations; A.cov3D_precomp = in.cov3D_precomp; A.shjac = g.shjac; A.shs_rest = in.shs_rest;
     K1Outputs O;
     O.depth_key = g.depth_key; O.g2d = g.g2d; O.rect = g.rect; O.tiles_touched = g.tiles_touched; O.keep = g.keep; O.radii = radii;
     O.mean2D = mean2D; O.rec_count = g.rec_count;
@@ -448,16 +466,24 @@ hipError_t launch_preprocess_fwd(const BagsSettings& s, const BagsInputs& in, co
         const int gy = cdiv(s.image_height, BAGS_TILE), T = grid_x * gy, T2 = (T + 1) / 2;
         const int per = binned_per_block(P), B = cdiv(P, per);
         const size_t lds = (size_t)T2 * 4;
+        const void* fn = in.shs_rest ? reinterpret_cast<const void*>(preprocess_fwd_count_kernel<true>)
+                                     : reinterpret_cast<const void*>(preprocess_fwd_count_kernel<false>);
         if (lds + 1024 > 65536) {                            // beyond the default 64 KB of LDS per workgroup the launch has to opt in
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(preprocess_fwd_count_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(preprocess_fwd_count_kernel, dim3(B), dim3(BIN_THREADS), lds, st, A, s.viewmatrix, s.projmatrix, s.intrinsic,
-                           s.campos, in.shift_factors, O, per, grid_x, T2, count_into->cnt_rows, g.local_off, g.block_total);
+#define LAUNCH_COUNT(SP)                                                                                                       \
+        hipLaunchKernelGGL(preprocess_fwd_count_kernel<SP>, dim3(B), dim3(BIN_THREADS), lds, st, A, s.viewmatrix, s.projmatrix,  \
+                           s.intrinsic, s.campos, in.shift_factors, O, per, grid_x, T2, count_into->cnt_rows, g.local_off, g.block_total)
+        if (in.shs_rest) LAUNCH_COUNT(true); else LAUNCH_COUNT(false);
+#undef LAUNCH_COUNT
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, A, s.viewmatrix, s.projmatrix, s.intrinsic,
-                       s.campos, in.shift_factors, O);
+    if (in.shs_rest)
+        hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(cdiv(P, 256)), dim3(256), 0, st, A, s.viewmatrix, s.projmatrix, s.intrinsic,
+                           s.campos, in.shift_factors, O);
+    else
+        hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(cdiv(P, 256)), dim3(256), 0, st, A, s.viewmatrix, s.projmatrix, s.intrinsic,
+                           s.campos, in.shift_factors, O);
     return hipGetLastError();
 }

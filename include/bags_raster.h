@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BAGS_ABI_VERSION 6
+#define BAGS_ABI_VERSION 7
 #define BAGS_TILE 16
 
 enum { BAGS_OK = 0, BAGS_ERR_ARG = -1, BAGS_ERR_HIP = -2, BAGS_ERR_SIZE = -3, BAGS_ERR_DEVICE = -4 };
@@ -90,6 +90,10 @@ typedef struct BagsInputs {
     const float* scales;             /* (P,3) or NULL */
     const float* rotations;          /* (P,4) (w,x,y,z) or NULL */
     const float* cov3D_precomp;      /* (P,6) xx,xy,xz,yy,yz,zz or NULL (exactly one of scales+rotations / cov3D) */
+    /* (ABI 7) the reference's two feature parameters as they are stored, without GaussianModel.get_features' torch.cat
+     * (scene/gaussian_model.py:131-134: 96 MB read + 96 MB written per call at 500 k Gaussians, and as much again for the split of
+     * the gradient): when non-NULL, `shs` is features_dc (P,1,3) and this is features_rest (P,M-1,3), M = settings.sh_coeffs >= 2 */
+    const float* shs_rest;
 } BagsInputs;
 
 /* caller-owned state that survives from forward to backward */
@@ -135,6 +139,7 @@ typedef struct BagsBackwardArgs {
      * autograd would do with one add pass per view and tensor; every other output is overwritten as before (ABI 6) */
     int32_t accumulate;
     int32_t reserved1;
+    float* grad_shs_rest;            /* (P,M-1,3), with inputs.shs_rest: grad_shs is then the (P,1,3) gradient of features_dc (ABI 7) */
 } BagsBackwardArgs;
 
 /* integer artefacts for bit-exact parity checks (all device pointers, any may be NULL) */
@@ -218,6 +223,17 @@ int bags_loss_forward(const float* image, const float* gt, int32_t C, int32_t H,
 int bags_loss_backward(const float* image, const float* gt, int32_t C, int32_t H, int32_t W, const void* workspace,
                        size_t workspace_bytes, const float* grad_terms, float* grad_image, void* stream);
 
+/* The same pair with train.py:325's combination inside (ABI 7): loss = (1 - lambda_dssim) * L1 + lambda_dssim * (1 - SSIM), formed
+ * in fp32 with the roundings of the reference's PyTorch expression.  The scalar arithmetic around the two terms and its autograd
+ * backward were ten one-element PyTorch launches per iteration (48 us of a 1.05 ms iteration at 1080p).
+ *   out_loss_terms  device float[3]: { loss, mean |image-gt|, mean SSIM }
+ *   grad_loss       device float[1]: upstream dL/dloss (read on the device)
+ * Same workspace as above (bags_loss_workspace_size), kept from forward to backward. */
+int bags_photometric_loss_forward(const float* image, const float* gt, int32_t C, int32_t H, int32_t W, void* workspace,
+                                  size_t workspace_bytes, float lambda_dssim, float* out_loss_terms, void* stream);
+int bags_photometric_loss_backward(const float* image, const float* gt, int32_t C, int32_t H, int32_t W, const void* workspace,
+                                   size_t workspace_bytes, float lambda_dssim, const float* grad_loss, float* grad_image, void* stream);
+
 /* The pose -> matrix chain of scene/cameras.py:356-381 in one launch each way: replaces
  * get_world_view_transform / get_full_proj_transform / get_intrinsic / get_camera_center (~40 PyTorch kernels and six 4x4
  * inversions per render() call, gaussian_renderer/__init__.py:57,58,61) and their autograd backward.  All pointers are
@@ -263,7 +279,9 @@ int bags_resample_backward(const float* image, int32_t C, int32_t H, int32_t W, 
 
 /* The parameter activations that feed the op, one launch each way: GaussianModel.get_features
  * (cat of features_dc and features_rest), get_opacity (sigmoid), get_scaling (exp), get_rotation (normalize) --
- * scene/gaussian_model.py:118-141.  K = SH coefficients per Gaussian (1 + rest).  Outputs / gradients may be NULL. */
+ * scene/gaussian_model.py:118-141.  K = SH coefficients per Gaussian (1 + rest).  Outputs / gradients may be NULL; with
+ * shs (g_shs) NULL the feature pointers may be NULL too and the launch is one thread per Gaussian (a container that keeps
+ * features_dc and features_rest as views of one (P,K,3) tensor needs no concatenation: bags_raster.gaussians.GaussianBag). */
 typedef struct BagsRawGaussians {
     int32_t P, K;
     const float* features_dc;        /* (P,1,3)   */

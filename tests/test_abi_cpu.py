@@ -42,10 +42,10 @@ def test_buffer_sizes_grow_with_problem(lib):
 def test_struct_layout_matches_header(lib):
     # field counts and pointer-size packing of the POD structs (a mismatch would corrupt every call)
     assert C.sizeof(_lib.BagsSettings) == 14 * 4 + 5 * 8     # + clamp_grad, reserved0 (ABI 5)
-    assert C.sizeof(_lib.BagsInputs) == 8 + 9 * 8
+    assert C.sizeof(_lib.BagsInputs) == 8 + 9 * 8 + 8          # + shs_rest (ABI 7)
     assert C.sizeof(_lib.BagsState) == 6 * 8
     assert C.sizeof(_lib.BagsForwardOut) == 5 * 8
-    assert C.sizeof(_lib.BagsBackwardArgs) == 4 * 8 + 14 * 8 + 8 + 8      # + binning_capacity (ABI 4), accumulate + reserved1 (ABI 6)
+    assert C.sizeof(_lib.BagsBackwardArgs) == 4 * 8 + 14 * 8 + 8 + 8 + 8  # + binning_capacity (ABI 4), accumulate + reserved1 (ABI 6), grad_shs_rest (ABI 7)
     assert C.sizeof(_lib.BagsDebugViews) == 8 * 8
 
 

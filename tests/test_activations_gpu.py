@@ -43,3 +43,21 @@ def test_fused_activations_partial_use_and_errors():
     assert torch.allclose(pc._scaling.grad, torch.exp(pc._scaling.detach()))
     with pytest.raises(RuntimeError, match="GPU"):
         fused_activations(torch.zeros(2, 1, 3), torch.zeros(2, 15, 3), torch.zeros(2, 1), torch.zeros(2, 3), torch.ones(2, 4))
+
+
+
+def test_activations_without_the_feature_concatenation():
+    """activated(features=False): the three activations from one launch with one thread per Gaussian, no (P,K,3) tensor."""
+    sc = synth_scene(500, 4, 0.5, 3)
+    pc0 = GaussianBag.from_activated(sc, 3, device=DEV)
+    pc1 = GaussianBag.from_activated(sc, 3, device=DEV)
+    want, got = list(pc0.activated()), list(pc1.activated(features=False))
+    assert got[1] is None
+    g = torch.Generator().manual_seed(6)
+    for j in (2, 3, 4):
+        assert torch.equal(got[j], want[j])
+    cots = [torch.randn(w.shape, generator=g).to(DEV) for w in want]
+    torch.autograd.backward(want[2:], cots[2:]); torch.autograd.backward(got[2:], cots[2:])
+    for a, b in zip(pc1.leaves()[3:], pc0.leaves()[3:]):
+        assert torch.equal(a.grad, b.grad)
+    assert pc1._features_dc.grad is None and pc1._features_rest.grad is None

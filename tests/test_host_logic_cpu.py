@@ -94,3 +94,4 @@ def test_settings_reject_unknown_modes_before_touching_the_device():
     assert st.clamp_grad == "stock" and st.tile_bounds == "opacity" and st.binning == "auto"      # the operator's defaults
     with pytest.raises(RuntimeError, match="AMD GPU"):                                             # CPU tensors: no fallback
         GaussianRasterizer(st)(means3D=z(2, 3), means2D=z(2, 3), opacities=z(2, 1), shs=z(2, 1, 3), scales=z(2, 3), rotations=z(2, 4))
+

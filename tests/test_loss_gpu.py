@@ -74,6 +74,27 @@ def test_fused_loss_full_size_properties():
     assert ((a5.grad - 2.0 * a1.grad).norm() / a1.grad.norm()).item() < 1e-6
 
 
+@pytest.mark.parametrize("lam", [0.2, 0.0, 1.0, 0.37])
+def test_combined_loss_equals_the_two_term_composition(lam):
+    """bags_photometric_loss_* (the combination of train.py:325 inside the kernels) against the same expression written in
+    PyTorch on the two terms: the loss to two ulp, dL/dimage to rounding, scaled upstream gradients,
+    and the two logging terms detached."""
+    g = torch.Generator().manual_seed(11)
+    a = torch.rand(3, 70, 93, generator=g).to(DEV)
+    b = (a + 0.1 * torch.randn(3, 70, 93, generator=g).to(DEV)).clamp(0, 1)
+    a1 = a.clone().requires_grad_(True); a2 = a.clone().requires_grad_(True)
+    loss, l1c, sc = L.fused_photometric_loss(a1, b, lam, return_terms=True)
+    l1, s = L.fused_l1_ssim(a2, b)
+    ref = (1.0 - lam) * l1 + lam * (1.0 - s)
+    assert abs(loss.item() - ref.item()) <= 2.5e-7 and torch.equal(l1c, l1) and torch.equal(sc, s)     # (1 - lambda is rounded once on each side)
+    assert not l1c.requires_grad and not sc.requires_grad and loss.requires_grad
+    (2.5 * loss).backward(); (2.5 * ref).backward()
+    scale = a2.grad.abs().max().item()
+    assert (a1.grad - a2.grad).abs().max().item() <= 1e-6 * scale + 1e-12
+    with pytest.raises(RuntimeError, match="lambda_dssim"):
+        L.fused_photometric_loss(a1, b, 1.5)
+
+
 def test_fused_loss_rejects_bad_arguments():
     a = torch.rand(3, 8, 8)
     with pytest.raises(RuntimeError, match="GPU tensor"):

@@ -971,3 +971,64 @@ def test_zero_gaussians_render_the_background(binning):
     out[0].sum().backward()
     for k, v in ct.items():
         assert v.grad is None or float(v.grad.abs().max()) == 0.0, k
+
+
+@pytest.mark.parametrize("M,deg,P", [(16, 3, 3001), (16, 1, 700), (4, 1, 515), (9, 2, 130)])
+def test_split_sh_pair_equals_the_concatenated_tensor(M, deg, P):
+    """ABI 7: shs = features_dc (P,1,3) + shs_rest = features_rest (P,M-1,3), the reference's two parameters as they are stored
+    (scene/gaussian_model.py:131-134), against the same values concatenated: image, radii and every other gradient bit for bit,
+    the two feature gradients = the two slices of dL/dshs -- M = 16 goes through the staged whole-line stores (tail float4 of
+    an odd P included), other M through the per-row form; active degree below the stored one; then once more accumulating."""
+    from bags_raster import GaussianRasterizer
+    from bags_raster import rasterizer as R
+    from scenes import hip_settings
+    dev = torch.device("cuda", 0)
+    scene, cam = make_case(P, 176, 112, 1.5, 3, seed=5)
+    shs = scene["shs"][:, :M, :].contiguous()
+    rast = GaussianRasterizer(hip_settings(cam, deg, dev))
+    g = torch.randn(3, 112, 176, generator=torch.Generator().manual_seed(9)).to(dev)
+
+    def run(split, leaves=None, accumulate=False):
+        if leaves is None:
+            base = {k: scene[k].to(dev).clone().requires_grad_(True) for k in ("means3D", "opacities", "scales", "rotations")}
+            if split:
+                base["dc"] = shs[:, :1, :].contiguous().to(dev).requires_grad_(True)
+                base["rest"] = shs[:, 1:, :].contiguous().to(dev).requires_grad_(True)
+            else:
+                base["shs"] = shs.to(dev).clone().requires_grad_(True)
+            leaves = base
+        m2d = torch.zeros(P, 3, device=dev, requires_grad=True)
+        kw = dict(shs=leaves["dc"], shs_rest=leaves["rest"]) if split else dict(shs=leaves["shs"])
+        R.ACCUMULATE_IN_PLACE = accumulate
+        try:
+            out = rast(means3D=leaves["means3D"], means2D=m2d, means2D_densify=None, shift_factors=None, colors_precomp=None,
+                       opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"], cov3D_precomp=None, **kw)
+            out[0].backward(g)
+        finally:
+            R.ACCUMULATE_IN_PLACE = False
+        return out, leaves, m2d
+    o0, l0, m0 = run(False)
+    o1, l1, m1 = run(True)
+    assert torch.equal(o0[0], o1[0]) and torch.equal(o0[1], o1[1])
+    for k in ("means3D", "opacities", "scales", "rotations"):
+        assert torch.equal(l0[k].grad, l1[k].grad), k
+    assert torch.equal(m0.grad, m1.grad)
+    assert l1["dc"].grad.shape == (P, 1, 3) and l1["rest"].grad.shape == (P, M - 1, 3)
+    assert torch.equal(l1["dc"].grad, l0["shs"].grad[:, :1, :]) and torch.equal(l1["rest"].grad, l0["shs"].grad[:, 1:, :])
+    if deg < 3 and (deg + 1) ** 2 < M:
+        assert float(l1["rest"].grad[:, (deg + 1) ** 2 - 1:, :].abs().max()) == 0.0          # inactive coefficients: exact zeros
+    # a second view accumulating in place into the pair's .grad (the view-sharded step, sharding.py)
+    first = {k: v.grad.clone() for k, v in l1.items()}
+    run(True, l1, accumulate=True)
+    for k, v in l1.items():
+        assert torch.allclose(v.grad, 2.0 * first[k], rtol=1e-6, atol=1e-7), k
+    # only one of the pair wanted
+    dc = shs[:, :1, :].contiguous().to(dev); rest = shs[:, 1:, :].contiguous().to(dev).requires_grad_(True)
+    out = rast(means3D=l0["means3D"].detach(), means2D=None, means2D_densify=None, shift_factors=None, colors_precomp=None,
+               opacities=l0["opacities"].detach(), scales=l0["scales"].detach(), rotations=l0["rotations"].detach(),
+               cov3D_precomp=None, shs=dc, shs_rest=rest)
+    out[0].backward(g)
+    assert torch.equal(rest.grad, first["rest"])
+    with pytest.raises(ValueError, match="features_dc"):
+        rast(means3D=l0["means3D"], means2D=None, opacities=l0["opacities"], scales=l0["scales"], rotations=l0["rotations"],
+             shs=shs.to(dev), shs_rest=rest)

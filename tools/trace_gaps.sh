@@ -4,7 +4,12 @@
 # of ~12 kernels per step costs.
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/trg && rocprofv3 --kernel-trace --output-format csv -d /tmp/trg -- python3 $ROOT/bench.py --steps 60 --warmup 5 --settle-steps 100 --no-cpu-baseline --no-profile --no-aabb-leg --no-v4-leg "$@" > /tmp/trg.log 2>&1
+# TRACE_ITERATION=1: the same for one training iteration (tools/bench_iteration.py --fused-only: camera chain, activations, render, loss, backward)
+if [ -n "$TRACE_ITERATION" ]; then
+  rm -rf /tmp/trg && rocprofv3 --kernel-trace --output-format csv -d /tmp/trg -- python3 $ROOT/tools/bench_iteration.py --fused-only --steps 60 > /tmp/trg.log 2>&1
+else
+  rm -rf /tmp/trg && rocprofv3 --kernel-trace --output-format csv -d /tmp/trg -- python3 $ROOT/bench.py --steps 60 --warmup 5 --settle-steps 100 --no-cpu-baseline --no-profile --no-aabb-leg --no-v4-leg "$@" > /tmp/trg.log 2>&1
+fi
 f=$(find /tmp/trg -name "*kernel_trace.csv" | head -1)
 [ -z "$f" ] && { echo "no trace"; tail -5 /tmp/trg.log; exit 1; }
 python3 - "$f" <<'PY'
@@ -22,6 +27,10 @@ for a, b in zip(starts[:-1], starts[1:]):
     names = collections.Counter()
     for j, (s, e, n) in enumerate(seq):
         short = n.split('(')[0].replace('void ', '')[:40]
+        if short.startswith('at::native'):                     # PyTorch's own: keep the functor, it names the op
+            import re, os
+            m = re.search(r'(\w+Functor\w*|\w+_kernel_cuda\w*|FillFunctor|\w+Op<\w+>|direct_copy_kernel\w*|\w+_cuda\b)', n)
+            short = ('at::' + (m.group(1) if m else n[60:100]))[:40]
         names[short] += 1
         key = (short, names[short])
         if key not in order: order.append(key)
