@@ -61,15 +61,14 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, mlp_color, shift_
     # rasterizer-side SH colours: the two feature parameters go to the op as they are stored (shs = features_dc, shs_rest =
     # features_rest), without get_features' torch.cat; every other colour path needs the (P,K,3) tensor
     raster_sh = override_color is None and not (hybrid or pipe.convert_SHs_python)
-    split = (raster_sh and hasattr(pc, "activated") and getattr(pc, "_features_rest", None) is not None
-             and pc._features_rest.dim() == 3 and pc._features_rest.shape[1] >= 1 and pc._features_dc.is_cuda)
-    if split:
-        xyz, _, opacity, scaling, rotation = pc.activated(features=False)
-        features = None
-    elif hasattr(pc, "activated"):
-        xyz, features, opacity, scaling, rotation = pc.activated()
-    else:
-        xyz, features, opacity, scaling, rotation = pc.get_xyz, pc.get_features, pc.get_opacity, pc.get_scaling, pc.get_rotation
+    rest = getattr(pc, "_features_rest", None)
+    split = (raster_sh and torch.is_tensor(rest) and torch.is_tensor(getattr(pc, "_features_dc", None)) and rest.dim() == 3
+             and rest.shape[1] >= 1 and rest.is_cuda)
+    if hasattr(pc, "activated"):                               # GaussianBag: one fused launch each way
+        xyz, features, opacity, scaling, rotation = pc.activated(features=not split)
+    else:                                                      # any container with the reference's properties (GaussianModel)
+        xyz, opacity, scaling, rotation = pc.get_xyz, pc.get_opacity, pc.get_scaling, pc.get_rotation
+        features = None if split else pc.get_features
     # zero tensors whose .grad receives the screen-space gradients (:37-44)
     # (leaves: `.grad` is populated as with the reference's `zeros + 0` / retain_grad() pair, without the two adds and the two
     # 6 MB gradient copies that pair costs per call)

@@ -5,7 +5,7 @@ walks that block's list 16 splats per step; a wave runs max over its four rows o
 This script rebuilds the per-(tile, chunk, block) list lengths from the oracle's sorted lists and the kernel's reach-mask
 rule and prints how many of the issued lane slots hold a live (block, splat) pair under a few assignment policies.
 
-usage: python tests/analysis_lane_fill.py [--ring] [P] [W] [H] [sm]
+usage: python tests/analysis_lane_fill.py [--ring | --fwd] [P] [W] [H] [sm]
 """
 import os
 import sys
@@ -72,6 +72,27 @@ def main():
     print(f"P={P} {W}x{H} sm={sm}: I={I}, instances/tile mean {n_t.mean():.0f}, blocks reached per instance {m.sum(1).mean():.2f}")
     if globals().get("_RING"):
         ring_policies((m * (1 << np.arange(16))).sum(1).astype(np.uint16), ranges)
+        return
+    if globals().get("_FWD"):
+        # forward (blend_fwd_rows_kernel): one splat per step and row, chunks of 255 cut from the FRONT, a wave runs the longest
+        # of its four rows' lists per chunk: what the row imbalance costs and what other block -> wave groupings would give
+        ck = pos // 255
+        nck = int(ck.max()) + 1
+        L = np.zeros((gx * gy, nck, 16), dtype=np.int64)
+        for b in range(16):
+            np.add.at(L[:, :, b], (tile[m[:, b]], ck[m[:, b]]), 1)
+        live = L.sum()
+        quad_idx = [[qy * 8 + qx * 2, qy * 8 + qx * 2 + 1, qy * 8 + qx * 2 + 4, qy * 8 + qx * 2 + 5] for qy in range(2) for qx in range(2)]
+        quad = np.stack([L[:, :, q] for q in quad_idx], 2)
+        st_quad = quad.max(3).sum()
+        srt = np.sort(L, axis=2)[:, :, ::-1].reshape(gx * gy, nck, 4, 4)
+        st_chunk = srt.max(3).sum()
+        order = np.argsort(-L.sum(1), axis=1)                  # one grouping per tile, by the blocks' whole-tile list lengths
+        Ls = np.take_along_axis(L, order[:, None, :].repeat(nck, 1), axis=2).reshape(gx * gy, nck, 4, 4)
+        st_tile = Ls.max(3).sum()
+        print(f"  forward: {live / 1e6:.2f} M (splat, block) entries = {live / 4e6:.2f} M wave steps at perfect balance; quadrant rows "
+              f"{st_quad / 1e6:.2f} M ({live / 4 / st_quad:.3f}), ranked per tile {st_tile / 1e6:.2f} M ({live / 4 / st_tile:.3f}), "
+              f"ranked per chunk {st_chunk / 1e6:.2f} M ({live / 4 / st_chunk:.3f})")
         return
     for chunk in (128, 256):
         ck = (n_t[tile] - 1 - pos) // chunk                    # chunks are cut from the back of the list
@@ -144,4 +165,7 @@ if __name__ == "__main__":
         _RING = True
     else:
         _RING = False
+    _FWD = "--fwd" in sys.argv
+    if _FWD:
+        sys.argv.remove("--fwd")
     main()
