@@ -27,7 +27,7 @@
 template <bool EMIT>
 __device__ __forceinline__ u32 walk_block(u32* cnt, int P, int per_block, int grid_x, const uint2* __restrict__ rect,
                                           const u32* __restrict__ tiles_touched, const u64* __restrict__ keep,
-                                          const u32* __restrict__ depth_key, u64* __restrict__ words)
+                                          u32* __restrict__ ids)
 {
     const int lane = threadIdx.x & 63;
     const int per_thread = per_block / BIN_THREADS;
@@ -36,13 +36,12 @@ __device__ __forceinline__ u32 walk_block(u32* cnt, int P, int per_block, int gr
     for (int k0 = 0; k0 < per_thread; k0 += 4) {            // uniform trip counts: the ballots below need every lane
         // four Gaussians' counts, rectangles and masks requested together, unconditionally (clamped index): one memory
         // round trip per batch instead of three per Gaussian
-        u32 ntv[4]; uint2 rcv[4]; u64 kpv[4]; u32 dkv[4];
+        u32 ntv[4]; uint2 rcv[4]; u64 kpv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const long long g = g0 + k0 + u;
             const long long gc = g < P ? g : (long long)P - 1;
             ntv[u] = tiles_touched[gc]; rcv[u] = rect[gc]; kpv[u] = keep[gc];
-            dkv[u] = EMIT ? depth_key[gc] : 0u;
             if (!(g < P) || k0 + u >= per_thread) ntv[u] = 0u;
         }
 #pragma unroll
@@ -51,18 +50,16 @@ __device__ __forceinline__ u32 walk_block(u32* cnt, int P, int per_block, int gr
             const u32 nt = ntv[u]; const uint2 rc = rcv[u];
             const int w = (int)(rc.y & 0xFFFF) - (int)(rc.x & 0xFFFF), h = (int)(rc.y >> 16) - (int)(rc.x >> 16);
             mine += nt;                                     // a large rectangle emits every tile: nt is its area
-            const u64 word = ((u64)dkv[u] << 32) | (u64)(u32)g;   // what the per-tile sort orders: depth key, then id
-            if (nt > 0) {
-                if (rect_small(w, h)) walk_mask<EMIT>(cnt, rc, kpv[u], grid_x, word, words);
-                else if (nt <= BIN_COOP) walk_rect<EMIT>(cnt, rc, grid_x, lane, false, word, words);
+            if (nt > 0) {                                   // (the id alone is emitted: WordSrc, binning_common.h)
+                if (rect_small(w, h)) walk_mask<EMIT>(cnt, rc, kpv[u], grid_x, (u32)g, ids);
+                else if (nt <= BIN_COOP) walk_rect<EMIT>(cnt, rc, grid_x, lane, false, (u32)g, ids);
             }
             u64 big = __ballot(nt > BIN_COOP);              // never a small rectangle (at most 64 tiles)
             while (big) {
                 const int src = __ffsll((long long)big) - 1;
                 big &= big - 1;
                 const uint2 brc = make_uint2((u32)__shfl((int)rc.x, src), (u32)__shfl((int)rc.y, src));
-                const u64 bw = ((u64)(u32)__shfl((int)dkv[u], src) << 32) | (u64)(u32)__shfl((int)(u32)g, src);
-                walk_rect<EMIT>(cnt, brc, grid_x, lane, true, bw, words);
+                walk_rect<EMIT>(cnt, brc, grid_x, lane, true, (u32)__shfl((int)(u32)g, src), ids);
             }
         }
     }
@@ -366,9 +363,11 @@ emit_binned_kernel(int P, int per_block, int grid_x, int T, const uint2* __restr
     }
     if (s_gb[512] > capacity) return;                        // the lists do not fit the buffer: nothing is written (the caller reruns)
     const u32* prow = pre + (size_t)blockIdx.x * T;
-    for (int t = threadIdx.x; t < T; t += BIN_THREADS) cur[t] = s_gb[t >> 6] + tile_lstart[t] + prow[t];
+    // u32 cursors: a tile's ids go to the first half of its own slice of `words` (u32 index 2 * first instance + position)
+    for (int t = threadIdx.x; t < T; t += BIN_THREADS) cur[t] = 2u * (s_gb[t >> 6] + tile_lstart[t]) + prow[t];
     __syncthreads();
-    (void)walk_block<true>(cur, P, per_block, grid_x, rect, tiles_touched, keep, depth_key, words);
+    (void)depth_key;
+    (void)walk_block<true>(cur, P, per_block, grid_x, rect, tiles_touched, keep, reinterpret_cast<u32*>(words));
 }
 
 // ------------------------------------------------------------------------------------------------ 5. tile_sort (tile_sort.h)
@@ -378,7 +377,7 @@ emit_binned_kernel(int P, int per_block, int grid_x, int T, const uint2* __restr
 __global__ void __launch_bounds__(256)
 tile_sort_kernel(const uint4* __restrict__ tile_desc, const u32* __restrict__ n_active, const u64* __restrict__ words_in,
                  u64* __restrict__ scratch, u32* __restrict__ point_list, u32 capacity, const u32* __restrict__ n_dev, int T,
-                 u32 n_large_wg)
+                 u32 n_large_wg, const u32* __restrict__ depth_key)
 {
     __shared__ u64 t_all[TSORT_BLOCK];                       // one list of <= TSORT_BLOCK words, or four waves x TSORT_WAVE (slab sort / short lists)
     __shared__ u32 cnt_all[TSORT_BLOCK / 2];                 // packed 16-bit counters
@@ -387,14 +386,17 @@ tile_sort_kernel(const uint4* __restrict__ tile_desc, const u32* __restrict__ n_
     const int wave = threadIdx.x >> 6;
     if (blockIdx.x >= n_large_wg) {                          // short lists: a wave per tile
         const u32 d = (blockIdx.x - n_large_wg) * 4u + (u32)wave;
-        if (d < (u32)T) sort_wave_role(tile_desc[d], words_in, point_list, t_all + wave * TSORT_WAVE, cnt_all + wave * (TSORT_WAVE / 2));
+        if (d < (u32)T) {
+            const uint4 dd = tile_desc[d];
+            sort_wave_role(dd, tile_words(words_in, dd.y, depth_key), point_list, t_all + wave * TSORT_WAVE, cnt_all + wave * (TSORT_WAVE / 2));
+        }
         return;
     }
     const u32 n_long = n_active[1];
     for (u32 d = blockIdx.x; d < n_long; d += n_large_wg) {
         const uint4 desc = tile_desc[d];
         if (desc.z <= TSORT_WAVE) continue;                   // uniform over the workgroup
-        sort_list_block(desc, words_in, scratch, point_list, t_all, cnt_all, L);
+        sort_list_block(desc, tile_words(words_in, desc.y, depth_key), scratch, point_list, t_all, cnt_all, L);
     }
 }
 
@@ -480,7 +482,7 @@ hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int
     // long lists first (lowest workgroup ids): their few workgroups run beside the many short sorts
     const u32 n_large_wg = (u32)(T < 768 ? T : 768);
     hipLaunchKernelGGL(tile_sort_kernel, dim3(n_large_wg + (u32)cdiv(T, 4)), dim3(256), 0, st, im.tile_desc, im.n_active, words, scratch,
-                       point_list, capacity, n_dev, T, n_large_wg);
+                       point_list, capacity, n_dev, T, n_large_wg, g.depth_key);
     return hipGetLastError();
 }
 

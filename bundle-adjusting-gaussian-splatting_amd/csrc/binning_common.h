@@ -43,21 +43,36 @@ __device__ __forceinline__ u32 lds_count_tile(u32* cnt, u32 t) { return atomicAd
 // block, loaded as two coalesced rows); the returning LDS atomic hands the instance its final slot, and the Gaussian id is
 // the only thing written (the per-tile sort fetches the depth key by id: a 4-byte scattered store per instance instead of
 // two scattered loads and an 8-byte store -- the request rate of the L2 channels, not the bytes, bounded this kernel).
+// What the per-tile sort orders: (depth key << 32) | Gaussian id.  The emission writes only the 4-byte id (round 4: the 8-byte
+// word was 55 MB of partial-line HBM writes per step for 16.6 MB of words -- every word of a tile's list comes from another
+// workgroup, on another XCD); the sort forms the word when it loads the list, the key gathered from the 2 MB depth_key array,
+// which the L2 holds.  A tile's unsorted ids occupy the FIRST HALF of its own slice of the `words` buffer (u32 index
+// 2 * first + k): the slice stays the tile's private scratch afterwards (reach words, compacted positions: blend.hip).
+struct WordSrc {
+    const u32* __restrict__ ids;       // the tile's ids, offset so that ids[first + k] is its k-th entry (= words32 + first)
+    const u32* __restrict__ keys;      // GeomView::depth_key
+    __device__ __forceinline__ u64 operator[](const u32 i) const { const u32 id = ids[i]; return ((u64)keys[id] << 32) | (u64)id; }
+};
+__device__ __forceinline__ WordSrc tile_words(const void* words, const u32 first, const u32* __restrict__ keys)
+{
+    WordSrc w; w.ids = reinterpret_cast<const u32*>(words) + first; w.keys = keys; return w;
+}
+
 template <bool EMIT>
-__device__ __forceinline__ void walk_rect(u32* cnt, uint2 rc, int grid_x, int lane, bool coop, u64 word, u64* __restrict__ words)
+__device__ __forceinline__ void walk_rect(u32* cnt, uint2 rc, int grid_x, int lane, bool coop, u32 id, u32* __restrict__ ids)
 {
     const int minx = rc.x & 0xFFFF, miny = rc.x >> 16, w = (int)(rc.y & 0xFFFF) - minx, h = (int)(rc.y >> 16) - miny;
     const int nt = w * h;
     for (int k = coop ? lane : 0; k < nt; k += coop ? 64 : 1) {
         const int dy = k / w, dx = k - dy * w;
         const u32 t = (u32)((miny + dy) * grid_x + minx + dx);
-        if (EMIT) words[atomicAdd(&cnt[t], 1u)] = word;
+        if (EMIT) ids[atomicAdd(&cnt[t], 1u)] = id;
         else (void)lds_count_tile(cnt, t);
     }
 }
 // A rectangle of at most 8 x 8 tiles: the set bits of its tile mask (GeomView::keep), no division.
 template <bool EMIT>
-__device__ __forceinline__ void walk_mask(u32* cnt, uint2 rc, u64 m, int grid_x, u64 word, u64* __restrict__ words)
+__device__ __forceinline__ void walk_mask(u32* cnt, uint2 rc, u64 m, int grid_x, u32 id, u32* __restrict__ ids)
 {
     const int minx = rc.x & 0xFFFF, miny = rc.x >> 16;
     const u32 t0 = (u32)(miny * grid_x + minx);
@@ -65,7 +80,7 @@ __device__ __forceinline__ void walk_mask(u32* cnt, uint2 rc, u64 m, int grid_x,
         const int bit = __ffsll((long long)m) - 1;
         m &= m - 1ull;
         const u32 t = t0 + (u32)((bit >> 3) * grid_x + (bit & 7));
-        if (EMIT) words[atomicAdd(&cnt[t], 1u)] = word;
+        if (EMIT) ids[atomicAdd(&cnt[t], 1u)] = id;
         else (void)lds_count_tile(cnt, t);
     }
 }

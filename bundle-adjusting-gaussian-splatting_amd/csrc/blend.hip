@@ -926,7 +926,7 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
 template <int DUMMY>
 __global__ void __launch_bounds__(256, FWD_WG_PER_CU)
 blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_desc, u32* __restrict__ point_list,
-                      const u64* __restrict__ words_in, u64* __restrict__ sort_scratch,
+                      const u64* __restrict__ words_in, const u32* __restrict__ depth_key, u64* __restrict__ sort_scratch,
                       unsigned char* __restrict__ reach_mask, const u32 rm_stride, const float4* __restrict__ g2d, const float* __restrict__ bg, float* __restrict__ out_color,
                       float* __restrict__ out_depth, float* __restrict__ out_weights, float* __restrict__ final_T,
                       u32* __restrict__ n_contrib, const u32* __restrict__ n_dev, u32 capacity, const int test_keep,
@@ -982,15 +982,17 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
 #define FWD_SORT_BLOCK 0      // short lists by the whole workgroup (block sort: four waves, barriers) instead of by wave 0 alone
 #endif
         TileSortLds& TL = *reinterpret_cast<TileSortLds*>(lds_raw + LDS_TS_L);
-        if (n == 1) { if (tid == 0) point_list[desc.y] = (u32)words_in[desc.y]; }
-        else if (FWD_SORT_BLOCK && n <= 256) sort_one_block<1>(n, desc.y, words_in, point_list, t_all, cnt_all, TL.s_red);
-        else if (FWD_SORT_BLOCK && n <= 512) sort_one_block<2>(n, desc.y, words_in, point_list, t_all, cnt_all, TL.s_red);
+        // the emission left the tile's unsorted ids in the first half of its slice; the words are formed on load (WordSrc)
+        const WordSrc src = tile_words(words_in, desc.y, depth_key);
+        if (n == 1) { if (tid == 0) point_list[desc.y] = src.ids[desc.y]; }
+        else if (FWD_SORT_BLOCK && n <= 256) sort_one_block<1>(n, desc.y, src, point_list, t_all, cnt_all, TL.s_red);
+        else if (FWD_SORT_BLOCK && n <= 512) sort_one_block<2>(n, desc.y, src, point_list, t_all, cnt_all, TL.s_red);
         else if (n <= TSORT_WAVE) {
             u32* const mirror = FWD_SORT_MIRROR ? reinterpret_cast<u32*>(lds_raw + LDS_IDS) : nullptr;
-            if (wave == 0) sort_wave_role(desc, words_in, point_list, t_all, cnt_all, mirror);
+            if (wave == 0) sort_wave_role(desc, src, point_list, t_all, cnt_all, mirror);
             if (FWD_SORT_MIRROR && !(FWD_SORT_BLOCK)) ids_lds = mirror;
         }
-        else sort_list_block(desc, words_in, sort_scratch, point_list, t_all, cnt_all, *reinterpret_cast<TileSortLds*>(lds_raw + LDS_TS_L));
+        else sort_list_block(desc, src, sort_scratch, point_list, t_all, cnt_all, *reinterpret_cast<TileSortLds*>(lds_raw + LDS_TS_L));
         // without the LDS copy: the ids were stored by this workgroup and are loaded by it below (at agent scope: a line of the
         // neighbouring tile's slice may sit in this CU's L1 with our first ids still unsorted in it)
         if (ids_lds == nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1295,7 +1297,7 @@ hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinV
     if (T == 0) return hipSuccess;
     const int grid = cdiv(T, TILE_RUN) * TILE_RUN;
     hipLaunchKernelGGL(blend_fwd_rows_kernel<0>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
-                       im.tile_desc, b.point_list, (FWD_SORT && sort_here) ? b.words : nullptr, b.scratch,
+                       im.tile_desc, b.point_list, (FWD_SORT && sort_here) ? b.words : nullptr, g.depth_key, b.scratch,
                        reinterpret_cast<unsigned char*>(b.reach_mask), b.words ? 8u : 2u, g.g2d, s.bg, out.color, out.depth, out.weights,
                        im.final_T, im.n_contrib, n_dev, capacity, (b.words && s.tile_bounds != BAGS_TILES_OPACITY) ? 1 : 0, im.tile_aux);
     return hipGetLastError();

@@ -421,15 +421,15 @@ preprocess_fwd_count_kernel(const K1Args A, const float* __restrict__ viewmatrix
         const uint2 rc = R.rect;
         const int w = (int)(rc.y & 0xFFFF) - (int)(rc.x & 0xFFFF), h = (int)(rc.y >> 16) - (int)(rc.x >> 16);
         if (nt > 0) {
-            if (rect_small(w, h)) walk_mask<false>(cnt, rc, R.keep, grid_x, 0ull, nullptr);
-            else if (nt <= BIN_COOP) walk_rect<false>(cnt, rc, grid_x, lane, false, 0ull, nullptr);
+            if (rect_small(w, h)) walk_mask<false>(cnt, rc, R.keep, grid_x, 0u, nullptr);
+            else if (nt <= BIN_COOP) walk_rect<false>(cnt, rc, grid_x, lane, false, 0u, nullptr);
         }
         u64 big = __ballot(nt > BIN_COOP);                   // never a small rectangle (at most 64 tiles)
         while (big) {
             const int src = __ffsll((long long)big) - 1;
             big &= big - 1;
             const uint2 brc = make_uint2((u32)__shfl((int)rc.x, src), (u32)__shfl((int)rc.y, src));
-            walk_rect<false>(cnt, brc, grid_x, lane, true, 0ull, nullptr);
+            walk_rect<false>(cnt, brc, grid_x, lane, true, 0u, nullptr);
         }
         // ---- the wave's range of record slots inside the block (records, not list instances: see K1Args::rec_opacity)
         const u32 nrec = R.rtiles;

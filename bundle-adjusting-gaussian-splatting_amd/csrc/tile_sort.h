@@ -109,7 +109,7 @@ __device__ __forceinline__ void wave_sort_words(const u64 (&e)[PER], u32 n, u32 
 // its own quarter of the workgroup's LDS; neighbouring descriptors hold lists of similar length).
 #define TS_PER (TSORT_WAVE / 64)
 template <int PER>
-__device__ __forceinline__ void sort_wave_list(u32 n, u32 start, const u64* __restrict__ words_in, u32* __restrict__ point_list, u64* t, u32* cnt,
+__device__ __forceinline__ void sort_wave_list(u32 n, u32 start, const WordSrc words_in, u32* __restrict__ point_list, u64* t, u32* cnt,
                                                u32* mirror = nullptr)
 {
     const u32 lane = threadIdx.x & 63;
@@ -126,12 +126,12 @@ __device__ __forceinline__ void sort_wave_list(u32 n, u32 start, const u64* __re
     }
     wave_sort_words<PER>(e, n, wave_min(kmin), wave_max(kmax), point_list + start, t, cnt, mirror);
 }
-__device__ __forceinline__ void sort_wave_role(const uint4 desc, const u64* __restrict__ words_in, u32* __restrict__ point_list, u64* t, u32* cnt,
+__device__ __forceinline__ void sort_wave_role(const uint4 desc, const WordSrc words_in, u32* __restrict__ point_list, u64* t, u32* cnt,
                                                u32* mirror = nullptr)
 {
     const u32 n = desc.z, start = desc.y;
     if (n == 0 || n > TSORT_WAVE) return;
-    if (n == 1) { if ((threadIdx.x & 63) == 0) point_list[start] = (u32)words_in[start]; return; }
+    if (n == 1) { if ((threadIdx.x & 63) == 0) point_list[start] = words_in.ids[start]; return; }
     // every pass of the sort is unrolled over the entries a lane CAN hold: a list of half the capacity takes the half-size
     // instance (wave-uniform choice; the median tile of the bench scene holds 254 entries)
     if (n <= TSORT_WAVE / 2) sort_wave_list<TS_PER / 2>(n, start, words_in, point_list, t, cnt, mirror);
@@ -235,7 +235,7 @@ __device__ __forceinline__ void block_sort_words(const u64 (&e)[PER], u32 n, u32
 // One list of at most 256 * BP entries by the whole 256-thread workgroup: its words in one batch of coalesced loads, then the
 // block-wide bucket sort (every thread calls it; it starts and ends on barriers).
 template <int BP>
-__device__ __forceinline__ void sort_one_block(const u32 n, const u32 start, const u64* __restrict__ words_in, u32* __restrict__ point_list,
+__device__ __forceinline__ void sort_one_block(const u32 n, const u32 start, const WordSrc words_in, u32* __restrict__ point_list,
                                                u64* t_all, u32* cnt_all, u32* s_red)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -265,7 +265,7 @@ struct TileSortLds {                                         // small state of t
     u32 slab_cnt[TS_SLABS_MAX + 1], slab_start[TS_SLABS_MAX + 1], s_next, s_bad;
 };
 // One list of more than TSORT_WAVE entries, by a whole 256-thread workgroup (every thread calls it).
-__device__ __forceinline__ void sort_list_block(const uint4 desc, const u64* __restrict__ words_in, u64* __restrict__ scratch,
+__device__ __forceinline__ void sort_list_block(const uint4 desc, const WordSrc words_in, u64* __restrict__ scratch,
                                                 u32* __restrict__ point_list, u64* t_all, u32* cnt_all, TileSortLds& L)
 {
     u32* const s_red = L.s_red; u32* const slab_cnt = L.slab_cnt; u32* const slab_start = L.slab_start;
