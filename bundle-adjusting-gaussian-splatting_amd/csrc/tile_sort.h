@@ -318,22 +318,28 @@ __device__ __forceinline__ void sort_list_block(const uint4 desc, const WordSrc 
                 k = (u32)__builtin_amdgcn_readfirstlane((int)k);
                 if (k >= K) break;
                 const u32 s0 = slab_start[k], m = slab_start[k + 1] - s0;
-                if (m == 0) return;
-                u64 e[TS_PER];
-                u32 lo = 0xFFFFFFFFu, hi = 0u;
+                // An empty slab is skipped; a one-entry slab takes the general path.  Until round 4 both were early exits -- `return`
+                // for the wave, so that with depth-clustered lists every wave could leave on an empty slab before the last slabs
+                // were drawn and their part of point_list kept whatever the buffer held before (found by tools/soak.py: a camera
+                // drifted into the scene), and, once that was a `continue`, the one-entry special case `if (m == 1) { if (lane
+                // == 0) store; continue; }` came out of the compiler re-sorting slab 0 with an entry missing
+                // (tools/ubench/sort_slabs.hip).  No `continue`, no special case:
+                if (m != 0) {
+                    u64 e[TS_PER];
+                    u32 lo = 0xFFFFFFFFu, hi = 0u;
 #pragma unroll
-                for (u32 r = 0; r < TS_PER; ++r) {
-                    // written by other waves of this workgroup just above: read at agent scope (L2)
-                    const u64 raw = __hip_atomic_load(&scratch[start + s0 + min(r * 64 + (u32)lane, m - 1)],
-                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const u32 wkey = (u32)(raw >> 32);
-                    const bool valid = r * 64 + lane < m;
-                    e[r] = valid ? raw : ~0ull;
-                    lo = min(lo, valid ? wkey : 0xFFFFFFFFu); hi = max(hi, valid ? wkey : 0u);
+                    for (u32 r = 0; r < TS_PER; ++r) {
+                        // written by other waves of this workgroup just above: read at agent scope (L2)
+                        const u64 raw = __hip_atomic_load(&scratch[start + s0 + min(r * 64 + (u32)lane, m - 1)],
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const u32 wkey = (u32)(raw >> 32);
+                        const bool valid = r * 64 + lane < m;
+                        e[r] = valid ? raw : ~0ull;
+                        lo = min(lo, valid ? wkey : 0xFFFFFFFFu); hi = max(hi, valid ? wkey : 0u);
+                    }
+                    wave_sort_words<TS_PER>(e, m, wave_min(lo), wave_max(hi), point_list + start + s0, t_all + wave * TSORT_WAVE,
+                                            cnt_all + wave * (TSORT_WAVE / 2));
                 }
-                if (m == 1) { if (lane == 0) point_list[start + s0] = (u32)e[0]; return; }
-                wave_sort_words<TS_PER>(e, m, wave_min(lo), wave_max(hi), point_list + start + s0, t_all + wave * TSORT_WAVE,
-                                        cnt_all + wave * (TSORT_WAVE / 2));
             }
             return;
         }

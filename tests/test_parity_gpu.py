@@ -850,6 +850,45 @@ def test_tile_sort_size_boundaries(N):
         assert_report(rep, grad_tol=3e-4, skip_zero=("campos",))
 
 
+@pytest.mark.parametrize("N,bands", [(2304, (0, 2, 4, 6, 8)), (2304, (0, 1, 7, 8)), (5000, (0, 3, 4, 9, 10, 15, 19))])
+def test_slab_sort_with_empty_and_single_entry_slabs(N, bands):
+    """The two-level sort of a 2049..16384-entry list cuts the depth-key range into K = ceil(N / 256) equal slabs and lets the
+    four waves draw them from a counter.  Depth-clustered lists leave slabs EMPTY or with ONE entry: a wave that drew such a slab
+    used to leave the list altogether (`return` for `continue`, csrc/tile_sort.h), and with enough of them no wave was left
+    for the last slabs -- their part of the sorted list kept whatever the buffer held before (tools/soak.py: a memory fault
+    once a camera had drifted into the scene).  One tile, depths in bands that populate only the slabs in ``bands`` plus a
+    lone entry in an otherwise empty slab; the list must be the radix path's, bit for bit."""
+    scene, cam = make_case(N, 48, 48, 1.0, 0, seed=N)
+    gen = torch.Generator().manual_seed(N + len(bands))
+    K = (N + 255) // 256
+    xyz = 0.004 * torch.randn(N, 3, generator=gen)          # all of them project into the middle of tile (1, 1)
+    # view depth = z + 4 in [4, 4 + span]: inside one binade, so the float bits -- the sort key -- are linear in it
+    span = 1.8
+    w = span / K
+    which = torch.tensor(bands)[torch.randint(0, len(bands), (N,), generator=gen)]
+    z = (which.float() + 0.1 + 0.8 * torch.rand(N, generator=gen)) * w
+    lone = [k for k in range(K) if k not in bands][0]
+    z[0], z[1], z[2] = 0.0, span * (1 - 1e-6), (lone + 0.5) * w          # first key, last key, the lone entry
+    xyz[:, 2] = z
+    scene["means3D"] = xyz
+    scene["scales"] = torch.full((N, 3), 0.003)
+    scene["opacities"] = torch.full((N, 1), 0.02)
+    g = torch.randn(3, 48, 48, generator=gen)
+    o_r, g_r, v_r = run_hip(scene, cam, 0, g, binning="radix")
+    lens = v_r["ranges"][:, 1] - v_r["ranges"][:, 0]
+    assert int(lens.max()) == N and int((lens > 0).sum()) == 1, lens
+    for attempt in range(3):                                # which wave draws which slab varies from run to run
+        o_a, g_a, v_a = run_hip(scene, cam, 0, g, binning="auto")
+        assert v_a["num_rendered"] == v_r["num_rendered"] == N
+        for k in ("point_list", "keys_sorted", "n_contrib"):
+            assert torch.equal(v_a[k], v_r[k]), (k, attempt)
+        for a, b in zip(o_a, o_r):
+            assert torch.equal(a, b)
+        for k in g_a:
+            if g_a[k] is not None:
+                assert torch.equal(g_a[k], g_r[k]), k
+
+
 @pytest.mark.parametrize("W,H,P,sm,shrink,fovy", [
     (10, 7, 200, 3.0, 1.0, None),            # less than one tile
     (16, 2000, 1500, 0.2, 1.0, None),        # one column of 125 tiles
