@@ -24,12 +24,25 @@ def main():
     ap.add_argument("--iters", type=int, default=400)
     ap.add_argument("--P", type=int, default=200_000)
     ap.add_argument("--check-every", type=int, default=50)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--tile-bounds", default="opacity", choices=("opacity", "aabb"))
+    ap.add_argument("--depth-key", default="z", choices=("z", "distance"))
+    ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    W, H = 1280, 720
-    pc = GaussianBag.from_activated(synth_scene(args.P, 1, 0.7, 3), 3, device=dev)
+    W, H = args.width, args.height
+    import bags_raster.render
+    RR = sys.modules["bags_raster.render"]
+    settings_cls = RR.GaussianRasterizationSettings
+    extra = {"tile_bounds": args.tile_bounds}
+
+    def settings_with(**over):                               # render() builds the settings: route the soak's switches into them
+        return lambda **kw: settings_cls(**dict(kw, **extra, **over))
+    RR.GaussianRasterizationSettings = settings_with()
+    pc = GaussianBag.from_activated(synth_scene(args.P, args.seed, 0.7, 3), 3, device=dev)
     cams = sphere_views(40, W, H, noise=0.1, device=dev)
-    gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(2)).to(dev)
+    gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(args.seed + 1)).to(dev)
     bg = torch.zeros(3, device=dev)
     pipe = PipelineParams()
     redo = 0
@@ -44,7 +57,7 @@ def main():
             pc.active_sh_degree = min(3, it // 60)                  # the degree ramps up as in training
             log = (lambda m: (print(f"it {it}: {m}", file=sys.stderr), sys.stderr.flush())) if os.environ.get("SOAK_LOG") else (lambda m: None)
             log("render")
-            out = render(cam, pc, pipe, bg, 0.0, None, hybrid=False)
+            out = render(cam, pc, pipe, bg, 0.0, None, hybrid=False, depth_key=args.depth_key)
             log(f"rendered, I = {R.LAST_NUM_RENDERED}")
             loss = L.fused_photometric_loss(out["render"], gt)
             log("loss done")
@@ -53,8 +66,12 @@ def main():
             if it % args.check_every in (0, 1):
                 with torch.no_grad():
                     ref = render(cam, type("C", (), {"__getattr__": lambda s, k: None if k == "_features_rest" else getattr(pc, k)})(),
-                                 pipe, bg, 0.0, None, hybrid=False)["render"]
+                                 pipe, bg, 0.0, None, hybrid=False, depth_key=args.depth_key)["render"]
+                    RR.GaussianRasterizationSettings = settings_with(binning="radix")          # ... and the radix path's lists
+                    rad = render(cam, pc, pipe, bg, 0.0, None, hybrid=False, depth_key=args.depth_key)["render"]
+                    RR.GaussianRasterizationSettings = settings_with()
                 assert torch.equal(ref, out["render"]), f"iteration {it}: split-SH image differs from the concatenated call"
+                assert torch.equal(rad, out["render"]), f"iteration {it}: tile-binned image differs from the radix path's"
                 bad = [i for i, t in enumerate(leaves) if t.grad is None or not bool(torch.isfinite(t.grad).all())]
                 assert not bad, f"iteration {it}: non-finite or missing gradients for leaves {bad}"
                 losses.append(float(loss))
@@ -73,7 +90,7 @@ def main():
         torch.cuda.synchronize()
         redo = sum(1 for w in wlist if "capacity" in str(w.message).lower() or "overflow" in str(w.message).lower())
         other = sorted({str(w.message)[:80] for w in wlist if not ("capacity" in str(w.message).lower() or "overflow" in str(w.message).lower())})
-    print(json.dumps({"iters": args.iters, "P": args.P, "losses": losses, "speculation_redo_warnings": redo, "other_warnings": other,
+    print(json.dumps({"iters": args.iters, "P": args.P, "size": [W, H], "tile_bounds": args.tile_bounds, "depth_key": args.depth_key, "losses": losses, "speculation_redo_warnings": redo, "other_warnings": other,
                       "last_num_rendered": int(getattr(R, "LAST_NUM_RENDERED", 0))}))
 
 
