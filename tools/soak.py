@@ -29,9 +29,14 @@ def main():
     ap.add_argument("--tile-bounds", default="opacity", choices=("opacity", "aabb"))
     ap.add_argument("--depth-key", default="z", choices=("z", "distance"))
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--hybrid", action="store_true", help="Python-side SH colours (the reference's default colour path: colors_precomp)")
+    ap.add_argument("--host-wait", default="forward", choices=("forward", "lazy"),
+                    help="lazy: the count is read at the backward's entry; an overflow recovers with a warning (LAZY_RECOVER)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     W, H = args.width, args.height
+    R.HOST_WAIT = args.host_wait
+    R.LAZY_RECOVER = args.host_wait == "lazy"
     import bags_raster.render
     RR = sys.modules["bags_raster.render"]
     settings_cls = RR.GaussianRasterizationSettings
@@ -57,7 +62,7 @@ def main():
             pc.active_sh_degree = min(3, it // 60)                  # the degree ramps up as in training
             log = (lambda m: (print(f"it {it}: {m}", file=sys.stderr), sys.stderr.flush())) if os.environ.get("SOAK_LOG") else (lambda m: None)
             log("render")
-            out = render(cam, pc, pipe, bg, 0.0, None, hybrid=False, depth_key=args.depth_key)
+            out = render(cam, pc, pipe, bg, 0.0, None, hybrid=args.hybrid, depth_key=args.depth_key)
             log(f"rendered, I = {R.LAST_NUM_RENDERED}")
             loss = L.fused_photometric_loss(out["render"], gt)
             log("loss done")
@@ -66,9 +71,9 @@ def main():
             if it % args.check_every in (0, 1):
                 with torch.no_grad():
                     ref = render(cam, type("C", (), {"__getattr__": lambda s, k: None if k == "_features_rest" else getattr(pc, k)})(),
-                                 pipe, bg, 0.0, None, hybrid=False, depth_key=args.depth_key)["render"]
+                                 pipe, bg, 0.0, None, hybrid=args.hybrid, depth_key=args.depth_key)["render"]
                     RR.GaussianRasterizationSettings = settings_with(binning="radix")          # ... and the radix path's lists
-                    rad = render(cam, pc, pipe, bg, 0.0, None, hybrid=False, depth_key=args.depth_key)["render"]
+                    rad = render(cam, pc, pipe, bg, 0.0, None, hybrid=args.hybrid, depth_key=args.depth_key)["render"]
                     RR.GaussianRasterizationSettings = settings_with()
                 assert torch.equal(ref, out["render"]), f"iteration {it}: split-SH image differs from the concatenated call"
                 assert torch.equal(rad, out["render"]), f"iteration {it}: tile-binned image differs from the radix path's"
