@@ -1,0 +1,86 @@
+"""Randomised differential run on the GPU box (not a test): the tile-binned lists against the radix path's on scenes the parity
+tests do not have -- depth in bands / on one plane / a shell around the camera, splats from tiny to screen-filling, scenes
+shrunk into a handful of tiles, both tile rules and depth keys.  Lists, ranges, outputs: bit-identical; gradients: bit-identical
+with the default tile rule, to summation order with the stock one.  Prints the tag of every trial before it runs (a device fault
+ends the process: the last tag names the scene) and a summary.  Usage: python tools/fuzz_paths.py [--trials 150] [--seed 7]"""
+import argparse, json, math, os, sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "bundle-adjusting-gaussian-splatting_amd"), os.path.join(ROOT, "tests")]
+from parity import run_hip
+from scenes import make_case, rel_err
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trials", type=int, default=150)
+    ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--long", action="store_true", help="bias towards long tile lists: 3000 .. 60000 Gaussians in compact scenes")
+    args = ap.parse_args()
+    rng = torch.Generator().manual_seed(args.seed)
+    U = lambda a, b: float(torch.empty(1).uniform_(a, b, generator=rng))
+    I = lambda a, b: int(torch.randint(a, b, (1,), generator=rng))
+    bad = []
+    for trial in range(args.trials):
+        P = max(1, int(math.exp(U(math.log(3000.0) if args.long else 0.0, math.log(60000.0 if args.long else 40000.0)))))
+        W, H = I(16, 640), I(16, 480)
+        sm = math.exp(U(math.log(0.2), math.log(10.0)))
+        deg = I(0, 4)
+        depth = ("uniform", "banded", "flat", "shell")[I(0, 4)]
+        shrink = ((0.3, 0.05, 0.02) if args.long else (1.0, 0.3, 0.05))[I(0, 3)]
+        kw = dict(tile_bounds="aabb" if I(0, 3) == 0 else "opacity", depth_key="distance" if I(0, 2) else "z")
+        tag = dict(trial=trial, P=P, W=W, H=H, sm=round(sm, 3), deg=deg, depth=depth, shrink=shrink, **kw)
+        print(json.dumps(tag), flush=True)
+        scene, cam = make_case(P, W, H, sm, deg, seed=5000 + trial)
+        xyz = scene["means3D"] * shrink
+        if depth == "banded":
+            nb = I(2, 6)
+            xyz[:, 2] = (torch.randint(0, nb, (P,), generator=rng).float() / nb - 0.5) * 2.0 + 0.01 * torch.randn(P, generator=rng)
+        elif depth == "flat":
+            xyz[:, 2] = 0.25
+        elif depth == "shell":                               # around the camera (which sits at z = -4 looking at the origin)
+            d = torch.randn(P, 3, generator=rng); d = d / d.norm(dim=1, keepdim=True)
+            xyz = d * torch.empty(P, 1).uniform_(0.25, 1.5, generator=rng) + torch.tensor([0.0, 0.0, -4.0])
+        scene["means3D"] = xyz
+        if I(0, 3) == 0:
+            scene["opacities"] = scene["opacities"] * 0.05    # long lists that do not saturate
+        g = torch.randn(3, H, W, generator=rng)
+        try:
+            o_a, g_a, v_a = run_hip(scene, cam, deg, g, binning="auto", **kw)
+            o_r, g_r, v_r = run_hip(scene, cam, deg, g, binning="radix", **kw)
+            why = None
+            if v_a["num_rendered"] != v_r["num_rendered"]:
+                why = "num_rendered"
+            else:
+                for k in ("point_list", "keys_sorted", "n_contrib", "tiles_touched", "rect"):
+                    if not torch.equal(v_a[k], v_r[k]):
+                        why = k; break
+            if why is None and not torch.equal(v_a["ranges"][:, 1] - v_a["ranges"][:, 0], v_r["ranges"][:, 1] - v_r["ranges"][:, 0]):
+                why = "ranges"
+            if why is None:
+                for j, (a, b) in enumerate(zip(o_a, o_r)):
+                    if not torch.equal(a, b):
+                        why = f"output {j}"; break
+            if why is None:
+                for k in g_a:
+                    if g_a[k] is None:
+                        continue
+                    if kw["tile_bounds"] == "opacity":
+                        if not torch.equal(g_a[k], g_r[k]):
+                            why = f"grad {k}"; break
+                    elif rel_err(g_a[k], g_r[k]) > 3e-3:
+                        why = f"grad {k} {rel_err(g_a[k], g_r[k]):.2e}"; break
+            longest = int((v_r["ranges"][:, 1] - v_r["ranges"][:, 0]).max()) if v_r["ranges"].numel() else 0
+            print(f"  I = {v_r['num_rendered']}, longest list {longest}: {'ok' if why is None else 'MISMATCH ' + why}", flush=True)
+            if why is not None:
+                bad.append(dict(tag, why=why))
+        except Exception as e:                               # (an exception of the op, not a device fault)
+            print(f"  EXCEPTION {type(e).__name__}: {str(e)[:200]}", flush=True)
+            bad.append(dict(tag, why=f"exception {type(e).__name__}"))
+    print(json.dumps({"trials": args.trials, "failures": bad}))
+
+
+if __name__ == "__main__":
+    main()
