@@ -9,7 +9,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bundle-adjusting-gaussian-splatting_amd"), os.path.join(ROOT, "tests")]
-from parity import run_hip
+from parity import assert_report, compare, run_hip
 from scenes import make_case, rel_err
 
 
@@ -17,6 +17,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=150)
     ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--oracle", action="store_true", help="small scenes (<= 2500 Gaussians, <= 160 x 120) against the CPU oracle instead "
+                                                          "of the radix path: integer artefacts bit for bit, floats by the parity tolerances")
     ap.add_argument("--long", action="store_true", help="bias towards long tile lists: 3000 .. 60000 Gaussians in compact scenes")
     args = ap.parse_args()
     rng = torch.Generator().manual_seed(args.seed)
@@ -26,6 +28,8 @@ def main():
     for trial in range(args.trials):
         P = max(1, int(math.exp(U(math.log(3000.0) if args.long else 0.0, math.log(60000.0 if args.long else 40000.0)))))
         W, H = I(16, 640), I(16, 480)
+        if args.oracle:
+            P, W, H = min(P, 2500), min(W, 160), min(H, 120)
         sm = math.exp(U(math.log(0.2), math.log(10.0)))
         deg = I(0, 4)
         depth = ("uniform", "banded", "flat", "shell")[I(0, 4)]
@@ -47,6 +51,19 @@ def main():
         if I(0, 3) == 0:
             scene["opacities"] = scene["opacities"] * 0.05    # long lists that do not saturate
         g = torch.randn(3, H, W, generator=rng)
+        if args.oracle:
+            try:
+                rep = compare(scene, cam, deg, check_fp64=True, **kw)
+                try:
+                    assert_report(rep, grad_tol=3e-4, skip_zero=("campos",))
+                    print(f"  I = {rep['num_rendered'][0]}: ok", flush=True)
+                except AssertionError as e:
+                    print(f"  I = {rep['num_rendered'][0]}: MISMATCH {str(e)[:300]}", flush=True)
+                    bad.append(dict(tag, why=str(e)[:300]))
+            except Exception as e:
+                print(f"  EXCEPTION {type(e).__name__}: {str(e)[:200]}", flush=True)
+                bad.append(dict(tag, why=f"exception {type(e).__name__}"))
+            continue
         try:
             o_a, g_a, v_a = run_hip(scene, cam, deg, g, binning="auto", **kw)
             o_r, g_r, v_r = run_hip(scene, cam, deg, g, binning="radix", **kw)
