@@ -1,0 +1,30 @@
+"""Short forms of the two robustness tools (tools/soak.py, tools/fuzz_paths.py), each in a process of its own so that a device
+fault fails the test instead of ending the test run: regimes the parity scenes do not have (depth-clustered long lists, poses
+drifting into the scene, splats growing eightfold between two iterations)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(script, *args, timeout=600):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), *args], capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0 and "Memory access fault" not in r.stderr, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.timeout(900)
+def test_short_soak_with_growing_splats_and_drifting_poses():
+    out = _run("soak.py", "--iters", "160", "--P", "120000", "--width", "800", "--height", "448", "--check-every", "25")
+    assert out["iters"] == 160 and len(out["losses"]) >= 12 and all(x == x for x in out["losses"])
+
+
+@pytest.mark.timeout(900)
+def test_short_fuzz_of_the_two_list_builders():
+    out = _run("fuzz_paths.py", "--trials", "30", "--seed", "3", "--long")
+    assert out["trials"] == 30 and out["failures"] == [], out["failures"]
