@@ -229,8 +229,8 @@ __device__ __forceinline__ void block_sort_words(const u64 (&e)[PER], u32 n, u32
 #ifndef TSORT_BLOCK
 #define TSORT_BLOCK 2048
 #endif
-#define TSORT_LARGE 16384
-#define TS_SLABS_MAX 64
+#define TSORT_LARGE 65536                                    // (16384 / 64 slabs until round 4: the global-memory network above that is 55 x
+#define TS_SLABS_MAX 256                                     //  slower per entry than the LDS sorts, tools/ubench/sort_rate.hip)
 
 // One list of at most 256 * BP entries by the whole 256-thread workgroup: its words in one batch of coalesced loads, then the
 // block-wide bucket sort (every thread calls it; it starts and ends on barriers).
@@ -283,7 +283,7 @@ __device__ __forceinline__ void sort_list_block(const uint4 desc, const WordSrc 
         kmin = wave_min(kmin); kmax = wave_max(kmax);
         __syncthreads();                                  // the previous list's state is no longer in use
         if (lane == 0) { s_red[wave] = kmin; s_red[4 + wave] = kmax; }
-        if (tid <= TS_SLABS_MAX) slab_cnt[tid] = 0u;
+        for (u32 i = tid; i <= TS_SLABS_MAX; i += 256) slab_cnt[i] = 0u;
         if (tid == 0) { s_next = 0u; s_bad = 0u; }
         __syncthreads();
         kmin = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
@@ -308,8 +308,13 @@ __device__ __forceinline__ void sort_list_block(const uint4 desc, const WordSrc 
                 const u32 k = min(K - 1, (u32)((float)((u32)(w >> 32) - kmin) * scale));
                 scratch[start + slab_start[k] + atomicAdd(&slab_cnt[k], 1u)] = w;
             }
+            // The words are read back by OTHER WAVES OF THIS WORKGROUP only: same CU, same L1 (write-through), same L2, and the
+            // reads below go to the L2 (agent-scope loads).  Completed stores + a workgroup-scope fence are enough.  Until the end
+            // of round 4 this was __threadfence(): an agent-scope fence, i.e. `buffer_wbl2` -- a write-back of the whole L2's
+            // dirty lines by every long-list workgroup (lists just above 2048 entries sorted 15 x slower per entry than lists
+            // just below, tools/ubench/sort_rate.hip; blend_fwd 1.07 ms at sm 2.0).
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
             // ---- level 2: a wave per slab
             for (;;) {
@@ -349,7 +354,7 @@ __device__ __forceinline__ void sort_list_block(const uint4 desc, const WordSrc 
     __syncthreads();
     for (u32 i = tid; i < n; i += 256) scratch[start + i] = words_in[start + i];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (read back by this workgroup's waves at agent scope: see above)
     __syncthreads();
     u64* gsm = scratch + start;
     auto ld = [&](u32 i) -> u64 { return __hip_atomic_load(&gsm[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
