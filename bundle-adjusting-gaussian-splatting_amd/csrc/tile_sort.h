@@ -264,6 +264,23 @@ struct TileSortLds {                                         // small state of t
     u32 s_red[8];
     u32 slab_cnt[TS_SLABS_MAX + 1], slab_start[TS_SLABS_MAX + 1], s_next, s_bad;
 };
+// f(word) for every entry of the list, 256 threads, EIGHT entries per thread in flight: the ids of a batch are requested
+// together, then their keys (a thread's plain loop -- id, then key, then the use, entry after entry -- was two dependent memory
+// latencies per entry: ~70 of them in series per pass for a 3000-entry list, which is what the long-list sort's time was).
+template <typename F>
+__device__ __forceinline__ void for_each_word_256(const WordSrc words_in, const u32 start, const u32 n, const u32 tid, F f)
+{
+    for (u32 base = tid; base < n; base += 256u * 8u) {
+        u32 id[8], key[8];
+#pragma unroll
+        for (u32 j = 0; j < 8; ++j) id[j] = words_in.ids[start + min(base + 256u * j, n - 1)];
+#pragma unroll
+        for (u32 j = 0; j < 8; ++j) key[j] = words_in.keys[id[j]];
+#pragma unroll
+        for (u32 j = 0; j < 8; ++j)
+            if (base + 256u * j < n) f(((u64)key[j] << 32) | (u64)id[j]);
+    }
+}
 // One list of more than TSORT_WAVE entries, by a whole 256-thread workgroup (every thread calls it).
 __device__ __forceinline__ void sort_list_block(const uint4 desc, const WordSrc words_in, u64* __restrict__ scratch,
                                                 u32* __restrict__ point_list, u64* t_all, u32* cnt_all, TileSortLds& L)
@@ -279,7 +296,7 @@ __device__ __forceinline__ void sort_list_block(const uint4 desc, const WordSrc 
         // ---- level 1: key range, slab of every entry, slab counts
         const u32 K = min((u32)TS_SLABS_MAX, (n + TSORT_WAVE / 2 - 1) / (TSORT_WAVE / 2));
         u32 kmin = 0xFFFFFFFFu, kmax = 0u;
-        for (u32 i = tid; i < n; i += 256) { const u32 key = (u32)(words_in[start + i] >> 32); kmin = min(kmin, key); kmax = max(kmax, key); }
+        for_each_word_256(words_in, start, n, (u32)tid, [&](const u64 w) { const u32 key = (u32)(w >> 32); kmin = min(kmin, key); kmax = max(kmax, key); });
         kmin = wave_min(kmin); kmax = wave_max(kmax);
         __syncthreads();                                  // the previous list's state is no longer in use
         if (lane == 0) { s_red[wave] = kmin; s_red[4 + wave] = kmax; }
@@ -289,10 +306,9 @@ __device__ __forceinline__ void sort_list_block(const uint4 desc, const WordSrc 
         kmin = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
         kmax = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
         const float scale = (float)K / ((float)(kmax - kmin) + 1.0f);
-        for (u32 i = tid; i < n; i += 256) {
-            const u32 key = (u32)(words_in[start + i] >> 32);
-            atomicAdd(&slab_cnt[min(K - 1, (u32)((float)(key - kmin) * scale))], 1u);
-        }
+        for_each_word_256(words_in, start, n, (u32)tid, [&](const u64 w) {
+            atomicAdd(&slab_cnt[min(K - 1, (u32)((float)((u32)(w >> 32) - kmin) * scale))], 1u);
+        });
         __syncthreads();
         if (tid == 0) {
             u32 run = 0, bad = 0;
@@ -303,11 +319,10 @@ __device__ __forceinline__ void sort_list_block(const uint4 desc, const WordSrc 
         network = s_bad != 0u;
         if (!network) {
             // ---- words grouped by slab in the scratch array (order inside a slab arbitrary)
-            for (u32 i = tid; i < n; i += 256) {
-                const u64 w = words_in[start + i];
+            for_each_word_256(words_in, start, n, (u32)tid, [&](const u64 w) {
                 const u32 k = min(K - 1, (u32)((float)((u32)(w >> 32) - kmin) * scale));
                 scratch[start + slab_start[k] + atomicAdd(&slab_cnt[k], 1u)] = w;
-            }
+            });
             // The words are read back by OTHER WAVES OF THIS WORKGROUP only: same CU, same L1 (write-through), same L2, and the
             // reads below go to the L2 (agent-scope loads).  Completed stores + a workgroup-scope fence are enough.  Until the end
             // of round 4 this was __threadfence(): an agent-scope fence, i.e. `buffer_wbl2` -- a write-back of the whole L2's
