@@ -427,7 +427,7 @@ int bags_backward(const BagsSettings* s, const BagsInputs* in, const BagsState* 
     if (I > 0) {
         // (blend_bwd also clears the tickets of the folded pose reduction behind it: no memset launch)
         { ProfScope ps(ST_BLEND_BWD, st); HIP_TRY(launch_blend_bwd(*s, g, b, im, a->grad_color, partials, a->grad_means2D_densify != nullptr, use_binned(s, in->P), st,
-                                                                  fold ? tickets : nullptr, fold ? n_tickets : 0)); }
+                                                                  fold ? tickets : nullptr, fold ? n_tickets : 0, I)); }
         DEBUG_SYNC(s, st, "blend_bwd");
     } else if (fold) {
         HIP_TRY(hipMemsetAsync(tickets, 0, (size_t)n_tickets * sizeof(u32), st));

@@ -174,7 +174,8 @@ bool blend_fwd_sorts();      // the build's blend_fwd sorts the tile lists of th
 // (radix path) it is gathered from g.inst_off
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
                             const float* grad_color, float* partials, bool want_abs, bool binned, hipStream_t st,
-                            u32* zero_words = nullptr, int n_zero = 0);   // words the launch clears for the kernel behind it (pose tickets)
+                            u32* zero_words = nullptr, int n_zero = 0,    // words the launch clears for the kernel behind it (pose tickets)
+                            long long n_records = 0);                     // instance count when the host knows it (dense scenes: one memset)
 hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, const int32_t* radii_or_null,
                                  const float* partials, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a, hipStream_t st, float* sums,
                                  bool binned, u32* fold_tickets, unsigned long long* fold_rows);

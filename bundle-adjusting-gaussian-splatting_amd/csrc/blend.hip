@@ -90,6 +90,9 @@ struct __attribute__((aligned(16))) SplatRec {
 #ifndef TILE_ILV
 #define TILE_ILV 16
 #endif
+#ifndef BWD_PREZERO_PER_TILE
+#define BWD_PREZERO_PER_TILE 1000       // instances per tile above which blend_bwd's zero records come from one memset (0: never; profiles/r04/ab_prezero.txt)
+#endif
 #define TILE_RUN (8 * TILE_ILV)        // virtual blocks [k TILE_RUN, (k+1) TILE_RUN) permute descriptors of the same interval
 __device__ __forceinline__ int slot_of_vblock(int v)
 {
@@ -294,7 +297,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                       const float4* __restrict__ g2d, const u32* __restrict__ inst_off, const u32* __restrict__ block_base,
                       const float* __restrict__ bg, const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
                       const float* __restrict__ grad_color, float* __restrict__ partials, u32* __restrict__ zero_words, const int n_zero,
-                      const int test_keep, const uint4* __restrict__ tile_aux)
+                      const int test_keep, const uint4* __restrict__ tile_aux, const int skip_zero)
 {
     // One workgroup per tile that holds at least one instance, heavy tiles first (slot_of_vblock).  Tried and dropped:
     // persistent workgroups that run the chunk pipeline over the flattened (tile, chunk) sequence, with the next tile's
@@ -449,6 +452,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         }
         // zero records for the record-holding instances no chunk will visit: those at or behind the deepest contributor.
         // COMPACT: first the staged ones (compacted entries hi0 .. n_live), then, below, the positions the forward never staged
+        if (skip_zero) return;                               // dense scene: launch_blend_bwd cleared the whole record array with one memset
         if (COMPACT) {
             for (u32 k = hi0 + tid; k < n_live; k += 256) {
                 const u32 g = point_list[t.rx + cposp[k]];
@@ -868,18 +872,24 @@ extern "C" void bags_diag_phases(unsigned long long* out) { hipMemcpyFromSymbol(
 #endif
 
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
-                            const float* grad_color, float* partials, bool want_abs, bool binned, hipStream_t st, u32* zero_words, int n_zero)
+                            const float* grad_color, float* partials, bool want_abs, bool binned, hipStream_t st, u32* zero_words, int n_zero,
+                            long long n_records)
 {
     const int gx = cdiv(s.image_width, BAGS_TILE), gy = cdiv(s.image_height, BAGS_TILE);
     const int T = gx * gy;
     if (T == 0) return hipSuccess;
     const int grid = cdiv(T, TILE_RUN) * TILE_RUN;
     const bool compact = binned && s.tile_bounds != BAGS_TILES_OPACITY;
+    // Dense scenes (long tile lists, most of each list behind the deepest contributor): clearing the record array with one
+    // streaming memset is cheaper than the per-tile zero loops, which gather an id and two geometry lines per dead instance.
+    static const long long prezero_per_tile = getenv("BAGS_PREZERO_PER_TILE") ? atoll(getenv("BAGS_PREZERO_PER_TILE")) : BWD_PREZERO_PER_TILE;
+    const int skip_zero = (prezero_per_tile > 0 && n_records > prezero_per_tile * (long long)T) ? 1 : 0;
+    if (skip_zero) { hipError_t e = hipMemsetAsync(partials, 0, (size_t)n_records * PART_FLOATS * sizeof(float), st); if (e != hipSuccess) return e; }
 #define BWD_LAUNCH(ABS_, CMP_)                                                                                                       \
     hipLaunchKernelGGL((blend_bwd_scan_kernel<ABS_, CMP_>), dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,     \
                        im.tile_desc, b.point_list, reinterpret_cast<const unsigned char*>(b.reach_mask), binned ? 8u : 2u, g.g2d,    \
                        binned ? nullptr : g.inst_off, g.block_base, s.bg, im.final_T, im.n_contrib, grad_color, partials, zero_words, \
-                       n_zero, compact ? 1 : 0, im.tile_aux)
+                       n_zero, compact ? 1 : 0, im.tile_aux, skip_zero)
     if (want_abs) { if (compact) BWD_LAUNCH(true, true); else BWD_LAUNCH(true, false); }
     else          { if (compact) BWD_LAUNCH(false, true); else BWD_LAUNCH(false, false); }
 #undef BWD_LAUNCH

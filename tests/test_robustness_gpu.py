@@ -12,8 +12,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(script, *args, timeout=600):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), *args], capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+def _run(script, *args, timeout=600, env=None):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), *args], capture_output=True, text=True, timeout=timeout, cwd=ROOT,
+                       env=dict(os.environ, **(env or {})))
     assert r.returncode == 0 and "Memory access fault" not in r.stderr, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
     return json.loads(r.stdout.strip().splitlines()[-1])
 
@@ -28,3 +29,11 @@ def test_short_soak_with_growing_splats_and_drifting_poses():
 def test_short_fuzz_of_the_two_list_builders():
     out = _run("fuzz_paths.py", "--trials", "30", "--seed", "3", "--long")
     assert out["trials"] == 30 and out["failures"] == [], out["failures"]
+
+
+@pytest.mark.timeout(900)
+def test_memset_zero_records_match_the_oracle():
+    """Dense scenes take blend_bwd's zero records from one memset of the record array (blend.hip, BWD_PREZERO_PER_TILE); the
+    threshold is forced down here so that every trial takes that path, and the gradients are checked against the CPU oracle."""
+    out = _run("fuzz_paths.py", "--trials", "16", "--seed", "11", "--oracle", env={"BAGS_PREZERO_PER_TILE": "1"})
+    assert out["trials"] == 16 and out["failures"] == [], out["failures"]
