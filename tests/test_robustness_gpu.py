@@ -21,8 +21,8 @@ def _run(script, *args, timeout=600, env=None):
 
 @pytest.mark.timeout(900)
 def test_short_soak_with_growing_splats_and_drifting_poses():
-    out = _run("soak.py", "--iters", "160", "--P", "120000", "--width", "800", "--height", "448", "--check-every", "25")
-    assert out["iters"] == 160 and len(out["losses"]) >= 12 and all(x == x for x in out["losses"])
+    out = _run("soak.py", "--iters", "120", "--P", "120000", "--width", "800", "--height", "448", "--check-every", "25")
+    assert out["iters"] == 120 and len(out["losses"]) >= 9 and all(x == x for x in out["losses"])
 
 
 @pytest.mark.timeout(900)
@@ -35,5 +35,5 @@ def test_short_fuzz_of_the_two_list_builders():
 def test_memset_zero_records_match_the_oracle():
     """Dense scenes take blend_bwd's zero records from one memset of the record array (blend.hip, BWD_PREZERO_PER_TILE); the
     threshold is forced down here so that every trial takes that path, and the gradients are checked against the CPU oracle."""
-    out = _run("fuzz_paths.py", "--trials", "16", "--seed", "11", "--oracle", env={"BAGS_PREZERO_PER_TILE": "1"})
-    assert out["trials"] == 16 and out["failures"] == [], out["failures"]
+    out = _run("fuzz_paths.py", "--trials", "10", "--seed", "11", "--oracle", env={"BAGS_PREZERO_PER_TILE": "1"})
+    assert out["trials"] == 10 and out["failures"] == [], out["failures"]
