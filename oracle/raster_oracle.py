@@ -25,7 +25,10 @@ Design of the oracle
   arithmetic only;
 * blending is evaluated tile by tile as dense (256 x N) tensors; backward runs tile by tile as well
   (bounded memory), accumulating into per-Gaussian 2-D leaves that are then pulled back through the
-  preprocess graph.
+  preprocess graph;
+* the dense formulation is held against the published per-pixel loops and their hand-derived back-to-front
+  recurrences (oracle/published_blend.py, tests/test_oracle_cpu.py): identical n_contrib, values and 2-D
+  gradients to float64 round-off.
 
 Semantics decided here because the fork is unavailable (also listed in DESIGN.md):
   D1  focal lengths come from ``intrinsic``: fx = intrinsic[0,0]*W/2, fy = intrinsic[1,1]*H/2

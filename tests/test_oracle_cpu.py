@@ -103,3 +103,43 @@ def test_exact_sqrt_helper_is_correctly_rounded():
     import numpy as np
     x = torch.rand(200000, generator=torch.Generator().manual_seed(0)) * 50
     assert (O._sqrt(x).numpy() == np.sqrt(x.numpy())).all()
+
+
+@pytest.mark.parametrize("P,sm,boost", [(500, 3.0, 3.0), (250, 1.2, 1.0)])
+def test_autograd_blend_equals_the_published_recurrences(P, sm, boost):
+    """The oracle's blend (dense tensors, gradients by autograd) against oracle/published_blend.py: the published per-pixel
+    loops with the hand-derived back-to-front recurrences, both in float64 on the same 2-D
+    splats and lists.  Covers the skips (power > 0, alpha < 1/255), the 0.99 clamp passed straight through (D3), the
+    early stop before the entry that would take T below 1e-4 (first scene: every pixel saturates), the background term
+    (second scene: half-transparent pixels, T_final of order 1), a ragged image (W, H not multiples of 16) and the
+    abs-gradient accumulator of the fork (D4)."""
+    import numpy as np
+    from oracle import published_blend as PB
+    W, H = 44, 37
+    scene, cam = make_case(P, W, H, sm, 1, seed=7)
+    scene["opacities"] = (scene["opacities"] * boost).clamp(max=0.999)
+    bg = torch.tensor([0.3, 0.1, 0.7])
+    g = torch.randn(3, H, W, generator=torch.Generator().manual_seed(5))
+    st, gr = run_oracle(scene, cam, 1, g, torch.float64, bg=bg)
+    pre = st.pre
+    a = [t.detach().numpy() for t in (pre.xy, pre.conic, pre.opacity, pre.rgb)]
+    pl, rg = st.point_list.numpy().astype(np.int64), st.ranges.numpy().astype(np.int64)
+    image, final_T, n_contrib = PB.blend_forward(*a, pl, rg, bg.double().numpy(), W, H)
+    assert np.array_equal(n_contrib, st.n_contrib.numpy())
+    cnt = (rg[:, 1] - rg[:, 0])
+    gx = (W + 15) // 16
+    per_pixel_len = cnt[(np.arange(H)[:, None] // 16) * gx + np.arange(W)[None, :] // 16]
+    if boost > 1.0:
+        assert (n_contrib < per_pixel_len).mean() > 0.5 and (final_T < 1e-3).mean() > 0.5       # the stop rule is exercised
+    else:
+        assert 0.1 < final_T.mean() < 0.9 and n_contrib.max() > 8                                # ... and so is the background term
+    assert np.abs(image - st.image.numpy()).max() < 1e-13
+    assert np.abs(final_T - st.final_T.numpy()).max() < 1e-15
+    pub = PB.blend_backward(*a, pl, rg, bg.double().numpy(), W, H, final_T, n_contrib, g.double().numpy())
+    two_d = gr["_2d"]
+    for k in ("xy", "conic", "opacity", "rgb"):
+        ref = two_d[k].numpy()
+        assert np.abs(ref).max() > 0
+        assert np.linalg.norm(pub[k] - ref) <= 1e-12 * np.linalg.norm(ref), (k, np.linalg.norm(pub[k] - ref) / np.linalg.norm(ref))
+    dens = gr["means2D_densify"].numpy()
+    assert np.linalg.norm(pub["absgrad"] - dens[:, :2]) <= 1e-12 * np.linalg.norm(dens) and not dens[:, 2].any()
