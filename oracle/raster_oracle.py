@@ -28,7 +28,8 @@ Design of the oracle
   preprocess graph;
 * the dense formulation is held against the published per-pixel loops and their hand-derived back-to-front
   recurrences (oracle/published_blend.py, tests/test_oracle_cpu.py): identical n_contrib, values and 2-D
-  gradients to float64 round-off.
+  gradients to float64 round-off; the per-Gaussian backward (incl. D8 and the four camera tensors) likewise
+  against the hand-derived chain of oracle/published_preprocess.py.
 
 Semantics decided here because the fork is unavailable (also listed in DESIGN.md):
   D1  focal lengths come from ``intrinsic``: fx = intrinsic[0,0]*W/2, fy = intrinsic[1,1]*H/2

@@ -143,3 +143,42 @@ def test_autograd_blend_equals_the_published_recurrences(P, sm, boost):
         assert np.linalg.norm(pub[k] - ref) <= 1e-12 * np.linalg.norm(ref), (k, np.linalg.norm(pub[k] - ref) / np.linalg.norm(ref))
     dens = gr["means2D_densify"].numpy()
     assert np.linalg.norm(pub["absgrad"] - dens[:, :2]) <= 1e-12 * np.linalg.norm(dens) and not dens[:, 2].any()
+
+
+@pytest.mark.parametrize("clamp_grad", ["stock", "exact"])
+def test_autograd_preprocess_backward_equals_the_hand_derivation(clamp_grad):
+    """The oracle's per-Gaussian backward (autograd; D8 "stock" written as a detach of the clamped coordinate) against
+    oracle/published_preprocess.py: the same chain written out by hand in the structure of the published kernels -- conic ->
+    cov2D -> (cov3D, T) -> J -> t -> mean with x_grad_mul at the frustum clamp, pixel -> mean, SH colour (basis gradients of
+    degree 3, clamped channels) -> coefficients and view direction, cov3D -> scale and un-normalised quaternion.  The camera
+    sits inside a cloud of huge splats so that more than a hundred frustum-clamped Gaussians reach the image; float64."""
+    import numpy as np
+    from oracle import published_preprocess as PP
+    from scenes import camera_tensors
+    P, W, H, deg = 900, 96, 64, 3
+    scene, cam = make_case(P, W, H, 5.0, deg, seed=5, dist=1.6)
+    g = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1))
+    st, gr = run_oracle(scene, cam, deg, g, torch.float64, clamp_grad=clamp_grad)
+    ct = {k: v.double().numpy() for k, v in camera_tensors(cam).items()}
+    two_d = {k: v.numpy() for k, v in gr["_2d"].items()}
+    live = np.zeros(P, dtype=bool); live[st.pre.extras["_graph"]["idx"].numpy()] = True
+    pub = PP.preprocess_backward(scene["means3D"].double().numpy(), scene["scales"].double().numpy(),
+                                 scene["rotations"].double().numpy(), scene["shs"].double().numpy(), ct["viewmatrix"],
+                                 ct["projmatrix"], ct["intrinsic"], ct["campos"], W, H, math.tan(cam.FoVx * 0.5),
+                                 math.tan(cam.FoVy * 0.5), 1.0, deg, live, two_d["xy"], two_d["conic"], two_d["opacity"],
+                                 two_d["rgb"], clamp_grad=clamp_grad)
+    touched = np.abs(two_d["conic"]).sum(1) > 0
+    assert int((pub["clamped"] & touched).sum()) > 50                      # the clamp rule is exercised (104)
+    assert bool(st.pre.clamped.any())                                      # ... and so are clamped colour channels
+    for k in ("means3D", "scales", "rotations", "shs", "opacities", "viewmatrix", "projmatrix", "intrinsic", "campos"):
+        ref = gr[k].numpy()
+        err = np.linalg.norm(pub[k] - ref) / np.linalg.norm(ref)
+        assert err < 1e-11, (k, err)
+    # the two readings of D8 are different functions on clamped Gaussians, and only there
+    other = PP.preprocess_backward(scene["means3D"].double().numpy(), scene["scales"].double().numpy(),
+                                   scene["rotations"].double().numpy(), scene["shs"].double().numpy(), ct["viewmatrix"],
+                                   ct["projmatrix"], ct["intrinsic"], ct["campos"], W, H, math.tan(cam.FoVx * 0.5),
+                                   math.tan(cam.FoVy * 0.5), 1.0, deg, live, two_d["xy"], two_d["conic"], two_d["opacity"],
+                                   two_d["rgb"], clamp_grad="exact" if clamp_grad == "stock" else "stock")
+    moved = np.abs(other["means3D"] - pub["means3D"]).sum(1) > 0
+    assert moved.sum() > 50 and not (moved & ~pub["clamped"]).any()
