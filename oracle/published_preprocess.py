@@ -195,5 +195,10 @@ def preprocess_backward(means3D, scales, rotations, shs, viewmatrix, projmatrix,
                     + x * g[:, 2, 0] + y * g[:, 2, 1])
     d_rot[idx] = dq
     clamped = np.zeros(P, dtype=bool); clamped[idx] = clx | cly
+    # ---- the forward values of the same Gaussians (A.1), for the comparison with raster_oracle.preprocess
+    fwd = dict(idx=idx, conic=np.stack([c / det, -b / det, a / det], 1),
+               xy=np.stack([((hom[:, 0] * mw + 1.0) * W - 1.0) * 0.5, ((hom[:, 1] * mw + 1.0) * H - 1.0) * 0.5], 1),
+               radius=np.ceil(3.0 * np.sqrt(0.5 * (a + c) + np.sqrt(np.maximum(0.1, (0.5 * (a + c)) ** 2 - det)))),
+               rgb=np.maximum(raw, 0.0) if shs is not None else None, depth=tz)
     return dict(means3D=d_mean, scales=d_scale, rotations=d_rot, shs=d_sh, opacities=g_opacity.reshape(P, 1).copy(), clamped=clamped,
-                viewmatrix=d_view, projmatrix=d_proj, intrinsic=d_intr, campos=d_campos)
+                viewmatrix=d_view, projmatrix=d_proj, intrinsic=d_intr, campos=d_campos, forward=fwd)

@@ -167,6 +167,13 @@ def test_autograd_preprocess_backward_equals_the_hand_derivation(clamp_grad):
                                  ct["projmatrix"], ct["intrinsic"], ct["campos"], W, H, math.tan(cam.FoVx * 0.5),
                                  math.tan(cam.FoVy * 0.5), 1.0, deg, live, two_d["xy"], two_d["conic"], two_d["opacity"],
                                  two_d["rgb"], clamp_grad=clamp_grad)
+    # forward values (Appendix A.1) of the same restatement: pixel centre, conic, colour, depth, 3-sigma radius
+    f = pub["forward"]
+    vis = st.pre.visible.numpy()[f["idx"]]
+    for name, ref in (("xy", st.pre.xy), ("conic", st.pre.conic), ("rgb", st.pre.rgb)):
+        assert np.abs(f[name] - ref.detach().numpy()[f["idx"]]).max() < 1e-11, name
+    assert np.abs(f["depth"] - st.pre.depth.detach().numpy()[f["idx"]]).max() < 1e-13
+    assert np.array_equal(f["radius"][vis].astype(np.int64), st.pre.radii.numpy()[f["idx"]][vis].astype(np.int64)) and vis.sum() > 500
     touched = np.abs(two_d["conic"]).sum(1) > 0
     assert int((pub["clamped"] & touched).sum()) > 50                      # the clamp rule is exercised (104)
     assert bool(st.pre.clamped.any())                                      # ... and so are clamped colour channels
