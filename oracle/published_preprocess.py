@@ -87,11 +87,12 @@ def rotation_of(q):
 
 
 def preprocess_backward(means3D, scales, rotations, shs, viewmatrix, projmatrix, intrinsic, campos, W, H, tanfovx, tanfovy,
-                        scale_modifier, sh_degree, live, g_xy, g_conic, g_opacity, g_rgb, clamp_grad="stock"):
+                        scale_modifier, sh_degree, live, g_xy, g_conic, g_opacity, g_rgb, clamp_grad="stock", det_reg=0.0):
     """``live`` (P,) bool: the Gaussians that took part (raster_oracle: near-plane survivors); g_* the 2-D gradients the
     blend backward accumulated (pixel units; g_conic[:, 1] w.r.t. the conic's b itself).  Returns the gradients of means3D,
     scales, rotations, shs, opacities, of the four camera tensors (viewmatrix, projmatrix, intrinsic, campos; shift_factors = 0),
-    and the mask of frustum-clamped Gaussians."""
+    and the mask of frustum-clamped Gaussians.  ``det_reg``: upstream's 1e-7 added to det^2 in the conic step (decision D9: 0 here
+    and in the kernels; the test measures what the difference amounts to)."""
     P = means3D.shape[0]
     v, m, k = viewmatrix.reshape(4, 4), projmatrix.reshape(4, 4), intrinsic.reshape(4, 4)
     d_mean = np.zeros((P, 3)); d_scale = np.zeros((P, 3)); d_rot = np.zeros((P, 4)); d_sh = np.zeros_like(shs)
@@ -120,7 +121,7 @@ def preprocess_backward(means3D, scales, rotations, shs, viewmatrix, projmatrix,
     det = a * c - b * b
     # ---- conic -> cov2D
     gA, gB, gC = gcon[:, 0], gcon[:, 1], gcon[:, 2]
-    inv2 = 1.0 / (det * det)
+    inv2 = 1.0 / (det * det + det_reg)
     dLa = inv2 * (-c * c * gA + b * c * gB - b * b * gC)
     dLc = inv2 * (-a * a * gC + a * b * gB - b * b * gA)
     dLb = inv2 * (2 * b * c * gA - (det + 2 * b * b) * gB + 2 * a * b * gC)
