@@ -218,3 +218,42 @@ def test_upstream_conic_regulariser_is_below_the_parity_bar():
         assert 0 < e < 1.3e-5, (k, e)
         worst = max(worst, e)
     print("largest relative effect of the 1e-7 regulariser:", worst)
+
+
+def test_binning_equals_the_published_loops():
+    """Appendix A.2 as plain loops (duplicateWithKeys: for every visible Gaussian in id order, for y then x over its tile
+    rectangle, key = tile << 32 | depth bits; one stable sort; identifyTileRanges from key changes) against the oracle's
+    vectorised bin_and_sort, with the stock 3-sigma rectangles (tile_bounds="aabb": the reference's own instance list)."""
+    import struct
+    scene, cam = make_case(700, 100, 70, 2.0, 0, seed=12)
+    st, _ = run_oracle(scene, cam, 0, tile_bounds="aabb")
+    rect, radii = st.pre.rect.tolist(), st.pre.radii.tolist()
+    depth = st.pre.depth.detach().float().tolist()
+    gx, T = st.gx, st.gx * st.gy
+    keys, ids = [], []
+    for i in range(700):
+        if radii[i] <= 0:
+            continue
+        x0, y0, x1, y1 = rect[i]
+        bits = struct.unpack("<I", struct.pack("<f", depth[i]))[0]
+        for y in range(y0, y1):
+            for x in range(x0, x1):
+                keys.append(((y * gx + x) << 32) | bits)
+                ids.append(i)
+    order = sorted(range(len(keys)), key=lambda j: keys[j])               # Python's sort is stable
+    ks, pl = [keys[j] for j in order], [ids[j] for j in order]
+    assert len(ks) == st.keys_sorted.numel() > 3000
+    assert ks == st.keys_sorted.tolist() and pl == st.point_list.tolist()
+    ranges = [[0, 0] for _ in range(T)]
+    for j, k in enumerate(ks):                                             # identifyTileRanges
+        t = k >> 32
+        if j == 0 or (ks[j - 1] >> 32) != t:
+            ranges[t][0] = j
+        if j == len(ks) - 1 or (ks[j + 1] >> 32) != t:
+            ranges[t][1] = j + 1
+    got = st.ranges.tolist()
+    for t in range(T):
+        if ranges[t][1] > ranges[t][0]:
+            assert got[t] == ranges[t], t
+        else:
+            assert got[t][1] == got[t][0], t
