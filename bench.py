@@ -295,6 +295,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the rasterizer has no CPU path")
+    if world > 1 and args.backend == "nccl" and torch.cuda.device_count() < world:
+        # one rank per GPU over RCCL: two ranks on one device would deadlock or fail inside the first collective -- say so instead
+        raise SystemExit(f"--gpus {world} over RCCL needs {world} visible GPUs, this node shows {torch.cuda.device_count()}")
     local = local % max(torch.cuda.device_count(), 1)      # gloo self-test: several ranks may share one GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -307,6 +310,13 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+        # the ranks that actually take part in a collective, counted BY a collective: the figure printed as rccl_ranks.  Fewer
+        # than --gpus (a launcher that started fewer processes, a communicator that split) is an error, never a smaller bench.
+        ones = torch.ones(1, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        if dist.get_world_size() != args.gpus or ranks_seen != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus}: the process group holds {dist.get_world_size()} ranks, {ranks_seen} answered the first all-reduce")
 
     from bags_raster import _lib
     from bags_raster.sharding import GradAllReducer, PipelinedExchange
@@ -501,6 +511,10 @@ def main():
             aabb["roofline"] = {"bound": "hbm", "kernel": "blend_bwd", "achieved": ab / (t_bwd * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
                                 "unit": "GB/s", "frac": ab / (t_bwd * 1e-3) / HBM_PEAK, "traffic": None,
                                 "alg_bytes_per_launch": ab, "mean_launch_ms": t_bwd}
+        # op level, same formula as the headline's op_roofline with this leg's instance count, over the wall time of a step
+        b_alg_a = G * 850 + (P - G) * 28 + I_a * 168 + H * W * 40
+        aabb["op_roofline"] = {"bound": "hbm", "alg_bytes_per_step": b_alg_a, "achieved": b_alg_a / (aabb["ms_per_step"] * 1e-3) / 1e9,
+                               "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac_wall": b_alg_a / (aabb["ms_per_step"] * 1e-3) / HBM_PEAK}
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -545,7 +559,7 @@ def main():
             "instances_per_s": world * V * I * args.steps / elapsed,
             "ms_per_view": ms_step / V,
             "ms_per_step_cold": cold / args.steps * 1e3,    # W warm-up + K timed steps from an idle device: no settle steps
-            "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0,
+            "rccl_ranks": ranks_seen if (world > 1 and args.backend == "nccl") else 0,   # counted by an all-reduce at start-up
             "exchange_ms": exchange_ms,                    # per step, hipEvents around the collective on the launch stream (rank 0)
             "compute_ms": ms_step - exchange_ms,
             "exchange_bytes": ((exch.exchanges[0] if args.overlap else exch).bucket.numel * 4) if exch is not None else 0,
@@ -570,14 +584,21 @@ def main():
                 # HBM bytes of this kernel from the newest committed PMC pass of this workload (profiles/rNN/traffic.json:
                 # separate rocprofv3 --pmc runs for FETCH_SIZE and WRITE_SIZE; KiB counters x 1024; FETCH_SIZE doubled as
                 # MI355X_MICROARCH.md prescribes for gfx950 -- an upper bound here, the reads being 64-byte line gathers)
-                tj, src = None, None
+                # Only counters collected ON THIS BUILD are printed: tools/make_traffic.py stamps the file with the library's
+                # bags_build_info() (hash of the kernel sources + last commit that touched them); a file from another build of the
+                # kernels leaves `traffic` null and is named in `traffic_stale` (round 4 printed an earlier build's number here).
+                tj, src, stale = None, None, None
+                build = _lib.load().bags_build_info().decode()
+                src_hash = build.split()[0]
                 key = {"P": P, "width": W, "height": H, "sm": args.sm, "tile_bounds": args.tile_bounds}
                 for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
                     try:
                         cand = json.load(open(os.path.join(ROOT, "profiles", rnd, "traffic.json")))
                         if cand.get("key") == key and dom in cand:
-                            tj, src = cand, cand.get("source", "profiles/" + rnd)
-                            break
+                            if str(cand.get("build", "")).split()[:1] == [src_hash]:
+                                tj, src = cand, "profiles/" + rnd + "/traffic.json"
+                                break
+                            stale = stale or {"file": "profiles/" + rnd + "/traffic.json", "build": cand.get("build", "unstamped")}
                     except (OSError, ValueError):
                         continue
                 traffic = va = None
@@ -588,6 +609,9 @@ def main():
                                    "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic,
                                    "traffic_uncorrected": None if tj is None else tj[dom]["fetch_bytes"] + tj[dom]["write_bytes"],
                                    "alg_bytes_per_launch": alg[dom], "mean_launch_ms": stages[dom],
+                                   "library_build": build,
+                                   "traffic_commit": None if tj is None else (tj["build"].split("commit=")[-1] if "commit=" in tj["build"] else None),
+                                   "traffic_build": None if tj is None else tj["build"], "traffic_stale": None if tj is not None else stale,
                                    "note": "this kernel is bound by vector-instruction throughput, not by HBM (DESIGN.md section 3: at one "
                                            "workgroup per CU it already runs at 82 % of a single wave's issue rate; HBM traffic stays near "
                                            "its algorithmic bytes); PMC source: " + str(src)}

@@ -11,11 +11,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # tests).  Not a fallback: a missing file still raises.
 LIB_PATH = os.environ.get("BAGS_RASTER_LIB") or os.path.join(_HERE, "libbags_raster.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 TILES_AABB, TILES_OPACITY = 0, 1
 DEPTH_Z, DEPTH_DISTANCE = 0, 1
 BINNING_AUTO, BINNING_RADIX = 0, 1
 CLAMP_GRAD_STOCK, CLAMP_GRAD_EXACT = 0, 1
+CONIC_GRAD_STOCK, CONIC_GRAD_EXACT = 0, 1
 
 c_fp = C.c_void_p  # device pointers travel as integers
 
@@ -24,7 +25,7 @@ class BagsSettings(C.Structure):
     _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
                 ("scale_modifier", C.c_float), ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32),
                 ("depth_key", C.c_int32), ("debug", C.c_int32), ("debug_iter", C.c_int32),
-                ("tile_bounds", C.c_int32), ("binning", C.c_int32), ("clamp_grad", C.c_int32), ("reserved0", C.c_int32),
+                ("tile_bounds", C.c_int32), ("binning", C.c_int32), ("clamp_grad", C.c_int32), ("conic_grad", C.c_int32),
                 ("bg", c_fp), ("viewmatrix", c_fp), ("projmatrix", c_fp), ("intrinsic", c_fp), ("campos", c_fp)]
 
 
@@ -49,7 +50,7 @@ class BagsBackwardArgs(C.Structure):
                 ("grad_colors_precomp", c_fp), ("grad_opacities", c_fp), ("grad_scales", c_fp), ("grad_rotations", c_fp),
                 ("grad_cov3D_precomp", c_fp), ("grad_viewmatrix", c_fp), ("grad_projmatrix", c_fp),
                 ("grad_intrinsic", c_fp), ("grad_campos", c_fp), ("grad_shift_factors", c_fp),
-                ("binning_capacity", C.c_int64), ("accumulate", C.c_int32), ("reserved1", C.c_int32), ("grad_shs_rest", c_fp)]
+                ("binning_capacity", C.c_int64), ("accumulate", C.c_int32), ("prezero_per_tile", C.c_int32), ("grad_shs_rest", c_fp)]
 
 
 class BagsDebugViews(C.Structure):
@@ -72,6 +73,7 @@ class BagsRawGaussians(C.Structure):
 
 SYMBOLS = {
     "bags_abi_version": (C.c_int, []),
+    "bags_build_info": (C.c_char_p, []),
     "bags_last_error": (C.c_char_p, []),
     "bags_geom_size": (C.c_size_t, [C.c_int32]),
     "bags_binning_size": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),

@@ -53,6 +53,9 @@ class GaussianRasterizationSettings(NamedTuple):
     # gradient of the EWA Jacobian at the 1.3 x FoV clamp: "stock" = upstream diff-gaussian-rasterization's rule (clamped t.x
     # held constant inside dL/dt.z), which the reference's fork inherits; "exact" differentiates the clamped expression itself
     clamp_grad: str = "stock"
+    # backward of conic = cov2D^-1: "stock" = upstream's computeCov2DCUDA, which divides by det^2 + 1e-7 (the fork inherits it;
+    # default since round 5); "exact" = det^2.  At most 1.2e-5 relative on one Gaussian's dL/dcov2D (det >= 0.09)
+    conic_grad: str = "stock"
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -139,6 +142,8 @@ class _Packed:
             raise ValueError("binning must be 'auto' or 'radix'")
         if settings.clamp_grad not in ("stock", "exact"):
             raise ValueError("clamp_grad must be 'stock' or 'exact'")
+        if settings.conic_grad not in ("stock", "exact"):
+            raise ValueError("conic_grad must be 'stock' or 'exact'")
         self.settings = L.BagsSettings(
             int(settings.image_height), int(settings.image_width), float(settings.tanfovx), float(settings.tanfovy),
             float(settings.scale_modifier), int(settings.sh_degree), int(M),
@@ -146,7 +151,8 @@ class _Packed:
             int(settings.debug_iter) if settings.debug_iter is not None else -1,
             L.TILES_OPACITY if settings.tile_bounds == "opacity" else L.TILES_AABB,
             L.BINNING_RADIX if settings.binning == "radix" else L.BINNING_AUTO,
-            L.CLAMP_GRAD_EXACT if settings.clamp_grad == "exact" else L.CLAMP_GRAD_STOCK, 0,
+            L.CLAMP_GRAD_EXACT if settings.clamp_grad == "exact" else L.CLAMP_GRAD_STOCK,
+            L.CONIC_GRAD_EXACT if settings.conic_grad == "exact" else L.CONIC_GRAD_STOCK,
             _ptr(k["bg"]), _ptr(k["viewmatrix"]), _ptr(k["projmatrix"]), _ptr(k["intrinsic"]), _ptr(k["campos"]))
         self.inputs = L.BagsInputs(P, _ptr(k["means3D"]), _ptr(k["means2D"]), _ptr(k["shift_factors"]), _ptr(k["shs"]),
                                    _ptr(k["colors_precomp"]), _ptr(k["opacities"]), _ptr(k["scales"]),
@@ -198,6 +204,9 @@ LAZY_RECOVER = False
 # (BagsBackwardArgs.accumulate) and hands autograd None for them -- no flat buffer, no add pass per tensor and view.  The sums are
 # what autograd's own accumulation gives; tensor hooks on those parameters do not see the per-view gradients.
 ACCUMULATE_IN_PLACE = False
+# BagsBackwardArgs.prezero_per_tile: 0 = the library's threshold for taking blend_bwd's zero records from one memset (dense scenes),
+# < 0 never, > 0 that many instances per tile.  Results do not depend on it; tools/fuzz_paths.py forces both paths with it.
+PREZERO_PER_TILE = 0
 CAPACITY_HEADROOM = 4.0      # lazy forwards only; a waiting forward sizes for 1.2 x the largest count seen and redoes on overflow
 _HINT_KEYS_MAX = 64
 _capacity_hint = {}          # (device index, P, W, H) -> largest instance count seen for the shape (a hint only); insertion order = LRU
@@ -536,7 +545,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             args = L.BagsBackwardArgs(gc.data_ptr(), fw.num_rendered, ws.data_ptr(), ws.numel(), _ptr(g_means3D),
                                       _ptr(g_means2D), _ptr(g_densify), _ptr(g_sh), _ptr(g_col), _ptr(g_opac),
                                       _ptr(g_scales), _ptr(g_rot), _ptr(g_cov), _ptr(g_view), _ptr(g_proj),
-                                      _ptr(g_intr), _ptr(g_campos), _ptr(g_shift), fw.capacity, 1 if in_place is not None else 0, 0,
+                                      _ptr(g_intr), _ptr(g_campos), _ptr(g_shift), fw.capacity, 1 if in_place is not None else 0, int(PREZERO_PER_TILE),
                                       _ptr(g_sh_rest))
             state = _state_of(fw)
             L.check(lib.bags_backward(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(args), stream),

@@ -204,15 +204,16 @@ static int check_common(const BagsSettings* s, const BagsInputs* in, const BagsS
     return BAGS_OK;
 }
 
-// folded pose reduction (preprocess_bwd.hip): tickets [1 + groups] u32, group rows [groups][POSE_VALS] fp64
-static int fold_groups(int P) { const int nb = cdiv(P > 0 ? P : 1, 256); return cdiv(nb, pose_group_size(nb)); }
-static size_t fold_ticket_bytes(int P) { return align_up((size_t)(1 + fold_groups(P)) * sizeof(u32), 256); }
-static size_t fold_bytes(int P) { return fold_ticket_bytes(P) + align_up((size_t)fold_groups(P) * POSE_VALS * sizeof(double), 256); }
 
 // ---------------------------------------------------------------------------------------------- C ABI
 extern "C" {
 
 int bags_abi_version(void) { return BAGS_ABI_VERSION; }
+#ifndef BAGS_SRC_HASH
+#define BAGS_SRC_HASH "unknown"
+#define BAGS_KERNEL_COMMIT "unknown"
+#endif
+const char* bags_build_info(void) { return "src=" BAGS_SRC_HASH " commit=" BAGS_KERNEL_COMMIT; }
 const char* bags_last_error(void) { return g_err; }
 
 size_t bags_geom_size(int32_t P) { return carve_geom(nullptr, P, nullptr) + 256; }
@@ -226,8 +227,7 @@ size_t bags_backward_workspace_size(int32_t P, int64_t I)
 {
     const size_t part = align_up((size_t)(I > 0 ? I : 1) * PART_FLOATS * sizeof(float), 256);
     const size_t slab = align_up((size_t)(cdiv(P > 0 ? P : 1, 256)) * POSE_VALS * sizeof(float), 256);
-    const size_t sums = align_up((size_t)(P > 0 ? P : 1) * 12 * sizeof(float), 256);
-    return part + slab + sums + fold_bytes(P) + 256;
+    return part + slab + 256;
 }
 
 // tile-binned lists (binning.hip) unless the caller asked for the radix path or the problem is outside their limits
@@ -290,7 +290,7 @@ static int enqueue_finish(const BagsSettings* s, const BagsInputs* in, const Geo
         if (in->P == 0) HIP_TRY(launch_binned_empty(g, im, gx * gy, st));      // no prepare phase ran: an all-empty tile list
         if (I > 0 && in->P > 0) {
             ProfScope ps(ST_TILE_SORT, st);
-            HIP_TRY(launch_binned_finish(g, im, in->P, gx, gx * gy, b.words, b.scratch, b.point_list, (u32)I, n_dev, st, !blend_fwd_sorts(), speculative));
+            HIP_TRY(launch_binned_finish(g, im, in->P, gx, gx * gy, b.words, b.scratch, b.point_list, (u32)I, n_dev, st, speculative));
         } else if (in->P > 0) {
             HIP_TRY(launch_binned_desc_only(im, gx * gy, st));                   // nothing to emit: only the (all-empty) tile list
         }
@@ -418,27 +418,16 @@ int bags_backward(const BagsSettings* s, const BagsInputs* in, const BagsState* 
     char* ws = reinterpret_cast<char*>(align256(a->workspace));
     float* partials = reinterpret_cast<float*>(ws);
     float* slab = reinterpret_cast<float*>(ws + align_up((size_t)(I > 0 ? I : 1) * PART_FLOATS * sizeof(float), 256));
-    float* sums = reinterpret_cast<float*>(reinterpret_cast<char*>(slab) +
-                                           align_up((size_t)(cdiv(in->P > 0 ? in->P : 1, 256)) * POSE_VALS * sizeof(float), 256));
-    u32* tickets = reinterpret_cast<u32*>(reinterpret_cast<char*>(sums) + align_up((size_t)(in->P > 0 ? in->P : 1) * 12 * sizeof(float), 256));
-    unsigned long long* group_rows = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(tickets) + fold_ticket_bytes(in->P));
-    const int n_tickets = 1 + fold_groups(in->P);
-    const bool fold = pose_fold_enabled() && in->P > 0;
     if (I > 0) {
-        // (blend_bwd also clears the tickets of the folded pose reduction behind it: no memset launch)
         { ProfScope ps(ST_BLEND_BWD, st); HIP_TRY(launch_blend_bwd(*s, g, b, im, a->grad_color, partials, a->grad_means2D_densify != nullptr, use_binned(s, in->P), st,
-                                                                  fold ? tickets : nullptr, fold ? n_tickets : 0, I)); }
+                                                                  I, a->prezero_per_tile)); }
         DEBUG_SYNC(s, st, "blend_bwd");
-    } else if (fold) {
-        HIP_TRY(hipMemsetAsync(tickets, 0, (size_t)n_tickets * sizeof(u32), st));
     }
     int nblocks = 0;
-    { ProfScope ps(ST_PRE_BWD, st); HIP_TRY(launch_preprocess_bwd(*s, *in, g, nullptr, partials, slab, &nblocks, *a, st, sums, use_binned(s, in->P), tickets, group_rows)); }
+    { ProfScope ps(ST_PRE_BWD, st); HIP_TRY(launch_preprocess_bwd(*s, *in, g, nullptr, partials, slab, &nblocks, *a, st, use_binned(s, in->P))); }
     DEBUG_SYNC(s, st, "preprocess_bwd");
-    if (!fold) {
-        { ProfScope ps(ST_POSE_REDUCE, st); HIP_TRY(launch_pose_reduce(slab, nblocks, *a, st)); }
-        DEBUG_SYNC(s, st, "pose_reduce");
-    }
+    { ProfScope ps(ST_POSE_REDUCE, st); HIP_TRY(launch_pose_reduce(slab, nblocks, *a, st)); }
+    DEBUG_SYNC(s, st, "pose_reduce");
     if (s->debug) {
         const size_t P = (size_t)in->P;
         const ScanItem items[] = {{"grad_means3D", a->grad_means3D, 3 * P}, {"grad_means2D", a->grad_means2D, 3 * P},

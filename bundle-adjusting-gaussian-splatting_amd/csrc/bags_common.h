@@ -169,18 +169,15 @@ hipError_t launch_tile_ranges(const u32* tile_sorted, long long I, uint2* ranges
 hipError_t launch_tile_order(const uint2* ranges, int T, uint4* tile_desc, u32* n_active, hipStream_t st);
 hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
                             const BagsForwardOut& out, hipStream_t st, const u32* n_dev = nullptr, u32 capacity = 0, bool sort_here = false);
-bool blend_fwd_sorts();      // the build's blend_fwd sorts the tile lists of the tile-binned path itself (no tile_sort launch)
 // binned: the record base of a Gaussian is block_base[line.q3.y] + line.q3.z (K1 wrote both into the geometry line); otherwise
 // (radix path) it is gathered from g.inst_off
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
                             const float* grad_color, float* partials, bool want_abs, bool binned, hipStream_t st,
-                            u32* zero_words = nullptr, int n_zero = 0,    // words the launch clears for the kernel behind it (pose tickets)
-                            long long n_records = 0);                     // instance count when the host knows it (dense scenes: one memset)
+                            long long n_records = 0,                      // instance count when the host knows it (dense scenes: one memset)
+                            int prezero_per_tile = 0);                    // BagsBackwardArgs.prezero_per_tile
 hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, const int32_t* radii_or_null,
-                                 const float* partials, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a, hipStream_t st, float* sums,
-                                 bool binned, u32* fold_tickets, unsigned long long* fold_rows);
-int pose_group_size(int nblocks);            // preprocess workgroups per group of the folded pose reduction
-bool pose_fold_enabled();                    // the build's preprocess_bwd sums the pose slab itself (no pose_reduce launch)
+                                 const float* partials, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a, hipStream_t st,
+                                 bool binned);
 hipError_t launch_pose_reduce(const float* pose_slab, int nblocks, const BagsBackwardArgs& a, hipStream_t st);
 // loss.hip: fused L1 + SSIM terms and their image gradient
 size_t loss_workspace_bytes(int C, int H, int W);
@@ -223,7 +220,7 @@ hipError_t launch_binned_desc_only(const ImgView& im, int T, hipStream_t st);
 hipError_t launch_binned_prepare(const GeomView& g, const ImgView& im, int P, int grid_x, int T, hipStream_t st, u32* host_count = nullptr,
                                  bool count_now = true);
 hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int grid_x, int T, u64* words, u64* scratch, u32* point_list,
-                                u32 capacity, const u32* n_dev, hipStream_t st, bool sort_lists = true, bool deliver_count = false);
+                                u32 capacity, const u32* n_dev, hipStream_t st, bool deliver_count = false);
 hipError_t launch_debug_keys_ranges(const uint2* ranges, const u32* point_list, const u32* depth_key, int T, u64* out, hipStream_t st);
 hipError_t launch_debug_keys(const u32* tile_sorted, const u32* point_list, const u32* depth_key, long long I, u64* out, hipStream_t st);
 hipError_t launch_unpack_rect(const uint2* rect, int P, u32* out, hipStream_t st);

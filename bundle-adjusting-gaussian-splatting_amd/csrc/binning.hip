@@ -370,35 +370,8 @@ emit_binned_kernel(int P, int per_block, int grid_x, int T, const uint2* __restr
     (void)walk_block<true>(cur, P, per_block, grid_x, rect, tiles_touched, keep, reinterpret_cast<u32*>(words));
 }
 
-// ------------------------------------------------------------------------------------------------ 5. tile_sort (tile_sort.h)
-// ONE launch for every list (round 3; the long-list kernel used to be a launch of its own: ~5 us of stream time even when no
-// list is long, every frame): workgroups [0, n_large_wg) take the long lists, the ones behind them four short lists each.
-// (Round 4: not launched any more unless built with -DFWD_SORT=0 -- blend_fwd sorts its own tile's list, tile_sort.h.)
-__global__ void __launch_bounds__(256)
-tile_sort_kernel(const uint4* __restrict__ tile_desc, const u32* __restrict__ n_active, const u64* __restrict__ words_in,
-                 u64* __restrict__ scratch, u32* __restrict__ point_list, u32 capacity, const u32* __restrict__ n_dev, int T,
-                 u32 n_large_wg, const u32* __restrict__ depth_key)
-{
-    __shared__ u64 t_all[TSORT_BLOCK];                       // one list of <= TSORT_BLOCK words, or four waves x TSORT_WAVE (slab sort / short lists)
-    __shared__ u32 cnt_all[TSORT_BLOCK / 2];                 // packed 16-bit counters
-    __shared__ TileSortLds L;
-    if (n_dev && *n_dev > capacity) return;
-    const int wave = threadIdx.x >> 6;
-    if (blockIdx.x >= n_large_wg) {                          // short lists: a wave per tile
-        const u32 d = (blockIdx.x - n_large_wg) * 4u + (u32)wave;
-        if (d < (u32)T) {
-            const uint4 dd = tile_desc[d];
-            sort_wave_role(dd, tile_words(words_in, dd.y, depth_key), point_list, t_all + wave * TSORT_WAVE, cnt_all + wave * (TSORT_WAVE / 2));
-        }
-        return;
-    }
-    const u32 n_long = n_active[1];
-    for (u32 d = blockIdx.x; d < n_long; d += n_large_wg) {
-        const uint4 desc = tile_desc[d];
-        if (desc.z <= TSORT_WAVE) continue;                   // uniform over the workgroup
-        sort_list_block(desc, tile_words(words_in, desc.y, depth_key), scratch, point_list, t_all, cnt_all, L);
-    }
-}
+// (5. the per-tile sorts: tile_sort.h, run by each tile's own blend_fwd workgroup since round 4 -- the kernel that used to launch
+//  them here, one launch for every list, is in the git history.)
 
 // ------------------------------------------------------------------------------------------------ launchers
 static size_t ord_tr_bytes(int per) { return (size_t)16 * (64 * per + 2 * per) * 4; }   // 34 / 68 / 135 KB
@@ -465,7 +438,7 @@ hipError_t launch_binned_empty(const GeomView& g, const ImgView& im, int T, hipS
 }
 
 hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int grid_x, int T, u64* words, u64* scratch, u32* point_list,
-                                u32 capacity, const u32* n_dev, hipStream_t st, bool sort_lists, bool deliver_count)
+                                u32 capacity, const u32* n_dev, hipStream_t st, bool deliver_count)
 {
     const int per = binned_per_block(P), B = cdiv(P, per);
     // T slot cursors (up to 128 KB at 32768 tiles: one workgroup per CU); the descriptor workgroup's transposes fit beside
@@ -477,13 +450,8 @@ hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int
                 im.tile_total, im.tile_desc, im.n_active, g.num_rendered, g.block_total, B, g.block_base, deliver_count ? 1 : 0); }
     switch (ord_per_for(T)) { case 8: EM_LAUNCH(8) break; case 16: EM_LAUNCH(16) break; default: EM_LAUNCH(32) }
 #undef EM_LAUNCH
-    if (e != hipSuccess) return e;
-    if (!sort_lists) return hipGetLastError();               // blend_fwd sorts every tile's list itself (tile_sort.h)
-    // long lists first (lowest workgroup ids): their few workgroups run beside the many short sorts
-    const u32 n_large_wg = (u32)(T < 768 ? T : 768);
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(n_large_wg + (u32)cdiv(T, 4)), dim3(256), 0, st, im.tile_desc, im.n_active, words, scratch,
-                       point_list, capacity, n_dev, T, n_large_wg, g.depth_key);
-    return hipGetLastError();
+    (void)scratch; (void)point_list; (void)n_dev;            // blend_fwd sorts every tile's list itself (tile_sort.h)
+    return e != hipSuccess ? e : hipGetLastError();
 }
 
 // 64-bit (tile | depth) keys of the sorted list, for the parity tests

@@ -23,54 +23,22 @@
 #define ALPHA_MIN (1.0f / 255.0f)
 #define T_EPS 0.0001f
 
-// tuning knobs (tools/sweep_blend.sh sweeps them with -D...)
-#ifndef CHUNK
-#define CHUNK 256           // splats staged per step (LDS: 48 B record + 4 x 48 B accumulator copies + 16 list bytes each)
-#endif
+// Sizes that tools/sweep_blend.sh sweeps with -D...; every other switch this file once had lost its A/B and is gone (the
+// measurements are in profiles/r0*/ab_*.txt and DESIGN.md section 3, the code in the git history).
+#define CHUNK 256             // forward: splats staged per chunk (255 + the all-zero sentinel record in slot 255)
 #ifndef BCHUNK
-#define BCHUNK 176          // the backward's chunk: 4 x 48 B x BCHUNK of accumulator copies dominate its LDS (33 of 51 KB at 176: the
-                            // largest chunk that leaves room for 3 workgroups per CU; 128 / 144 / 160 / 176 measured 0.385 / 0.385 / 0.376 / 0.371 ms)
+#define BCHUNK 176            // the backward's chunk: 4 x 48 B x BCHUNK of accumulator copies dominate its LDS (33 of 51 KB at 176: the
+                              // largest chunk that leaves room for 3 workgroups per CU; 128 / 144 / 160 / 176 measured 0.385 / 0.385 / 0.376 / 0.371 ms)
 #endif
 #ifndef SCAN_WG_PER_CU
-#define SCAN_WG_PER_CU 3    // backward workgroups per CU: 3 x 41 KB of LDS, 168 VGPRs (measured: 128/3 beats 256/2 by 3 %)
+#define SCAN_WG_PER_CU 3      // backward workgroups per CU: 3 x 51 KB of LDS, 168 VGPRs (measured: 128/3 beats 256/2 by 3 %)
 #endif
-#ifndef SCAN_UNROLL
-#define SCAN_UNROLL 1
-#endif
-#ifndef PRIO_SERIAL
-#define PRIO_SERIAL 3       // backward: wave priority in the serial section between a chunk's two barriers ...
-#endif
-#ifndef PRIO_GROUPS
-#define PRIO_GROUPS 0       // ... and in its list-building / scan phase (0/0, 1/0, 3/1 measured: flat)
-#endif
-// round-3 knobs of the backward's row loop (tools/variants.sh A/Bs them with -DKNOB=0)
-#ifndef TF_FOLD
-#define TF_FOLD 1           // the per-pixel carry of prod(1 - alpha) starts at 1 / T_final: T in front of a splat is rcp(carry * A),
-#endif                      // no multiply by T_final, and a pixel pair is 3 float4 of LDS instead of 4
-#ifndef SCALAR_ACC
-#define SCALAR_ACC 1        // sums that only need the ROW total of q (sum q, q dy, q dy^2, q dx, q dx dy) on plain fp32: a packed
-#endif                      // op costs 1.6x a plain one on gfx950 (tools/ubench/issue_rates.hip), so folding first is cheaper
-#ifndef NC_SKIP
-#define NC_SKIP 1           // tiles where no pixel stopped early (flag from the forward) skip the `pos <= n_contrib` test
-#endif
-#define PQ (TF_FOLD ? 3 : 4)                 // float4s per pixel pair in LDS
-#ifndef PIX_NARROW
-#define PIX_NARROW 1        // pixel pair = [g0A g0B g1A g1B] [g2A g2B AcA AcB] [RcA RcB ncA ncB]: the row loop of tiles without an early stop
-#endif                      // does not need nc, so its third read is 8 bytes (80 instead of 96 bytes per lane and row step)
-// round-4 knobs
-#ifndef BAL_WRITE
-#define BAL_WRITE 0         // (measured twice on one device: 0.3509 = 0.3509 and 0.3459 -> 0.3420 ms without it; kept as a knob) the record sums of a chunk (four wave copies -> one 48-B record) spread over all 256 threads, one float4
-#endif                      // each: conflict-free LDS reads, three lanes per record on the way out (was: thread = record, 176 of 256 busy)
-#ifndef P_SKIP
-#define P_SKIP 1            // tiles whose staged splats are all well conditioned (flag from the forward) skip the `power <= 0` test: it cannot fail there
-#endif
-#ifndef ABS_FMA
-#define ABS_FMA 1           // sum |q dpower/dcentre| as v_fma_f32 acc, |q|, |h|, acc (8 per row step instead of 4 packed muls + 8 adds)
-#endif
-
-#ifndef FWD_PK
-#define FWD_PK 0            // forward: (dx, dy) and (ap dx, cp dy) as two packed fp32 instructions (record order x y ap cp | bp ...):
-#endif                      // 151.2 us against 148.5 -- every v_pk_*_f32 result needs a wait state before its first use
+#define FWD_WG_PER_CU 6       // forward workgroups per CU (= waves per SIMD): 80 VGPRs (8 / 7 / 6: 148.3 / 146.9 / 144.3 us)
+#define PRIO_SERIAL 3         // backward: wave priority in the serial section between a chunk's two barriers ...
+#define PRIO_GROUPS 0         // ... and in its list-building / scan phase (0/0, 1/0, 3/1 measured: flat)
+#define PQ 3                  // float4s per pixel pair in the backward's LDS image (below)
+#define BWD_PREZERO_PER_TILE 1000       // instances per tile above which blend_bwd's zero records come from one memset (profiles/r04/ab_prezero.txt);
+                                        // BagsBackwardArgs.prezero_per_tile overrides it
 struct __attribute__((aligned(16))) SplatRec {
     float x, y, ap, cp;       // centre, pre-scaled conic: exp2(ap dx^2 + bp dx dy + cp dy^2) == exp(power)
     float bp, o, r, g;
@@ -89,9 +57,6 @@ struct __attribute__((aligned(16))) SplatRec {
 // Placement only affects speed: every tile is computed independently of where and when it runs.
 #ifndef TILE_ILV
 #define TILE_ILV 16
-#endif
-#ifndef BWD_PREZERO_PER_TILE
-#define BWD_PREZERO_PER_TILE 1000       // instances per tile above which blend_bwd's zero records come from one memset (0: never; profiles/r04/ab_prezero.txt)
 #endif
 #define TILE_RUN (8 * TILE_ILV)        // virtual blocks [k TILE_RUN, (k+1) TILE_RUN) permute descriptors of the same interval
 __device__ __forceinline__ int slot_of_vblock(int v)
@@ -122,28 +87,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // between here).  Lane l ends with (A_l, b_l) such that F_l(F_{l-1}(...F_0(x))) = A_l x + b_l, lane 0 innermost.
 // A step with shift d combines lane l with lane l-d:  b_l += a_l * b_{l-d};  a_l *= a_{l-d}  (b first: it needs the old a_l).
 // Lanes whose source falls outside the row are not written (bound_ctrl off), which is the identity they need.
-#define AFF4_STEP(PAT)                                                                                   \
-        "v_fmac_f32_dpp %4, %4, %0 " PAT "\n\t" "v_fmac_f32_dpp %5, %5, %1 " PAT "\n\t"                   \
-        "v_fmac_f32_dpp %6, %6, %2 " PAT "\n\t" "v_fmac_f32_dpp %7, %7, %3 " PAT "\n\t"                   \
-        "v_mul_f32_dpp %0, %0, %0 " PAT "\n\t"  "v_mul_f32_dpp %1, %1, %1 " PAT "\n\t"                    \
-        "v_mul_f32_dpp %2, %2, %2 " PAT "\n\t"  "v_mul_f32_dpp %3, %3, %3 " PAT "\n\t"
-__device__ __forceinline__ void scan_affine16x4(float& a0, float& a1, float& a2, float& a3, float& b0, float& b1, float& b2, float& b3)
-{
-    asm volatile(
-        "s_nop 1\n\t"
-        AFF4_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
-        AFF4_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
-        AFF4_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
-        AFF4_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
-        "s_nop 1"
-        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
-}
-// The same scan on register PAIRS pinned to v[152:159]: the values on either side of it are packed (v_pk_*_f32 needs even-aligned
+// The scan works on register PAIRS pinned to v[152:159]: the values on either side of it are packed (v_pk_*_f32 needs even-aligned
 // pairs) while DPP instructions name single registers, and an asm operand cannot name half of a pair -- with free operands the
 // compiler splits and re-joins the pairs by copies (134 -> 132 vector instructions per row step, 355.9 -> 352.7 us).
-#ifndef SCAN_PINNED
-#define SCAN_PINNED 1
-#endif
 #define AFF4P_STEP(PAT)                                                                                  \
         "v_fmac_f32_dpp v156, v156, v152 " PAT "\n\t" "v_fmac_f32_dpp v157, v157, v153 " PAT "\n\t"     \
         "v_fmac_f32_dpp v158, v158, v154 " PAT "\n\t" "v_fmac_f32_dpp v159, v159, v155 " PAT "\n\t"     \
@@ -242,13 +188,20 @@ __device__ __forceinline__ u32 block_mask16(float x, float y, float a, float b, 
     return m;
 }
 
+// Two diagnostic builds (tools/diag_phases.py, tools/diag_pairs.sh; tests/test_abi_cpu.py compiles both so that they keep building):
+// PH(...) / PH_MARK(i) exist only with -DDIAG_PHASES, DG(...) only with -DDIAG_PAIRS.
 #ifdef DIAG_PHASES
 __device__ unsigned long long g_phase_cycles[8];
+#define PH(...) __VA_ARGS__
 #define PH_MARK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tlast; tlast = t_; } while (0)
 #else
+#define PH(...)
 #define PH_MARK(i) do {} while (0)
 #endif
-#ifdef DIAG_PAIRS
+#ifndef DIAG_PAIRS
+#define DG(...)
+#else
+#define DG(...) __VA_ARGS__
 // Diagnostic build (tools/diag_pairs.sh): (pixel, splat) pairs the blend kernels EVALUATE (every pixel of every 4x4 block a
 // staged splat's reach mask admits) against the pairs that CONTRIBUTE (pass the alpha / power / n_contrib tests), summed
 // over all launches since the last read: [0] backward evaluated, [1] backward contributing, [2] / [3] the same, forward.
@@ -296,7 +249,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                       const u32* __restrict__ point_list, const unsigned char* __restrict__ reach_mask, const u32 rm_stride,
                       const float4* __restrict__ g2d, const u32* __restrict__ inst_off, const u32* __restrict__ block_base,
                       const float* __restrict__ bg, const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
-                      const float* __restrict__ grad_color, float* __restrict__ partials, u32* __restrict__ zero_words, const int n_zero,
+                      const float* __restrict__ grad_color, float* __restrict__ partials,
                       const int test_keep, const uint4* __restrict__ tile_aux, const int skip_zero)
 {
     // One workgroup per tile that holds at least one instance, heavy tiles first (slot_of_vblock).  Tried and dropped:
@@ -306,7 +259,6 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     // the wave timeline: the hardware dispatcher refills a CU as soon as any workgroup leaves, while a persistent
     // workgroup keeps its four waves coupled at two barriers per chunk for the whole launch.
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (blockIdx.x == 0) for (int i = tid; i < n_zero; i += 256) zero_words[i] = 0u;   // tickets of preprocess_bwd's folded pose reduction
     const int dslot = slot_of_vblock((int)blockIdx.x);
     if (dslot >= T) return;
     const uint4 desc = tile_desc[dslot];                     // {tile, first instance, instances, deepest contributor}
@@ -329,20 +281,9 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     __shared__ float acc[4][BCHUNK][12];              // 33 KB, one copy per wave (LDS float atomics on a shared copy were 1.6x slower)
     __shared__ u32 blk_maxc[16];                     // last contributor over the 16 pixels of each block
     __shared__ u32 chunk_pos[COMPACT ? BCHUNK : 1];  // COMPACT: list position of every staged slot (the slots are no longer consecutive positions)
-#if BAL_WRITE
-    __shared__ u32 rec_e[2][BCHUNK];                 // 1.4 KB: emission slots of the staged chunk, two chunks alive (the balanced write-out
-                                                     // of chunk k reads them while faster waves already publish chunk k+1)
-#endif
-#ifdef LDS_PAD                                       // experiment knob: extra LDS per workgroup lowers the occupancy without touching the code
-    __shared__ u32 lds_pad[LDS_PAD / 4];
-    if (threadIdx.x == 0xFFFF) lds_pad[blockIdx.x & 7] = 1u;
-    asm volatile("" :: "v"(lds_pad[threadIdx.x & 7]));
-#endif
 
-#ifdef DIAG_PHASES
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tlast = __builtin_amdgcn_s_memtime();
-#endif
+    PH(unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};)
+    PH(unsigned long long tlast = __builtin_amdgcn_s_memtime();)
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     struct Raw { float4 q0, q1, q2; u32 io, blk; u64 kp; };   // conic+opacity | x y r g | b z rect | record offset (in its block) | block | tile mask
     // id (x) and 4x4-block reach mask (y, as the forward staged it) of this thread's slot in the chunk of a tile's list that ends at hi_
@@ -407,11 +348,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
             rec.ap = -0.5f * LOG2E * co.x; rec.bp = -LOG2E * co.y; rec.cp = -0.5f * LOG2E * co.z; rec.o = co.w;
             rec.r = cz.x; rec.g = cz.y; rec.b = cz.z;
             rec.pos = (COMPACT ? pos_ : lo_ + tid) + 1;
-#ifdef BWD_OWN_MASKS
-            rec.mask = block_mask16(c2.x, c2.y, co.x, co.y, co.z, co.w, (float)(t.tx * BAGS_TILE), (float)(t.ty * BAGS_TILE));
-#else
             rec.mask = mask_;                 // block_mask16 of this (tile, splat), evaluated once: by the forward
-#endif
         }
         return rec;
     };
@@ -433,18 +370,8 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
             const float bgg = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;          // what lies behind the deepest splat
             float* pp = reinterpret_cast<float*>(&pixq[tid >> 4][((tid >> 1) & 7) * PQ]);
             const int h = tid & 1;                        // A or B of the pair
-#if TF_FOLD
-#if PIX_NARROW
             pp[0 + h] = g0; pp[2 + h] = g1; pp[4 + h] = g2; pp[6 + h] = 1.0f / Tf;   // T_final >= 1e-6: a pixel stops before T falls below 1e-4 and alpha <= 0.99
             pp[8 + h] = bgg; pp[10 + h] = __uint_as_float(nc);
-#else
-            pp[0 + h] = g0; pp[2 + h] = g1; pp[4 + h] = g2; pp[6 + h] = __uint_as_float(nc);
-            pp[8 + h] = 1.0f / Tf; pp[10 + h] = bgg;      // T_final >= 1e-6: a pixel stops before T falls below 1e-4 and alpha <= 0.99
-#endif
-#else
-            pp[0 + h] = g0; pp[2 + h] = g1; pp[4 + h] = g2; pp[6 + h] = Tf;
-            pp[8 + h] = 0.f; pp[10 + h] = __uint_as_float(nc); pp[12 + h] = 1.f; pp[14 + h] = bgg;
-#endif
             u32 m = nc;
 #pragma unroll
             for (int d = 8; d >= 1; d >>= 1) m = max(m, (u32)__shfl_xor((int)m, d));   // 16 consecutive threads = one block
@@ -514,13 +441,8 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     const int qx = (wave & 1) * 2, qy = (wave >> 1) * 2;
     const int myblk = (qy + (row >> 1)) * 4 + qx + (row & 1);
     float4* const pixb = &pixq[myblk][0];
-#ifdef DIAG_PAIRS
-    u32 dg_eval = 0, dg_con = 0, dg_ent = 0, dg_ent0 = 0, dg_steps = 0, dg_chunks = 0;
-#endif
+    DG(u32 dg_eval = 0, dg_con = 0, dg_ent = 0, dg_ent0 = 0, dg_steps = 0, dg_chunks = 0;)
 
-#if BAL_WRITE
-    u32 par = 0;                                             // chunk parity (rec_e buffer)
-#endif
     for (u32 hi = hi0;;) {
         const u32 cnt = min(hi, (u32)BCHUNK);
         const u32 lo = hi - cnt;
@@ -528,9 +450,6 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         if (tid < BCHUNK) {                                  // safe without a barrier: after the previous chunk's second barrier nobody reads them
             recs[tid] = rec; masks[tid] = rec.mask;
             if (COMPACT) chunk_pos[tid] = rec.pos - 1u;
-#if BAL_WRITE
-            rec_e[par][tid] = rec.e;
-#endif
         }
         lds_barrier();
         PH_MARK(2);    // barrier 1
@@ -544,40 +463,22 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         // interleave without pipeline bubbles.  `s` is the lane's splat, (bx0, by0) its block origin, pixb its block's
         // pixel pairs, `carry` marks the lane that holds the scan totals (the shallowest of its segment).
         f2 a0, a1, a2, a6, a9, a10;
-#if SCALAR_ACC
         float sa3, sa4, sa5, sa7, sa8;
-#else
-        f2 a3, a4, a5, a7, a8;
-#endif
         auto block_rows = [&](auto skip_nc_tag, auto skip_p_tag, const ChunkRec& s, const bool live, const float bx0, const float by0, float4* pixb, const bool carry) {
             constexpr bool SKIP_NC = decltype(skip_nc_tag)::value;
             constexpr bool SKIP_P = decltype(skip_p_tag)::value;
             a0 = (f2){0.f, 0.f}; a1 = a0; a2 = a0; a6 = a0; a9 = a0; a10 = a0;
-#if SCALAR_ACC
             sa3 = sa4 = sa5 = sa7 = sa8 = 0.f;
-#else
-            a3 = a0; a4 = a0; a5 = a0; a7 = a0; a8 = a0;
-#endif
             float pyf = by0;                                // the row's pixel y: integers, so the += 1 below is exact and dy is
                                                             // the forward's s.y - (float)py bit for bit
-#pragma unroll SCAN_UNROLL
+#pragma unroll 1
             for (int iy = 0; iy < 4; ++iy) {
                 float4* P0 = pixb + iy * 2 * PQ;
                 float4* P1 = P0 + PQ;
-#if TF_FOLD && PIX_NARROW
                 const float4 q00 = P0[0], q01 = P0[1], q02 = P0[2];       // q*1.zw: carry of prod (1 - alpha); q*2 = Rc Rc nc nc
                 const float4 q10 = P1[0], q11 = P1[1], q12 = P1[2];
                 const u32 nc0 = __float_as_uint(q02.z), nc1 = __float_as_uint(q02.w), nc2 = __float_as_uint(q12.z), nc3 = __float_as_uint(q12.w);
                 const float4 q03 = make_float4(q01.z, q01.w, q02.x, q02.y), q13 = make_float4(q11.z, q11.w, q12.x, q12.y);   // (Ac Ac Rc Rc)
-#elif TF_FOLD
-                const float4 q00 = P0[0], q01 = P0[1], q03 = P0[2];
-                const float4 q10 = P1[0], q11 = P1[1], q13 = P1[2];
-                const u32 nc0 = __float_as_uint(q01.z), nc1 = __float_as_uint(q01.w), nc2 = __float_as_uint(q11.z), nc3 = __float_as_uint(q11.w);
-#else
-                const float4 q00 = P0[0], q01 = P0[1], q02 = P0[2], q03 = P0[3];
-                const float4 q10 = P1[0], q11 = P1[1], q12 = P1[2], q13 = P1[3];
-                const u32 nc0 = __float_as_uint(q02.z), nc1 = __float_as_uint(q02.w), nc2 = __float_as_uint(q12.z), nc3 = __float_as_uint(q12.w);
-#endif
                 const float dy = s.y - pyf;
                 pyf += 1.0f;
                 const float u = __fmul_rn(__fmul_rn(s.cp, dy), dy);
@@ -603,9 +504,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                 const bool v2 = live & (SKIP_P | (pb.x <= 0.f)) & (aub.x >= ALPHA_MIN) & (SKIP_NC | (s.pos <= nc2));
                 const bool v3 = live & (SKIP_P | (pb.y <= 0.f)) & (aub.y >= ALPHA_MIN) & (SKIP_NC | (s.pos <= nc3));
                 aua.x = v0 ? aua.x : 0.f; aua.y = v1 ? aua.y : 0.f; aub.x = v2 ? aub.x : 0.f; aub.y = v3 ? aub.y : 0.f;
-#ifdef DIAG_PAIRS
-                dg_eval += live ? 4u : 0u; dg_con += (u32)v0 + (u32)v1 + (u32)v2 + (u32)v3;
-#endif
+                DG(dg_eval += live ? 4u : 0u; dg_con += (u32)v0 + (u32)v1 + (u32)v2 + (u32)v3;)
                 const f2 ala = {fminf(0.99f, aua.x), fminf(0.99f, aua.y)}, alb = {fminf(0.99f, aub.x), fminf(0.99f, aub.y)};
                 const f2 oma = 1.f - ala, omb = 1.f - alb;
                 const f2 g0a = {q00.x, q00.y}, g1a = {q00.z, q00.w}, g2a = {q01.x, q01.y};
@@ -614,24 +513,13 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                 const f2 sdb = __builtin_elementwise_fma((f2){s.b, s.b}, g2b, __builtin_elementwise_fma((f2){s.g, s.g}, g1b, s.r * g0b));
                 // ---- one affine scan per pixel: F_i(x) = alpha_i (c_i . g) + (1 - alpha_i) x, lane 0 (deepest) innermost
                 const f2 ofa = ala * sda, ofb = alb * sdb;
-#if SCAN_PINNED
                 f2 A01 = oma, A23 = omb, O01 = ofa, O23 = ofb;
                 scan_affine16x4_pinned(A01, A23, O01, O23);
                 const float A0 = A01.x, A1 = A01.y, A2 = A23.x, A3 = A23.y, o0 = O01.x, o1 = O01.y, o2 = O23.x, o3 = O23.y;
-#else
-                float A0 = oma.x, A1 = oma.y, A2 = omb.x, A3 = omb.y;
-                float o0 = ofa.x, o1 = ofa.y, o2 = ofb.x, o3 = ofb.y;
-                scan_affine16x4(A0, A1, A2, A3, o0, o1, o2, o3);
-#endif
                 // carries in q*3: .xy = prod (1 - alpha) behind the group, .zw = colour . g seen behind the group
                 const f2 Ba = (f2){A0, A1} * (f2){q03.x, q03.y}, Bb = (f2){A2, A3} * (f2){q13.x, q13.y};
-#if TF_FOLD
                 const f2 Tna = {__builtin_amdgcn_rcpf(Ba.x), __builtin_amdgcn_rcpf(Ba.y)};                   // T in front of i
                 const f2 Tnb = {__builtin_amdgcn_rcpf(Bb.x), __builtin_amdgcn_rcpf(Bb.y)};
-#else
-                const f2 Tna = {q01.z * __builtin_amdgcn_rcpf(Ba.x), q01.w * __builtin_amdgcn_rcpf(Ba.y)};   // T in front of i
-                const f2 Tnb = {q11.z * __builtin_amdgcn_rcpf(Bb.x), q11.w * __builtin_amdgcn_rcpf(Bb.y)};
-#endif
                 const f2 wa = ala * Tna, wb = alb * Tnb;
                 // what is seen at the FRONT face of i; the next deeper lane's value is what lies BEHIND i
                 const f2 Va = __builtin_elementwise_fma((f2){A0, A1}, (f2){q03.z, q03.w}, (f2){o0, o1});
@@ -639,13 +527,8 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                 float R0 = q03.z, R1 = q03.w, R2 = q13.z, R3 = q13.w;
                 shift_up16x4(R0, R1, R2, R3, Va.x, Va.y, Vb.x, Vb.y);     // (pinned like the scan: same instruction count, same time)
                 if (carry) {                                            // carries for the next (shallower) group
-#if TF_FOLD && PIX_NARROW
                     reinterpret_cast<float2*>(P0 + 1)[1] = make_float2(Ba.x, Ba.y); reinterpret_cast<float2*>(P0 + 2)[0] = make_float2(Va.x, Va.y);
                     reinterpret_cast<float2*>(P1 + 1)[1] = make_float2(Bb.x, Bb.y); reinterpret_cast<float2*>(P1 + 2)[0] = make_float2(Vb.x, Vb.y);
-#else
-                    P0[PQ - 1] = make_float4(Ba.x, Ba.y, Va.x, Va.y);
-                    P1[PQ - 1] = make_float4(Bb.x, Bb.y, Vb.x, Vb.y);
-#endif
                 }
                 const f2 dLa = Tna * (sda - (f2){R0, R1});
                 const f2 dLb = Tnb * (sdb - (f2){R2, R3});
@@ -658,41 +541,23 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                 const f2 qdxa = qva * dxa, qdxb = qvb * dxb;
                 const f2 rq = qva + qvb, rqdx = qdxa + qdxb;
                 a6 = __builtin_elementwise_fma(qdxa, dxa, a6); a6 = __builtin_elementwise_fma(qdxb, dxb, a6);
-#if SCALAR_ACC
                 const float rqs = rq.x + rq.y, rqdxs = rqdx.x + rqdx.y;
                 const float rqdys = rqs * dy;
                 sa3 += rqs; sa4 += rqdxs; sa5 += rqdys;
                 sa7 = __fmaf_rn(rqdxs, dy, sa7);
                 sa8 = __fmaf_rn(rqdys, dy, sa8);
-#else
-                a3 = a3 + rq; a4 = a4 + rqdx;
-                const f2 rqdy = rq * dyy;
-                a5 = a5 + rqdy;
-                a7 = __builtin_elementwise_fma(rqdx, dyy, a7);
-                a8 = __builtin_elementwise_fma(rqdy, dyy, a8);
-#endif
                 if (ABS) {                                              // sum |q d power / d centre| per pixel
                     const f2 bp2 = {s.bp, s.bp};
                     const f2 hxa = ta + apdxa, hxb = tb + apdxb;                              // 2 ap dx + bp dy
                     const float cdy2 = 2.f * s.cp * dy;
                     const f2 hya = __builtin_elementwise_fma(bp2, dxa, (f2){cdy2, cdy2});       // 2 cp dy + bp dx
                     const f2 hyb = __builtin_elementwise_fma(bp2, dxb, (f2){cdy2, cdy2});
-#if ABS_FMA
                     // acc += |q| |h| as ONE v_fma_f32 with abs source modifiers (8 per row step; packed fp32 has no modifiers:
                     // four v_pk_mul + eight v_add with |.| before)
 #define ACC_ABS2(acc, q, h) asm("v_fma_f32 %0, |%1|, |%2|, %0" : "+v"(acc) : "v"(q), "v"(h))
                     ACC_ABS2(a9.x, qva.x, hxa.x); ACC_ABS2(a9.y, qva.y, hxa.y); ACC_ABS2(a9.x, qvb.x, hxb.x); ACC_ABS2(a9.y, qvb.y, hxb.y);
                     ACC_ABS2(a10.x, qva.x, hya.x); ACC_ABS2(a10.y, qva.y, hya.y); ACC_ABS2(a10.x, qvb.x, hyb.x); ACC_ABS2(a10.y, qvb.y, hyb.y);
 #undef ACC_ABS2
-#else
-                    const f2 mxa = qva * hxa, mxb = qvb * hxb, mya = qva * hya, myb = qvb * hyb;
-                    // acc += |v| as ONE v_add_f32 with the abs source modifier (packed fp32 has none: the compiler's
-                    // version is two v_and + one v_pk_add per pair)
-#define ACC_ABS(acc, v) asm("v_add_f32 %0, %0, |%1|" : "+v"(acc) : "v"(v))
-                    ACC_ABS(a9.x, mxa.x); ACC_ABS(a9.y, mxa.y); ACC_ABS(a9.x, mxb.x); ACC_ABS(a9.y, mxb.y);
-                    ACC_ABS(a10.x, mya.x); ACC_ABS(a10.y, mya.y); ACC_ABS(a10.x, myb.x); ACC_ABS(a10.y, myb.y);
-#undef ACC_ABS
-#endif
                 }
             }
         };
@@ -700,15 +565,9 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         // phase is issued for the whole wave although only one 16-lane row takes part in it
         float4 h0, h1, h2;
         auto fold_pairs = [&]() {
-#if SCALAR_ACC
             h0 = make_float4(a0.x + a0.y, a1.x + a1.y, a2.x + a2.y, sa3);
             h1 = make_float4(sa4, sa5, a6.x + a6.y, sa7);
             h2 = make_float4(sa8, a9.x + a9.y, a10.x + a10.y, 0.f);
-#else
-            h0 = make_float4(a0.x + a0.y, a1.x + a1.y, a2.x + a2.y, a3.x + a3.y);
-            h1 = make_float4(a4.x + a4.y, a5.x + a5.y, a6.x + a6.y, a7.x + a7.y);
-            h2 = make_float4(a8.x + a8.y, a9.x + a9.y, a10.x + a10.y, 0.f);
-#endif
         };
         auto add_to_copy = [&](const int slot) {      // plain read-modify-write of the wave's own copy
             float4* d4 = reinterpret_cast<float4*>(&acc[wave][slot][0]);
@@ -758,19 +617,15 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
             const ChunkRec s = recs[slot];
             // the next step's list entry is read now: list byte -> record is a chain of two LDS latencies otherwise
             slot_next = (li < gend - 16) ? (int)lists[myblk][gend - 17 - li] : 0;
-#ifdef DIAG_PAIRS
-            const u32 dg_before = dg_con;
-#endif
+            DG(const u32 dg_before = dg_con;)
             // three instances of the row loop (wave-uniform choice per tile): the fast one for tiles where no pixel stopped early
             // and every staged conic is well conditioned; without the position test only; with both tests
             const bool cry = (li == 15) && (gend > 0);
-            if (NC_SKIP && P_SKIP && !A.early && !A.needle) block_rows(std::true_type{}, std::true_type{}, s, live, bx0, by0, pixb, cry);
-            else if (P_SKIP && !A.needle) block_rows(std::false_type{}, std::true_type{}, s, live, bx0, by0, pixb, cry);
-            else if (NC_SKIP && !A.early) block_rows(std::true_type{}, std::false_type{}, s, live, bx0, by0, pixb, cry);
+            if (!A.early && !A.needle) block_rows(std::true_type{}, std::true_type{}, s, live, bx0, by0, pixb, cry);
+            else if (!A.needle) block_rows(std::false_type{}, std::true_type{}, s, live, bx0, by0, pixb, cry);
+            else if (!A.early) block_rows(std::true_type{}, std::false_type{}, s, live, bx0, by0, pixb, cry);
             else block_rows(std::false_type{}, std::false_type{}, s, live, bx0, by0, pixb, cry);
-#ifdef DIAG_PAIRS
-            dg_ent += live ? 1u : 0u; dg_ent0 += (live && dg_con == dg_before) ? 1u : 0u; dg_steps += (lane == 0) ? 1u : 0u;
-#endif
+            DG(dg_ent += live ? 1u : 0u; dg_ent0 += (live && dg_con == dg_before) ? 1u : 0u; dg_steps += (lane == 0) ? 1u : 0u;)
             // the same splat can sit in several rows (it reaches several blocks of the quadrant): one row at a time
             fold_pairs();
 #pragma unroll
@@ -779,9 +634,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
             PH_MARK(4);    // groups
         }
         PH_MARK(3);
-#ifdef DIAG_PAIRS
-        dg_chunks += (lane == 0) ? 1u : 0u;
-#endif
+        DG(dg_chunks += (lane == 0) ? 1u : 0u;)
         lds_barrier();
         PH_MARK(5);    // barrier 2
         // The short serial section between the two barriers shares its SIMDs with another workgroup that is usually in
@@ -789,9 +642,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         // the skew is paid at the next barrier.
         __builtin_amdgcn_s_setprio(PRIO_SERIAL);
         // ---- next chunk: its gathers were issued before the groups; turn them into the staged record
-#if !BAL_WRITE
         const ChunkRec cur = rec;
-#endif
         // Keep every loaded register -- also the components nobody reads (q1 z, q3 yzw are not loaded; q2.y, the view
         // depth, is) -- and the id word "in use" up to this point.  Otherwise the register allocator recycles a dead
         // component of an in-flight load as scratch, which needs s_waitcnt vmcnt(0) right after the loads were issued
@@ -804,35 +655,6 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         PH_MARK(1);
         // ---- one record per staged instance: the four wave copies added in fixed order.  The record holds the raw sums (sum q
         // rather than sum q / o, the abs sums on the scaled conic): preprocess_bwd applies the per-Gaussian factors once.
-#if BAL_WRITE
-        // float4 number f of the chunk's record array (record f / 3, part f % 3) is float4 number f of every wave copy: thread
-        // tid takes f = tid, tid + 256, tid + 512 -- consecutive lanes read consecutive 16 bytes of LDS (no bank conflicts; thread =
-        // record had a 48-byte lane stride) and three lanes write the 48 contiguous bytes of one record; all four waves take
-        // part (thread = record left 80 of the 256 threads idle in the serial section between the two barriers).
-        {
-            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            float4* const acc4 = reinterpret_cast<float4*>(&acc[0][0][0]);
-#pragma unroll
-            for (int j = 0; j < (3 * BCHUNK + 255) / 256; ++j) {
-                const u32 f = (u32)tid + 256u * (u32)j;
-                if (f < 3u * cnt) {
-                    float4 r = z4;
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        float4* p = acc4 + (u32)w * (3u * BCHUNK) + f;
-                        const float4 x = *p;
-                        *p = z4;                                        // re-zeroed for the next chunk
-                        r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w;
-                    }
-                    const u32 rcd = (f * 43691u) >> 17;                 // f / 3 (exact below 98304)
-                    const u32 part = f - 3u * rcd;
-                    const u32 e_ = rec_e[par][rcd];
-                    if (e_ != 0xFFFFFFFFu) reinterpret_cast<float4*>(partials + (size_t)e_ * PART_FLOATS)[part] = r;
-                }
-            }
-            par ^= 1u;
-        }
-#else
         if ((u32)tid < cnt) {
             float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
             if (cur.mask != 0) {
@@ -852,28 +674,21 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                 dst[0] = r0; dst[1] = r1; dst[2] = r2;
             }
         }
-#endif
         PH_MARK(6);    // record sums + stores
         // no barrier here: the next chunk's first barrier orders these LDS accesses before any reuse
         if (lo == 0) break;
         hi = lo;
     }
-#ifdef DIAG_PHASES
-    if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_cycles[i], ph[i]);
-#endif
-#ifdef DIAG_PAIRS
-    diag_pairs_flush(0, dg_eval, dg_con);
-    diag_pairs_flush(4, dg_ent, dg_ent0);
-    diag_pairs_flush(6, dg_steps, dg_chunks);
-#endif
+    PH(if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_cycles[i], ph[i]);)
+    DG(diag_pairs_flush(0, dg_eval, dg_con);)
+    DG(diag_pairs_flush(4, dg_ent, dg_ent0);)
+    DG(diag_pairs_flush(6, dg_steps, dg_chunks);)
 }
-#ifdef DIAG_PHASES
-extern "C" void bags_diag_phases(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 8); }
-#endif
+PH(extern "C" void bags_diag_phases(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 8); })
 
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
-                            const float* grad_color, float* partials, bool want_abs, bool binned, hipStream_t st, u32* zero_words, int n_zero,
-                            long long n_records)
+                            const float* grad_color, float* partials, bool want_abs, bool binned, hipStream_t st,
+                            long long n_records, int prezero_per_tile_arg)
 {
     const int gx = cdiv(s.image_width, BAGS_TILE), gy = cdiv(s.image_height, BAGS_TILE);
     const int T = gx * gy;
@@ -882,14 +697,15 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     const bool compact = binned && s.tile_bounds != BAGS_TILES_OPACITY;
     // Dense scenes (long tile lists, most of each list behind the deepest contributor): clearing the record array with one
     // streaming memset is cheaper than the per-tile zero loops, which gather an id and two geometry lines per dead instance.
-    static const long long prezero_per_tile = getenv("BAGS_PREZERO_PER_TILE") ? atoll(getenv("BAGS_PREZERO_PER_TILE")) : BWD_PREZERO_PER_TILE;
+    // (BagsBackwardArgs.prezero_per_tile: 0 = the default above, < 0 = never, > 0 = that threshold -- the robustness tests force both paths)
+    const long long prezero_per_tile = prezero_per_tile_arg == 0 ? BWD_PREZERO_PER_TILE : prezero_per_tile_arg;
     const int skip_zero = (prezero_per_tile > 0 && n_records > prezero_per_tile * (long long)T) ? 1 : 0;
     if (skip_zero) { hipError_t e = hipMemsetAsync(partials, 0, (size_t)n_records * PART_FLOATS * sizeof(float), st); if (e != hipSuccess) return e; }
 #define BWD_LAUNCH(ABS_, CMP_)                                                                                                       \
     hipLaunchKernelGGL((blend_bwd_scan_kernel<ABS_, CMP_>), dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,     \
                        im.tile_desc, b.point_list, reinterpret_cast<const unsigned char*>(b.reach_mask), binned ? 8u : 2u, g.g2d,    \
-                       binned ? nullptr : g.inst_off, g.block_base, s.bg, im.final_T, im.n_contrib, grad_color, partials, zero_words, \
-                       n_zero, compact ? 1 : 0, im.tile_aux, skip_zero)
+                       binned ? nullptr : g.inst_off, g.block_base, s.bg, im.final_T, im.n_contrib, grad_color, partials, \
+                       compact ? 1 : 0, im.tile_aux, skip_zero)
     if (want_abs) { if (compact) BWD_LAUNCH(true, true); else BWD_LAUNCH(true, false); }
     else          { if (compact) BWD_LAUNCH(false, true); else BWD_LAUNCH(false, false); }
 #undef BWD_LAUNCH
@@ -910,29 +726,7 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
 // hold it at 4-5 waves per SIMD against 8 here and a wave waits on the longest of 8 block lists instead of 4: 0.169-0.171 ms
 // against 0.167 ms.
 // ================================================================================================================
-#ifndef FWD_WG_PER_CU
-#define FWD_WG_PER_CU 6       // forward workgroups per CU (= waves per SIMD): 80 VGPRs (8 / 7 / 6: 148.3 / 146.9 / 144.3 us)
-#endif
-#ifdef DIAG_PAIRS             // the pair counters live in the plain C++ form of the step
-#define FWD_ASM 0
-#define FWD_SENTINEL 0
-#endif
-#ifndef FWD_ASM
-#define FWD_ASM 1             // the contribute / stop / composite decision of a walk step as ONE exec-masked block (v_cmpx chain)
-#endif
-#ifndef FWD_SENTINEL
-#define FWD_SENTINEL 1        // slot CHUNK-1 always holds an all-zero record and pads every list: no `i < Lrow` test per step
-#endif
-#if FWD_ASM && !FWD_SENTINEL
-#error "the asm step has no list-length test: it needs the sentinel"
-#endif
-#ifndef FWD_PIPE
-#define FWD_PIPE 1            // record reads issued one step ahead of their use (two register sets)
-#endif
-#define FWD_STAGE (FWD_SENTINEL ? CHUNK - 1 : CHUNK)          // splats staged per chunk
-#ifndef FWD_SORT
-#define FWD_SORT 1            // tile-binned path: the tile's workgroup sorts its own (depth key, id) words before it stages them (no
-#endif                        // tile_sort launch: its chains of LDS round trips hide behind the issue-bound walks of the CU's other tiles)
+#define FWD_STAGE (CHUNK - 1)  // splats staged per chunk: slot CHUNK-1 always holds an all-zero record and pads every list (no `i < Lrow` test per step)
 template <int DUMMY>
 __global__ void __launch_bounds__(256, FWD_WG_PER_CU)
 blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_desc, u32* __restrict__ point_list,
@@ -963,11 +757,8 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
     constexpr int LDS_RECS = 0, LDS_LISTS = CHUNK * (int)sizeof(SplatRec), LDS_MASKS = LDS_LISTS + 16 * CHUNK * (int)sizeof(list_t) + 16;
     constexpr int LDS_BLEND = LDS_MASKS + CHUNK * 4;
     constexpr int LDS_TS_CNT = TS_LDS_WORDS * 8, LDS_TS_L = LDS_TS_CNT + TS_LDS_WORDS * 2, LDS_SORT = LDS_TS_L + (int)sizeof(TileSortLds);
-#ifndef FWD_SORT_MIRROR
-#define FWD_SORT_MIRROR 0     // (1: measured 0.5 us, nothing; 2 KB of LDS) lists of up to TSORT_WAVE entries: the sorted ids also stay in LDS (2 KB behind everything else), so the
-#endif                        // staging below neither waits for the stores to point_list nor loads them back from the L2
     constexpr int LDS_IDS = (LDS_SORT > LDS_BLEND ? LDS_SORT : LDS_BLEND);                 // u32 ids[TSORT_WAVE]
-    constexpr int LDS_BYTES = FWD_SORT ? LDS_IDS + (FWD_SORT_MIRROR ? TSORT_WAVE * 4 : 0) : LDS_BLEND;
+    constexpr int LDS_BYTES = LDS_IDS;
     static_assert(LDS_MASKS % 16 == 0 && LDS_TS_L % 8 == 0 && LDS_IDS % 4 == 0, "alignment of the carved arrays");
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
     SplatRec* const recs = reinterpret_cast<SplatRec*>(lds_raw + LDS_RECS);
@@ -982,33 +773,20 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
     // the deepest contributor, compact entries, list positions staged, -}.
     u32 n_live_run = 0, n_staged = 0;
     u32* const cpos = reinterpret_cast<u32*>(reach_mask + (size_t)range.x * 8u) + n;
-    const u32* ids_lds = nullptr;                            // sorted ids of the whole list in LDS (short lists sorted here)
-#if FWD_SORT
     if (words_in != nullptr && n > 0) {
         // ---- the tile's list: (depth key, id) words grouped by the emission, unsorted -> ids in depth order in point_list
         u64* const t_all = reinterpret_cast<u64*>(lds_raw);
         u32* const cnt_all = reinterpret_cast<u32*>(lds_raw + LDS_TS_CNT);
-#ifndef FWD_SORT_BLOCK
-#define FWD_SORT_BLOCK 0      // short lists by the whole workgroup (block sort: four waves, barriers) instead of by wave 0 alone
-#endif
-        TileSortLds& TL = *reinterpret_cast<TileSortLds*>(lds_raw + LDS_TS_L);
         // the emission left the tile's unsorted ids in the first half of its slice; the words are formed on load (WordSrc)
         const WordSrc src = tile_words(words_in, desc.y, depth_key);
         if (n == 1) { if (tid == 0) point_list[desc.y] = src.ids[desc.y]; }
-        else if (FWD_SORT_BLOCK && n <= 256) sort_one_block<1>(n, desc.y, src, point_list, t_all, cnt_all, TL.s_red);
-        else if (FWD_SORT_BLOCK && n <= 512) sort_one_block<2>(n, desc.y, src, point_list, t_all, cnt_all, TL.s_red);
-        else if (n <= TSORT_WAVE) {
-            u32* const mirror = FWD_SORT_MIRROR ? reinterpret_cast<u32*>(lds_raw + LDS_IDS) : nullptr;
-            if (wave == 0) sort_wave_role(desc, src, point_list, t_all, cnt_all, mirror);
-            if (FWD_SORT_MIRROR && !(FWD_SORT_BLOCK)) ids_lds = mirror;
-        }
+        else if (n <= TSORT_WAVE) { if (wave == 0) sort_wave_role(desc, src, point_list, t_all, cnt_all); }
         else sort_list_block(desc, src, sort_scratch, point_list, t_all, cnt_all, *reinterpret_cast<TileSortLds*>(lds_raw + LDS_TS_L));
-        // without the LDS copy: the ids were stored by this workgroup and are loaded by it below (at agent scope: a line of the
-        // neighbouring tile's slice may sit in this CU's L1 with our first ids still unsorted in it)
-        if (ids_lds == nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the ids were stored by this workgroup and are loaded by it below (at agent scope: a line of the neighbouring tile's
+        // slice may sit in this CU's L1 with our first ids still unsorted in it)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-#endif
 
     const int bx = (wave & 1) * 2 + (row & 1), by = (wave >> 1) * 2 + (row >> 1), blk = by * 4 + bx;
     const int px = tile_x * BAGS_TILE + bx * 4 + (li & 3), py = tile_y * BAGS_TILE + by * 4 + (li >> 2);
@@ -1022,9 +800,7 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
     u32 last = 0;
     bool needle = false;                                     // wave-uniform: a thread of this wave staged a splat with an ill-conditioned conic
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-#ifdef DIAG_PAIRS
-    u32 dg_eval = 0, dg_con = 0;
-#endif
+    DG(u32 dg_eval = 0, dg_con = 0;)
     // blocks of this wave's rows 0..3
     const int qb = (wave >> 1) * 8 + (wave & 1) * 2;         // block index of row 0; rows: +0, +1, +4, +5
 
@@ -1037,8 +813,7 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
         SplatRec rec; rec.mask = 0; rec.x = rec.y = rec.ap = rec.bp = rec.cp = rec.o = rec.r = rec.g = rec.b = rec.z = 0.f; rec.pos = 0;
         bool ill = false, live_rec = false;
         if ((u32)tid < cnt) {
-            const u32 g = ids_lds ? ids_lds[base + tid]
-                        : (FWD_SORT && words_in) ? __hip_atomic_load(&point_list[range.x + base + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+            const u32 g = words_in ? __hip_atomic_load(&point_list[range.x + base + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                                  : point_list[range.x + base + tid];
             const float4* grec = g2d + 4 * (size_t)g;             // one 64-byte line per instance
             const float4 co = grec[0], g1 = grec[1], g2v = grec[2];
@@ -1070,7 +845,6 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
         if (test_keep && lane == 0) s_cnt[wave] = (u32)__popcll(rec_b);
         n_staged = base + cnt;
         if (tid < CHUNK) { recs[tid] = rec; masks[tid] = rec.mask; }
-#if FWD_SENTINEL
         // this wave's four lists (rows qb, qb+1 | qb+4, qb+5: two runs of 2 x CHUNK bytes) start out as all-sentinel: a row
         // past the end of its own list composites the zero record of slot CHUNK-1 (opacity 0: alpha = 0 fails the 1/255 test)
         {
@@ -1081,7 +855,6 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
             dst[0] = make_uint4(f, f, f, f);
             if (sizeof(list_t) == 2) dst[1] = make_uint4(f, f, f, f);
         }
-#endif
         __syncthreads();
         if (test_keep) {                                     // the chunk's record-holding positions, compacted in list order
             const u32 c0 = s_cnt[0], c1 = s_cnt[1], c2_ = s_cnt[2], c3 = s_cnt[3];
@@ -1106,7 +879,8 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
             if (h3) lists[(qb + 5) * CHUNK + L3 + __popcll(b3 & lt_mask)] = LIST_ENTRY(slot);
             L0 += __popcll(b0); L1 += __popcll(b1); L2 += __popcll(b2); L3 += __popcll(b3);
         }
-        const int Lrow = (row == 0) ? L0 : (row == 1) ? L1 : (row == 2) ? L2 : L3;
+        const int Lrow = (row == 0) ? L0 : (row == 1) ? L1 : (row == 2) ? L2 : L3;         // (only the DIAG_PAIRS step reads it)
+        (void)Lrow;
         const int Lmax = __builtin_amdgcn_readfirstlane(max(max(L0, L1), max(L2, L3)));
         __builtin_amdgcn_wave_barrier();
         // ---- every row walks its own list; the next list entry is fetched while the current splat is composited
@@ -1115,10 +889,6 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
         // and with the sentinel a row past the end of its list needs no test (it composites the zero record).
         const list_t* mylist = &lists[blk * CHUNK];
         static_assert(sizeof(SplatRec) == 48, "record stride is spelled out in the instruction below");
-#ifndef FWD_NARROW
-#define FWD_NARROW 1          // the walk reads 40 of a record's 48 bytes (b128 + b128 + b64): the list position of the last contributor
-#endif                        // is derived from the record's byte offset once per chunk instead of being read with every record
-#if FWD_NARROW
         struct SplatW { float x, y, ap, cp, bp, o, r, g, b, z; u32 pos; };      // pos: the record's byte offset in `recs`
         auto load = [&](u32 roff) {
             const char* p = reinterpret_cast<const char*>(recs) + roff;
@@ -1128,26 +898,12 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
             return w;
         };
         u32 last_off = 0xFFFFFFFFu;                          // byte offset of the record of this chunk's last contributor (per pixel)
-#define LAST_VAR last_off
-#else
-        typedef SplatRec SplatW;
-        auto load = [&](u32 roff) { return *reinterpret_cast<const SplatRec*>(reinterpret_cast<const char*>(recs) + roff); };
-#define LAST_VAR last
-#endif
         auto step = [&](int i, const SplatW& s) {
-            const bool act = FWD_SENTINEL ? true : (i < Lrow);
-#if FWD_PK
-            // pair_power2 with its two independent first products packed: the same roundings in the same order
-            const f2 d = f2{s.x, s.y} - f2{pxf, pyf};
-            const f2 m = d * f2{s.ap, s.cp};
-            const float p2 = __fmaf_rn(d.x, __fmaf_rn(s.bp, d.y, m.x), __fmul_rn(m.y, d.y));
-#else
             const float dx = s.x - pxf, dy = s.y - pyf;
             const float p2 = pair_power2(dx, dy, s.ap, s.bp, s.cp);
-#endif
             const float G = __builtin_amdgcn_exp2f(p2);
             const float alpha = fminf(0.99f, s.o * G);
-#if FWD_ASM && !defined(DIAG_PAIRS)
+#ifndef DIAG_PAIRS
             // contribute (power <= 0, alpha >= 1/255), then stop (T would fall below 1e-4, or the pixel has finished: sign set) or
             // composite: each v_cmpx narrows EXEC, so there is no mask arithmetic on the scalar unit (the compiler's form of the
             // same logic is 3 s_and + 3 saveexec + 2 s_or + 2 branches per step, and this kernel is as busy on its scalar unit
@@ -1170,17 +926,15 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
                     "v_fmac_f32 %[dq], %[t1], %[z]\n\t"
                     "v_mov_b32 %[last], %[pos]\n\t"
                     "s_mov_b64 exec, -1"
-                    : [T] "+v"(Tq), [cr] "+v"(Cr), [cg] "+v"(Cg), [cb] "+v"(Cb), [dq] "+v"(Dq), [last] "+v"(LAST_VAR),
+                    : [T] "+v"(Tq), [cr] "+v"(Cr), [cg] "+v"(Cg), [cb] "+v"(Cb), [dq] "+v"(Dq), [last] "+v"(last_off),
                       [t0] "=&v"(t0), [t1] "=&v"(t1)
                     : [p2] "v"(p2), [al] "v"(alpha), [r] "v"(s.r), [g] "v"(s.g), [b] "v"(s.b), [z] "v"(s.z), [pos] "v"(s.pos)
                     : "vcc");
-                (void)act;
+                (void)i;
             }
-#else
-            const bool contrib = act && (p2 <= 0.f) && (alpha >= ALPHA_MIN) && (Tq > 0.f);
-#ifdef DIAG_PAIRS
-            dg_eval += act ? 1u : 0u; dg_con += contrib ? 1u : 0u;
-#endif
+#else           // the pair counters live in the plain C++ form of the step (a row past the end of its list composites the sentinel: not counted)
+            const bool contrib = (i < Lrow) && (p2 <= 0.f) && (alpha >= ALPHA_MIN) && (Tq > 0.f);
+            dg_eval += (i < Lrow) ? 1u : 0u; dg_con += contrib ? 1u : 0u;
             if (contrib) {
                 const float test_T = Tq * (1.f - alpha);
                 if (test_T < T_EPS) {
@@ -1190,12 +944,11 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
                     Cr = __fmaf_rn(w, s.r, Cr); Cg = __fmaf_rn(w, s.g, Cg); Cb = __fmaf_rn(w, s.b, Cb);
                     Dq = __fmaf_rn(w, s.z, Dq);
                     Tq = test_T;
-                    LAST_VAR = s.pos;
+                    last_off = s.pos;
                 }
             }
 #endif
         };
-#if FWD_SENTINEL
         // two steps per trip, no remainder: entry Lmax of every list is the sentinel (at most CHUNK - 1 real entries), and
         // inline asm is `convergent`, which keeps the compiler from unrolling a loop with a run-time trip count by itself.
         // The two list bytes of the NEXT trip are one 16-bit read at the top of this one; record address = byte * 48 (SDWA
@@ -1206,7 +959,6 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
                 "v_mul_u32_u24_sdwa %1, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD"
                 : "=&v"(ra), "=v"(rb) : "v"(two), "s"(48u));
         };
-#if FWD_PIPE
         // Software pipeline over two register sets, no copies: a record is requested one step before it is composited (its
         // three LDS reads land behind the other record's arithmetic), its address one trip before that.  Left to itself the
         // compiler issued a step's third read after its exp and waited for it: two exposed LDS latencies per step, and
@@ -1229,30 +981,8 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
             asm("" : "+v"(nxt));                             // (keeps the zero extension with the load, not behind the loop's phi)
             two = nxt; rb = rb2;
         }
-#else
-        u32 two = (u32)mypairs[0];
-        for (int i = 0; i < Lmax; i += 2) {
-            u32 ra, rb;
-            addr2(two, ra, rb);
-            u32 nxt = (u32)mypairs[(i >> 1) + 1];
-            step(i, load(ra)); step(i + 1, load(rb));
-            asm("" : "+v"(nxt));                             // (keeps the zero extension with the load, not behind the loop's phi)
-            two = nxt;
-        }
-#endif
-#else
-        u32 slot = (u32)mylist[0];
-        for (int i = 0; i < Lmax; ++i) {
-            const u32 roff = __umul24(slot, 48u);
-            slot = (u32)mylist[i + 1];
-            step(i, load(roff));
-        }
-#endif
-#if FWD_NARROW
         // record offset -> slot (/ 48: x 43691 >> 21, exact below 2^17 slots) -> 1-based list position
         if (last_off != 0xFFFFFFFFu) last = base + ((last_off * 43691u) >> 21) + 1u;
-#endif
-#undef LAST_VAR
     }
     const bool stopped = Tq < 0.f;                           // stopped early (T would fall below 1e-4) or outside the image
     Tq = fabsf(Tq);
@@ -1294,9 +1024,7 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
         __syncthreads();
         if (tid == 0) tile_aux[dslot] = make_uint4(s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3], n_live_run, n_staged, 0u);
     }
-#ifdef DIAG_PAIRS
-    diag_pairs_flush(2, dg_eval, dg_con);
-#endif
+    DG(diag_pairs_flush(2, dg_eval, dg_con);)
 }
 
 hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
@@ -1307,10 +1035,8 @@ hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinV
     if (T == 0) return hipSuccess;
     const int grid = cdiv(T, TILE_RUN) * TILE_RUN;
     hipLaunchKernelGGL(blend_fwd_rows_kernel<0>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
-                       im.tile_desc, b.point_list, (FWD_SORT && sort_here) ? b.words : nullptr, g.depth_key, b.scratch,
+                       im.tile_desc, b.point_list, sort_here ? b.words : nullptr, g.depth_key, b.scratch,
                        reinterpret_cast<unsigned char*>(b.reach_mask), b.words ? 8u : 2u, g.g2d, s.bg, out.color, out.depth, out.weights,
                        im.final_T, im.n_contrib, n_dev, capacity, (b.words && s.tile_bounds != BAGS_TILES_OPACITY) ? 1 : 0, im.tile_aux);
     return hipGetLastError();
 }
-
-bool blend_fwd_sorts() { return FWD_SORT != 0; }

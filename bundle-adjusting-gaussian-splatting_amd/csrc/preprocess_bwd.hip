@@ -91,36 +91,9 @@ __device__ __forceinline__ void sum_records(u32 nrec, u32 first, const float* __
         }
     }
 }
-__global__ void __launch_bounds__(256)
-sum_partials_kernel(int P, const u32* __restrict__ tiles_touched, const u32* __restrict__ inst_off, const u32* __restrict__ local_off,
-                    const u32* __restrict__ block_base, int per_block, const float* __restrict__ partials, float4* __restrict__ sums)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 nrec = 0, first = 0;
-    if (i < P) {            // the record count from the compact array (4 coalesced bytes), not from the Gaussian's 64-byte geometry line
-        nrec = tiles_touched[i];
-        first = inst_off ? inst_off[i] : local_off[i] + block_base[(blockIdx.x * 256u) / (u32)per_block];
-    }
-    float4 s0, s1, s2;
-    sum_records(nrec, first, partials, s0, s1, s2);
-    if (i < P) { sums[3 * (size_t)i] = s0; sums[3 * (size_t)i + 1] = s1; sums[3 * (size_t)i + 2] = s2; }
-}
-
-#ifndef PB_FUSED
-#define PB_FUSED 1           // preprocess_bwd sums the records itself (no sum_partials launch, no sums array written and read back);
-                             // summing before or after the input rows are requested makes no difference (68.4 / 68.8 us)
-#endif
-#ifndef SH_STAGE
-#define SH_STAGE 1
-#endif
-#ifndef POSE_FOLD
-#define POSE_FOLD 0          // 1: the last workgroups to finish sum the pose slab themselves (no pose_reduce launch).  Correct, deterministic,
-                             // and no faster: every workgroup pays a write-through store + a memory-side ticket at its end (preprocess_bwd
-                             // 60.4 -> 69.4 us for the 8.8 us launch it removes; profiles/r04/ab_pose_fold.txt)
-#endif
-#ifndef PRE_BWD_WAVES
-#define PRE_BWD_WAVES (PB_FUSED ? 4 : 1)   // fused: 128 VGPRs (12 spilled) and 4 workgroups per CU: 68.4 us; left free (146, 3 per CU) 76.1;
-#endif                                     // 5 per CU 105.  Separate sum_partials (23.1) + preprocess_bwd (53.1): 76.2
+#define PRE_BWD_WAVES 4        // 128 VGPRs without spills and 4 workgroups per CU (58 us; left free -- 146 VGPRs, 3 per CU -- 76 us, 5 per CU 105 us).
+                               // The kernel sums the records itself: as two kernels (sum_partials + this one, the sums through memory) 76 us;
+                               // folding the pose reduction in as well was correct and no faster (profiles/r04/ab_pose_fold.txt)
 
 // Slab column t (summed over all Gaussians) -> its place in the five pose tensors.
 // slab layout: [0..11] viewmatrix rows 0..3 x cols 0..2, [12..23] projmatrix rows 0..3 x cols 0,1,3,
@@ -154,7 +127,7 @@ __device__ __forceinline__ void pose_write_out(const int t, const float val, flo
 // views of one step accumulate in place: no separate add pass per view); means2D / densify / pose outputs are overwritten.
 template <bool COV3D, bool ACCUM>   // COV3D: precomputed 3D covariances instead of scales + rotations (uniform: no branch at the top)
 __global__ void __launch_bounds__(256, PRE_BWD_WAVES)
-preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod, int clamp_stock,
+preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod, int clamp_stock, int conic_stock,
                       const float* __restrict__ means3D, const float* __restrict__ shift_factors,
                       const float* __restrict__ shs, const float* __restrict__ colors_precomp,
                       const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -167,10 +140,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                       const float* __restrict__ partials, float* __restrict__ pose_slab,
                       float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_densify,
                       float* __restrict__ g_shs, float* __restrict__ g_shs_rest, float* __restrict__ g_colors, float* __restrict__ g_opac,
-                      float* __restrict__ g_scales, float* __restrict__ g_rot, float* __restrict__ g_cov3D,
-                      u32* __restrict__ tickets, unsigned long long* __restrict__ group_rows, int group_size, int nblocks,
-                      float* __restrict__ g_view, float* __restrict__ g_proj, float* __restrict__ g_intr,
-                      float* __restrict__ g_campos, float* __restrict__ g_shift)
+                      float* __restrict__ g_scales, float* __restrict__ g_rot, float* __restrict__ g_cov3D)
 {
     // A wave's life in this kernel is a handful of memory round trips, not arithmetic (55 % of the wave cycles were spent
     // waiting): round 2 had SEVEN of them in series at the top -- three for the camera constants (vector loads -> LDS ->
@@ -185,7 +155,6 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     const float sf0 = shift_factors ? shift_factors[0] : 0.0f, sf1 = shift_factors ? shift_factors[1] : 0.0f,
                 sf2 = shift_factors ? shift_factors[2] : 0.0f;
     const float cpx = campos_p[0], cpy = campos_p[1], cpz = campos_p[2];
-#if SH_STAGE
     // The SH-GRADIENT rows of the workgroup's 256 Gaussians are ONE contiguous 48 KB span of dL/dshs.  A thread writing its
     // own 192-byte row 16 bytes at a time puts 64 separate requests per instruction on the L2 channels (12 such instructions
     // per Gaussian), so the span leaves as whole lines: thread t stores float4 number k * 256 + t of it.  A gradient row is an
@@ -197,7 +166,6 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     __shared__ float srow[256][20];                     // basis[16] (zero beyond the active degree), dL/dcolour[3], pad
     const bool stage = (M == 16) && (colors_precomp == nullptr) && (shs != nullptr) && (g_shs != nullptr);      // uniform
     const size_t base4 = (size_t)blockIdx.x * (256 * 12), lim4 = (size_t)P * 12;
-#endif
 
     float dmx = 0.f, dmy = 0.f, dmz = 0.f;           // dL/dmeans3D
     float gm2x = 0.f, gm2y = 0.f, gdx = 0.f, gdy = 0.f, gop = 0.f;
@@ -209,12 +177,10 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     // (nothing is read from the Gaussian's 64-byte geometry line any more: the conic is re-derived below bit for bit, the
     // visibility comes from the compact tiles_touched array, the SH clamp bits ride in the tenth word of shjac)
     const u32 n_inst = tiles_touched[ic];
-#if PB_FUSED
     // first record of the Gaussian: radix path inst_off[i]; tile-binned path block_base[block] + local_off[i], the block being
     // uniform over the workgroup (per_block is a multiple of 1024)
     u32 first_rec = inst_off ? inst_off[ic] : local_off[ic];
     if (!inst_off) first_rec += block_base[(blockIdx.x * 256u) / (u32)per_block];
-#endif
     const float opac = opacities[ic];
     float x = means3D[3 * ic + 0], y = means3D[3 * ic + 1], z = means3D[3 * ic + 2];
     float in_s0 = 0.f, in_s1 = 0.f, in_s2 = 0.f;
@@ -231,15 +197,10 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     float mj[10];                                                                           // K1's d(colour)/d(direction) + clamp bits (SH path)
 #pragma unroll
     for (int t = 0; t < 10; ++t) mj[t] = shjac[10 * ic + t];
-#if PB_FUSED
     // the Gaussian's records (blend_bwd's, `partials` is the record array) summed here, with every other input in flight
     float4 sm_a, sm_b, sm_c;
     __builtin_amdgcn_sched_barrier(0);
     sum_records(i < P ? n_inst : 0u, first_rec, partials, sm_a, sm_b, sm_c);
-#else
-    const float4* sm = reinterpret_cast<const float4*>(partials) + 3 * ic;                  // K8a's per-Gaussian sums
-    const float4 sm_a = sm[0], sm_b = sm[1], sm_c = sm[2];
-#endif
     // every one of those loads is IN FLIGHT before the first of them is waited for (the compiler otherwise sinks the ones only
     // the visible branch needs behind the visibility test: one more round trip per group)
     asm volatile("" :: "v"(opac), "v"(n_inst), "v"(mj[9]), "v"(x), "v"(y), "v"(z), "v"(in_s0), "v"(in_s1), "v"(in_s2), "v"(in_q.x), "v"(in_c[0]),
@@ -330,7 +291,13 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         // that component at rounding level.  It is the order reverse-mode differentiation of the forward lines produces.
         // The file is compiled with -ffp-contract=off so cov2D and det are bit-identical to what preprocess_fwd used.
         const float det = cxx * cyy - cxy * cxy;
-        const float di = 1.0f / det, di2 = di * di;
+        const float di = 1.0f / det;
+        // BagsSettings.conic_grad (decision D9).  Upstream's computeCov2DCUDA backward multiplies every term by denom2inv =
+        // 1 / (det^2 + 1e-7) where the derivative of the inverse has 1 / det^2 -- in the two-step form below that is 1 / det ->
+        // det * denom2inv and 1 / det^2 -> denom2inv (the same three sums as upstream's expanded polynomial, term for term).
+        // BAGS_CONIC_GRAD_EXACT: the exact derivative.  The forward's conic keeps the exact 1 / det either way.
+        const float di2 = conic_stock ? 1.0f / (det * det + 1.0e-7f) : di * di;
+        const float dig = conic_stock ? det * di2 : di;
         {   // K1's conic = (cyy, -cxy, cxx) / det from the same operations (contraction off in both files): bit-identical
             const float con_a = cyy * di, con_b = -cxy * di, con_c = cxx * di;
             const float dpx = -(con_a * Mx + con_b * My);     // dL/d centre (pixel units)
@@ -338,9 +305,9 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
             gm2x = dpx * (0.5f * (float)W); gm2y = dpy * (0.5f * (float)H);
         }
         const float ddet = -((gA * cyy - gB * cxy + gC * cxx) * di2);
-        const float dcxx = gC * di + ddet * cyy;
-        const float dcyy = gA * di + ddet * cxx;
-        const float dcxy = -(gB * di) - 2.f * (ddet * cxy);
+        const float dcxx = gC * dig + ddet * cyy;
+        const float dcyy = gA * dig + ddet * cxx;
+        const float dcxy = -(gB * dig) - 2.f * (ddet * cxy);
         // cov2D -> Sigma (unique entries)
         gc[0] = dcxx * a00 * a00 + dcxy * a00 * a10 + dcyy * a10 * a10;
         gc[3] = dcxx * a01 * a01 + dcxy * a01 * a11 + dcyy * a11 * a11;
@@ -460,8 +427,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
             const float ddy = mj[3] * drgb[0] + mj[4] * drgb[1] + mj[5] * drgb[2];
             const float ddz = mj[6] * drgb[0] + mj[7] * drgb[1] + mj[8] * drgb[2];
             // dL/dsh[t][c] = basis_t dL/dcolour_c: no input row needed
-            if (M == 16 && (SH_STAGE || !g_shs_rest)) {
-#if SH_STAGE
+            if (M == 16) {
                 if (stage) {
                     float4* d4 = reinterpret_cast<float4*>(&srow[threadIdx.x][0]);
                     d4[0] = make_float4(bs[0], nb > 1 ? bs[1] : 0.f, nb > 1 ? bs[2] : 0.f, nb > 1 ? bs[3] : 0.f);
@@ -470,28 +436,6 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                     d4[3] = make_float4(nb > 9 ? bs[12] : 0.f, nb > 9 ? bs[13] : 0.f, nb > 9 ? bs[14] : 0.f, nb > 9 ? bs[15] : 0.f);
                     d4[4] = make_float4(drgb[0], drgb[1], drgb[2], 0.f);
                 }
-#else
-                float4* g4 = reinterpret_cast<float4*>(gsh);
-                if (g_shs) {
-#pragma unroll
-                    for (int tb = 0; tb < 4; ++tb) {
-                        float o[12];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int t = tb * 4 + u;
-                            const bool on = t < nb;
-                            o[3 * u] = on ? bs[t] * drgb[0] : 0.f; o[3 * u + 1] = on ? bs[t] * drgb[1] : 0.f; o[3 * u + 2] = on ? bs[t] * drgb[2] : 0.f;
-                        }
-                        if (ACCUM) {
-#pragma unroll
-                            for (int q = 0; q < 3; ++q) { const float4 old = g4[3 * tb + q]; o[4 * q] += old.x; o[4 * q + 1] += old.y; o[4 * q + 2] += old.z; o[4 * q + 3] += old.w; }
-                        }
-                        g4[3 * tb] = make_float4(o[0], o[1], o[2], o[3]);
-                        g4[3 * tb + 1] = make_float4(o[4], o[5], o[6], o[7]);
-                        g4[3 * tb + 2] = make_float4(o[8], o[9], o[10], o[11]);
-                    }
-                }
-#endif
             } else if (gsh)
             for (int t = 0; t < M; ++t) {
                 const bool on = t < nb;
@@ -508,26 +452,17 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     } else if (i < P && g_shs && !colors_precomp) {       // a culled Gaussian: its gradient row is zero
         float* gsh = g_shs_rest ? g_shs + 3 * (size_t)i : g_shs + (size_t)i * M * 3;
         float* gsr = g_shs_rest ? g_shs_rest + (size_t)i * (M - 1) * 3 : gsh + 3;
-        if (M == 16 && (SH_STAGE || !g_shs_rest)) {
-#if SH_STAGE
+        if (M == 16) {
             if (stage) {
                 float4* d4 = reinterpret_cast<float4*>(&srow[threadIdx.x][0]);
 #pragma unroll
                 for (int t = 0; t < 5; ++t) d4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-#else
-            float4* g4 = reinterpret_cast<float4*>(gsh);
-            if (!ACCUM) {
-#pragma unroll
-                for (int t = 0; t < 12; ++t) g4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#endif
         } else if (!ACCUM) {
             gsh[0] = gsh[1] = gsh[2] = 0.f;
             for (int t = 0; t < 3 * (M - 1); ++t) gsr[t] = 0.f;
         }
     }
-#if SH_STAGE
     if (stage && g_shs_rest) {                       // ... as two spans: 256 DC triples (3 KB) and 256 rows of 45 floats (45 KB)
         __syncthreads();
         auto span = [&](float* __restrict__ out, const u32 R, const u32 t0, const u32 rounds) {      // R floats per row, first coefficient t0
@@ -580,7 +515,6 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
             }
         }
     }
-#endif
 
     if (i < P) {
         if (ACCUM) {                                     // += into the caller's running sums
@@ -617,66 +551,8 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         const int t = threadIdx.x;
         float r = (t < 35) ? (wpose[0][t] + wpose[1][t]) + (wpose[2][t] + wpose[3][t]) : 0.f;
         if (t < 9) r += (wpose[0][35 + t] + wpose[1][35 + t]) + (wpose[2][35 + t] + wpose[3][35 + t]);
-#if POSE_FOLD
-        // agent-scope store: written through to where every XCD sees it (the row is read by a workgroup of another CU)
-        __hip_atomic_store(&pose_slab[(size_t)blockIdx.x * POSE_VALS + t], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
         pose_slab[(size_t)blockIdx.x * POSE_VALS + t] = r;
-#endif
     }
-#if POSE_FOLD
-    // ---- 6. slab rows -> the five pose tensors without another launch (pose_reduce_kernel was 6-8 us of launch floor behind this
-    // kernel).  Two levels of "the last one to arrive does the sum": workgroup b belongs to group b / group_size; whoever draws
-    // the group's last ticket adds the group's rows IN ROW ORDER (fp64) into one group row and draws a ticket of the top
-    // counter; the last of those adds the group rows in group order and writes the outputs.  Who does a sum varies from run to
-    // run, what is summed in which order does not: deterministic.  Rows and tickets cross CUs and XCDs: rows are stored and
-    // loaded with agent-scope atomics (write-through / cache-bypassing), a row's stores are complete (s_waitcnt vmcnt(0), same
-    // wave) before its ticket is drawn, and a reader only looks after it has seen the last ticket -- no L2 write-back fence
-    // (buffer_wbl2) in a kernel that streams 130 MB of gradients through the L2.  The tickets were zeroed by blend_bwd.
-    __shared__ u32 s_role;
-    __shared__ double s_part[6][POSE_VALS];
-    const u32 grp = blockIdx.x / (u32)group_size;
-    const u32 gsz = min((u32)group_size, (u32)nblocks - grp * (u32)group_size);
-    const u32 ngroups = ((u32)nblocks + (u32)group_size - 1) / (u32)group_size;
-    if (threadIdx.x < 64) {                                  // wave 0 stored the row
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (threadIdx.x == 0)
-            s_role = (__hip_atomic_fetch_add(&tickets[1 + grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gsz) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (s_role == 0u) return;
-    const int pc = threadIdx.x % POSE_VALS, ps = threadIdx.x / POSE_VALS;     // column, row slice (6 slices; threads 240.. idle)
-    if (ps < 6) {
-        double acc = 0.0;
-        const float* rows = pose_slab + (size_t)grp * group_size * POSE_VALS + pc;
-        for (u32 r = (u32)ps; r < gsz; r += 6u) acc += (double)__hip_atomic_load(rows + (size_t)r * POSE_VALS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_part[ps][pc] = acc;
-    }
-    __syncthreads();
-    if (threadIdx.x < POSE_VALS) {
-        const double tot = ((((s_part[0][pc] + s_part[1][pc]) + s_part[2][pc]) + s_part[3][pc]) + s_part[4][pc]) + s_part[5][pc];
-        __hip_atomic_store(&group_rows[(size_t)grp * POSE_VALS + pc], (unsigned long long)__double_as_longlong(tot), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (threadIdx.x < 64) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (threadIdx.x == 0)
-            s_role = (__hip_atomic_fetch_add(&tickets[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == ngroups) ? 2u : 0u;
-    }
-    __syncthreads();                                         // (also: s_part is free again)
-    if (s_role != 2u) return;
-    if (ps < 6) {
-        double acc = 0.0;
-        for (u32 r = (u32)ps; r < ngroups; r += 6u)
-            acc += __longlong_as_double((long long)__hip_atomic_load(&group_rows[(size_t)r * POSE_VALS + pc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        s_part[ps][pc] = acc;
-    }
-    __syncthreads();
-    if (threadIdx.x < 35) {
-        const double tot = ((((s_part[0][pc] + s_part[1][pc]) + s_part[2][pc]) + s_part[3][pc]) + s_part[4][pc]) + s_part[5][pc];
-        pose_write_out(pc, (float)tot, g_view, g_proj, g_intr, g_campos, g_shift);
-    }
-#endif
 }
 
 // rows -> the five pose tensors, summed in fp64.  One workgroup per slab column (35 used): thread t adds rows t, t + 256, ...
@@ -710,30 +586,21 @@ pose_reduce_kernel(const float* __restrict__ slab, int nblocks, float* __restric
 
 hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, const int32_t*,
                                  const float* partials_records, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a,
-                                 hipStream_t st, float* sums, bool binned, u32* fold_tickets, unsigned long long* fold_rows)
+                                 hipStream_t st, bool binned)
 {
     const int P = in.P;
     const int nb = cdiv(P, 256);
     *nblocks_out = nb;
     if (P == 0) return hipSuccess;
-#if PB_FUSED
-    (void)sums;
     const float* partials = partials_records;
-#else
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(nb), dim3(256), 0, st, P, g.rec_count, binned ? nullptr : g.inst_off, g.local_off,
-                       g.block_base, binned_per_block(P), partials_records,
-                       reinterpret_cast<float4*>(sums));
-    const float* partials = sums;
-#endif
 #define PRE_BWD_LAUNCH(COV)     hipLaunchKernelGGL((preprocess_bwd_kernel<COV, ACC_>), dim3(nb), dim3(256), 0, st, P, s.sh_coeffs, s.sh_degree, s.image_width, \
-                       s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, (s.clamp_grad == BAGS_CLAMP_GRAD_EXACT) ? 0 : 1, in.means3D, in.shift_factors, in.shs, \
+                       s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, (s.clamp_grad == BAGS_CLAMP_GRAD_EXACT) ? 0 : 1, \
+                       (s.conic_grad == BAGS_CONIC_GRAD_EXACT) ? 0 : 1, in.means3D, in.shift_factors, in.shs, \
                        in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, s.viewmatrix, s.projmatrix, \
                        s.intrinsic, s.campos, in.opacities, g.rec_count, binned ? nullptr : g.inst_off, g.local_off, g.block_base, \
                        binned_per_block(P), g.shjac, partials, \
                        pose_slab, a.grad_means3D, a.grad_means2D, a.grad_means2D_densify, a.grad_shs, in.shs_rest ? a.grad_shs_rest : nullptr, \
-                       a.grad_colors_precomp, a.grad_opacities, a.grad_scales, a.grad_rotations, a.grad_cov3D_precomp, \
-                       fold_tickets, fold_rows, pose_group_size(nb), nb, a.grad_viewmatrix, a.grad_projmatrix, a.grad_intrinsic, \
-                       a.grad_campos, a.grad_shift_factors);
+                       a.grad_colors_precomp, a.grad_opacities, a.grad_scales, a.grad_rotations, a.grad_cov3D_precomp);
     if (a.accumulate) {
 #define ACC_ true
         if (in.cov3D_precomp) { PRE_BWD_LAUNCH(true) } else { PRE_BWD_LAUNCH(false) }
@@ -753,7 +620,3 @@ hipError_t launch_pose_reduce(const float* pose_slab, int nblocks, const BagsBac
                        a.grad_projmatrix, a.grad_intrinsic, a.grad_campos, a.grad_shift_factors);
     return hipGetLastError();
 }
-
-// pose slab rows summed per group by the last workgroup of the group (POSE_FOLD)
-int pose_group_size(int nblocks) { return nblocks <= 4096 ? 32 : 128; }
-bool pose_fold_enabled() { return POSE_FOLD != 0; }

@@ -1,7 +1,7 @@
 // tile_sort.h -- step 5 of the tile-binned lists: one tile's (depth key, id) words sorted into its slice of point_list.
-// Shared by binning.hip (tile_sort_kernel, a launch of its own: -DFWD_SORT=0 builds) and blend.hip (round 4: the tile's own
-// blend_fwd workgroup sorts the list before it stages it -- the sort is a chain of LDS round trips, the blend is issue bound, so
-// the two overlap across the workgroups of a CU, and the step has one launch fewer).
+// Used by blend.hip: since round 4 the tile's own blend_fwd workgroup sorts the list before it stages it -- the sort is a chain of
+// LDS round trips, the blend is issue bound, so the two overlap across the workgroups of a CU, and the step has one launch fewer
+// (until then binning.hip launched these functions as a kernel of their own).
 #pragma once
 #include "binning_common.h"
 

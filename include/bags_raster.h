@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BAGS_ABI_VERSION 7
+#define BAGS_ABI_VERSION 8
 #define BAGS_TILE 16
 
 enum { BAGS_OK = 0, BAGS_ERR_ARG = -1, BAGS_ERR_HIP = -2, BAGS_ERR_SIZE = -3, BAGS_ERR_DEVICE = -4 };
@@ -56,6 +56,11 @@ enum { BAGS_BINNING_AUTO = 0, BAGS_BINNING_RADIX = 1 };
  * (README.md:126) inherits: dL/dt.x is zeroed (x_grad_mul) and dL/dt.z takes 2 h_x t.x / t.z^3 dL/dJ02 with the clamped t.x
  * held CONSTANT.  EXACT: differentiates the clamped expression itself (t.x moves with t.z), i.e. half of that one term. */
 enum { BAGS_CLAMP_GRAD_STOCK = 0, BAGS_CLAMP_GRAD_EXACT = 1 };
+/* Backward of conic = cov2D^-1.  STOCK (default, ABI 8): upstream computeCov2DCUDA divides by det^2 + 1e-7 where the derivative of the
+ * 2x2 inverse has det^2 ("denom2inv"); the reference's fork (README.md:126) inherits it.  EXACT: det^2 (what rounds 1-4 shipped).
+ * det >= 0.09 (the 0.3 px dilation), so the two differ by at most 1.2e-5 relative on one Gaussian's dL/dcov2D (measured 2e-7 on the
+ * gradient tensors of a scene of small splats, tests/test_oracle_cpu.py).  Forward values do not depend on this switch. */
+enum { BAGS_CONIC_GRAD_STOCK = 0, BAGS_CONIC_GRAD_EXACT = 1 };
 
 /* GaussianRasterizationSettings (gaussian_renderer/__init__.py:50-65) */
 typedef struct BagsSettings {
@@ -70,7 +75,7 @@ typedef struct BagsSettings {
     int32_t tile_bounds;             /* BAGS_TILES_AABB | BAGS_TILES_OPACITY */
     int32_t binning;                 /* BAGS_BINNING_AUTO | BAGS_BINNING_RADIX */
     int32_t clamp_grad;              /* BAGS_CLAMP_GRAD_STOCK | BAGS_CLAMP_GRAD_EXACT (backward only) */
-    int32_t reserved0;               /* 0 (keeps the pointers 8-byte aligned) */
+    int32_t conic_grad;              /* BAGS_CONIC_GRAD_STOCK | BAGS_CONIC_GRAD_EXACT (backward only; was reserved0 = 0 before ABI 8) */
     const float* bg;                 /* (3)   */
     const float* viewmatrix;         /* (4,4) world->view, transposed (W2C^T) */
     const float* projmatrix;         /* (4,4) viewmatrix * intrinsic */
@@ -138,7 +143,11 @@ typedef struct BagsBackwardArgs {
      * ADDED to what their buffers hold instead of overwriting them -- the views of one optimisation step accumulate in place, as
      * autograd would do with one add pass per view and tensor; every other output is overwritten as before (ABI 6) */
     int32_t accumulate;
-    int32_t reserved1;
+    /* blend_bwd writes a zero record for every instance behind its tile's deepest contributor.  Above this many instances per tile
+     * (scene average) the zeros come from ONE memset of the record array instead of per-tile loops: 0 = the library's default
+     * (1000; profiles/r04/ab_prezero.txt), < 0 = never, > 0 = that threshold.  Results do not depend on it (ABI 8; the field was
+     * reserved1 = 0 before, and rounds 3-4 read an environment variable here). */
+    int32_t prezero_per_tile;
     float* grad_shs_rest;            /* (P,M-1,3), with inputs.shs_rest: grad_shs is then the (P,1,3) gradient of features_dc (ABI 7) */
 } BagsBackwardArgs;
 
@@ -156,6 +165,10 @@ typedef struct BagsDebugViews {
 
 int         bags_abi_version(void);
 const char* bags_last_error(void);
+/* "src=<12 hex digits> commit=<git short hash|nogit>[+dirty]": a hash of the kernel sources this library was compiled from and
+ * the last commit that touched them (ABI 8).  Measurement bookkeeping only: profiles/rNN/traffic.json records the string of the
+ * build its counters were collected on, and bench.py prints roofline.traffic only when it matches the library it is timing. */
+const char* bags_build_info(void);
 
 size_t bags_geom_size(int32_t P);
 size_t bags_binning_size(int64_t num_rendered, int32_t width, int32_t height);

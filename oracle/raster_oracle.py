@@ -51,6 +51,10 @@ Semantics decided here because the fork is unavailable (also listed in DESIGN.md
       ``clamp_grad="exact"`` differentiates the clamped expression itself (dL/dt.z sees t.x move with t.z: half of that one
       term).  The two differ on clamped Gaussians only (tests/test_parity_gpu.py::test_frustum_clamp_gradient_semantic);
       forward values are identical.
+  D9  conic = cov2D^-1: default ``conic_grad="stock"`` (round 5, here and in preprocess_bwd.hip): upstream computeCov2DCUDA's
+      backward, which multiplies every term by 1 / (det^2 + 1e-7) where the derivative of the inverse has 1 / det^2
+      (_ConicStock below restates its three lines); ``conic_grad="exact"`` lets autograd differentiate the division.
+      det >= 0.09, so the two differ by <= 1.2e-5 relative on dL/dcov2D; forward values are identical.
 """
 from __future__ import annotations
 
@@ -113,6 +117,7 @@ class OracleSettings:
     depth_key: str = "z"
     tile_bounds: str = "opacity"      # "aabb": stock 3-sigma square; "opacity": intersected with the alpha >= 1/255 bounds
     clamp_grad: str = "stock"         # D8; "stock": upstream's x_grad_mul treatment of frustum-clamped points; "exact"
+    conic_grad: str = "stock"         # D9; "stock": upstream's det^2 + 1e-7 in the backward of the 2x2 inverse; "exact"
 
 
 @dataclass
@@ -166,6 +171,39 @@ def _atan2_pos(rho: torch.Tensor, tz: torch.Tensor) -> torch.Tensor:
     a = w + w * (s * p)
     a = torch.where(red, f(0.785398185) + a, a)
     return torch.where(rho.detach() > tz.detach(), f(1.57079637) - a, a)
+
+
+class _ConicStock(torch.autograd.Function):
+    """conic = (cyy, -cxy, cxx) / det with upstream's backward (diff-gaussian-rasterization, computeCov2DCUDA):
+
+        denom2inv = 1 / (det^2 + 1e-7)
+        dL/da = denom2inv (-c^2 Gx + 2 b c Gy' + (det - a c) Gz)          a, b, c = cov2D xx, xy, yy
+        dL/dc = denom2inv (-a^2 Gz + 2 a b Gy' + (det - a c) Gx)          G = dL/dconic, upstream's Gy' = Gy / 2 (its blend
+        dL/db = denom2inv 2 (b c Gx - (det + 2 b^2) Gy' + a b Gz)          backward accumulates -0.5 G dx dy for conic.y)
+
+    The forward values are the exact division, operation for operation what the plain path does (bit-exact integers do not
+    depend on the switch).  The sums are formed in float64 and rounded once: the expanded polynomial cancels by lambda1 / lambda2
+    on needle-shaped splats ("Needle-shaped splats"), which would make the fp32 oracle the inaccurate side."""
+
+    @staticmethod
+    def forward(ctx, cxx, cxy, cyy):
+        det = cxx * cyy - cxy * cxy
+        ok = det != 0.0
+        det_inv = 1.0 / torch.where(ok, det, torch.ones_like(det))
+        ctx.save_for_backward(cxx, cxy, cyy)
+        return cyy * det_inv, -cxy * det_inv, cxx * det_inv
+
+    @staticmethod
+    def backward(ctx, ga, gb, gc):
+        a, b, c = (t.double() for t in ctx.saved_tensors)
+        Gx, Gy, Gz = ga.double(), 0.5 * gb.double(), gc.double()
+        det = a * c - b * b
+        d2i = 1.0 / (det * det + 1.0e-7)
+        da = d2i * (-c * c * Gx + 2.0 * b * c * Gy + (det - a * c) * Gz)
+        dc = d2i * (-a * a * Gz + 2.0 * a * b * Gy + (det - a * c) * Gx)
+        db = d2i * 2.0 * (b * c * Gx - (det + 2.0 * b * b) * Gy + a * b * Gz)
+        dt = ctx.saved_tensors[0].dtype
+        return da.to(dt), db.to(dt), dc.to(dt)
 
 
 def _rect_full_mask(w, h):
@@ -339,10 +377,13 @@ def preprocess(means3D, means2D, shift_factors, shs, colors_precomp, opacities, 
     cyy = b10 * a10 + b11 * a11 + b12 * a12 + 0.3
     det = cxx * cyy - cxy * cxy
     det_ok = det.detach() != 0.0
-    det_inv = 1.0 / torch.where(det_ok, det, torch.ones_like(det))
-    con_a = cyy * det_inv
-    con_b = -cxy * det_inv
-    con_c = cxx * det_inv
+    if s.conic_grad == "stock":
+        con_a, con_b, con_c = _ConicStock.apply(cxx, cxy, cyy)
+    else:
+        det_inv = 1.0 / torch.where(det_ok, det, torch.ones_like(det))
+        con_a = cyy * det_inv
+        con_b = -cxy * det_inv
+        con_c = cxx * det_inv
     mid = 0.5 * (cxx + cyy)
     lam = mid + _sqrt(torch.clamp_min(mid * mid - det, 0.1))
     radius_f = torch.ceil(3.0 * _sqrt(lam))

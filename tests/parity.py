@@ -26,21 +26,25 @@ GRAD_NAMES = ("means3D", "means2D", "means2D_densify", "shift_factors", "shs", "
 
 def run_hip(scene, cam, deg, grad_image=None, device="cuda", bg=None, shift=None, colors=None, cov3D=None,
             scale_modifier=1.0, depth_key="z", debug=False, means2D=None, tile_bounds="opacity", binning="auto",
-            clamp_grad="stock"):
-    """Forward (+ backward) through the product op.  Returns (outputs, grads dict, views dict)."""
+            clamp_grad="stock", frozen_camera=False, conic_grad="stock"):
+    """Forward (+ backward) through the product op.  Returns (outputs, grads dict, views dict).
+    frozen_camera: the op as the reference calls it when neither --opt_cam nor --opt_intrinsic is given (train.py:472-485 steps the
+    camera leaves only under those flags; BASELINE config 2, "fixed pose"): the four camera tensors do not require a gradient,
+    means2D_densify and shift_factors are None -- the library then gets NULL for grad_viewmatrix .. grad_campos,
+    grad_means2D_densify (the backward's instantiation without the abs sums) and grad_shift_factors."""
     from bags_raster import GaussianRasterizer, debug_views
     dev = torch.device(device)
     want = grad_image is not None
     t = {k: v.to(dev).clone().requires_grad_(want) for k, v in scene.items()}
-    ct = {k: v.clone().requires_grad_(want) for k, v in camera_tensors(cam, dev).items()}
+    ct = {k: v.clone().requires_grad_(want and not frozen_camera) for k, v in camera_tensors(cam, dev).items()}
     P = t["means3D"].shape[0]
     m2 = (torch.zeros(P, 3) if means2D is None else means2D).to(dev).requires_grad_(want)
-    m2d = torch.zeros(P, 3, device=dev, requires_grad=want)
-    sf = (torch.zeros(3) if shift is None else shift).to(dev).requires_grad_(want)
+    m2d = None if frozen_camera else torch.zeros(P, 3, device=dev, requires_grad=want)
+    sf = None if frozen_camera else (torch.zeros(3) if shift is None else shift).to(dev).requires_grad_(want)
     col = None if colors is None else colors.to(dev).clone().requires_grad_(want)
     cov = None if cov3D is None else cov3D.to(dev).clone().requires_grad_(want)
     st = hip_settings(cam, deg, dev, bg=bg, scale_modifier=scale_modifier, depth_key=depth_key, tensors=ct, debug=debug,
-                      tile_bounds=tile_bounds, binning=binning, clamp_grad=clamp_grad)
+                      tile_bounds=tile_bounds, binning=binning, clamp_grad=clamp_grad, conic_grad=conic_grad)
     rast = GaussianRasterizer(st)
     kw = dict(means3D=t["means3D"], means2D=m2, means2D_densify=m2d, shift_factors=sf,
               shs=None if col is not None else t["shs"], colors_precomp=col, opacities=t["opacities"],
@@ -64,9 +68,9 @@ def run_hip(scene, cam, deg, grad_image=None, device="cuda", bg=None, shift=None
 
 def run_oracle(scene, cam, deg, grad_image=None, dtype=torch.float32, bg=None, shift=None, colors=None, cov3D=None,
                scale_modifier=1.0, depth_key="z", discrete=None, means2D=None, tile_bounds="opacity", clamp_grad="stock",
-               binning=None):
+               binning=None, frozen_camera=None, conic_grad="stock"):
     s = oracle_settings(cam, deg, bg=bg, scale_modifier=scale_modifier, depth_key=depth_key, tile_bounds=tile_bounds,
-                        clamp_grad=clamp_grad)
+                        clamp_grad=clamp_grad, conic_grad=conic_grad)
     inp = dict(scene)
     inp["shift_factors"] = torch.zeros(3) if shift is None else shift
     if means2D is not None:
@@ -155,7 +159,7 @@ def compare_sampled(scene, cam, deg, tiles, seed=1, check_fp64=False, return_gra
         mask[ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16] = True
     g = torch.randn(3, H, W, generator=torch.Generator().manual_seed(seed)) * mask
     outs, grads, views = run_hip(scene, cam, deg, g, **kw)
-    s = oracle_settings(cam, deg, **{k: v for k, v in kw.items() if k in ("bg", "scale_modifier", "depth_key", "tile_bounds", "clamp_grad")})
+    s = oracle_settings(cam, deg, **{k: v for k, v in kw.items() if k in ("bg", "scale_modifier", "depth_key", "tile_bounds", "clamp_grad", "conic_grad")})
     inp = dict(scene)
     inp["shift_factors"] = kw.get("shift") if kw.get("shift") is not None else torch.zeros(3)
     st32, gr32 = O.render_and_grad(inp, s, g, dtype=torch.float32, tiles=tiles)
@@ -197,6 +201,50 @@ def compare_sampled(scene, cam, deg, tiles, seed=1, check_fp64=False, return_gra
     return rep
 
 
+def tile_sort_paths(keys_sorted, ranges):
+    """Which way through csrc/tile_sort.h every tile's list went on the tile-binned path, re-derived on the host from the sorted
+    (tile << 32 | depth bits) keys and the ranges -- the same fp32 arithmetic as the kernels' bucket / slab functions:
+      'wave256' / 'wave512'  one wave, bucket sort (half-size instance up to 256 entries)
+      'block'                513..2048 entries: the whole workgroup, bucket sort
+      'slabs'                2049..65536 entries: depth slabs through global memory, a wave per slab
+      'network'              more than 65536 entries, or a slab that outgrows a wave (> 512 entries): bitonic network in global memory
+      '+bitonic'             appended when more than 24 entries share a bucket: the LDS bitonic fallback of that size class
+    Returns {path: number of lists}."""
+    import numpy as np
+    keys = keys_sorted.numpy().astype(np.uint64) & np.uint64(0xFFFFFFFF)
+    out = {}
+    for lo, hi in ranges.numpy().astype(np.int64):
+        n = int(hi - lo)
+        if n <= 1:
+            continue
+        k = keys[lo:hi].astype(np.int64)
+        kmin, kmax = int(k[0]), int(k[-1])
+
+        def crowded(kk, nb):
+            scale = np.float32(nb) / (np.float32(int(kk[-1]) - int(kk[0])) + np.float32(1.0))
+            bk = np.minimum(nb - 1, ((kk - kk[0]).astype(np.float32) * scale).astype(np.int64))
+            return int(np.bincount(bk, minlength=nb).max()) > 24
+        if n <= 512:
+            path = ("wave256" if n <= 256 else "wave512") + ("+bitonic" if crowded(k, n) else "")
+        elif n <= 2048:
+            path = "block" + ("+bitonic" if crowded(k, n) else "")
+        elif n <= 65536:
+            K = min(256, (n + 255) // 256)
+            scale = np.float32(K) / (np.float32(kmax - kmin) + np.float32(1.0))
+            slab = np.minimum(K - 1, ((k - kmin).astype(np.float32) * scale).astype(np.int64))
+            cnt = np.bincount(slab, minlength=K)
+            if int(cnt.max()) > 512:
+                path = "network"
+            else:
+                edges = np.concatenate([[0], np.cumsum(cnt)])
+                bit = any(cnt[j] > 1 and crowded(k[edges[j]:edges[j + 1]], int(cnt[j])) for j in range(K))
+                path = "slabs" + ("+bitonic" if bit else "")
+        else:
+            path = "network"
+        out[path] = out.get(path, 0) + 1
+    return out
+
+
 INT_KEYS = ("radii_equal", "tiles_touched_equal", "rect_equal", "depth_bits_equal", "point_list_equal", "keys_equal",
             "ranges_equal")
 
@@ -218,11 +266,14 @@ def assert_ill_conditioned(rep, slack=3.0, floor=1e-4):
             assert rep["grad_rel_fp64"][k] <= slack * ref + floor, f"grad[{k}]: {rep['grad_rel_fp64'][k]:.3e} vs oracle32 {ref:.3e}"
 
 
-def assert_report(rep, grad_tol=1e-4, img_tol=1e-5, skip_zero=(), tol_override=None):
+def assert_report(rep, grad_tol=1e-4, img_tol=1e-5, skip_zero=(), tol_override=None, n_contrib_mismatch=0.0):
+    """n_contrib_mismatch: fraction of pixels whose last contributor may differ from the oracle's.  0 by default -- n_contrib is an
+    integer artefact; a test passes an allowance only where a documented threshold pair exists (T (1 - alpha) within an ulp of
+    1e-4, or alpha of 1/255, decided differently by the oracle's libm exp and the device's v_exp_f32)."""
     for k in INT_KEYS:
         assert rep[k], f"{k} failed: {rep}"
     assert rep["num_rendered"][0] == rep["num_rendered"][1]
-    assert rep["n_contrib_mismatch_frac"] <= 1e-4, rep["n_contrib_mismatch_frac"]
+    assert rep["n_contrib_mismatch_frac"] <= n_contrib_mismatch, rep["n_contrib_mismatch_frac"]
     # image: |d| <= 1e-5 (1+|x|) against the oracle; at most 2e-4 of the pixels may sit on a flipped threshold pair
     assert rep["image_bad_frac"] <= 2e-4 and rep["image_max_err"] <= 5e-3, (rep["image_bad_frac"], rep["image_max_err"])
     assert rep["depth_bad_frac"] <= 2e-4 and rep["weights_bad_frac"] <= 2e-4, (rep["depth_bad_frac"], rep["weights_bad_frac"])

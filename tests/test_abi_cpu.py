@@ -41,11 +41,11 @@ def test_buffer_sizes_grow_with_problem(lib):
 
 def test_struct_layout_matches_header(lib):
     # field counts and pointer-size packing of the POD structs (a mismatch would corrupt every call)
-    assert C.sizeof(_lib.BagsSettings) == 14 * 4 + 5 * 8     # + clamp_grad, reserved0 (ABI 5)
+    assert C.sizeof(_lib.BagsSettings) == 14 * 4 + 5 * 8     # + clamp_grad (ABI 5), conic_grad (ABI 8; reserved0 before)
     assert C.sizeof(_lib.BagsInputs) == 8 + 9 * 8 + 8          # + shs_rest (ABI 7)
     assert C.sizeof(_lib.BagsState) == 6 * 8
     assert C.sizeof(_lib.BagsForwardOut) == 5 * 8
-    assert C.sizeof(_lib.BagsBackwardArgs) == 4 * 8 + 14 * 8 + 8 + 8 + 8  # + binning_capacity (ABI 4), accumulate + reserved1 (ABI 6), grad_shs_rest (ABI 7)
+    assert C.sizeof(_lib.BagsBackwardArgs) == 4 * 8 + 14 * 8 + 8 + 8 + 8  # + binning_capacity (ABI 4), accumulate + prezero_per_tile (ABI 6 / 8), grad_shs_rest (ABI 7)
     assert C.sizeof(_lib.BagsDebugViews) == 8 * 8
 
 
@@ -123,3 +123,23 @@ def test_host_side_is_clean_under_address_sanitizer():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
                         "-k", "not address_sanitizer"], capture_output=True, text=True, env=env, cwd=ROOT)
     assert r.returncode == 0 and "AddressSanitizer" not in r.stderr, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("define", ["DIAG_PAIRS", "DIAG_PHASES"])
+def test_diagnostic_builds_of_the_blend_kernels_still_compile(define, tmp_path):
+    """csrc/blend.hip keeps two diagnostic builds (tools/diag_pairs.sh: evaluated against contributing (pixel, splat) pairs;
+    tools/diag_phases.py: a wave's time per phase of the backward) behind -DDIAG_PAIRS / -DDIAG_PHASES.  Nothing else compiles
+    them, so they are compiled here (gfx950 cross-compile, no GPU) to keep them from rotting, and the shipped source is held to
+    the handful of preprocessor conditionals that remain (every tuning switch whose A/B lost was deleted in round 5)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "bundle-adjusting-gaussian-splatting_amd", "csrc")
+    r = subprocess.run([hipcc, "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", f"-D{define}", "-c", os.path.join(csrc, "blend.hip"),
+                        "-o", str(tmp_path / "blend_diag.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    n_if = sum(1 for ln in open(os.path.join(csrc, "blend.hip")) if ln.lstrip().startswith(("#if", "#elif")))
+    assert n_if <= 15, n_if

@@ -166,7 +166,7 @@ def test_autograd_preprocess_backward_equals_the_hand_derivation(clamp_grad):
                                  scene["rotations"].double().numpy(), scene["shs"].double().numpy(), ct["viewmatrix"],
                                  ct["projmatrix"], ct["intrinsic"], ct["campos"], W, H, math.tan(cam.FoVx * 0.5),
                                  math.tan(cam.FoVy * 0.5), 1.0, deg, live, two_d["xy"], two_d["conic"], two_d["opacity"],
-                                 two_d["rgb"], clamp_grad=clamp_grad)
+                                 two_d["rgb"], clamp_grad=clamp_grad, det_reg=1e-7)       # (the oracle's default conic_grad="stock")
     # forward values (Appendix A.1) of the same restatement: pixel centre, conic, colour, depth, 3-sigma radius
     f = pub["forward"]
     vis = st.pre.visible.numpy()[f["idx"]]
@@ -186,15 +186,17 @@ def test_autograd_preprocess_backward_equals_the_hand_derivation(clamp_grad):
                                    scene["rotations"].double().numpy(), scene["shs"].double().numpy(), ct["viewmatrix"],
                                    ct["projmatrix"], ct["intrinsic"], ct["campos"], W, H, math.tan(cam.FoVx * 0.5),
                                    math.tan(cam.FoVy * 0.5), 1.0, deg, live, two_d["xy"], two_d["conic"], two_d["opacity"],
-                                   two_d["rgb"], clamp_grad="exact" if clamp_grad == "stock" else "stock")
+                                   two_d["rgb"], clamp_grad="exact" if clamp_grad == "stock" else "stock", det_reg=1e-7)
     moved = np.abs(other["means3D"] - pub["means3D"]).sum(1) > 0
     assert moved.sum() > 50 and not (moved & ~pub["clamped"]).any()
 
 
 def test_upstream_conic_regulariser_is_below_the_parity_bar():
-    """Decision D9: upstream divides by det^2 + 1e-7 in the conic -> cov2D step, oracle and kernels by det^2.  Measured on a
-    scene of SMALL splats (where det is closest to its floor of 0.09, i.e. the per-Gaussian effect closest to its ceiling of
-    1e-7 / 0.09^2 = 1.2e-5): the gradient tensors move by 2e-7 relative, far below the 1e-4 parity bar."""
+    """Decision D9: upstream divides by det^2 + 1e-7 in the conic -> cov2D step; oracle and kernels follow it by default since round
+    5 (conic_grad="stock"; "exact" = det^2, what rounds 1-4 shipped).  Measured on a scene of SMALL splats (where det is closest
+    to its floor of 0.09, i.e. the per-Gaussian effect closest to its ceiling of 1e-7 / 0.09^2 = 1.2e-5): the gradient tensors
+    move by 2e-7 relative, far below the 1e-4 parity bar -- and the oracle's two modes ARE the hand derivation with and without
+    the regulariser."""
     import numpy as np
     from oracle import published_preprocess as PP
     from scenes import camera_tensors
@@ -202,6 +204,7 @@ def test_upstream_conic_regulariser_is_below_the_parity_bar():
     scene, cam = make_case(P, W, H, 0.25, deg, seed=9)
     g = torch.randn(3, H, W, generator=torch.Generator().manual_seed(2))
     st, gr = run_oracle(scene, cam, deg, g, torch.float64)
+    _, gr_exact = run_oracle(scene, cam, deg, g, torch.float64, conic_grad="exact")
     ct = {k: v.double().numpy() for k, v in camera_tensors(cam).items()}
     two_d = {k: v.numpy() for k, v in gr["_2d"].items()}
     live = np.zeros(P, dtype=bool); live[st.pre.extras["_graph"]["idx"].numpy()] = True
@@ -217,6 +220,10 @@ def test_upstream_conic_regulariser_is_below_the_parity_bar():
         e = np.linalg.norm(reg[k] - exact[k]) / np.linalg.norm(exact[k])
         assert 0 < e < 1.3e-5, (k, e)
         worst = max(worst, e)
+        # the oracle's default (stock) is the regularised hand derivation, its "exact" mode the other one -- each far closer to
+        # its own than the two are to one another
+        assert np.linalg.norm(gr[k].numpy() - reg[k]) < 1e-3 * np.linalg.norm(reg[k] - exact[k]), k
+        assert np.linalg.norm(gr_exact[k].numpy() - exact[k]) < 1e-3 * np.linalg.norm(reg[k] - exact[k]), k
     print("largest relative effect of the 1e-7 regulariser:", worst)
 
 

@@ -5,7 +5,8 @@ fp32 oracle and to the fp64 oracle replaying the fp32 run's discrete decisions; 
 import pytest
 import torch
 
-from parity import assert_ill_conditioned, assert_report, compare, compare_sampled, run_hip, run_oracle, sample_tiles
+from parity import (assert_ill_conditioned, assert_report, compare, compare_sampled, run_hip, run_oracle, sample_tiles,
+                    tile_sort_paths)
 from scenes import make_case, rel_err
 
 pytestmark = pytest.mark.gpu
@@ -798,8 +799,8 @@ def test_binning_paths_agree_on_random_scenes():
 def test_long_and_clustered_tile_lists_take_every_sort_path(P, shrink, flat):
     """The per-tile sort of the tile-binned path (csrc/binning.hip) has four ways through it; each must give the oracle's list:
     thousands of splats over a handful of tiles (a camera far from a compact scene) leave the one-wave bucket sort for the
-    workgroup-wide one (513..2048 entries) or the two-level slab sort (P = 3000 and 20000) and the global-memory network
-    (> 16384 entries: P = 40000); `flat` puts every splat at the SAME depth (identical 32-bit keys: the order is decided by the
+    workgroup-wide one (513..2048 entries) or the two-level slab sort (P = 3000, 20000 and 40000: 2049..65536 entries; the
+    global-memory network above that has its own test, test_tile_sort_limit_of_the_slab_path); `flat` puts every splat at the SAME depth (identical 32-bit keys: the order is decided by the
     Gaussian id alone), which overflows the buckets / slabs and takes the bitonic fallbacks (in LDS for P = 600 and 2500, in
     global memory for P = 5000)."""
     scene, cam = make_case(P, 64, 48, 1.0, 0, seed=P + 1)
@@ -852,7 +853,7 @@ def test_tile_sort_size_boundaries(N):
 
 @pytest.mark.parametrize("N,bands", [(2304, (0, 2, 4, 6, 8)), (2304, (0, 1, 7, 8)), (5000, (0, 3, 4, 9, 10, 15, 19))])
 def test_slab_sort_with_empty_and_single_entry_slabs(N, bands):
-    """The two-level sort of a 2049..16384-entry list cuts the depth-key range into K = ceil(N / 256) equal slabs and lets the
+    """The two-level sort of a 2049..65536-entry list cuts the depth-key range into K = min(256, ceil(N / 256)) equal slabs and lets the
     four waves draw them from a counter.  Depth-clustered lists leave slabs EMPTY or with ONE entry: a wave that drew such a slab
     used to leave the list altogether (`return` for `continue`, csrc/tile_sort.h), and with enough of them no wave was left
     for the last slabs -- their part of the sorted list kept whatever the buffer held before (tools/soak.py: a memory fault
@@ -887,6 +888,126 @@ def test_slab_sort_with_empty_and_single_entry_slabs(N, bands):
         for k in g_a:
             if g_a[k] is not None:
                 assert torch.equal(g_a[k], g_r[k]), k
+
+
+def test_conic_backward_semantic():
+    """Decision D9.  DEFAULT conic_grad="stock": upstream computeCov2DCUDA's backward of the 2x2 inverse divides by det^2 + 1e-7
+    (the reference's fork inherits it, README.md:126); "exact" divides by det^2 (rounds 1-4).  A scene of small splats (det near
+    its floor of 0.09, where the regulariser weighs most): each mode against the oracle of the SAME mode to the ordinary bars,
+    forward outputs bit-identical between the modes, the gradients of the two modes apart by more than rounding and by less than
+    the 1.2e-5 ceiling."""
+    scene, cam = make_case(4000, 160, 96, 0.25, 1, seed=9)
+    g = torch.randn(3, 96, 160, generator=torch.Generator().manual_seed(2))
+    res = {}
+    for mode in ("stock", "exact"):
+        rep = compare(scene, cam, 1, conic_grad=mode)
+        _report({k: rep[k] for k in ("num_rendered", "image_max_err", "grad_rel_fp32", "grad_rel_fp64")})
+        assert_report(rep)
+        res[mode] = run_hip(scene, cam, 1, g, conic_grad=mode)
+    for a, b in zip(res["stock"][0], res["exact"][0]):
+        assert torch.equal(a, b)
+    for k in ("means3D", "scales", "rotations"):
+        e = rel_err(res["stock"][1][k], res["exact"][1][k])
+        assert 1e-9 < e < 1.3e-5, (k, e)
+    for k in ("shs", "opacities", "means2D"):                   # nothing downstream of the conic
+        assert torch.equal(res["stock"][1][k], res["exact"][1][k]), k
+
+
+def _oracle_lists(scene, cam, deg, **kw):
+    """The oracle's instance list alone (preprocess + binning; no blending): sorted ids, 64-bit keys, tile ranges."""
+    from oracle import raster_oracle as O
+    from scenes import oracle_settings
+    s = oracle_settings(cam, deg, **kw)
+    P = scene["means3D"].shape[0]
+    with torch.no_grad():
+        pre = O.preprocess(scene["means3D"], torch.zeros(P, 3), torch.zeros(3), scene["shs"], None, scene["opacities"], scene["scales"],
+                           scene["rotations"], None, s, torch.float32, None)
+        gx, gy = (cam.image_width + 15) // 16, (cam.image_height + 15) // 16
+        keys, pl, ranges, _ = O.bin_and_sort(pre.depth.float(), pre.rect, pre.tiles_touched, gx, gy, pre.keep)
+    return keys, pl, ranges
+
+
+@pytest.mark.parametrize("N", [65535, 65536, 65537])
+@pytest.mark.parametrize("depths", ["spread", "banded", "flat"])
+def test_tile_sort_limit_of_the_slab_path(N, depths):
+    """ONE tile holding exactly N instances, N on either side of TSORT_LARGE = 65536 (csrc/tile_sort.h): up to there the two-level
+    slab sort (256 slabs of ~256 entries, a wave per slab), above it the bitonic network in global memory -- the limit was
+    16384 until the end of round 4 and no test stood at the new one.  `spread`: depths uniform, every slab ~256 entries (slabs
+    at 65535 / 65536, network at 65537); `banded`: three quarters of the slabs populated, the others empty (the shape that lost
+    entries in rounds 3-4); `flat`: one identical depth, i.e. one slab that outgrows a wave -> the network on both sides.  The
+    list must be the radix path's AND the oracle's, bit for bit; image, n_contrib and gradients the radix path's."""
+    scene, cam = make_case(N, 48, 48, 1.0, 0, seed=N)
+    gen = torch.Generator().manual_seed(N + len(depths))
+    xyz = 0.004 * torch.randn(N, 3, generator=gen)          # all of them project into the middle of tile (1, 1)
+    span = 1.8                                              # view depth = z + 4 in [4, 5.8]: one binade, keys linear in depth
+    if depths == "spread":
+        z = span * torch.rand(N, generator=gen)
+    elif depths == "banded":
+        K = 256
+        r = torch.randint(0, 3 * K // 4, (N,), generator=gen)
+        band = r + r // 3                                   # slabs 3, 7, 11, ... stay empty, the others hold ~341 entries
+        z = (band.float() + 0.1 + 0.8 * torch.rand(N, generator=gen)) * (span / K)
+        z[0], z[1] = 0.0, span * (1 - 1e-6)                 # first and last key pin the slab grid
+    else:
+        z = torch.full((N,), 0.25)
+    xyz[:, 2] = z
+    scene["means3D"] = xyz
+    scene["scales"] = torch.full((N, 3), 0.003)
+    scene["opacities"] = torch.full((N, 1), 0.02)
+    g = torch.randn(3, 48, 48, generator=gen)
+    o_r, g_r, v_r = run_hip(scene, cam, 0, g, binning="radix")
+    lens = v_r["ranges"][:, 1] - v_r["ranges"][:, 0]
+    assert int(lens.max()) == N and int((lens > 0).sum()) == 1, lens
+    took = tile_sort_paths(v_r["keys_sorted"], v_r["ranges"])
+    want = "network" if (N > 65536 or depths == "flat") else "slabs"
+    assert list(took) == [want], (took, want)               # the side of the limit this case is meant to stand on
+    o_a, g_a, v_a = run_hip(scene, cam, 0, g, binning="auto")
+    assert v_a["num_rendered"] == v_r["num_rendered"] == N
+    for k in ("point_list", "keys_sorted", "n_contrib"):
+        assert torch.equal(v_a[k], v_r[k]), k
+    for a, b in zip(o_a, o_r):
+        assert torch.equal(a, b)
+    for k in g_a:
+        if g_a[k] is not None:
+            assert torch.equal(g_a[k], g_r[k]), k
+    keys, pl, ranges = _oracle_lists(scene, cam, 0)
+    assert torch.equal(v_a["point_list"], pl) and torch.equal(v_a["keys_sorted"], keys)
+    nz = ranges[:, 1] > ranges[:, 0]
+    assert torch.equal(v_a["ranges"][nz], ranges[nz])
+
+
+@pytest.mark.parametrize("tile_bounds", ["opacity", "aabb"])
+def test_frozen_camera_mode_against_oracle(tile_bounds):
+    """The op as the reference calls it without --opt_cam / --opt_intrinsic (train.py:472-485 steps the camera leaves only under
+    those flags; BASELINE config 2, "fixed pose"): camera tensors without a gradient, means2D_densify = None, shift_factors =
+    None, i.e. NULL for grad_viewmatrix .. grad_campos, grad_means2D_densify (the backward instantiated without the abs sums)
+    and grad_shift_factors (gaussian_renderer/__init__.py:110-121 passes the same keywords).  Until round 5 this mode was timed
+    and compared with itself only.  Every Gaussian gradient against the oracle, and against the op's own full mode."""
+    scene, cam = make_case(3000, 200, 136, 1.5, 3, seed=3000)
+    rep = compare(scene, cam, 3, frozen_camera=True, tile_bounds=tile_bounds)
+    _report({k: rep[k] for k in ("num_rendered", "image_max_err", "n_contrib_mismatch_frac", "grad_rel_fp32", "grad_rel_fp64")})
+    assert set(rep["grad_rel_fp32"]) == {"means3D", "means2D", "shs", "opacities", "scales", "rotations"}, rep["grad_rel_fp32"].keys()
+    assert_report(rep)
+    g = torch.randn(3, 136, 200, generator=torch.Generator().manual_seed(1))
+    o_f, g_f, _ = run_hip(scene, cam, 3, g, frozen_camera=True, tile_bounds=tile_bounds)
+    o_p, g_p, _ = run_hip(scene, cam, 3, g, tile_bounds=tile_bounds)
+    for a, b in zip(o_f, o_p):
+        assert torch.equal(a, b)
+    for k in ("viewmatrix", "projmatrix", "intrinsic", "campos", "means2D_densify", "shift_factors"):
+        assert g_f[k] is None, k
+    for k in ("means3D", "means2D", "shs", "opacities", "scales", "rotations"):
+        assert rel_err(g_f[k], g_p[k]) <= 1e-6, (k, rel_err(g_f[k], g_p[k]))     # the same sums with and without the pose Jacobians beside them
+
+
+def test_frozen_camera_mode_at_config2_size():
+    """BASELINE config 2 itself: 500 k Gaussians, 1920x1080, SH degree 3, fixed pose.  Integers bit-exact for all Gaussians and
+    instances, image / n_contrib / Gaussian gradients on 96 sampled tiles (the cotangent is zero elsewhere)."""
+    scene, cam = make_case(500_000, 1920, 1080, 0.5, 3, seed=0)
+    rep = compare_sampled(scene, cam, 3, sample_tiles(1920, 1080, 96, seed=7), frozen_camera=True)
+    _report({n: rep[n] for n in ("num_rendered", "instances_in_sample", "n_contrib_mismatch_frac", "image_max_err", "grad_rel_fp32")})
+    assert rep["num_rendered"][0] == 2_074_322
+    assert set(rep["grad_rel_fp32"]) == {"means3D", "means2D", "shs", "opacities", "scales", "rotations"}
+    _assert_sampled(rep)
 
 
 @pytest.mark.parametrize("W,H,P,sm,shrink,fovy", [

@@ -29,11 +29,17 @@ def test_short_soak_with_growing_splats_and_drifting_poses():
 def test_short_fuzz_of_the_two_list_builders():
     out = _run("fuzz_paths.py", "--trials", "30", "--seed", "3", "--long")
     assert out["trials"] == 30 and out["failures"] == [], out["failures"]
+    # every way through the per-tile sort (csrc/tile_sort.h) was taken by some list of the run: one wave (both sizes), the whole
+    # workgroup, depth slabs, the global-memory network, and the LDS bitonic fallback for crowded buckets
+    hit = out["sort_paths"]
+    for path in ("wave256", "wave512", "block", "slabs", "network"):
+        assert any(k.split("+")[0] == path for k in hit), (path, hit)
+    assert any(k.endswith("+bitonic") for k in hit), hit
 
 
 @pytest.mark.timeout(900)
 def test_memset_zero_records_match_the_oracle():
-    """Dense scenes take blend_bwd's zero records from one memset of the record array (blend.hip, BWD_PREZERO_PER_TILE); the
-    threshold is forced down here so that every trial takes that path, and the gradients are checked against the CPU oracle."""
-    out = _run("fuzz_paths.py", "--trials", "10", "--seed", "11", "--oracle", env={"BAGS_PREZERO_PER_TILE": "1"})
+    """Dense scenes take blend_bwd's zero records from one memset of the record array (blend.hip, BWD_PREZERO_PER_TILE /
+    BagsBackwardArgs.prezero_per_tile); the threshold is forced down here so that every trial takes that path, and the gradients are checked against the CPU oracle."""
+    out = _run("fuzz_paths.py", "--trials", "10", "--seed", "11", "--oracle", "--prezero", "1")
     assert out["trials"] == 10 and out["failures"] == [], out["failures"]

@@ -12,10 +12,10 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _views_and_scene():
+def _views_and_scene(n=5):
     from bags_raster.synth import sphere_views, synth_scene
     scene = synth_scene(320, 3, 3.0, 1)                    # 320: every gradient is a multiple of 64 floats (no padding in the flat buffer)
-    cams = sphere_views(5, 48, 32, noise=0.05)            # 5 views: uneven split over 2 ranks (3 + 2)
+    cams = sphere_views(n, 48, 32, noise=0.05)            # 5 views: uneven split over 2 ranks (3 + 2)
     return scene, cams
 
 
@@ -70,18 +70,18 @@ def _params(scene):
     return [scene[k].clone().requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs")]
 
 
-def _worker(rank, world, port, out, n_views, mode):
+def _worker(rank, world, port, out, n_views, mode, iters=2):
     _setup(rank, world, port)
     from bags_raster.sharding import ViewShardedRenderer, shard_views
-    scene, cams = _views_and_scene()
+    scene, cams = _views_and_scene(max(5, n_views))
     cams = cams[:n_views]
     params = _params(scene)
     r = ViewShardedRenderer(params, _make_render_fn(params), mode=mode)
-    for it in range(2):                                   # twice: the bucket must be zeroed between iterations
+    for it in range(iters):                               # twice: the bucket must be zeroed between iterations
         res = r.step(cams)
     assert res["views"] == shard_views(len(cams), rank, world)
     # ONE exchange per step whatever this rank rendered (no view at all included): 1 all-reduce, or 1 reduce-scatter + 1 all-gather
-    assert r.reducer.exchange.collectives_issued == 2 * (1 if mode == "all_reduce" else 2)      # sparse: mask + rows (or dense)
+    assert r.reducer.exchange.collectives_issued == iters * (1 if mode == "all_reduce" else 2)      # sparse: mask + rows (or dense)
     assert r.reducer.bucket.bound(), "p.grad is no longer a view of the flat bucket"
     if rank == 0:
         torch.save({"grads": [p.grad.clone() for p in params], "loss": res["loss_sum"]}, out)
@@ -99,7 +99,7 @@ def test_shard_views_round_robin():
 
 
 def _single_process_reference(n_views):
-    scene, cams = _views_and_scene()
+    scene, cams = _views_and_scene(max(5, n_views))
     params = _params(scene)
     render = _make_render_fn(params)
     total = 0.0
@@ -125,6 +125,25 @@ def test_two_rank_sum_equals_single_process(tmp_path, n_views, mode):
     for g2, p in zip(got["grads"], params):
         denom = p.grad.norm().item()
         assert (g2 - p.grad).norm().item() <= 1e-6 * max(denom, 1e-12), "N-rank sum differs from 1-process sum"
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("n_views,mode,iters", [(8, "all_reduce", 2),        # BASELINE config 5's split: 8 views per iteration, one per rank
+                                                (5, "reduce_scatter", 2),    # a batch smaller than the node: ranks 5, 6, 7 render nothing
+                                                (200, "all_reduce", 1)])     # BASELINE config 4's split: 200 views, 25 per rank behind one exchange
+def test_eight_rank_sum_equals_single_process(tmp_path, n_views, mode, iters):
+    """The partitioning the 8-GPU runs will execute first (views v = r mod 8, Gaussians replicated, ONE exchange
+    per step on a buffer whose layout does not depend on what a rank rendered) at world size 8 -- rounds 1-4 only ever ran it at
+    world size 2.  gloo on the CPU; the collective calls are the ones the RCCL backend gets."""
+    out = str(tmp_path / "rank0.pt")
+    port = 29500 + ((os.getpid() + 11 * n_views + len(mode)) % 500)
+    mp.spawn(_worker, args=(8, port, out, n_views, mode, iters), nprocs=8, join=True)
+    got = torch.load(out)
+    params, total = _single_process_reference(n_views)
+    assert abs(float(got["loss"]) - total) < 1e-5 * max(1.0, abs(total))
+    for g2, p in zip(got["grads"], params):
+        denom = p.grad.norm().item()
+        assert (g2 - p.grad).norm().item() <= 2e-6 * max(denom, 1e-12), "8-rank sum differs from 1-process sum"
 
 
 def _raw_leaf_worker(rank, world, port, out):

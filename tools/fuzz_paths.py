@@ -9,7 +9,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bundle-adjusting-gaussian-splatting_amd"), os.path.join(ROOT, "tests")]
-from parity import assert_report, compare, run_hip
+from parity import assert_report, compare, run_hip, tile_sort_paths
 from scenes import make_case, rel_err
 
 
@@ -20,11 +20,16 @@ def main():
     ap.add_argument("--oracle", action="store_true", help="small scenes (<= 2500 Gaussians, <= 160 x 120) against the CPU oracle instead "
                                                           "of the radix path: integer artefacts bit for bit, floats by the parity tolerances")
     ap.add_argument("--long", action="store_true", help="bias towards long tile lists: 3000 .. 60000 Gaussians in compact scenes")
+    ap.add_argument("--prezero", type=int, default=0, help="BagsBackwardArgs.prezero_per_tile (instances per tile above which blend_bwd's "
+                                                           "zero records come from one memset; 1 forces that path, -1 the per-tile loops)")
     args = ap.parse_args()
+    from bags_raster import rasterizer as _R
+    _R.PREZERO_PER_TILE = args.prezero
     rng = torch.Generator().manual_seed(args.seed)
     U = lambda a, b: float(torch.empty(1).uniform_(a, b, generator=rng))
     I = lambda a, b: int(torch.randint(a, b, (1,), generator=rng))
     bad = []
+    paths_hit = {}                                           # sort path (csrc/tile_sort.h) -> lists that took it, over all trials
     for trial in range(args.trials):
         P = max(1, int(math.exp(U(math.log(3000.0) if args.long else 0.0, math.log(60000.0 if args.long else 40000.0)))))
         W, H = I(16, 640), I(16, 480)
@@ -90,13 +95,16 @@ def main():
                     elif rel_err(g_a[k], g_r[k]) > 3e-3:
                         why = f"grad {k} {rel_err(g_a[k], g_r[k]):.2e}"; break
             longest = int((v_r["ranges"][:, 1] - v_r["ranges"][:, 0]).max()) if v_r["ranges"].numel() else 0
-            print(f"  I = {v_r['num_rendered']}, longest list {longest}: {'ok' if why is None else 'MISMATCH ' + why}", flush=True)
+            took = tile_sort_paths(v_r["keys_sorted"], v_r["ranges"])          # which sorts the tile-binned run went through
+            for k, c in took.items():
+                paths_hit[k] = paths_hit.get(k, 0) + c
+            print(f"  I = {v_r['num_rendered']}, longest list {longest}, sort paths {took}: {'ok' if why is None else 'MISMATCH ' + why}", flush=True)
             if why is not None:
                 bad.append(dict(tag, why=why))
         except Exception as e:                               # (an exception of the op, not a device fault)
             print(f"  EXCEPTION {type(e).__name__}: {str(e)[:200]}", flush=True)
             bad.append(dict(tag, why=f"exception {type(e).__name__}"))
-    print(json.dumps({"trials": args.trials, "failures": bad}))
+    print(json.dumps({"trials": args.trials, "failures": bad, "sort_paths": paths_hit}))
 
 
 if __name__ == "__main__":
