@@ -268,6 +268,8 @@ def main():
     ap.add_argument("--no-lazy-leg", action="store_true", help="skip the extra timed leg in the other host-wait mode")
     ap.add_argument("--no-median-leg", action="store_true", help="skip the 50-step leg with one hipEvent per step (median)")
     ap.add_argument("--fixed-pose", action="store_true", help="config 2 exactly: no pose/intrinsic gradients requested")
+    ap.add_argument("--dense-per-tile", type=int, default=0, help="BagsBackwardArgs.dense_per_tile (0 = library default; A/B of the "
+                                                                   "backward's dense-scene mode: tools/ab_dense.sh)")
     ap.add_argument("--views-per-exchange", type=int, default=0,
                     help="views every rank renders (fwd+bwd, gradients accumulated locally) behind ONE exchange; 0 = 1 view at "
                          "every --gpus N (a second leg with 4 views is timed in the same run and reported as 'v4')")
@@ -325,6 +327,7 @@ def main():
     P, W, H = args.P, args.width, args.height
     assert R.HOST_WAIT == "forward" and not R.LAZY_RECOVER, "the operator's defaults changed: the bench line must say so"
     R.HOST_WAIT = args.host_wait
+    R.DENSE_PER_TILE = args.dense_per_tile
     # ONE view per rank per exchange at every N (BASELINE configs 3-5: one view per GPU per iteration), so that the driver's
     # N = 1, 2, 4, 8 curve compares like with like; the V = 4 figure (the cubemap step renders 5 views per iteration,
     # utils/cubemap_utils.py:229,263-265) is a second leg of the same run, also at every N.

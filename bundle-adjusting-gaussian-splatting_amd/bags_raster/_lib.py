@@ -50,7 +50,7 @@ class BagsBackwardArgs(C.Structure):
                 ("grad_colors_precomp", c_fp), ("grad_opacities", c_fp), ("grad_scales", c_fp), ("grad_rotations", c_fp),
                 ("grad_cov3D_precomp", c_fp), ("grad_viewmatrix", c_fp), ("grad_projmatrix", c_fp),
                 ("grad_intrinsic", c_fp), ("grad_campos", c_fp), ("grad_shift_factors", c_fp),
-                ("binning_capacity", C.c_int64), ("accumulate", C.c_int32), ("prezero_per_tile", C.c_int32), ("grad_shs_rest", c_fp)]
+                ("binning_capacity", C.c_int64), ("accumulate", C.c_int32), ("dense_per_tile", C.c_int32), ("grad_shs_rest", c_fp)]
 
 
 class BagsDebugViews(C.Structure):

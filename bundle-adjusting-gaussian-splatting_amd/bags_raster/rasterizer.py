@@ -204,9 +204,10 @@ LAZY_RECOVER = False
 # (BagsBackwardArgs.accumulate) and hands autograd None for them -- no flat buffer, no add pass per tensor and view.  The sums are
 # what autograd's own accumulation gives; tensor hooks on those parameters do not see the per-view gradients.
 ACCUMULATE_IN_PLACE = False
-# BagsBackwardArgs.prezero_per_tile: 0 = the library's threshold for taking blend_bwd's zero records from one memset (dense scenes),
-# < 0 never, > 0 that many instances per tile.  Results do not depend on it; tools/fuzz_paths.py forces both paths with it.
-PREZERO_PER_TILE = 0
+# BagsBackwardArgs.dense_per_tile: 0 = the library's threshold (instances per tile, scene average) for the backward's dense-scene
+# mode (a byte per gradient record instead of zero records), < 0 never, > 0 that threshold.  Results do not depend on it;
+# tools/fuzz_paths.py forces both paths with it.
+DENSE_PER_TILE = 0
 CAPACITY_HEADROOM = 4.0      # lazy forwards only; a waiting forward sizes for 1.2 x the largest count seen and redoes on overflow
 _HINT_KEYS_MAX = 64
 _capacity_hint = {}          # (device index, P, W, H) -> largest instance count seen for the shape (a hint only); insertion order = LRU
@@ -545,7 +546,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             args = L.BagsBackwardArgs(gc.data_ptr(), fw.num_rendered, ws.data_ptr(), ws.numel(), _ptr(g_means3D),
                                       _ptr(g_means2D), _ptr(g_densify), _ptr(g_sh), _ptr(g_col), _ptr(g_opac),
                                       _ptr(g_scales), _ptr(g_rot), _ptr(g_cov), _ptr(g_view), _ptr(g_proj),
-                                      _ptr(g_intr), _ptr(g_campos), _ptr(g_shift), fw.capacity, 1 if in_place is not None else 0, int(PREZERO_PER_TILE),
+                                      _ptr(g_intr), _ptr(g_campos), _ptr(g_shift), fw.capacity, 1 if in_place is not None else 0, int(DENSE_PER_TILE),
                                       _ptr(g_sh_rest))
             state = _state_of(fw)
             L.check(lib.bags_backward(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(args), stream),

@@ -227,7 +227,8 @@ size_t bags_backward_workspace_size(int32_t P, int64_t I)
 {
     const size_t part = align_up((size_t)(I > 0 ? I : 1) * PART_FLOATS * sizeof(float), 256);
     const size_t slab = align_up((size_t)(cdiv(P > 0 ? P : 1, 256)) * POSE_VALS * sizeof(float), 256);
-    return part + slab + 256;
+    const size_t live = align_up((size_t)(I > 0 ? I : 1), 256);          // dense-scene mode: one byte per record
+    return part + slab + live + 256;
 }
 
 // tile-binned lists (binning.hip) unless the caller asked for the radix path or the problem is outside their limits
@@ -418,13 +419,15 @@ int bags_backward(const BagsSettings* s, const BagsInputs* in, const BagsState* 
     char* ws = reinterpret_cast<char*>(align256(a->workspace));
     float* partials = reinterpret_cast<float*>(ws);
     float* slab = reinterpret_cast<float*>(ws + align_up((size_t)(I > 0 ? I : 1) * PART_FLOATS * sizeof(float), 256));
+    unsigned char* live_map = reinterpret_cast<unsigned char*>(slab) + align_up((size_t)(cdiv(in->P > 0 ? in->P : 1, 256)) * POSE_VALS * sizeof(float), 256);
+    const bool dense = I > 0 && bwd_dense_mode(I, cdiv(W, BAGS_TILE) * cdiv(H, BAGS_TILE), a->dense_per_tile);
     if (I > 0) {
         { ProfScope ps(ST_BLEND_BWD, st); HIP_TRY(launch_blend_bwd(*s, g, b, im, a->grad_color, partials, a->grad_means2D_densify != nullptr, use_binned(s, in->P), st,
-                                                                  I, a->prezero_per_tile)); }
+                                                                  I, a->dense_per_tile, live_map)); }
         DEBUG_SYNC(s, st, "blend_bwd");
     }
     int nblocks = 0;
-    { ProfScope ps(ST_PRE_BWD, st); HIP_TRY(launch_preprocess_bwd(*s, *in, g, nullptr, partials, slab, &nblocks, *a, st, use_binned(s, in->P))); }
+    { ProfScope ps(ST_PRE_BWD, st); HIP_TRY(launch_preprocess_bwd(*s, *in, g, nullptr, partials, slab, &nblocks, *a, st, use_binned(s, in->P), dense ? live_map : nullptr)); }
     DEBUG_SYNC(s, st, "preprocess_bwd");
     { ProfScope ps(ST_POSE_REDUCE, st); HIP_TRY(launch_pose_reduce(slab, nblocks, *a, st)); }
     DEBUG_SYNC(s, st, "pose_reduce");

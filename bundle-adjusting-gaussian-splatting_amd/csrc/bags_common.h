@@ -173,11 +173,12 @@ hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinV
 // (radix path) it is gathered from g.inst_off
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
                             const float* grad_color, float* partials, bool want_abs, bool binned, hipStream_t st,
-                            long long n_records = 0,                      // instance count when the host knows it (dense scenes: one memset)
-                            int prezero_per_tile = 0);                    // BagsBackwardArgs.prezero_per_tile
+                            long long n_records = 0, int dense_per_tile = 0,       // instance count, BagsBackwardArgs.dense_per_tile
+                            unsigned char* live_map = nullptr);           // one byte per record (dense-scene mode), or null
+bool bwd_dense_mode(long long n_records, int T, int dense_per_tile);      // does a backward of this size run in dense-scene mode?
 hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, const int32_t* radii_or_null,
                                  const float* partials, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a, hipStream_t st,
-                                 bool binned);
+                                 bool binned, const unsigned char* live_map = nullptr);
 hipError_t launch_pose_reduce(const float* pose_slab, int nblocks, const BagsBackwardArgs& a, hipStream_t st);
 // loss.hip: fused L1 + SSIM terms and their image gradient
 size_t loss_workspace_bytes(int C, int H, int W);

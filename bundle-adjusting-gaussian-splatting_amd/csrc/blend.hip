@@ -37,8 +37,9 @@
 #define PRIO_SERIAL 3         // backward: wave priority in the serial section between a chunk's two barriers ...
 #define PRIO_GROUPS 0         // ... and in its list-building / scan phase (0/0, 1/0, 3/1 measured: flat)
 #define PQ 3                  // float4s per pixel pair in the backward's LDS image (below)
-#define BWD_PREZERO_PER_TILE 1000       // instances per tile above which blend_bwd's zero records come from one memset (profiles/r04/ab_prezero.txt);
-                                        // BagsBackwardArgs.prezero_per_tile overrides it
+#define BWD_DENSE_PER_TILE 600          // instances per tile (scene average) above which the backward runs in dense-scene mode: a byte per
+                                        // record says whether blend_bwd wrote it, nobody writes or reads a zero record
+                                        // (BagsBackwardArgs.dense_per_tile overrides it; profiles/r05/ab_dense.txt)
 struct __attribute__((aligned(16))) SplatRec {
     float x, y, ap, cp;       // centre, pre-scaled conic: exp2(ap dx^2 + bp dx dy + cp dy^2) == exp(power)
     float bp, o, r, g;
@@ -250,7 +251,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                       const float4* __restrict__ g2d, const u32* __restrict__ inst_off, const u32* __restrict__ block_base,
                       const float* __restrict__ bg, const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
                       const float* __restrict__ grad_color, float* __restrict__ partials,
-                      const int test_keep, const uint4* __restrict__ tile_aux, const int skip_zero)
+                      const int test_keep, const uint4* __restrict__ tile_aux, unsigned char* __restrict__ live_map)
 {
     // One workgroup per tile that holds at least one instance, heavy tiles first (slot_of_vblock).  Tried and dropped:
     // persistent workgroups that run the chunk pipeline over the flattened (tile, chunk) sequence, with the next tile's
@@ -379,7 +380,11 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         }
         // zero records for the record-holding instances no chunk will visit: those at or behind the deepest contributor.
         // COMPACT: first the staged ones (compacted entries hi0 .. n_live), then, below, the positions the forward never staged
-        if (skip_zero) return;                               // dense scene: launch_blend_bwd cleared the whole record array with one memset
+        // Dense scenes (thousands of entries per tile, the walk ends after a fraction of them): no zero records at all.  live_map
+        // holds one byte per record, cleared by the launcher (I bytes instead of 48 I); the write-out below marks the records
+        // it writes and preprocess_bwd sums only those.  (Round 4 cleared the whole record array with one memset instead:
+        // 700 MB written here and read back there at 1800 entries per tile.)
+        if (live_map) return;
         if (COMPACT) {
             for (u32 k = hi0 + tid; k < n_live; k += 256) {
                 const u32 g = point_list[t.rx + cposp[k]];
@@ -672,6 +677,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
             if (cur.e != 0xFFFFFFFFu) {
                 float4* dst = reinterpret_cast<float4*>(partials + (size_t)cur.e * PART_FLOATS);
                 dst[0] = r0; dst[1] = r1; dst[2] = r2;
+                if (live_map) live_map[cur.e] = 1;
             }
         }
         PH_MARK(6);    // record sums + stores
@@ -686,9 +692,15 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
 }
 PH(extern "C" void bags_diag_phases(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 8); })
 
+// BagsBackwardArgs.dense_per_tile: 0 = the default above, < 0 = never, > 0 = that threshold (the robustness tests force both paths)
+bool bwd_dense_mode(long long n_records, int T, int dense_per_tile_arg)
+{
+    const long long thr = dense_per_tile_arg == 0 ? BWD_DENSE_PER_TILE : dense_per_tile_arg;
+    return thr > 0 && n_records > thr * (long long)T;
+}
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
                             const float* grad_color, float* partials, bool want_abs, bool binned, hipStream_t st,
-                            long long n_records, int prezero_per_tile_arg)
+                            long long n_records, int dense_per_tile_arg, unsigned char* live_map)
 {
     const int gx = cdiv(s.image_width, BAGS_TILE), gy = cdiv(s.image_height, BAGS_TILE);
     const int T = gx * gy;
@@ -697,15 +709,13 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     const bool compact = binned && s.tile_bounds != BAGS_TILES_OPACITY;
     // Dense scenes (long tile lists, most of each list behind the deepest contributor): clearing the record array with one
     // streaming memset is cheaper than the per-tile zero loops, which gather an id and two geometry lines per dead instance.
-    // (BagsBackwardArgs.prezero_per_tile: 0 = the default above, < 0 = never, > 0 = that threshold -- the robustness tests force both paths)
-    const long long prezero_per_tile = prezero_per_tile_arg == 0 ? BWD_PREZERO_PER_TILE : prezero_per_tile_arg;
-    const int skip_zero = (prezero_per_tile > 0 && n_records > prezero_per_tile * (long long)T) ? 1 : 0;
-    if (skip_zero) { hipError_t e = hipMemsetAsync(partials, 0, (size_t)n_records * PART_FLOATS * sizeof(float), st); if (e != hipSuccess) return e; }
+    if (!bwd_dense_mode(n_records, T, dense_per_tile_arg)) live_map = nullptr;
+    if (live_map) { hipError_t e = hipMemsetAsync(live_map, 0, (size_t)n_records, st); if (e != hipSuccess) return e; }
 #define BWD_LAUNCH(ABS_, CMP_)                                                                                                       \
     hipLaunchKernelGGL((blend_bwd_scan_kernel<ABS_, CMP_>), dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,     \
                        im.tile_desc, b.point_list, reinterpret_cast<const unsigned char*>(b.reach_mask), binned ? 8u : 2u, g.g2d,    \
                        binned ? nullptr : g.inst_off, g.block_base, s.bg, im.final_T, im.n_contrib, grad_color, partials, \
-                       compact ? 1 : 0, im.tile_aux, skip_zero)
+                       compact ? 1 : 0, im.tile_aux, live_map)
     if (want_abs) { if (compact) BWD_LAUNCH(true, true); else BWD_LAUNCH(true, false); }
     else          { if (compact) BWD_LAUNCH(false, true); else BWD_LAUNCH(false, false); }
 #undef BWD_LAUNCH
@@ -781,6 +791,10 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
         const WordSrc src = tile_words(words_in, desc.y, depth_key);
         if (n == 1) { if (tid == 0) point_list[desc.y] = src.ids[desc.y]; }
         else if (n <= TSORT_WAVE) { if (wave == 0) sort_wave_role(desc, src, point_list, t_all, cnt_all); }
+        // (Round 5 ran the second level of the long-list sort LAZILY -- a slab sorted only when the walk was about to stage it, four
+        // at a time, the unsorted rest of a dense tile's list copied out as it lay -- and dropped it: the pixel state is live across
+        // that sort, the kernel went to 84 bytes of scratch per lane at its 80 VGPRs, and blend_fwd got 14 % slower on EVERY scene
+        // (0.1505 -> 0.1715 ms on the headline) for ~0.05 ms saved at 1800+ entries per tile: profiles/r05/ab_dense.txt.)
         else sort_list_block(desc, src, sort_scratch, point_list, t_all, cnt_all, *reinterpret_cast<TileSortLds*>(lds_raw + LDS_TS_L));
         // the ids were stored by this workgroup and are loaded by it below (at agent scope: a line of the neighbouring tile's
         // slice may sit in this CU's L1 with our first ids still unsorted in it)

@@ -42,11 +42,46 @@ __device__ __forceinline__ float wave_sum(float x)
 #define SUM_COOP 64
 #define RQ (PART_FLOATS / 4)          // float4s per record
 // The summation itself (whole wave: every lane calls it, lanes without a Gaussian with nrec = 0).
-__device__ __forceinline__ void sum_records(u32 nrec, u32 first, const float* __restrict__ partials, float4& s0, float4& s1, float4& s2)
+// LIVE (dense-scene mode, BagsBackwardArgs.dense_per_tile): live[e] != 0 iff blend_bwd wrote record e; the others -- instances behind
+// their tile's deepest contributor, 85 % of them at 1800 instances per tile -- hold whatever the buffer held before and are not
+// read.  The live ones are added in the same (slot) order as without the map, so the sums are the same bit for bit: the records
+// skipped are the ones that were zeros.
+template <bool LIVE>
+__device__ __forceinline__ void sum_records(u32 nrec, u32 first, const float* __restrict__ partials, const unsigned char* __restrict__ live,
+                                            float4& s0, float4& s1, float4& s2)
 {
     const int lane = threadIdx.x & 63;
     s0 = make_float4(0.f, 0.f, 0.f, 0.f); s1 = s0; s2 = s0;
-    if (nrec > 0 && nrec <= SUM_COOP) {
+    if (LIVE && nrec > 0 && nrec <= SUM_COOP) {
+        // the Gaussian's <= 64 marks first (consecutive bytes, all requested before the first is looked at), then its live records two
+        // at a time as below
+        u64 lm = 0ull;
+        const unsigned char* lp = live + first;
+        for (u32 r = 0; r < nrec; r += 8) {
+            u32 b[8];
+#pragma unroll
+            for (u32 u = 0; u < 8; ++u) b[u] = lp[min(r + u, nrec - 1)];
+#pragma unroll
+            for (u32 u = 0; u < 8; ++u) lm |= (u64)((b[u] != 0u && r + u < nrec) ? 1u : 0u) << (r + u);
+        }
+        const float4* rec = reinterpret_cast<const float4*>(partials + (size_t)first * PART_FLOATS);
+        while (lm) {
+            const u32 r = (u32)__builtin_ctzll(lm); lm &= lm - 1ull;
+            const bool two = lm != 0ull;
+            const u32 r1 = two ? (u32)__builtin_ctzll(lm) : r; if (two) lm &= lm - 1ull;
+            const float4 a0 = rec[RQ * r], b0 = rec[RQ * r + 1], c0 = rec[RQ * r + 2];
+            const float4 a1 = rec[RQ * r1], b1 = rec[RQ * r1 + 1], c1 = rec[RQ * r1 + 2];
+            s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+            s1.x += b0.x; s1.y += b0.y; s1.z += b0.z; s1.w += b0.w;
+            s2.x += c0.x; s2.y += c0.y; s2.z += c0.z;
+            if (two) {
+                s0.x += a1.x; s0.y += a1.y; s0.z += a1.z; s0.w += a1.w;
+                s1.x += b1.x; s1.y += b1.y; s1.z += b1.z; s1.w += b1.w;
+                s2.x += c1.x; s2.y += c1.y; s2.z += c1.z;
+            }
+        }
+    }
+    if (!LIVE && nrec > 0 && nrec <= SUM_COOP) {
         const float4* rec = reinterpret_cast<const float4*>(partials + (size_t)first * PART_FLOATS);
         u32 r = 0;
         for (; r + 1 < nrec; r += 2) {
@@ -76,6 +111,7 @@ __device__ __forceinline__ void sum_records(u32 nrec, u32 first, const float* __
 #pragma unroll
         for (int t = 0; t < 11; ++t) v[t] = 0.f;
         for (u32 r = lane; r < bn; r += 64) {
+            if (LIVE && live[bf + r] == 0) continue;
             const float4 a0 = rec[RQ * r], b0 = rec[RQ * r + 1], c0 = rec[RQ * r + 2];
             v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += b0.x; v[5] += b0.y; v[6] += b0.z; v[7] += b0.w;
             v[8] += c0.x; v[9] += c0.y; v[10] += c0.z;
@@ -125,7 +161,7 @@ __device__ __forceinline__ void pose_write_out(const int t, const float val, flo
 
 // ACCUM (BagsBackwardArgs.accumulate): the seven Gaussian-parameter gradients are ADDED to what their buffers hold (several
 // views of one step accumulate in place: no separate add pass per view); means2D / densify / pose outputs are overwritten.
-template <bool COV3D, bool ACCUM>   // COV3D: precomputed 3D covariances instead of scales + rotations (uniform: no branch at the top)
+template <bool COV3D, bool ACCUM, bool LIVE>   // COV3D: precomputed 3D covariances instead of scales + rotations (uniform: no branch at the top)
 __global__ void __launch_bounds__(256, PRE_BWD_WAVES)
 preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod, int clamp_stock, int conic_stock,
                       const float* __restrict__ means3D, const float* __restrict__ shift_factors,
@@ -137,7 +173,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                       const float* __restrict__ opacities,
                       const u32* __restrict__ tiles_touched, const u32* __restrict__ inst_off, const u32* __restrict__ local_off,
                       const u32* __restrict__ block_base, int per_block, const float* __restrict__ shjac,
-                      const float* __restrict__ partials, float* __restrict__ pose_slab,
+                      const float* __restrict__ partials, const unsigned char* __restrict__ live_map, float* __restrict__ pose_slab,
                       float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_densify,
                       float* __restrict__ g_shs, float* __restrict__ g_shs_rest, float* __restrict__ g_colors, float* __restrict__ g_opac,
                       float* __restrict__ g_scales, float* __restrict__ g_rot, float* __restrict__ g_cov3D)
@@ -200,7 +236,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
     // the Gaussian's records (blend_bwd's, `partials` is the record array) summed here, with every other input in flight
     float4 sm_a, sm_b, sm_c;
     __builtin_amdgcn_sched_barrier(0);
-    sum_records(i < P ? n_inst : 0u, first_rec, partials, sm_a, sm_b, sm_c);
+    sum_records<LIVE>(i < P ? n_inst : 0u, first_rec, partials, live_map, sm_a, sm_b, sm_c);
     // every one of those loads is IN FLIGHT before the first of them is waited for (the compiler otherwise sinks the ones only
     // the visible branch needs behind the visibility test: one more round trip per group)
     asm volatile("" :: "v"(opac), "v"(n_inst), "v"(mj[9]), "v"(x), "v"(y), "v"(z), "v"(in_s0), "v"(in_s1), "v"(in_s2), "v"(in_q.x), "v"(in_c[0]),
@@ -586,30 +622,48 @@ pose_reduce_kernel(const float* __restrict__ slab, int nblocks, float* __restric
 
 hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, const int32_t*,
                                  const float* partials_records, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a,
-                                 hipStream_t st, bool binned)
+                                 hipStream_t st, bool binned, const unsigned char* live_map)
 {
     const int P = in.P;
     const int nb = cdiv(P, 256);
     *nblocks_out = nb;
     if (P == 0) return hipSuccess;
     const float* partials = partials_records;
-#define PRE_BWD_LAUNCH(COV)     hipLaunchKernelGGL((preprocess_bwd_kernel<COV, ACC_>), dim3(nb), dim3(256), 0, st, P, s.sh_coeffs, s.sh_degree, s.image_width, \
+#define PRE_BWD_LAUNCH(COV)     hipLaunchKernelGGL((preprocess_bwd_kernel<COV, ACC_, LIVE_>), dim3(nb), dim3(256), 0, st, P, s.sh_coeffs, s.sh_degree, s.image_width, \
                        s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, (s.clamp_grad == BAGS_CLAMP_GRAD_EXACT) ? 0 : 1, \
                        (s.conic_grad == BAGS_CONIC_GRAD_EXACT) ? 0 : 1, in.means3D, in.shift_factors, in.shs, \
                        in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, s.viewmatrix, s.projmatrix, \
                        s.intrinsic, s.campos, in.opacities, g.rec_count, binned ? nullptr : g.inst_off, g.local_off, g.block_base, \
-                       binned_per_block(P), g.shjac, partials, \
+                       binned_per_block(P), g.shjac, partials, live_map, \
                        pose_slab, a.grad_means3D, a.grad_means2D, a.grad_means2D_densify, a.grad_shs, in.shs_rest ? a.grad_shs_rest : nullptr, \
                        a.grad_colors_precomp, a.grad_opacities, a.grad_scales, a.grad_rotations, a.grad_cov3D_precomp);
-    if (a.accumulate) {
+#define PRE_BWD_PICK if (in.cov3D_precomp) { PRE_BWD_LAUNCH(true) } else { PRE_BWD_LAUNCH(false) }
+    if (live_map) {
+#define LIVE_ true
+        if (a.accumulate) {
 #define ACC_ true
-        if (in.cov3D_precomp) { PRE_BWD_LAUNCH(true) } else { PRE_BWD_LAUNCH(false) }
+            PRE_BWD_PICK
 #undef ACC_
-    } else {
+        } else {
 #define ACC_ false
-        if (in.cov3D_precomp) { PRE_BWD_LAUNCH(true) } else { PRE_BWD_LAUNCH(false) }
+            PRE_BWD_PICK
 #undef ACC_
+        }
+#undef LIVE_
+    } else {
+#define LIVE_ false
+        if (a.accumulate) {
+#define ACC_ true
+            PRE_BWD_PICK
+#undef ACC_
+        } else {
+#define ACC_ false
+            PRE_BWD_PICK
+#undef ACC_
+        }
+#undef LIVE_
     }
+#undef PRE_BWD_PICK
 #undef PRE_BWD_LAUNCH
     return hipGetLastError();
 }

@@ -281,90 +281,87 @@ __device__ __forceinline__ void for_each_word_256(const WordSrc words_in, const 
             if (base + 256u * j < n) f(((u64)key[j] << 32) | (u64)id[j]);
     }
 }
-// One list of more than TSORT_WAVE entries, by a whole 256-thread workgroup (every thread calls it).
-__device__ __forceinline__ void sort_list_block(const uint4 desc, const WordSrc words_in, u64* __restrict__ scratch,
-                                                u32* __restrict__ point_list, u64* t_all, u32* cnt_all, TileSortLds& L)
+// ---- the two-level sort of a list of TSORT_BLOCK < n <= TSORT_LARGE entries, one function per level.  (Round 5 ran level 2 lazily
+// from blend_fwd -- a dense tile's walk ends after a fraction of its list and nothing behind the tile's deepest contributor needs an
+// ORDER -- and measured it slower: blend.hip, profiles/r05/ab_dense.txt.)
+// Level 1 (every thread of the workgroup calls it): key range, slab of every entry, slab starts, the (key, id) words grouped by slab
+// in the global scratch array (order inside a slab arbitrary).  Returns the number of slabs K, or 0 if the list has to take the
+// network instead (a slab outgrows a wave: very uneven depths).  Ends on a barrier; L.slab_start[0..K] stays valid afterwards.
+__device__ __forceinline__ u32 slab_prepare(const u32 n, const u32 start, const WordSrc words_in, u64* __restrict__ scratch, TileSortLds& L)
 {
     u32* const s_red = L.s_red; u32* const slab_cnt = L.slab_cnt; u32* const slab_start = L.slab_start;
     u32& s_next = L.s_next; u32& s_bad = L.s_bad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u32 n = desc.z, start = desc.y;
-    if (n <= TSORT_WAVE) return;                             // (the one-wave sort's sizes: sort_wave_role)
-    if (n <= TSORT_BLOCK) { sort_one_block<TSORT_BLOCK / 256>(n, start, words_in, point_list, t_all, cnt_all, s_red); return; }
-    bool network = n > TSORT_LARGE;
-    if (!network) {
-        // ---- level 1: key range, slab of every entry, slab counts
-        const u32 K = min((u32)TS_SLABS_MAX, (n + TSORT_WAVE / 2 - 1) / (TSORT_WAVE / 2));
-        u32 kmin = 0xFFFFFFFFu, kmax = 0u;
-        for_each_word_256(words_in, start, n, (u32)tid, [&](const u64 w) { const u32 key = (u32)(w >> 32); kmin = min(kmin, key); kmax = max(kmax, key); });
-        kmin = wave_min(kmin); kmax = wave_max(kmax);
-        __syncthreads();                                  // the previous list's state is no longer in use
-        if (lane == 0) { s_red[wave] = kmin; s_red[4 + wave] = kmax; }
-        for (u32 i = tid; i <= TS_SLABS_MAX; i += 256) slab_cnt[i] = 0u;
-        if (tid == 0) { s_next = 0u; s_bad = 0u; }
-        __syncthreads();
-        kmin = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
-        kmax = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
-        const float scale = (float)K / ((float)(kmax - kmin) + 1.0f);
-        for_each_word_256(words_in, start, n, (u32)tid, [&](const u64 w) {
-            atomicAdd(&slab_cnt[min(K - 1, (u32)((float)((u32)(w >> 32) - kmin) * scale))], 1u);
-        });
-        __syncthreads();
-        if (tid == 0) {
-            u32 run = 0, bad = 0;
-            for (u32 k = 0; k < K; ++k) { slab_start[k] = run; run += slab_cnt[k]; bad |= (slab_cnt[k] > TSORT_WAVE) ? 1u : 0u; slab_cnt[k] = 0u; }
-            slab_start[K] = run; s_bad = bad;
-        }
-        __syncthreads();
-        network = s_bad != 0u;
-        if (!network) {
-            // ---- words grouped by slab in the scratch array (order inside a slab arbitrary)
-            for_each_word_256(words_in, start, n, (u32)tid, [&](const u64 w) {
-                const u32 k = min(K - 1, (u32)((float)((u32)(w >> 32) - kmin) * scale));
-                scratch[start + slab_start[k] + atomicAdd(&slab_cnt[k], 1u)] = w;
-            });
-            // The words are read back by OTHER WAVES OF THIS WORKGROUP only: same CU, same L1 (write-through), same L2, and the
-            // reads below go to the L2 (agent-scope loads).  Completed stores + a workgroup-scope fence are enough.  Until the end
-            // of round 4 this was __threadfence(): an agent-scope fence, i.e. `buffer_wbl2` -- a write-back of the whole L2's
-            // dirty lines by every long-list workgroup (lists just above 2048 entries sorted 15 x slower per entry than lists
-            // just below, tools/ubench/sort_rate.hip; blend_fwd 1.07 ms at sm 2.0).
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __syncthreads();
-            // ---- level 2: a wave per slab
-            for (;;) {
-                u32 k = 0;
-                if (lane == 0) k = atomicAdd(&s_next, 1u);
-                k = (u32)__builtin_amdgcn_readfirstlane((int)k);
-                if (k >= K) break;
-                const u32 s0 = slab_start[k], m = slab_start[k + 1] - s0;
-                // An empty slab is skipped; a one-entry slab takes the general path.  Until round 4 both were early exits -- `return`
-                // for the wave, so that with depth-clustered lists every wave could leave on an empty slab before the last slabs
-                // were drawn and their part of point_list kept whatever the buffer held before (found by tools/soak.py: a camera
-                // drifted into the scene), and, once that was a `continue`, the one-entry special case `if (m == 1) { if (lane
-                // == 0) store; continue; }` came out of the compiler re-sorting slab 0 with an entry missing
-                // (tools/ubench/sort_slabs.hip).  No `continue`, no special case:
-                if (m != 0) {
-                    u64 e[TS_PER];
-                    u32 lo = 0xFFFFFFFFu, hi = 0u;
-#pragma unroll
-                    for (u32 r = 0; r < TS_PER; ++r) {
-                        // written by other waves of this workgroup just above: read at agent scope (L2)
-                        const u64 raw = __hip_atomic_load(&scratch[start + s0 + min(r * 64 + (u32)lane, m - 1)],
-                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const u32 wkey = (u32)(raw >> 32);
-                        const bool valid = r * 64 + lane < m;
-                        e[r] = valid ? raw : ~0ull;
-                        lo = min(lo, valid ? wkey : 0xFFFFFFFFu); hi = max(hi, valid ? wkey : 0u);
-                    }
-                    wave_sort_words<TS_PER>(e, m, wave_min(lo), wave_max(hi), point_list + start + s0, t_all + wave * TSORT_WAVE,
-                                            cnt_all + wave * (TSORT_WAVE / 2));
-                }
-            }
-            return;
-        }
+    const u32 K = min((u32)TS_SLABS_MAX, (n + TSORT_WAVE / 2 - 1) / (TSORT_WAVE / 2));
+    u32 kmin = 0xFFFFFFFFu, kmax = 0u;
+    for_each_word_256(words_in, start, n, (u32)tid, [&](const u64 w) { const u32 key = (u32)(w >> 32); kmin = min(kmin, key); kmax = max(kmax, key); });
+    kmin = wave_min(kmin); kmax = wave_max(kmax);
+    __syncthreads();                                  // the previous list's state is no longer in use
+    if (lane == 0) { s_red[wave] = kmin; s_red[4 + wave] = kmax; }
+    for (u32 i = tid; i <= TS_SLABS_MAX; i += 256) slab_cnt[i] = 0u;
+    if (tid == 0) { s_next = 0u; s_bad = 0u; }
+    __syncthreads();
+    kmin = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+    kmax = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+    const float scale = (float)K / ((float)(kmax - kmin) + 1.0f);
+    for_each_word_256(words_in, start, n, (u32)tid, [&](const u64 w) {
+        atomicAdd(&slab_cnt[min(K - 1, (u32)((float)((u32)(w >> 32) - kmin) * scale))], 1u);
+    });
+    __syncthreads();
+    if (tid == 0) {
+        u32 run = 0, bad = 0;
+        for (u32 k = 0; k < K; ++k) { slab_start[k] = run; run += slab_cnt[k]; bad |= (slab_cnt[k] > TSORT_WAVE) ? 1u : 0u; slab_cnt[k] = 0u; }
+        slab_start[K] = run; s_bad = bad;
     }
-    // ---- the network in global memory
+    __syncthreads();
+    if (s_bad != 0u) return 0u;
+    // ---- words grouped by slab in the scratch array (order inside a slab arbitrary)
+    for_each_word_256(words_in, start, n, (u32)tid, [&](const u64 w) {
+        const u32 k = min(K - 1, (u32)((float)((u32)(w >> 32) - kmin) * scale));
+        scratch[start + slab_start[k] + atomicAdd(&slab_cnt[k], 1u)] = w;
+    });
+    // The words are read back by OTHER WAVES OF THIS WORKGROUP only: same CU, same L1 (write-through), same L2, and the
+    // reads of level 2 go to the L2 (agent-scope loads).  Completed stores + a workgroup-scope fence are enough.  Until the end
+    // of round 4 this was __threadfence(): an agent-scope fence, i.e. `buffer_wbl2` -- a write-back of the whole L2's
+    // dirty lines by every long-list workgroup (lists just above 2048 entries sorted 15 x slower per entry than lists
+    // just below, tools/ubench/sort_rate.hip; blend_fwd 1.07 ms at sm 2.0).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    return K;
+}
+// Level 2, ONE slab by ONE wave (t / cnt: this wave's TSORT_WAVE words and TSORT_WAVE / 2 counter words of LDS).  An empty slab is
+// skipped; a one-entry slab takes the general path.  Until round 4 both were early exits -- `return` for the wave, so that with
+// depth-clustered lists every wave could leave on an empty slab before the last slabs were drawn and their part of point_list kept
+// whatever the buffer held before (found by tools/soak.py: a camera drifted into the scene), and, once that was a `continue`,
+// the one-entry special case `if (m == 1) { if (lane == 0) store; continue; }` came out of the compiler re-sorting slab 0 with an
+// entry missing (tools/ubench/sort_slabs.hip).  No early exit, no special case:
+__device__ __forceinline__ void slab_sort_wave(const u32 k, const u32 start, const u64* __restrict__ scratch, u32* __restrict__ point_list,
+                                               u64* t, u32* cnt, const TileSortLds& L)
+{
+    const int lane = threadIdx.x & 63;
+    const u32 s0 = L.slab_start[k], m = L.slab_start[k + 1] - s0;
+    if (m != 0) {
+        u64 e[TS_PER];
+        u32 lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+        for (u32 r = 0; r < TS_PER; ++r) {
+            // written by other waves of this workgroup in level 1: read at agent scope (L2)
+            const u64 raw = __hip_atomic_load(&scratch[start + s0 + min(r * 64 + (u32)lane, m - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u32 wkey = (u32)(raw >> 32);
+            const bool valid = r * 64 + lane < m;
+            e[r] = valid ? raw : ~0ull;
+            lo = min(lo, valid ? wkey : 0xFFFFFFFFu); hi = max(hi, valid ? wkey : 0u);
+        }
+        wave_sort_words<TS_PER>(e, m, wave_min(lo), wave_max(hi), point_list + start + s0, t, cnt);
+    }
+}
+// The bitonic network in global memory (more than TSORT_LARGE entries, or the fallback of the two-level sort): loads and stores at
+// agent scope so that the waves of the workgroup see each other's exchanges across the barriers.
+__device__ __forceinline__ void sort_list_network(const u32 n, const u32 start, const WordSrc words_in, u64* __restrict__ scratch,
+                                                  u32* __restrict__ point_list)
+{
+    const int tid = threadIdx.x;
     u32 N = 2; while (N < n) N <<= 1;
     __syncthreads();
     for (u32 i = tid; i < n; i += 256) scratch[start + i] = words_in[start + i];
@@ -393,4 +390,22 @@ __device__ __forceinline__ void sort_list_block(const uint4 desc, const WordSrc 
         }
     }
     for (u32 i = tid; i < n; i += 256) point_list[start + i] = (u32)ld(i);
+}
+// One list of more than TSORT_WAVE entries, sorted completely, by a whole 256-thread workgroup (every thread calls it).
+__device__ __forceinline__ void sort_list_block(const uint4 desc, const WordSrc words_in, u64* __restrict__ scratch,
+                                                u32* __restrict__ point_list, u64* t_all, u32* cnt_all, TileSortLds& L)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 n = desc.z, start = desc.y;
+    if (n <= TSORT_WAVE) return;                             // (the one-wave sort's sizes: sort_wave_role)
+    if (n <= TSORT_BLOCK) { sort_one_block<TSORT_BLOCK / 256>(n, start, words_in, point_list, t_all, cnt_all, L.s_red); return; }
+    const u32 K = (n > TSORT_LARGE) ? 0u : slab_prepare(n, start, words_in, scratch, L);
+    if (K == 0u) { sort_list_network(n, start, words_in, scratch, point_list); return; }
+    for (;;) {                                               // a wave per slab, drawn from a counter
+        u32 k = 0;
+        if (lane == 0) k = atomicAdd(&L.s_next, 1u);
+        k = (u32)__builtin_amdgcn_readfirstlane((int)k);
+        if (k >= K) break;
+        slab_sort_wave(k, start, scratch, point_list, t_all + wave * TSORT_WAVE, cnt_all + wave * (TSORT_WAVE / 2), L);
+    }
 }

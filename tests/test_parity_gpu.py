@@ -890,6 +890,36 @@ def test_slab_sort_with_empty_and_single_entry_slabs(N, bands):
                 assert torch.equal(g_a[k], g_r[k]), k
 
 
+def test_dense_scene_against_oracle(monkeypatch):
+    """A dense scene: sm 3.0, thousands of instances per tile (the longest list well above 3000: the two-level slab sort), every
+    pixel saturated long before its list ends, so that most instances lie behind their tile's deepest contributor.  The backward
+    then runs in dense-scene mode (a byte per gradient record; blend_bwd writes no zero records, preprocess_bwd reads none:
+    BagsBackwardArgs.dense_per_tile).  Lists, ranges and n_contrib bit-exact against the oracle, gradients to the ordinary bars --
+    and bit-identical between the two modes of the backward (the records one of them skips are the zeros of the other)."""
+    from bags_raster import rasterizer as R
+    scene, cam = make_case(20000, 128, 96, 3.0, 2, seed=33)
+    monkeypatch.setattr(R, "DENSE_PER_TILE", 0)               # library default: on for this scene
+    rep = compare(scene, cam, 2, check_fp64=False)
+    _report({k: rep[k] for k in ("num_rendered", "image_max_err", "n_contrib_mismatch_frac", "grad_rel_fp32")})
+    assert rep["num_rendered"][0] > 600 * 48, rep["num_rendered"]          # above the default threshold of the dense mode
+    assert_report(rep, grad_tol=2e-4)
+    g = torch.randn(3, 96, 128, generator=torch.Generator().manual_seed(4))
+    o_d, g_d, v_d = run_hip(scene, cam, 2, g)
+    lens = v_d["ranges"][:, 1] - v_d["ranges"][:, 0]
+    assert int(lens.max()) >= 3000, int(lens.max())
+    took = tile_sort_paths(v_d["keys_sorted"], v_d["ranges"])
+    assert any(k.startswith("slabs") for k in took), took
+    per_pixel_len = lens.view(6, 8)[torch.arange(96)[:, None] // 16, torch.arange(128)[None, :] // 16]
+    assert float((v_d["n_contrib"] < per_pixel_len // 2).float().mean()) > 0.8       # the walks end in the first half of their lists (0.89)
+    monkeypatch.setattr(R, "DENSE_PER_TILE", -1)              # never: zero records written and read
+    o_z, g_z, v_z = run_hip(scene, cam, 2, g)
+    for a, b in zip(o_d, o_z):
+        assert torch.equal(a, b)
+    for k in g_d:
+        if g_d[k] is not None:
+            assert torch.equal(g_d[k], g_z[k]), k
+
+
 def test_conic_backward_semantic():
     """Decision D9.  DEFAULT conic_grad="stock": upstream computeCov2DCUDA's backward of the 2x2 inverse divides by det^2 + 1e-7
     (the reference's fork inherits it, README.md:126); "exact" divides by det^2 (rounds 1-4).  A scene of small splats (det near

@@ -38,8 +38,11 @@ def test_short_fuzz_of_the_two_list_builders():
 
 
 @pytest.mark.timeout(900)
-def test_memset_zero_records_match_the_oracle():
-    """Dense scenes take blend_bwd's zero records from one memset of the record array (blend.hip, BWD_PREZERO_PER_TILE /
-    BagsBackwardArgs.prezero_per_tile); the threshold is forced down here so that every trial takes that path, and the gradients are checked against the CPU oracle."""
-    out = _run("fuzz_paths.py", "--trials", "10", "--seed", "11", "--oracle", "--prezero", "1")
+@pytest.mark.parametrize("dense", ["1", "-1"])
+def test_both_modes_of_the_backward_match_the_oracle(dense):
+    """Dense scenes run the backward with a byte per gradient record (blend_bwd marks what it writes, preprocess_bwd sums only
+    that) instead of zero records for the instances behind a tile's deepest contributor (blend.hip, BWD_DENSE_PER_TILE /
+    BagsBackwardArgs.dense_per_tile).  The threshold is forced down (1) so that every trial takes that mode, then up (-1) so that
+    none does; gradients against the CPU oracle either way."""
+    out = _run("fuzz_paths.py", "--trials", "10", "--seed", "11", "--oracle", "--dense", dense)
     assert out["trials"] == 10 and out["failures"] == [], out["failures"]

@@ -20,11 +20,11 @@ def main():
     ap.add_argument("--oracle", action="store_true", help="small scenes (<= 2500 Gaussians, <= 160 x 120) against the CPU oracle instead "
                                                           "of the radix path: integer artefacts bit for bit, floats by the parity tolerances")
     ap.add_argument("--long", action="store_true", help="bias towards long tile lists: 3000 .. 60000 Gaussians in compact scenes")
-    ap.add_argument("--prezero", type=int, default=0, help="BagsBackwardArgs.prezero_per_tile (instances per tile above which blend_bwd's "
-                                                           "zero records come from one memset; 1 forces that path, -1 the per-tile loops)")
+    ap.add_argument("--dense", type=int, default=0, help="BagsBackwardArgs.dense_per_tile (instances per tile above which the backward "
+                                                         "keeps a byte per record instead of zero records; 1 forces that mode, -1 the other)")
     args = ap.parse_args()
     from bags_raster import rasterizer as _R
-    _R.PREZERO_PER_TILE = args.prezero
+    _R.DENSE_PER_TILE = args.dense
     rng = torch.Generator().manual_seed(args.seed)
     U = lambda a, b: float(torch.empty(1).uniform_(a, b, generator=rng))
     I = lambda a, b: int(torch.randint(a, b, (1,), generator=rng))
