@@ -37,7 +37,7 @@
 #define PRIO_SERIAL 3         // backward: wave priority in the serial section between a chunk's two barriers ...
 #define PRIO_GROUPS 0         // ... and in its list-building / scan phase (0/0, 1/0, 3/1 measured: flat)
 #define PQ 3                  // float4s per pixel pair in the backward's LDS image (below)
-#define BWD_DENSE_PER_TILE 600          // instances per tile (scene average) above which the backward runs in dense-scene mode: a byte per
+#define BWD_DENSE_PER_TILE 480          // instances per tile (scene average) above which the backward runs in dense-scene mode: a byte per
                                         // record says whether blend_bwd wrote it, nobody writes or reads a zero record
                                         // (BagsBackwardArgs.dense_per_tile overrides it; profiles/r05/ab_dense.txt)
 struct __attribute__((aligned(16))) SplatRec {

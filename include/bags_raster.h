@@ -146,7 +146,7 @@ typedef struct BagsBackwardArgs {
     /* Dense-scene mode of the backward.  blend_bwd writes one 48-byte record per instance and preprocess_bwd sums each Gaussian's
      * records; an instance behind its tile's deepest contributor holds a ZERO record.  Above this many instances per tile (scene
      * average) a byte per record says whether blend_bwd wrote it: no zero record is written or read (at 1800 instances per tile
-     * 85 % of them are).  0 = the library's default (600; profiles/r05/ab_dense.txt), < 0 = never, > 0 = that threshold.  Results
+     * 85 % of them are).  0 = the library's default (480; profiles/r05/ab_dense.txt), < 0 = never, > 0 = that threshold.  Results
      * do not depend on it (ABI 8; the field was reserved1 = 0 before, and rounds 3-4 read an environment variable here). */
     int32_t dense_per_tile;
     float* grad_shs_rest;            /* (P,M-1,3), with inputs.shs_rest: grad_shs is then the (P,1,3) gradient of features_dc (ABI 7) */
