@@ -292,7 +292,8 @@ __device__ __forceinline__ K1Result k1_project(const K1Args& A, const CamConst& 
                                 const float4* s4 = reinterpret_cast<const float4*>(dcp);
 #pragma unroll
                                 for (int t = 0; t < 12; ++t) {
-                                    float4 w = s4[t];
+                                    float4 w = s4[t];      // (non-temporal loads here: K1 58 -> 93 us, profiles/r05/ab_k1.txt -- a lane's twelve
+                                                           //  16-byte pieces share 128-byte lines, and the lines have to stay cached between them)
                                     c[4 * t] = w.x; c[4 * t + 1] = w.y; c[4 * t + 2] = w.z; c[4 * t + 3] = w.w;
                                 }
                             }
