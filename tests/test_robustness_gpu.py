@@ -27,7 +27,8 @@ def test_short_soak_with_growing_splats_and_drifting_poses():
 
 @pytest.mark.timeout(900)
 def test_short_fuzz_of_the_two_list_builders():
-    out = _run("fuzz_paths.py", "--trials", "30", "--seed", "3", "--long")
+    # (--cross-dense: the tile-binned run with a byte per gradient record, the radix run with zero records: still bit-identical)
+    out = _run("fuzz_paths.py", "--trials", "30", "--seed", "3", "--long", "--cross-dense")
     assert out["trials"] == 30 and out["failures"] == [], out["failures"]
     # every way through the per-tile sort (csrc/tile_sort.h) was taken by some list of the run: one wave (both sizes), the whole
     # workgroup, depth slabs, the global-memory network, and the LDS bitonic fallback for crowded buckets

@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--long", action="store_true", help="bias towards long tile lists: 3000 .. 60000 Gaussians in compact scenes")
     ap.add_argument("--dense", type=int, default=0, help="BagsBackwardArgs.dense_per_tile (instances per tile above which the backward "
                                                          "keeps a byte per record instead of zero records; 1 forces that mode, -1 the other)")
+    ap.add_argument("--cross-dense", action="store_true", help="differential runs only: the tile-binned run in dense-scene mode, the radix run "
+                                                               "without it -- the gradients must still be bit-identical")
     args = ap.parse_args()
     from bags_raster import rasterizer as _R
     _R.DENSE_PER_TILE = args.dense
@@ -70,7 +72,11 @@ def main():
                 bad.append(dict(tag, why=f"exception {type(e).__name__}"))
             continue
         try:
+            if args.cross_dense:
+                _R.DENSE_PER_TILE = 1
             o_a, g_a, v_a = run_hip(scene, cam, deg, g, binning="auto", **kw)
+            if args.cross_dense:
+                _R.DENSE_PER_TILE = -1
             o_r, g_r, v_r = run_hip(scene, cam, deg, g, binning="radix", **kw)
             why = None
             if v_a["num_rendered"] != v_r["num_rendered"]:
