@@ -472,10 +472,14 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         auto block_rows = [&](auto skip_nc_tag, auto skip_p_tag, const ChunkRec& s, const bool live, const float bx0, const float by0, float4* pixb, const bool carry) {
             constexpr bool SKIP_NC = decltype(skip_nc_tag)::value;
             constexpr bool SKIP_P = decltype(skip_p_tag)::value;
-            a0 = (f2){0.f, 0.f}; a1 = a0; a2 = a0; a6 = a0; a9 = a0; a10 = a0;
-            sa3 = sa4 = sa5 = sa7 = sa8 = 0.f;
             float pyf = by0;                                // the row's pixel y: integers, so the += 1 below is exact and dy is
                                                             // the forward's s.y - (float)py bit for bit
+            a0 = (f2){0.f, 0.f}; a1 = a0; a2 = a0; a6 = a0; a9 = a0; a10 = a0;
+            sa3 = sa4 = sa5 = sa7 = sa8 = 0.f;
+            // (Round 5, measured and not kept, profiles/r05/ab_blend_bwd.txt: peeling the first pixel row so that it STARTS the sums
+            // instead of adding to 17 zeroed registers, the sums folded into register pairs once per step instead of inside every
+            // read-modify-write phase, 24-bit instead of 32- / 64-bit multiplies for the slot addresses -- ~30 fewer vector
+            // instructions per 16-splat step, 0.3462 -> 0.3474 / 0.3480 ms: plain instructions are not what this kernel waits for.)
 #pragma unroll 1
             for (int iy = 0; iy < 4; ++iy) {
                 float4* P0 = pixb + iy * 2 * PQ;
@@ -963,10 +967,10 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
             }
 #endif
         };
-        // two steps per trip, no remainder: entry Lmax of every list is the sentinel (at most CHUNK - 1 real entries), and
-        // inline asm is `convergent`, which keeps the compiler from unrolling a loop with a run-time trip count by itself.
-        // The two list bytes of the NEXT trip are one 16-bit read at the top of this one; record address = byte * 48 (SDWA
-        // byte select, the factor in a scalar register).
+        // FOUR steps per trip, no remainder: entry Lmax of every list is the sentinel (at most CHUNK - 1 real entries, the lists are
+        // pre-filled with it), and inline asm is `convergent`, which keeps the compiler from unrolling a loop with a run-time trip
+        // count by itself.  The two list bytes of a step pair are one 16-bit read; record address = byte * 48 (SDWA byte select, the
+        // factor in a scalar register).
         const unsigned short* mypairs = reinterpret_cast<const unsigned short*>(mylist);
         auto addr2 = [&](u32 two, u32& ra, u32& rb) {
             asm("v_mul_u32_u24_sdwa %0, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n\t"
@@ -974,26 +978,42 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
                 : "=&v"(ra), "=v"(rb) : "v"(two), "s"(48u));
         };
         // Software pipeline over two register sets, no copies: a record is requested one step before it is composited (its
-        // three LDS reads land behind the other record's arithmetic), its address one trip before that.  Left to itself the
+        // three LDS reads land behind the other record's arithmetic), its address one step pair before that.  Left to itself the
         // compiler issued a step's third read after its exp and waited for it: two exposed LDS latencies per step, and
         // dropping that read (timing experiment) bought 9 % -- latency, not bandwidth.  sched_barrier pins the issue points.
+        // Round 5: two step pairs per trip.  A record's byte offset doubles as its "list position" (`pos`), so an address register
+        // stays live until its record has been composited; with one pair per trip the next pair's addresses therefore needed
+        // registers of their own and two v_mov per trip to rotate them (2 of 49 vector instructions).  Over two pairs the roles
+        // alternate and the rotation is a renaming.  (Reads run up to 9 entries past Lmax: the next list or the 16 bytes of padding.)
         u32 ra, rb;
         addr2((u32)mypairs[0], ra, rb);
         SplatW S0 = load(ra);
-        u32 two = (u32)mypairs[1];                           // entries 2, 3 (reads run up to 5 entries past Lmax: see the padding)
-        for (int i = 0; i < Lmax; i += 2) {
+        u32 two = (u32)mypairs[1];                           // entries 2, 3
+        for (int i = 0; i < Lmax; i += 4) {
             const SplatW S1 = load(rb);
             u32 ra2, rb2;
             addr2(two, ra2, rb2);
-            u32 nxt = (u32)mypairs[(i >> 1) + 2];
+            u32 nxt = (u32)mypairs[(i >> 1) + 2];            // entries i + 4, i + 5
             __builtin_amdgcn_sched_barrier(0);
             step(i, S0);
             __builtin_amdgcn_sched_barrier(0);
-            S0 = load(ra2);
+            const SplatW S2 = load(ra2);
             __builtin_amdgcn_sched_barrier(0);
             step(i + 1, S1);
             asm("" : "+v"(nxt));                             // (keeps the zero extension with the load, not behind the loop's phi)
-            two = nxt; rb = rb2;
+            __builtin_amdgcn_sched_barrier(0);
+            const SplatW S3 = load(rb2);
+            u32 ra3, rb3;
+            addr2(nxt, ra3, rb3);
+            u32 nxt2 = (u32)mypairs[(i >> 1) + 3];           // entries i + 6, i + 7
+            __builtin_amdgcn_sched_barrier(0);
+            step(i + 2, S2);
+            __builtin_amdgcn_sched_barrier(0);
+            S0 = load(ra3);
+            __builtin_amdgcn_sched_barrier(0);
+            step(i + 3, S3);
+            asm("" : "+v"(nxt2));
+            two = nxt2; rb = rb3;
         }
         // record offset -> slot (/ 48: x 43691 >> 21, exact below 2^17 slots) -> 1-based list position
         if (last_off != 0xFFFFFFFFu) last = base + ((last_off * 43691u) >> 21) + 1u;
