@@ -572,19 +572,45 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         };
         // the two halves of every packed accumulator are added ONCE per step (h*), outside the four row phases below: each
         // phase is issued for the whole wave although only one 16-lane row takes part in it
-        float4 h0, h1, h2;
-        auto fold_pairs = [&]() {
-            h0 = make_float4(a0.x + a0.y, a1.x + a1.y, a2.x + a2.y, sa3);
-            h1 = make_float4(sa4, sa5, a6.x + a6.y, sa7);
-            h2 = make_float4(sa8, a9.x + a9.y, a10.x + a10.y, 0.f);
+        // ---- a step's eleven sums into the wave's LDS copy (round 5: "rotating quarters").  One splat sits in several rows of a wave in the
+        // same step (it reaches ~2 blocks of the quadrant), so the rows cannot all read-modify-write their slots at once; until round 5
+        // they took turns -- four phases of 16 lanes, 3 + 3 wide LDS instructions each, and timing builds showed the twelve exec-masked
+        // stores alone at 9 % of the kernel (a ds_write_b128 holds its SIMD's operand path ~13 cycles whatever its exec mask).  Now a slot's
+        // record is four QUARTERS of three sums, and in phase p a lane of row r updates quarter (r + p) mod 4 of its slot: all four rows
+        // are active in every phase, two lanes that share a slot are never on the same quarter, and over the four phases every lane has
+        // added all of its sums.  Per step 4 x (ds_read_b64 + ds_read_b32) and 4 x (ds_write_b64 + ds_write_b32) with full lanes instead
+        // of 12 + 12 wide ones with a quarter of them.  A (slot, quarter) receives its rows' terms in phase order -- fixed, so the sums
+        // stay bitwise reproducible.  LDS record (12 floats): quarter q = {s[3q], s[3q+1]} at floats 2q, 2q+1 and s[3q+2] at float 8 + q
+        // (s = the eleven sums in the order of the gradient record, s[11] = 0): every piece aligned for its access, the write-out below
+        // still reads three float4s per copy and puts the sums back in record order.
+        float t0[4], t1[4], t2[4];                          // t_j[k] = s[3k + j]
+        auto fold_sums = [&]() {
+            t0[0] = a0.x + a0.y; t1[0] = a1.x + a1.y; t2[0] = a2.x + a2.y;
+            t0[1] = sa3;         t1[1] = sa4;         t2[1] = sa5;
+            t0[2] = a6.x + a6.y; t1[2] = sa7;         t2[2] = sa8;
+            t0[3] = a9.x + a9.y; t1[3] = a10.x + a10.y; t2[3] = 0.f;
+            // rotate by the lane's row: afterwards t_j[p] belongs to quarter (row + p) & 3 (two stages of selects per component)
+            const bool b0 = (row & 1) != 0, b1 = (row & 2) != 0;
+#define ROT4(t) { const float x0 = b0 ? t[1] : t[0], x1 = b0 ? t[2] : t[1], x2 = b0 ? t[3] : t[2], x3 = b0 ? t[0] : t[3];            \
+                  t[0] = b1 ? x2 : x0; t[1] = b1 ? x3 : x1; t[2] = b1 ? x0 : x2; t[3] = b1 ? x1 : x3; }
+            ROT4(t0) ROT4(t1) ROT4(t2)
+#undef ROT4
         };
-        auto add_to_copy = [&](const int slot) {      // plain read-modify-write of the wave's own copy
-            float4* d4 = reinterpret_cast<float4*>(&acc[wave][slot][0]);
-            float4 r0 = d4[0], r1 = d4[1], r2 = d4[2];
-            r0.x += h0.x; r0.y += h0.y; r0.z += h0.z; r0.w += h0.w;
-            r1.x += h1.x; r1.y += h1.y; r1.z += h1.z; r1.w += h1.w;
-            r2.x += h2.x; r2.y += h2.y; r2.z += h2.z;
-            d4[0] = r0; d4[1] = r1; d4[2] = r2;
+        char* const acc_wave = reinterpret_cast<char*>(&acc[wave][0][0]);
+        auto add_to_copy = [&](const int slot) {      // (every live lane calls it: no row takes turns any more)
+            char* const base = acc_wave + __umul24((u32)slot, 48u);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const u32 q = (u32)(row + p) & 3u;
+                float2* const pq = reinterpret_cast<float2*>(base + 8u * q);
+                float* const ps = reinterpret_cast<float*>(base + 32u + 4u * q);
+                float2 v = *pq; float w = *ps;
+                v.x += t0[p]; v.y += t1[p]; w += t2[p];
+                *pq = v; *ps = w;
+                // another LANE's next phase may read what this phase wrote (same slot in another row): the hardware keeps a wave's LDS
+                // accesses in program order, the compiler must too (to it the two addresses belong to different quarters of one record)
+                asm volatile("" ::: "memory");
+            }
         };
         u32 mreg[(BCHUNK + 63) / 64];
 #pragma unroll
@@ -636,10 +662,8 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
             else block_rows(std::false_type{}, std::false_type{}, s, live, bx0, by0, pixb, cry);
             DG(dg_ent += live ? 1u : 0u; dg_ent0 += (live && dg_con == dg_before) ? 1u : 0u; dg_steps += (lane == 0) ? 1u : 0u;)
             // the same splat can sit in several rows (it reaches several blocks of the quadrant): one row at a time
-            fold_pairs();
-#pragma unroll
-            for (int ph = 0; ph < 4; ++ph)
-                if (row == ph && live) add_to_copy(slot);
+            fold_sums();
+            if (live) add_to_copy(slot);
             PH_MARK(4);    // groups
         }
         PH_MARK(3);
@@ -673,9 +697,10 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                     float4* a4 = reinterpret_cast<float4*>(&acc[w][tid][0]);
                     const float4 x0 = a4[0], x1 = a4[1], x2 = a4[2];
                     a4[0] = z4; a4[1] = z4; a4[2] = z4;               // owner re-zeroes its slot for the next chunk
-                    r0.x += x0.x; r0.y += x0.y; r0.z += x0.z; r0.w += x0.w;
-                    r1.x += x1.x; r1.y += x1.y; r1.z += x1.z; r1.w += x1.w;
-                    r2.x += x2.x; r2.y += x2.y; r2.z += x2.z;
+                    // LDS layout (s0 s1 s3 s4 | s6 s7 s9 s10 | s2 s5 s8 -) -> record order (s0 s1 s2 s3 | s4 s5 s6 s7 | s8 s9 s10 -)
+                    r0.x += x0.x; r0.y += x0.y; r0.z += x2.x; r0.w += x0.z;
+                    r1.x += x0.w; r1.y += x2.y; r1.z += x1.x; r1.w += x1.y;
+                    r2.x += x2.z; r2.y += x1.z; r2.z += x1.w;
                 }
             }
             if (cur.e != 0xFFFFFFFFu) {
