@@ -26,12 +26,31 @@
 // Sizes that tools/sweep_blend.sh sweeps with -D...; every other switch this file once had lost its A/B and is gone (the
 // measurements are in profiles/r0*/ab_*.txt and DESIGN.md section 3, the code in the git history).
 #define CHUNK 256             // forward: splats staged per chunk (255 + the all-zero sentinel record in slot 255)
+// The backward's chunk.  A wave's LDS copy of the per-splat sums holds only the staged splats that REACH its quadrant (56 % of them on the
+// bench scene), indexed by their rank among those: BSLOTS slots per copy for BCHUNK staged splats.  A chunk in which more than BSLOTS splats
+// reach some quadrant runs its group phase twice, once per half (blend_bwd_scan_kernel).  Until round 5 every copy held a slot for every
+// staged splat: 176-splat chunks in the same LDS (4 x 48 B x 176 = 33 of 51 KB); chunks of 128 / 144 / 160 / 176 measured 0.385 / 0.385 /
+// 0.376 / 0.371 ms then, and the longer ones now: profiles/r05/ab_blend_bwd.txt section 11 (lane fill 0.826 -> 0.85, a fifth fewer chunks).
+// Two geometries, chosen per launch by the scene's instances per tile (BWD_SPARSE_PER_TILE): 224 / 176 overflows only where 79 % of a
+// full chunk reach one quadrant and is never slower than 176 / 176 was (sm 0.5 .. 2.0); 240 / 168 is another 1 % faster on scenes of small
+// splats and up to 6 % slower on dense ones.  LDS: 53.8 KB is the most a workgroup may hold at three per CU (54.2 KB measured: two per CU).
 #ifndef BCHUNK
-#define BCHUNK 176            // the backward's chunk: 4 x 48 B x BCHUNK of accumulator copies dominate its LDS (33 of 51 KB at 176: the
-                              // largest chunk that leaves room for 3 workgroups per CU; 128 / 144 / 160 / 176 measured 0.385 / 0.385 / 0.376 / 0.371 ms)
+#define BCHUNK 224
+#endif
+#ifndef BSLOTS
+#define BSLOTS 176
+#endif
+#ifndef WCHUNK
+#define WCHUNK 240            // ... on sparse scenes
+#endif
+#ifndef WSLOTS
+#define WSLOTS 168
+#endif
+#ifndef BWD_SPARSE_PER_TILE
+#define BWD_SPARSE_PER_TILE 300   // instances per tile (scene average) up to which WCHUNK / WSLOTS are used (bench scene: 254; sm 0.625: 325)
 #endif
 #ifndef SCAN_WG_PER_CU
-#define SCAN_WG_PER_CU 3      // backward workgroups per CU: 3 x 51 KB of LDS, 168 VGPRs (measured: 128/3 beats 256/2 by 3 %)
+#define SCAN_WG_PER_CU 3      // backward workgroups per CU: 3 x 53 KB of LDS, 160 VGPRs (measured: 128/3 beats 256/2 by 3 %)
 #endif
 #define FWD_WG_PER_CU 6       // forward workgroups per CU (= waves per SIMD): 80 VGPRs (8 / 7 / 6: 148.3 / 146.9 / 144.3 us)
 #define PRIO_SERIAL 3         // backward: wave priority in the serial section between a chunk's two barriers ...
@@ -76,6 +95,8 @@ __device__ __forceinline__ float pair_power2(float dx, float dy, float ap, float
 }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+// number of set bits of a wave ballot below this lane: v_mbcnt_lo + v_mbcnt_hi, no per-lane mask register
+__device__ __forceinline__ u32 ballot_rank(u64 bal) { return __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u)); }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter
 // (s_waitcnt vmcnt(0)), which would stall every wave on the gathers it has just put in flight for the NEXT chunk
@@ -139,6 +160,7 @@ __device__ __forceinline__ void shift_up16x4(float& r0, float& r1, float& r2, fl
 //     own LDS copy of the chunk's records, one row after the other (a splat can sit in several rows); the four copies
 //     are added in fixed order => bitwise reproducible.
 // ================================================================================================================
+struct StagedSplat { float x, y, ap, bp, cp, o, r, g, b; u32 pos; };   // what the row loop reads of a staged splat (pos: 1-based list position)
 struct __attribute__((aligned(16))) ChunkRec {
     float x, y, ap, bp;
     float cp, o, r, g;
@@ -244,7 +266,7 @@ struct TileRef { int tx, ty; u32 rx, n, maxc; bool early, needle; };   // early:
 // COMPACT (stock tile rule on the tile-binned path): the chunks are staged from the forward's compacted list of record-holding
 // positions (tile_aux, cpos) instead of from consecutive list positions; everything that needs a list POSITION (the pos <=
 // n_contrib test, the per-block "behind the last contributor" filter) takes it from the compacted entry.
-template <bool ABS, bool COMPACT>
+template <bool ABS, bool COMPACT, bool SPARSE>
 __global__ void __launch_bounds__(256, SCAN_WG_PER_CU)
 blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__ tile_desc,
                       const u32* __restrict__ point_list, const unsigned char* __restrict__ reach_mask, const u32 rm_stride,
@@ -259,7 +281,19 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     // Every variant was 2-8 % SLOWER than one workgroup per tile although the per-tile dependent chain disappears from
     // the wave timeline: the hardware dispatcher refills a CU as soon as any workgroup leaves, while a persistent
     // workgroup keeps its four waves coupled at two barriers per chunk for the whole launch.
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int CH = SPARSE ? WCHUNK : BCHUNK;                              // splats staged per chunk
+    constexpr int SL = (SPARSE ? WSLOTS : BSLOTS) - (COMPACT ? 8 : 0);        // slots per wave copy of the sums (COMPACT: chunk_pos needs the LDS of two slots x 4)
+    static_assert(CH > 128 && CH <= 256 && 128 <= SL && SL <= 255, "a chunk is four 64-slot segments; each half of it must fit a wave copy; indices are bytes");
+    constexpr int NSEG = (CH + 63) / 64;                     // 64-slot segments of a chunk: thread tid stages slot tid of segment tid >> 6
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // The chunk loop never reads `tid`: a thread index that is live across the row loop (which uses every register) is spilled, and its
+    // reload at the loop's back edge puts an s_waitcnt vmcnt(0) -- a drain of the chunk's record stores and of the id prefetch -- at the
+    // top of every chunk.  Each section of the loop forms the index anew from the (scalar) wave number and v_mbcnt.
+    auto tid_now = [&]() -> int {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return (wave << 6) | l;
+    };
     const int dslot = slot_of_vblock((int)blockIdx.x);
     if (dslot >= T) return;
     const uint4 desc = tile_desc[dslot];                     // {tile, first instance, instances, deepest contributor}
@@ -273,23 +307,29 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     if (COMPACT) { const uint4 ax = tile_aux[dslot]; hi0 = min(ax.x, A.n); n_live = min(ax.y, A.n); n_staged = min(ax.z, A.n); }
     const u32* const cposp = reinterpret_cast<const u32*>(reach_mask + (size_t)A.rx * 8u) + A.n;   // COMPACT: positions of the record holders
 
-    __shared__ ChunkRec recs[BCHUNK];                 // 8.25 KB
+    // the staged records as the row loop reads them: (x y ap bp) (cp o r g) (b) -- 36 bytes per slot; the emission slot and the reach mask
+    // stay with the thread that staged the slot
+    __shared__ float4 recA[CH], recB[CH];
+    __shared__ float recC[CH];
     // 8 pixel pairs (PixPair = 4 x float4) per block + one float4 of padding: the four rows of a wave read four different
     // blocks in one ds_read_b128, and a 512-B block stride would put all four on the same banks
     __shared__ float4 pixq[16][8 * PQ + 1];          //  6.25 KB (8.25 without TF_FOLD)
-    __shared__ unsigned char lists[16][BCHUNK];       //  2.75 KB
-    __shared__ u32 masks[BCHUNK];                     //  0.5 KB: block reach masks, compact (the 48-B record stride bank-conflicts)
-    __shared__ float acc[4][BCHUNK][12];              // 33 KB, one copy per wave (LDS float atomics on a shared copy were 1.6x slower)
+    __shared__ unsigned char lists[16][CH];
+    __shared__ u32 masks[CH];                        // block reach masks
+    __shared__ float acc[4][SL][12];                 // 33 KB, one copy per wave (LDS float atomics: 2.7x slower, profiles/r05/ab_blend_bwd.txt)
     __shared__ u32 blk_maxc[16];                     // last contributor over the 16 pixels of each block
-    __shared__ u32 chunk_pos[COMPACT ? BCHUNK : 1];  // COMPACT: list position of every staged slot (the slots are no longer consecutive positions)
+    __shared__ u32 chunk_pos[COMPACT ? CH : 1];      // COMPACT: list position of every staged slot (the slots are no longer consecutive positions)
+    // a slot's index in wave w's copy = its rank among the chunk's slots that reach quadrant w: rk4[slot] holds the four ranks INSIDE the slot's
+    // 64-slot segment (a byte each, from a ballot of the staging wave), segtot[segment] the segment's four totals
+    __shared__ u32 rk4[CH];
+    __shared__ __attribute__((aligned(16))) u32 segtot[4];
 
     PH(unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};)
     PH(unsigned long long tlast = __builtin_amdgcn_s_memtime();)
-    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     struct Raw { float4 q0, q1, q2; u32 io, blk; u64 kp; };   // conic+opacity | x y r g | b z rect | record offset (in its block) | block | tile mask
     // id (x) and 4x4-block reach mask (y, as the forward staged it) of this thread's slot in the chunk of a tile's list that ends at hi_
-    auto fetch_id = [&](u32 rx_, u32 hi_, u32& pos_) -> uint2 {
-        const u32 c_ = min(hi_, (u32)BCHUNK);
+    auto fetch_id = [&](u32 rx_, u32 hi_, u32& pos_, const int tid) -> uint2 {
+        const u32 c_ = min(hi_, (u32)CH);
         pos_ = 0u;
         if ((u32)tid >= c_) return make_uint2(0xFFFFFFFFu, 0u);
         if (COMPACT) {                                   // entry (hi_ - c_) + tid of the compacted list -> its position -> id, reach word
@@ -338,7 +378,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         const u32 base_ = inst_off ? 0u : block_base[rw.blk];
         return emission_slot(base_ + rw.io, make_uint2(__float_as_uint(rw.q2.z), __float_as_uint(rw.q2.w)), rw.kp, t.tx, t.ty);
     };
-    auto make_rec = [&](const Raw& rw, const u32 e_, const u32 mask_, const TileRef& t, u32 lo_, u32 cnt_, const u32 pos_) {
+    auto make_rec = [&](const Raw& rw, const u32 e_, const u32 mask_, const TileRef& t, u32 lo_, u32 cnt_, const u32 pos_, const int tid) {
         ChunkRec rec; rec.mask = 0; rec.e = 0;
         rec.x = rec.y = rec.ap = rec.bp = rec.cp = rec.o = rec.r = rec.g = rec.b = 0.f; rec.pos = 0;
         if ((u32)tid < cnt_) {
@@ -416,11 +456,11 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     // requested before anything else and the pixel loads of tile_begin overlap them: the per-tile dependent chain is
     // descriptor -> ids -> gathers.
     u32 gid0p, gid1p = 0u;                                   // (COMPACT: list positions of the fetched ids)
-    const uint2 gid0 = fetch_id(A.rx, hi0, gid0p);
-    uint2 gid1 = (hi0 > BCHUNK) ? fetch_id(A.rx, hi0 - BCHUNK, gid1p) : make_uint2(0xFFFFFFFFu, 0u);      // ids of chunk 1, in flight with chunk 0's
+    const uint2 gid0 = fetch_id(A.rx, hi0, gid0p, tid);
+    uint2 gid1 = (hi0 > CH) ? fetch_id(A.rx, hi0 - CH, gid1p, tid) : make_uint2(0xFFFFFFFFu, 0u);      // ids of chunk 1, in flight with chunk 0's
     tile_begin(A);
     if (hi0 == 0) return;                                    // nothing contributed anywhere in the tile: all records are zero
-    if (tid < BCHUNK) {
+    if (tid < SL) {
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -438,7 +478,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     ChunkRec rec;
     {
         const Raw raw0 = fetch(gid0.x);
-        rec = make_rec(raw0, slot_of(raw0, gid0.x != 0xFFFFFFFFu, A), gid0.y, A, hi0 - min(hi0, (u32)BCHUNK), min(hi0, (u32)BCHUNK), gid0p);
+        rec = make_rec(raw0, slot_of(raw0, gid0.x != 0xFFFFFFFFu, A), gid0.y, A, hi0 - min(hi0, (u32)CH), min(hi0, (u32)CH), gid0p, tid);
     }
     asm volatile("" :: "v"(gid1.x), "v"(gid1.y), "v"(gid1p));    // complete before the loop: a pending load on the entry edge costs a vmcnt(0) at every loop top
 
@@ -449,27 +489,41 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     DG(u32 dg_eval = 0, dg_con = 0, dg_ent = 0, dg_ent0 = 0, dg_steps = 0, dg_chunks = 0;)
 
     for (u32 hi = hi0;;) {
-        const u32 cnt = min(hi, (u32)BCHUNK);
+        const u32 cnt = min(hi, (u32)CH);
         const u32 lo = hi - cnt;
         // ---- publish the staged chunk [lo, hi) of tile A: slot s <-> list position lo + s (front to back)
-        if (tid < BCHUNK) {                                  // safe without a barrier: after the previous chunk's second barrier nobody reads them
-            recs[tid] = rec; masks[tid] = rec.mask;
-            if (COMPACT) chunk_pos[tid] = rec.pos - 1u;
+        // (the slot index formed here, see tid_now: from a loop-invariant index the compiler also hoists the six LDS addresses of this section
+        // out of the chunk loop, spills them around the row loop and reloads each behind an s_waitcnt vmcnt(0))
+        const int ptid = tid_now();
+        if (ptid < CH) {                                      // safe without a barrier: after the previous chunk's second barrier nobody reads them
+            recA[ptid] = make_float4(rec.x, rec.y, rec.ap, rec.bp); recB[ptid] = make_float4(rec.cp, rec.o, rec.r, rec.g); recC[ptid] = rec.b;
+            masks[ptid] = rec.mask;
+            if (COMPACT) chunk_pos[ptid] = rec.pos - 1u;
+        }
+        // ranks of this slot among its segment's slots that reach quadrant 0..3 (an empty slot has mask 0), and the segment's totals
+        u32 myidx;
+        {
+            const u64 b0 = __ballot((rec.mask & 0x0033u) != 0u), b1 = __ballot((rec.mask & 0x00CCu) != 0u);
+            const u64 b2 = __ballot((rec.mask & 0x3300u) != 0u), b3 = __ballot((rec.mask & 0xCC00u) != 0u);
+            myidx = ballot_rank(b0) | (ballot_rank(b1) << 8) | (ballot_rank(b2) << 16) | (ballot_rank(b3) << 24);
+            if (ptid < CH) rk4[ptid] = myidx;
+            // (a byte per quadrant: a segment's totals are at most 64, a chunk's at most CH <= 255, so the prefix sums below are plain adds)
+            if ((ptid & 63) == 0) segtot[wave] = (u32)__popcll(b0) | ((u32)__popcll(b1) << 8) | ((u32)__popcll(b2) << 16) | ((u32)__popcll(b3) << 24);
         }
         lds_barrier();
         PH_MARK(2);    // barrier 1
         __builtin_amdgcn_s_setprio(PRIO_GROUPS);
-        const u32 nx_cnt = min(lo, (u32)BCHUNK), nx_lo = lo - nx_cnt;                  // chunk k+1 = [nx_lo, lo)
+        const u32 nx_cnt = min(lo, (u32)CH), nx_lo = lo - nx_cnt;                      // chunk k+1 = [nx_lo, lo)
         Raw raw_n = fetch(lo > 0 ? gid1.x : 0xFFFFFFFFu);                           // gathers of chunk k+1
         u32 gid2p = 0u;
-        const uint2 gid2 = (nx_lo > 0) ? fetch_id(A.rx, nx_lo, gid2p) : make_uint2(0xFFFFFFFFu, 0u);   // ids of chunk k+2
+        const uint2 gid2 = (nx_lo > 0) ? fetch_id(A.rx, nx_lo, gid2p, ptid) : make_uint2(0xFFFFFFFFu, 0u);   // ids of chunk k+2
 
         // The per-(splat, block) work: one block row (4 pixels = two packed pairs) per step; four independent scan chains
         // interleave without pipeline bubbles.  `s` is the lane's splat, (bx0, by0) its block origin, pixb its block's
         // pixel pairs, `carry` marks the lane that holds the scan totals (the shallowest of its segment).
         f2 a0, a1, a2, a6, a9, a10;
         float sa3, sa4, sa5, sa7, sa8;
-        auto block_rows = [&](auto skip_nc_tag, auto skip_p_tag, const ChunkRec& s, const bool live, const float bx0, const float by0, float4* pixb, const bool carry) {
+        auto block_rows = [&](auto skip_nc_tag, auto skip_p_tag, const StagedSplat s, const bool live, const float bx0, const float by0, float4* pixb, const bool carry) {
             constexpr bool SKIP_NC = decltype(skip_nc_tag)::value;
             constexpr bool SKIP_P = decltype(skip_p_tag)::value;
             float pyf = by0;                                // the row's pixel y: integers, so the += 1 below is exact and dy is
@@ -612,44 +666,72 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                 asm volatile("" ::: "memory");
             }
         };
-        u32 mreg[(BCHUNK + 63) / 64];
-#pragma unroll
-        for (int r = 0; r < (BCHUNK + 63) / 64; ++r) mreg[r] = (r * 64 + lane < BCHUNK) ? masks[r * 64 + lane] : 0u;
-        // ballot-compact the chunk's slots that reach block `blk` (list order = depth order); returns the list length
-        auto build_list = [&](const int blk) -> int {
+        // ---- where this chunk's slots sit in the wave copies.  Normally a slot's index in copy w is its rank among ALL the chunk's slots that
+        // reach quadrant w; if some quadrant is reached by more than SL of them, the group phase runs twice -- first for
+        // the deeper half of the slots (segments 2, 3), then for the other -- and the ranks count from the start of a slot's own half (at
+        // most CH / 2 <= SL).  Everything here is uniform over the workgroup.
+        const uint4 stq = *reinterpret_cast<const uint4*>(&segtot[0]);
+        const u32 g0 = (u32)__builtin_amdgcn_readfirstlane((int)stq.x), g1 = (u32)__builtin_amdgcn_readfirstlane((int)stq.y);
+        const u32 g2 = (u32)__builtin_amdgcn_readfirstlane((int)stq.z), g3 = (u32)__builtin_amdgcn_readfirstlane((int)stq.w);
+        const u32 p2 = g0 + g1, tot = p2 + g2 + g3;        // (scalars, four byte lanes each)
+        const bool split = max(max(tot & 0xFFu, (tot >> 8) & 0xFFu), max((tot >> 16) & 0xFFu, tot >> 24)) > (u32)SL;
+        // index base of each segment, all four quadrants at once: b1 = g0, b2 = g0 + g1 (0 in a split chunk), b3 = b2 + g2
+        const u32 pb2 = split ? 0u : p2, pb3 = pb2 + g2;
+        myidx += wave == 0 ? 0u : wave == 1 ? g0 : wave == 2 ? pb2 : pb3;       // the staging thread's own four indices
+        // ... and, for the row loop of THIS wave's quadrant, the bases as plain numbers
+        const u32 cb1 = (g0 >> (8 * wave)) & 0xFFu, cb2 = (pb2 >> (8 * wave)) & 0xFFu, cb3 = (pb3 >> (8 * wave)) & 0xFFu;
+        const int rk_shift = 8 * wave;
+        u32 mreg[NSEG];
+        int llane = 0;                                   // (lane id, formed anew per round: see tid_now)
+        // ballot-compact the slots of segments [r_lo, r_hi) that reach block `blk` (list order = depth order); returns the list length
+        auto build_list = [&](const int blk, const int r_lo, const int r_hi) -> int {
             int L = 0;
             const u32 bmax = blk_maxc[blk];              // splats behind every pixel's last contributor cannot matter here
 #pragma unroll
-            for (int r = 0; r < (BCHUNK + 63) / 64; ++r) {
-                const int slot = r * 64 + lane;
+            for (int r = 0; r < NSEG; ++r) {
+                if (r < r_lo || r >= r_hi) continue;    // (uniform: the other half of a split chunk, or segments past the chunk's last slot)
+                const int slot = r * 64 + llane;
                 // pos = lo + slot + 1, or the compacted entry's own position
-                const u32 posv = COMPACT ? (slot < BCHUNK ? chunk_pos[slot] : 0xFFFFFFFFu) : lo + (u32)slot;
+                const u32 posv = COMPACT ? (slot < CH ? chunk_pos[slot] : 0xFFFFFFFFu) : lo + (u32)slot;
                 const bool hit = ((mreg[r] >> blk) & 1u) && (posv < bmax);
                 const u64 bal = __ballot(hit);
-                if (hit) lists[blk][L + __popcll(bal & lt_mask)] = (unsigned char)slot;
+                if (hit) lists[blk][L + ballot_rank(bal)] = (unsigned char)slot;
                 L += __popcll(bal);
             }
             return L;
         };
+        const float bx0 = (float)(A.tx * BAGS_TILE) + 4.f * (float)(myblk & 3), by0 = (float)(A.ty * BAGS_TILE) + 4.f * (float)(myblk >> 2);
+        u32 e_n = 0xFFFFFFFFu;
+        const int nround = split ? 2 : 1;
+#pragma unroll 1
+        for (int rd = 0; rd < nround; ++rd) {
+        const int r_lo = (split && rd == 0) ? 2 : 0, r_hi = (split && rd == 1) ? 2 : min(NSEG, (int)((cnt + 63u) >> 6));
         // ---- the wave owns quadrant `wave`; DPP row r of the wave owns one 4x4 block of it and walks that block's
         // list 16 splats per step (deepest in the row's lane 0).  Against "64 lanes = 64 splats of one block" (in the git
         // history) this quantises the lists at 16 instead of 64 entries and shortens the scans from six DPP steps to four.
+        llane = tid_now() & 63;
+#pragma unroll
+        for (int r = 0; r < NSEG; ++r) mreg[r] = (r * 64 + llane < CH) ? masks[r * 64 + llane] : 0u;
         int Lr[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) Lr[j] = build_list((qy + (j >> 1)) * 4 + qx + (j & 1));
+        for (int j = 0; j < 4; ++j) Lr[j] = build_list((qy + (j >> 1)) * 4 + qx + (j & 1), r_lo, r_hi);
         PH_MARK(3);    // list building
         // the lines of chunk k+1 have landed by now (a list-building phase is several memory latencies long): their emission
         // slots are formed here and used after the second barrier
-        const u32 e_n = slot_of(raw_n, lo > 0 && gid1.x != 0xFFFFFFFFu, A);
+        if (rd == 0) {
+            asm volatile("" : "+v"(raw_n.blk));            // (the table address is formed HERE: formed at the gather it is spilled across the list building)
+            e_n = slot_of(raw_n, lo > 0 && gid1.x != 0xFFFFFFFFu, A);
+        }
         const int myL = (row == 0) ? Lr[0] : (row == 1) ? Lr[1] : (row == 2) ? Lr[2] : Lr[3];
         const int nIter = (max(max(Lr[0], Lr[1]), max(Lr[2], Lr[3])) + 15) >> 4;
-        const float bx0 = (float)(A.tx * BAGS_TILE) + 4.f * (float)(myblk & 3), by0 = (float)(A.ty * BAGS_TILE) + 4.f * (float)(myblk >> 2);
         int slot_next = (li < myL) ? (int)lists[myblk][myL - 1 - li] : 0;
         for (int it = 0; it < nIter; ++it) {
             const int gend = myL - 16 * it;                 // <= 0: this row's list is exhausted
             const bool live = li < gend;
             const int slot = slot_next;
-            const ChunkRec s = recs[slot];
+            const float4 ra = recA[slot], rb = recB[slot];
+            const StagedSplat s = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w, recC[slot], (COMPACT ? chunk_pos[slot] : lo + (u32)slot) + 1u};
+            const u32 rkw = rk4[slot];                      // (consumed at the end of the step)
             // the next step's list entry is read now: list byte -> record is a chain of two LDS latencies otherwise
             slot_next = (li < gend - 16) ? (int)lists[myblk][gend - 17 - li] : 0;
             DG(const u32 dg_before = dg_con;)
@@ -661,9 +743,11 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
             else if (!A.early) block_rows(std::true_type{}, std::false_type{}, s, live, bx0, by0, pixb, cry);
             else block_rows(std::false_type{}, std::false_type{}, s, live, bx0, by0, pixb, cry);
             DG(dg_ent += live ? 1u : 0u; dg_ent0 += (live && dg_con == dg_before) ? 1u : 0u; dg_steps += (lane == 0) ? 1u : 0u;)
-            // the same splat can sit in several rows (it reaches several blocks of the quadrant): one row at a time
+            // the same splat can sit in several rows (it reaches several blocks of the quadrant): rotating quarters
             fold_sums();
-            if (live) add_to_copy(slot);
+            const int sg = slot >> 6;
+            const u32 cidx = ((rkw >> rk_shift) & 0xFFu) + (sg == 0 ? 0u : sg == 1 ? cb1 : sg == 2 ? cb2 : cb3);
+            if (live) add_to_copy((int)cidx);
             PH_MARK(4);    // groups
         }
         PH_MARK(3);
@@ -674,27 +758,30 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         // its VALU-saturated group phase; without priority the four waves crawl through it at different speeds and
         // the skew is paid at the next barrier.
         __builtin_amdgcn_s_setprio(PRIO_SERIAL);
-        // ---- next chunk: its gathers were issued before the groups; turn them into the staged record
-        const ChunkRec cur = rec;
-        // Keep every loaded register -- also the components nobody reads (q1 z, q3 yzw are not loaded; q2.y, the view
-        // depth, is) -- and the id word "in use" up to this point.  Otherwise the register allocator recycles a dead
-        // component of an in-flight load as scratch, which needs s_waitcnt vmcnt(0) right after the loads were issued
-        // and exposes the whole gather latency once per chunk (seen in the ISA; 20 % of the wave time).  Touching gid2
-        // here also retires the id load before this chunk's record stores are issued, so the top of the next chunk
-        // does not have to drain the stores to be sure the id has arrived.
-        asm volatile("" :: "v"(raw_n.q2.y), "v"(gid2.x), "v"(gid2.y), "v"(e_n), "v"(gid2p));
-        if (lo > 0) rec = make_rec(raw_n, e_n, gid1.y, A, nx_lo, nx_cnt, gid1p);
-        gid1 = gid2; gid1p = gid2p;
+        const u32 cur_e = rec.e, cur_mask = rec.mask;
+        const int wtid = tid_now();
+        if (rd == nround - 1) {
+            // ---- next chunk: its gathers were issued before the groups; turn them into the staged record.
+            // Keep every loaded register -- also the components nobody reads (q1 z, q3 yzw are not loaded; q2.y, the view
+            // depth, is) -- and the id word "in use" up to this point.  Otherwise the register allocator recycles a dead
+            // component of an in-flight load as scratch, which needs s_waitcnt vmcnt(0) right after the loads were issued
+            // and exposes the whole gather latency once per chunk (seen in the ISA; 20 % of the wave time).  Touching gid2
+            // here also retires the id load before this chunk's record stores are issued, so the top of the next chunk
+            // does not have to drain the stores to be sure the id has arrived.
+            asm volatile("" :: "v"(raw_n.q2.y), "v"(gid2.x), "v"(gid2.y), "v"(e_n), "v"(gid2p));
+            if (lo > 0) rec = make_rec(raw_n, e_n, gid1.y, A, nx_lo, nx_cnt, gid1p, wtid);
+            gid1 = gid2; gid1p = gid2p;
+        }
         PH_MARK(1);
-        // ---- one record per staged instance: the four wave copies added in fixed order.  The record holds the raw sums (sum q
-        // rather than sum q / o, the abs sums on the scaled conic): preprocess_bwd applies the per-Gaussian factors once.
-        if ((u32)tid < cnt) {
+        // ---- one record per staged instance of the round's segments: the wave copies it sits in added in fixed order.  The record holds
+        // the raw sums (sum q rather than sum q / o, the abs sums on the scaled conic): preprocess_bwd applies the per-Gaussian factors once.
+        if ((u32)wtid < cnt && wave >= r_lo && wave < r_hi) {
             float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-            if (cur.mask != 0) {
-                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    float4* a4 = reinterpret_cast<float4*>(&acc[w][tid][0]);
+            for (int w = 0; w < 4; ++w) {
+                if (cur_mask & (w == 0 ? 0x0033u : w == 1 ? 0x00CCu : w == 2 ? 0x3300u : 0xCC00u)) {
+                    float4* a4 = reinterpret_cast<float4*>(&acc[w][(myidx >> (8 * w)) & 0xFFu][0]);
                     const float4 x0 = a4[0], x1 = a4[1], x2 = a4[2];
                     a4[0] = z4; a4[1] = z4; a4[2] = z4;               // owner re-zeroes its slot for the next chunk
                     // LDS layout (s0 s1 s3 s4 | s6 s7 s9 s10 | s2 s5 s8 -) -> record order (s0 s1 s2 s3 | s4 s5 s6 s7 | s8 s9 s10 -)
@@ -703,14 +790,17 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                     r2.x += x2.z; r2.y += x1.z; r2.z += x1.w;
                 }
             }
-            if (cur.e != 0xFFFFFFFFu) {
-                float4* dst = reinterpret_cast<float4*>(partials + (size_t)cur.e * PART_FLOATS);
+            if (cur_e != 0xFFFFFFFFu) {
+                float4* dst = reinterpret_cast<float4*>(partials + (size_t)cur_e * PART_FLOATS);
                 dst[0] = r0; dst[1] = r1; dst[2] = r2;
-                if (live_map) live_map[cur.e] = 1;
+                if (live_map) live_map[cur_e] = 1;
             }
         }
         PH_MARK(6);    // record sums + stores
-        // no barrier here: the next chunk's first barrier orders these LDS accesses before any reuse
+        // between two rounds of one chunk: the second round's adds must not meet the first round's write-out (the slots it re-zeroes).
+        // After the last round no barrier: the next chunk's first barrier orders these LDS accesses before any reuse
+        if (rd + 1 < nround) { lds_barrier(); __builtin_amdgcn_s_setprio(PRIO_GROUPS); }
+        }
         if (lo == 0) break;
         hi = lo;
     }
@@ -740,14 +830,19 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     // streaming memset is cheaper than the per-tile zero loops, which gather an id and two geometry lines per dead instance.
     if (!bwd_dense_mode(n_records, T, dense_per_tile_arg)) live_map = nullptr;
     if (live_map) { hipError_t e = hipMemsetAsync(live_map, 0, (size_t)n_records, st); if (e != hipSuccess) return e; }
-#define BWD_LAUNCH(ABS_, CMP_)                                                                                                       \
-    hipLaunchKernelGGL((blend_bwd_scan_kernel<ABS_, CMP_>), dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,     \
+#define BWD_LAUNCH_(ABS_, CMP_, SPARSE_)                                                                                             \
+    hipLaunchKernelGGL((blend_bwd_scan_kernel<ABS_, CMP_, SPARSE_>), dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T, \
                        im.tile_desc, b.point_list, reinterpret_cast<const unsigned char*>(b.reach_mask), binned ? 8u : 2u, g.g2d,    \
                        binned ? nullptr : g.inst_off, g.block_base, s.bg, im.final_T, im.n_contrib, grad_color, partials, \
                        compact ? 1 : 0, im.tile_aux, live_map)
+    // The chunk geometry follows the SCENE, not dense_per_tile_arg: forcing the dense-scene mode on or off leaves the arithmetic
+    // untouched, so the two modes stay bit-identical (tests, tools/fuzz_paths.py --cross-dense)
+    const bool sparse = n_records <= (long long)BWD_SPARSE_PER_TILE * T;
+#define BWD_LAUNCH(ABS_, CMP_) do { if (sparse) BWD_LAUNCH_(ABS_, CMP_, true); else BWD_LAUNCH_(ABS_, CMP_, false); } while (0)
     if (want_abs) { if (compact) BWD_LAUNCH(true, true); else BWD_LAUNCH(true, false); }
     else          { if (compact) BWD_LAUNCH(false, true); else BWD_LAUNCH(false, false); }
 #undef BWD_LAUNCH
+#undef BWD_LAUNCH_
     return hipGetLastError();
 }
 

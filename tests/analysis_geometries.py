@@ -178,6 +178,63 @@ def main():
         price("D 4x2, 16-lane groups, wave = 4 sub-blocks (8 per tile)", L42, d_groups, 16, 2, ROW_STEP, STEP_OVERHEAD, 64, 4, chunk)
         f_groups = [[r * 4 + i for i in range(4)] for r in range(16)]
         price("F 2x2, 16-lane groups, wave = 4 sub-blocks (16 per tile)", L22, f_groups, 16, 1, ROW_STEP, STEP_OVERHEAD, 64, 4, chunk)
+    # A with COMPACT per-wave copies: a wave's copy holds only the staged splats that reach its quadrant (S slots), so the same LDS stages a longer
+    # chunk (C positions); a chunk is cut from the back of the list and ends at C positions or when some quadrant's copy is full.  LDS budget at
+    # three workgroups per CU: 68 B per position (record, 16 list bytes, mask) + 4 x 48 B per slot <= 47 KB.
+    m44 = masks["4x4"]
+    quad_reach = np.stack([m44[:, g].any(1) for g in quadrant_groups(4, 4)], 1)             # (I, 4)
+    print(f"  staged splats reaching a quadrant: {quad_reach.mean():.3f} of the positions")
+    for C, S in ((176, 176), (256, 160), (288, 148), (320, 137), (384, 114)):
+        ck = np.zeros(I, dtype=np.int64)
+        for t in range(T):
+            n = int(n_t[t])
+            if n == 0:
+                continue
+            r0 = int(ranges[t, 0])
+            qr = quad_reach[r0:r0 + n][::-1]                                                  # back to front
+            cs = np.cumsum(qr, 0)
+            k, start, out = 0, 0, np.empty(n, dtype=np.int64)
+            while start < n:
+                base_ = cs[start - 1] if start > 0 else 0
+                end = min(n, start + C)
+                over = np.nonzero(((cs[start:end] - base_) > S).any(1))[0]
+                if over.size:
+                    end = start + int(over[0])
+                out[start:end] = k
+                k += 1
+                start = end
+            ck[r0:r0 + n] = out[::-1]
+        L = lists_per_chunk(m44, tile, ck, T)
+        nchunks = int((L.sum(2) > 0).sum())
+        price(f"A compact copies: <= {C} positions, {S} slots per wave ({nchunks / 1e3:.1f} k chunks)", L, quadrant_groups(4, 4), 16, 4, ROW_STEP, STEP_OVERHEAD + 2 * C_PLAIN, 64, 4, C)
+    # the same with a FIXED staging window of C positions and a fallback instead of a variable extent: a window in which some quadrant's count
+    # exceeds S runs its group phase twice, once per half (each half has at most C / 2 <= S reaching splats)
+    for C, S in ((256, 160), (256, 152), (256, 144), (240, 160), (224, 176)):
+        ck = np.zeros(I, dtype=np.int64)
+        n_split = n_win = 0
+        for t in range(T):
+            n = int(n_t[t])
+            if n == 0:
+                continue
+            r0 = int(ranges[t, 0])
+            qr = quad_reach[r0:r0 + n][::-1]
+            out = np.empty(n, dtype=np.int64)
+            k = 0
+            for start in range(0, n, C):
+                end = min(n, start + C)
+                n_win += 1
+                if (qr[start:end].sum(0) > S).any():
+                    mid = start + C // 2
+                    out[start:mid] = k
+                    out[mid:end] = k + 1
+                    k += 2
+                    n_split += 1
+                else:
+                    out[start:end] = k
+                    k += 1
+            ck[r0:r0 + n] = out[::-1]
+        L = lists_per_chunk(m44, tile, ck, T)
+        price(f"A compact copies, window {C}, {S} slots, halves on overflow ({n_split} of {n_win} windows)", L, quadrant_groups(4, 4), 16, 4, ROW_STEP, STEP_OVERHEAD + 2 * C_PLAIN, 64, 4, C)
     print("(the shipped kernel, A at chunk 176, measures 0.345 ms)")
 
 

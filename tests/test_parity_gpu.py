@@ -920,6 +920,44 @@ def test_dense_scene_against_oracle(monkeypatch):
             assert torch.equal(g_d[k], g_z[k]), k
 
 
+def test_wide_chunks_that_overflow_a_wave_copy():
+    """The backward stages 256 splats per chunk and keeps, per wave, 160 slots for the ones that reach the wave's quadrant (blend.hip,
+    WCHUNK / WSLOTS); a chunk in which more than 160 reach some quadrant runs its group phase twice, once per half.  A scene of huge,
+    faint splats on a 4 x 3-tile image: ~400 instances in every tile (below the density at which the launcher falls back to 176-splat
+    chunks), every splat reaching every quadrant, walks that go deep into the lists -- every full chunk overflows.  Against the oracle to
+    the ordinary bars; the host re-derives that the case is what it claims."""
+    import numpy as np
+    from oracle import raster_oracle as O
+    from scenes import oracle_settings
+    from analysis_geometries import sub_masks, quadrant_groups
+    scene, cam = make_case(420, 64, 48, 8.0, 1, seed=21)
+    scene["opacities"] = scene["opacities"] * 0.2
+    rep = compare(scene, cam, 1)
+    _report({k: rep[k] for k in ("num_rendered", "image_max_err", "n_contrib_mismatch_frac", "grad_rel_fp32", "grad_rel_fp64")})
+    assert_report(rep)
+    T = 12
+    assert 300 * T < rep["num_rendered"][0] <= 480 * T, rep["num_rendered"]       # the wide geometry's side of BWD_DENSE_PER_TILE
+    g = torch.randn(3, 48, 64, generator=torch.Generator().manual_seed(1))
+    _, _, v = run_hip(scene, cam, 1, g)
+    s = oracle_settings(cam, 1)
+    P = scene["means3D"].shape[0]
+    with torch.no_grad():
+        pre = O.preprocess(scene["means3D"], torch.zeros(P, 3), torch.zeros(3), scene["shs"], None, scene["opacities"], scene["scales"],
+                           scene["rotations"], None, s, torch.float32, None)
+    xy, conic, op = pre.xy.numpy().astype(np.float64), pre.conic.numpy().astype(np.float64), pre.opacity.numpy().astype(np.float64)
+    pl, ranges, nc = v["point_list"].numpy().astype(np.int64), v["ranges"].numpy().astype(np.int64), v["n_contrib"].numpy()
+    overflowing = two_chunks = 0
+    for t in range(T):
+        ty, tx = divmod(t, 4)
+        hi0 = int(nc[ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16].max())          # the tile's deepest contributor: where its chunks start
+        two_chunks += hi0 > 256
+        ids = pl[ranges[t, 0] + max(0, hi0 - 256):ranges[t, 0] + hi0]            # the first (deepest) chunk
+        n = ids.size
+        m = sub_masks(xy[ids, 0], xy[ids, 1], conic[ids, 0], conic[ids, 1], conic[ids, 2], op[ids], np.full(n, tx * 16.0), np.full(n, ty * 16.0), 4, 4)
+        overflowing += max(int(m[:, q].any(1).sum()) for q in quadrant_groups(4, 4)) > 160
+    assert overflowing >= 6 and two_chunks >= 3, (overflowing, two_chunks)
+
+
 def test_conic_backward_semantic():
     """Decision D9.  DEFAULT conic_grad="stock": upstream computeCov2DCUDA's backward of the 2x2 inverse divides by det^2 + 1e-7
     (the reference's fork inherits it, README.md:126); "exact" divides by det^2 (rounds 1-4).  A scene of small splats (det near
