@@ -121,11 +121,12 @@ struct BinView {
     u32*    tile_sorted;     // keys after the last pass (radix path only)
     u64*    words;           // tile-binned path: (depth key << 32 | Gaussian id) per instance, grouped by tile, unsorted inside a tile
     u64*    scratch;         // tile-binned path: scratch of the two-level / global-memory sorts (lists of > 4096 entries only)
-    // 16-bit reach mask of the 4x4-pixel blocks per sorted instance: written by blend_fwd when it stages the instance, read
-    // back by blend_bwd instead of evaluating block_mask16 again.  Lives in memory that is dead once the lists are sorted: the
-    // radix path's spare key buffer (u16 per instance), or -- tile-binned path -- the tile's OWN slice of `words` (instance j of
-    // a tile that starts at instance s: byte 8 s + 2 j; blend_fwd sorts its tile's list itself, so other tiles' words may
-    // still be unsorted when it writes).
+    // A 32-bit word per sorted instance -- bits 0..15 the reach mask of the tile's 4x4-pixel blocks, bit 16 "has a gradient record" --
+    // written by blend_fwd when it stages the instance, read back by blend_bwd instead of evaluating block_mask16 again.  Lives in
+    // memory that is dead once the lists are sorted: the radix path's spare key buffer (instance i: word i), or -- tile-binned path --
+    // the tile's OWN slice of `words` (instance j of a tile that starts at instance s: byte 8 s + 4 j; blend_fwd sorts its tile's
+    // list itself, so other tiles' words may still be unsorted when it writes; the second half of the slice holds the compacted
+    // positions of the record holders, stock tile rule).
     unsigned short* reach_mask;
 };
 struct ImgView {

@@ -326,42 +326,63 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
 
     PH(unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};)
     PH(unsigned long long tlast = __builtin_amdgcn_s_memtime();)
-    struct Raw { float4 q0, q1, q2; u32 io, blk; u64 kp; };   // conic+opacity | x y r g | b z rect | record offset (in its block) | block | tile mask
+    struct Raw { float4 q0, q1, q2; u32 io, blk, kpl, kph; };   // conic+opacity | x y r g | b z rect | record offset (in its block) | block | tile mask (two halves)
     // id (x) and 4x4-block reach mask (y, as the forward staged it) of this thread's slot in the chunk of a tile's list that ends at hi_
-    auto fetch_id = [&](u32 rx_, u32 hi_, u32& pos_, const int tid) -> uint2 {
+    // COMPACT: entry (hi_ - c_) + tid of the compacted list -> its list position (fetch_pos) -> id, reach word (fetch_id with that position).
+    // Two dependent loads: the position is requested a chunk before the id (three chunks before the slot is staged), so that no wait for it
+    // sits behind the gathers of another chunk.
+    auto fetch_pos = [&](u32 hi_, const int tid) -> u32 {
         const u32 c_ = min(hi_, (u32)CH);
-        pos_ = 0u;
+        return ((u32)tid < c_) ? cposp[(hi_ - c_) + tid] : 0u;
+    };
+    auto fetch_id = [&](u32 rx_, u32 hi_, u32& pos_, const int tid) -> uint2 {      // (COMPACT: pos_ comes IN, from fetch_pos)
+        const u32 c_ = min(hi_, (u32)CH);
+        if (!COMPACT) pos_ = 0u;
         if ((u32)tid >= c_) return make_uint2(0xFFFFFFFFu, 0u);
-        if (COMPACT) {                                   // entry (hi_ - c_) + tid of the compacted list -> its position -> id, reach word
-            pos_ = cposp[(hi_ - c_) + tid];
+        if (COMPACT) {
             const u32 info = reinterpret_cast<const u32*>(reach_mask + (size_t)rx_ * 8u)[pos_];
-            return make_uint2(point_list[rx_ + pos_], info & 0xFFFFu);
+            return make_uint2(point_list[rx_ + pos_], info);
         }
         const u32 at = rx_ + (hi_ - c_) + tid;
-        // the reach masks of a tile sit at byte rm_stride * (tile's first instance): inside the tile's own slice of the (dead)
-        // unsorted words on the tile-binned path (stride 8), plainly per instance on the radix path (stride 2)
-        // Tile-binned path: a 32-bit word per instance -- bits 0..15 the reach mask, bit 16 "this instance has a record" (with
-        // the stock tile rule the lists hold instances whose tile the opacity rule drops: no record, nothing to gather, nothing
-        // to write; they come back as an empty slot).  Radix path: 16-bit masks, every instance has a record.
-        u32 info;
-        if (rm_stride == 8u) info = reinterpret_cast<const u32*>(reach_mask + (size_t)rx_ * 8u)[at - rx_];
-        else info = 0x10000u | (u32)reinterpret_cast<const unsigned short*>(reach_mask + (size_t)rx_ * 2u)[at - rx_];
-        if (!(info & 0x10000u)) return make_uint2(0xFFFFFFFFu, 0u);
-        return make_uint2(point_list[at], info & 0xFFFFu);
+        // The forward left a 32-bit word per staged instance -- bits 0..15 the reach mask, bit 16 "this instance has a record" (with the
+        // stock tile rule the lists hold instances whose tile the opacity rule drops: no record, nothing to gather, nothing to write;
+        // they come back as an empty slot) -- at byte rm_stride * (the tile's first instance) of a buffer that is dead by then: the tile's own
+        // slice of the unsorted words (tile-binned path: 8 bytes per instance), the key half the last radix pass read (radix path: 4).
+        // Word and id are loaded side by side, no branch between them: behind a branch on the word the id load waits for it -- an
+        // s_waitcnt vmcnt(0) that also drains the gathers just issued for the chunk before, once per chunk (so it was until round 5,
+        // when the radix path still kept 16-bit masks and the two layouts were told apart here).
+        const u32 info = reinterpret_cast<const u32*>(reach_mask + (size_t)rx_ * rm_stride)[at - rx_];
+        return make_uint2(point_list[at], info);             // raw: decode_id() where the pair is consumed
     };
+    // (id, word) as fetched -> (id or "empty slot", reach mask).  Arithmetic, not a select: the compiler turns `word says record ? id : none`
+    // back into a branch around the id load.  Applied where the pair is CONSUMED, a chunk after the loads were issued: any arithmetic on
+    // a loaded value sits right behind its load in the instruction stream, with the wait
+    // `one`: the number 1 through an empty asm at the point of consumption, so that none of this can be scheduled above that point
+    auto decode_id = [&](const uint2 raw, const u32 one) -> uint2 {
+        const u32 lo16 = (one << 16) - one;
+        if (COMPACT) return make_uint2(raw.x, raw.y & lo16);
+        const u32 has = (raw.y >> (15u + one)) & one;
+        return make_uint2(raw.x | (has - one), raw.y & lo16 & (0u - has));
+    };
+    // The geometry line of a staged instance, straight into the registers it stays in.  Lessons of the ISA, all of the same kind -- a
+    // register COPY of a loaded value waits for the load, i.e. drains the gathers where they were issued instead of under the list building:
+    //   * no branch around the loads: an empty slot (g = ~0) reads line 0 -- nobody looks at it: its reach mask is 0 and its emission slot
+    //     "none" (with zeroed registers on the other path the two meet in copies);
+    //   * the fourth float4 word by word, the tile mask as two halves (joining them is a copy), and not merged into a wide load whose dead
+    //     components the register allocator would lend out as scratch while the load is in flight;
+    //   * the record offset -- tile-binned path: in the line since K1 counts the (block, tile) matrix itself (round 4; the gather of
+    //     inst_off[g] was a second line miss per instance); radix path: the inst_off array -- by ONE load through a selected address.
     auto fetch = [&](u32 g) {
-        Raw r; r.q0 = make_float4(0.f, 0.f, 0.f, 0.f); r.q1 = r.q0; r.q2 = r.q0; r.io = 0u; r.blk = 0u; r.kp = 0ull;
-        if (g != 0xFFFFFFFFu) {                       // one 64-byte line
-            const float4* rec = g2d + 4 * (size_t)g;
-            r.q0 = rec[0]; r.q1 = rec[1]; r.q2 = rec[2];
-            const float4 q3 = rec[3];
-            r.kp = (u64)__float_as_uint(q3.x) | ((u64)__float_as_uint(q3.w) << 32);
-            // first record of the Gaussian: tile-binned path block_base[q3.y] + q3.z, both in the line since K1 counts the
-            // (block, tile) matrix itself (round 4; the 4-byte gather of inst_off[g] was a second line miss per instance);
-            // radix path: the inst_off array
-            if (inst_off) r.io = inst_off[g];
-            else { r.io = __float_as_uint(q3.z); r.blk = __float_as_uint(q3.y); }
-        }
+        Raw r;
+        const u32 gc = (g != 0xFFFFFFFFu) ? g : 0u;
+        const float4* rec = g2d + 4 * (size_t)gc;              // one 64-byte line
+        r.q0 = rec[0]; r.q1 = rec[1]; r.q2 = rec[2];
+        const u32* q3 = reinterpret_cast<const u32*>(rec + 3);
+        u32 o1 = 1u, o3 = 3u;
+        asm volatile("" : "+v"(o1), "+v"(o3));               // (opaque offsets: the four words are not to be merged into wider loads)
+        r.kpl = q3[0]; r.kph = q3[o3];
+        r.blk = q3[o1];
+        r.io = *(inst_off ? inst_off + gc : q3 + 2);
         return r;
     };
     // emission slot of a Gaussian's record for tile (tx, ty): the tile's rank among the tiles the Gaussian emits (its
@@ -376,9 +397,11 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     auto slot_of = [&](const Raw& rw, const bool have, const TileRef& t) -> u32 {
         if (!have) return 0xFFFFFFFFu;                        // an empty slot of the chunk: no record is written for it
         const u32 base_ = inst_off ? 0u : block_base[rw.blk];
-        return emission_slot(base_ + rw.io, make_uint2(__float_as_uint(rw.q2.z), __float_as_uint(rw.q2.w)), rw.kp, t.tx, t.ty);
+        return emission_slot(base_ + rw.io, make_uint2(__float_as_uint(rw.q2.z), __float_as_uint(rw.q2.w)), (u64)rw.kpl | ((u64)rw.kph << 32), t.tx, t.ty);
     };
-    auto make_rec = [&](const Raw& rw, const u32 e_, const u32 mask_, const TileRef& t, u32 lo_, u32 cnt_, const u32 pos_, const int tid) {
+    // (c_half = -0.5 log2(e), c_one = -log2(e): through an empty asm at the point of consumption, for the same reason as decode_id's `one`)
+    auto make_rec = [&](const Raw& rw, const u32 e_, const u32 mask_, const TileRef& t, u32 lo_, u32 cnt_, const u32 pos_, const int tid,
+                        const float c_half, const float c_one) {
         ChunkRec rec; rec.mask = 0; rec.e = 0;
         rec.x = rec.y = rec.ap = rec.bp = rec.cp = rec.o = rec.r = rec.g = rec.b = 0.f; rec.pos = 0;
         if ((u32)tid < cnt_) {
@@ -386,7 +409,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
             const float4 cz = make_float4(rw.q1.z, rw.q1.w, rw.q2.x, rw.q2.y);
             rec.e = e_;
             rec.x = c2.x; rec.y = c2.y;
-            rec.ap = -0.5f * LOG2E * co.x; rec.bp = -LOG2E * co.y; rec.cp = -0.5f * LOG2E * co.z; rec.o = co.w;
+            rec.ap = c_half * co.x; rec.bp = c_one * co.y; rec.cp = c_half * co.z; rec.o = co.w;
             rec.r = cz.x; rec.g = cz.y; rec.b = cz.z;
             rec.pos = (COMPACT ? pos_ : lo_ + tid) + 1;
             rec.mask = mask_;                 // block_mask16 of this (tile, splat), evaluated once: by the forward
@@ -455,8 +478,13 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     // The tile's descriptor carries its deepest contributor (from the forward), so the ids of the first two chunks are
     // requested before anything else and the pixel loads of tile_begin overlap them: the per-tile dependent chain is
     // descriptor -> ids -> gathers.
-    u32 gid0p, gid1p = 0u;                                   // (COMPACT: list positions of the fetched ids)
-    const uint2 gid0 = fetch_id(A.rx, hi0, gid0p, tid);
+    u32 gid0p = 0u, gid1p = 0u, pos2 = 0u;                   // (COMPACT: list positions of the slots of chunks 0, 1, 2)
+    if (COMPACT) {
+        gid0p = fetch_pos(hi0, tid);
+        if (hi0 > CH) gid1p = fetch_pos(hi0 - CH, tid);
+        if (hi0 > 2 * CH) pos2 = fetch_pos(hi0 - 2 * CH, tid);
+    }
+    const uint2 gid0r = fetch_id(A.rx, hi0, gid0p, tid);
     uint2 gid1 = (hi0 > CH) ? fetch_id(A.rx, hi0 - CH, gid1p, tid) : make_uint2(0xFFFFFFFFu, 0u);      // ids of chunk 1, in flight with chunk 0's
     tile_begin(A);
     if (hi0 == 0) return;                                    // nothing contributed anywhere in the tile: all records are zero
@@ -477,10 +505,13 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     //   barrier  consume gathers -> rec(k+1), ids(k+2); only then store the records of chunk k
     ChunkRec rec;
     {
+        const uint2 gid0 = decode_id(gid0r, 1u);
         const Raw raw0 = fetch(gid0.x);
-        rec = make_rec(raw0, slot_of(raw0, gid0.x != 0xFFFFFFFFu, A), gid0.y, A, hi0 - min(hi0, (u32)CH), min(hi0, (u32)CH), gid0p, tid);
+        rec = make_rec(raw0, slot_of(raw0, gid0.x != 0xFFFFFFFFu, A), gid0.y, A, hi0 - min(hi0, (u32)CH), min(hi0, (u32)CH), gid0p, tid,
+                       -0.5f * LOG2E, -LOG2E);
     }
-    asm volatile("" :: "v"(gid1.x), "v"(gid1.y), "v"(gid1p));    // complete before the loop: a pending load on the entry edge costs a vmcnt(0) at every loop top
+    asm volatile("" :: "v"(gid1.x), "v"(gid1.y), "v"(gid1p), "v"(pos2));    // complete before the loop: a pending load on the entry edge costs a vmcnt(0) at every loop top
+    gid1 = decode_id(gid1, 1u);
 
     const int row = lane >> 4, li = lane & 15;
     const int qx = (wave & 1) * 2, qy = (wave >> 1) * 2;
@@ -515,8 +546,10 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         __builtin_amdgcn_s_setprio(PRIO_GROUPS);
         const u32 nx_cnt = min(lo, (u32)CH), nx_lo = lo - nx_cnt;                      // chunk k+1 = [nx_lo, lo)
         Raw raw_n = fetch(lo > 0 ? gid1.x : 0xFFFFFFFFu);                           // gathers of chunk k+1
-        u32 gid2p = 0u;
-        const uint2 gid2 = (nx_lo > 0) ? fetch_id(A.rx, nx_lo, gid2p, ptid) : make_uint2(0xFFFFFFFFu, 0u);   // ids of chunk k+2
+        u32 gid2p = pos2;
+        const uint2 gid2 = (nx_lo > 0) ? fetch_id(A.rx, nx_lo, gid2p, ptid) : make_uint2(0xFFFFFFFFu, 0u);   // ids of chunk k+2 (as fetched: decode_id)
+        u32 pos3 = 0u;                                                               // COMPACT: positions of chunk k+3 = [.., nx2_lo)
+        if (COMPACT) { const u32 nx2_lo = nx_lo - min(nx_lo, (u32)CH); if (nx2_lo > 0) pos3 = fetch_pos(nx2_lo, ptid); }
 
         // The per-(splat, block) work: one block row (4 pixels = two packed pairs) per step; four independent scan chains
         // interleave without pipeline bubbles.  `s` is the lane's splat, (bx0, by0) its block origin, pixb its block's
@@ -702,6 +735,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         };
         const float bx0 = (float)(A.tx * BAGS_TILE) + 4.f * (float)(myblk & 3), by0 = (float)(A.ty * BAGS_TILE) + 4.f * (float)(myblk >> 2);
         u32 e_n = 0xFFFFFFFFu;
+        const u32 cur_e = rec.e, cur_mask = rec.mask;    // (this chunk's: `rec` becomes the next chunk's record inside the rounds)
         const int nround = split ? 2 : 1;
 #pragma unroll 1
         for (int rd = 0; rd < nround; ++rd) {
@@ -719,7 +753,9 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         // the lines of chunk k+1 have landed by now (a list-building phase is several memory latencies long): their emission
         // slots are formed here and used after the second barrier
         if (rd == 0) {
-            asm volatile("" : "+v"(raw_n.blk));            // (the table address is formed HERE: formed at the gather it is spilled across the list building)
+            // (everything the slot is formed from becomes visible to the compiler HERE: otherwise it schedules the rectangle arithmetic right
+            // behind the gathers -- a wait for them in front of the list building -- and spills the table address across it)
+            asm volatile("" : "+v"(raw_n.blk), "+v"(raw_n.io), "+v"(raw_n.q2.z), "+v"(raw_n.q2.w), "+v"(raw_n.kpl), "+v"(raw_n.kph));
             e_n = slot_of(raw_n, lo > 0 && gid1.x != 0xFFFFFFFFu, A);
         }
         const int myL = (row == 0) ? Lr[0] : (row == 1) ? Lr[1] : (row == 2) ? Lr[2] : Lr[3];
@@ -758,20 +794,22 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         // its VALU-saturated group phase; without priority the four waves crawl through it at different speeds and
         // the skew is paid at the next barrier.
         __builtin_amdgcn_s_setprio(PRIO_SERIAL);
-        const u32 cur_e = rec.e, cur_mask = rec.mask;
         const int wtid = tid_now();
-        if (rd == nround - 1) {
-            // ---- next chunk: its gathers were issued before the groups; turn them into the staged record.
-            // Keep every loaded register -- also the components nobody reads (q1 z, q3 yzw are not loaded; q2.y, the view
-            // depth, is) -- and the id word "in use" up to this point.  Otherwise the register allocator recycles a dead
-            // component of an in-flight load as scratch, which needs s_waitcnt vmcnt(0) right after the loads were issued
-            // and exposes the whole gather latency once per chunk (seen in the ISA; 20 % of the wave time).  Touching gid2
-            // here also retires the id load before this chunk's record stores are issued, so the top of the next chunk
-            // does not have to drain the stores to be sure the id has arrived.
-            asm volatile("" :: "v"(raw_n.q2.y), "v"(gid2.x), "v"(gid2.y), "v"(e_n), "v"(gid2p));
-            if (lo > 0) rec = make_rec(raw_n, e_n, gid1.y, A, nx_lo, nx_cnt, gid1p, wtid);
-            gid1 = gid2; gid1p = gid2p;
-        }
+        // ---- next chunk: its gathers were issued before the groups; turn them into the staged record.  Every loaded register is redefined
+        // an input of this asm, also the components nobody reads (q2.y, the view depth):
+        //   * the register allocator recycles a dead component of an in-flight load as scratch, which needs s_waitcnt vmcnt(0) right after
+        //     the loads were issued and exposes the whole gather latency once per chunk (seen in the ISA; 20 % of the wave time);
+        //   * arithmetic on a loaded value (make_rec's scaling of the conic, decode_id) is otherwise scheduled right behind the load: its
+        //     constants come out of this asm;
+        //   * the loads are retired before this chunk's record stores are issued, so the top of the next chunk does not have to drain
+        //     the stores to be sure they have arrived.
+        // In EVERY round, not only the last (the result is the same): with a path around it, the loads count as pending on the loop's
+        // back edge and the next chunk's first write to one of their registers waits for everything, the record stores included.
+        float c_half = -0.5f * LOG2E, c_one = -LOG2E;
+        asm volatile("" : "+v"(c_half), "+v"(c_one)
+                        : "v"(gid2.x), "v"(gid2.y), "v"(raw_n.q0.x), "v"(raw_n.q0.y), "v"(raw_n.q0.z), "v"(raw_n.q0.w), "v"(raw_n.q1.x), "v"(raw_n.q1.y),
+                          "v"(raw_n.q1.z), "v"(raw_n.q1.w), "v"(raw_n.q2.x), "v"(raw_n.q2.y), "v"(e_n), "v"(gid2p), "v"(pos3));
+        if (lo > 0) rec = make_rec(raw_n, e_n, gid1.y, A, nx_lo, nx_cnt, gid1p, wtid, c_half, c_one);
         PH_MARK(1);
         // ---- one record per staged instance of the round's segments: the wave copies it sits in added in fixed order.  The record holds
         // the raw sums (sum q rather than sum q / o, the abs sums on the scaled conic): preprocess_bwd applies the per-Gaussian factors once.
@@ -800,6 +838,11 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         // between two rounds of one chunk: the second round's adds must not meet the first round's write-out (the slots it re-zeroes).
         // After the last round no barrier: the next chunk's first barrier orders these LDS accesses before any reuse
         if (rd + 1 < nround) { lds_barrier(); __builtin_amdgcn_s_setprio(PRIO_GROUPS); }
+        }
+        {
+            u32 one = 1u;
+            asm volatile("" : "+v"(one) : "v"(gid2.x), "v"(gid2.y));
+            gid1 = decode_id(gid2, one); gid1p = gid2p; pos2 = pos3;
         }
         if (lo == 0) break;
         hi = lo;
@@ -832,7 +875,7 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     if (live_map) { hipError_t e = hipMemsetAsync(live_map, 0, (size_t)n_records, st); if (e != hipSuccess) return e; }
 #define BWD_LAUNCH_(ABS_, CMP_, SPARSE_)                                                                                             \
     hipLaunchKernelGGL((blend_bwd_scan_kernel<ABS_, CMP_, SPARSE_>), dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T, \
-                       im.tile_desc, b.point_list, reinterpret_cast<const unsigned char*>(b.reach_mask), binned ? 8u : 2u, g.g2d,    \
+                       im.tile_desc, b.point_list, reinterpret_cast<const unsigned char*>(b.reach_mask), binned ? 8u : 4u, g.g2d,    \
                        binned ? nullptr : g.inst_off, g.block_base, s.bg, im.final_T, im.n_contrib, grad_color, partials, \
                        compact ? 1 : 0, im.tile_aux, live_map)
     // The chunk geometry follows the SCENE, not dense_per_tile_arg: forcing the dense-scene mode on or off leaves the arithmetic
@@ -971,10 +1014,9 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
                                           (u64)__float_as_uint(q3.x) | ((u64)__float_as_uint(q3.w) << 32), tile_x, tile_y);
             }
             rec.mask = has_rec ? block_mask16(c2.x, c2.y, co.x, co.y, co.z, co.w, X0, Y0) : 0u;
-            // the backward stages the same instance: it reads this (tile-binned path: a 32-bit word, mask | has-record << 16,
-            // inside the tile's own slice of the words, which this workgroup has just finished with; radix path: the mask)
-            if (rm_stride == 8u) reinterpret_cast<u32*>(reach_mask + (size_t)range.x * 8u)[base + tid] = rec.mask | (has_rec ? 0x10000u : 0u);
-            else reinterpret_cast<unsigned short*>(reach_mask + (size_t)range.x * 2u)[base + tid] = (unsigned short)rec.mask;
+            // the backward stages the same instance: it reads this word (mask | has-record << 16; tile-binned path: inside the tile's own
+            // slice of the words, which this workgroup has just finished with; radix path: in the dead half of the key buffers)
+            reinterpret_cast<u32*>(reach_mask + (size_t)range.x * rm_stride)[base + tid] = rec.mask | (has_rec ? 0x10000u : 0u);
             ill = conic_ill_conditioned(co.x, co.y, co.z);
             live_rec = has_rec;
         }
@@ -1190,7 +1232,7 @@ hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinV
     const int grid = cdiv(T, TILE_RUN) * TILE_RUN;
     hipLaunchKernelGGL(blend_fwd_rows_kernel<0>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
                        im.tile_desc, b.point_list, sort_here ? b.words : nullptr, g.depth_key, b.scratch,
-                       reinterpret_cast<unsigned char*>(b.reach_mask), b.words ? 8u : 2u, g.g2d, s.bg, out.color, out.depth, out.weights,
+                       reinterpret_cast<unsigned char*>(b.reach_mask), b.words ? 8u : 4u, g.g2d, s.bg, out.color, out.depth, out.weights,
                        im.final_T, im.n_contrib, n_dev, capacity, (b.words && s.tile_bounds != BAGS_TILES_OPACITY) ? 1 : 0, im.tile_aux);
     return hipGetLastError();
 }
