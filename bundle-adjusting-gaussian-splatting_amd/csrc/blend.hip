@@ -988,7 +988,10 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
     for (u32 base = 0; base < n; base += FWD_STAGE) {
         const u64 live_b = __ballot(Tq > 0.f);
         if (lane == 0) s_live[wave] = (live_b != 0ull);
-        __syncthreads();                                     // previous chunk consumed by every wave
+        // (lds_barrier, here and below: what the waves exchange is in LDS.  __syncthreads() is a workgroup-scope fence too -- s_waitcnt
+        // vmcnt(0) -- and CDNA4's vmcnt counts stores: every barrier of the chunk loop waited for the chunk's reach-word stores to be
+        // acknowledged, and the two of the epilogue for the tile's pixel stores)
+        lds_barrier();                                       // previous chunk consumed by every wave
         if (!(s_live[0] | s_live[1] | s_live[2] | s_live[3])) break;
         const u32 cnt = min((u32)FWD_STAGE, n - base);
         SplatRec rec; rec.mask = 0; rec.x = rec.y = rec.ap = rec.bp = rec.cp = rec.o = rec.r = rec.g = rec.b = rec.z = 0.f; rec.pos = 0;
@@ -1035,7 +1038,7 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
             dst[0] = make_uint4(f, f, f, f);
             if (sizeof(list_t) == 2) dst[1] = make_uint4(f, f, f, f);
         }
-        __syncthreads();
+        lds_barrier();
         if (test_keep) {                                     // the chunk's record-holding positions, compacted in list order
             const u32 c0 = s_cnt[0], c1 = s_cnt[1], c2_ = s_cnt[2], c3 = s_cnt[3];
             const u32 before = (wave > 0 ? c0 : 0u) + (wave > 1 ? c1 : 0u) + (wave > 2 ? c2_ : 0u);
@@ -1198,9 +1201,9 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (u32)__shfl_xor((int)m, d));
     const u32 early = ((__ballot(stopped) != 0ull) ? 0x80000000u : 0u) | (needle ? 0x40000000u : 0u);
-    __syncthreads();                                         // s_live is free again
+    lds_barrier();                                           // s_live is free again
     if (lane == 0) s_live[wave] = (int)(m | early);
-    __syncthreads();
+    lds_barrier();
     // bit 31: some pixel of the tile did not walk its whole list (the backward then needs its `pos <= n_contrib` test);
     // bit 30: some staged splat has an ill-conditioned conic (the backward then keeps its `power <= 0` test)
     const u32 w0 = (u32)s_live[0], w1 = (u32)s_live[1], w2 = (u32)s_live[2], w3 = (u32)s_live[3];
