@@ -145,9 +145,9 @@ __device__ __forceinline__ void shift_up16x4(float& r0, float& r1, float& r2, fl
 // Scan-based backward ("lane = splat").  PMC showed a lane = pixel backward saturates VALU issue (96 % of SIMD cycles)
 // and spends most of it on 64-wide work where a third of the lanes contribute, plus an 11-value cross-lane reduction
 // per (tile, splat).  Here the roles are swapped:
-//   * a 256-thread workgroup owns a tile; the tile list is consumed back to front in chunks of BCHUNK splats, staged
+//   * a 256-thread workgroup owns a tile; the tile list is consumed back to front in chunks of BCHUNK (224 / 240) splats, staged
 //     once in LDS together with a 16-bit mask of the 4x4-pixel blocks each splat's alpha >= 1/255 ellipse can reach
-//     (Mahalanobis triangle-inequality test, conservative);
+//     (Mahalanobis triangle-inequality test, conservative; evaluated by the forward, which leaves it next to the sorted list);
 //   * wave w owns quadrant w and ballot-compacts, per block, the chunk's splats that reach it;
 //   * each 16-lane DPP row of the wave owns one block and takes 16 entries of its list per step (deepest in the row's
 //     lane 0); the block's pixels are visited two at a time with packed fp32 math.  With x_i = c_i . dL/dC, the per-pixel
@@ -157,8 +157,11 @@ __device__ __forceinline__ void shift_up16x4(float& r0, float& r1, float& r2, fl
 //         R_i = (F_{i+1} o F_{i+2} o ...)(bg . dL/dC)      dL/dalpha_i = T_i (x_i - R_i)
 //     so no division by (1 - alpha) is needed.  (A, R) behind the group is carried through one pair per pixel in LDS;
 //   * every lane then owns its splat's 11 sums outright: no cross-lane reduction, no atomics.  Each wave adds into its
-//     own LDS copy of the chunk's records, one row after the other (a splat can sit in several rows); the four copies
-//     are added in fixed order => bitwise reproducible.
+//     own LDS copy of the sums -- a slot per staged splat that reaches the wave's quadrant, all four rows at once, each on
+//     another quarter of its slot's record (a splat can sit in several rows: "rotating quarters"); the four copies are
+//     added in fixed order => bitwise reproducible.
+//   * the gathers of chunk k+1 and the ids of chunk k+2 are in flight under the list building and the step loop of chunk k;
+//     nothing in the loop may copy or use a loaded register before the point of consumption (profiles/r05/ab_blend_bwd.txt 12).
 // ================================================================================================================
 struct StagedSplat { float x, y, ap, bp, cp, o, r, g, b; u32 pos; };   // what the row loop reads of a staged splat (pos: 1-based list position)
 struct __attribute__((aligned(16))) ChunkRec {
@@ -328,9 +331,8 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     PH(unsigned long long tlast = __builtin_amdgcn_s_memtime();)
     struct Raw { float4 q0, q1, q2; u32 io, blk, kpl, kph; };   // conic+opacity | x y r g | b z rect | record offset (in its block) | block | tile mask (two halves)
     // id (x) and 4x4-block reach mask (y, as the forward staged it) of this thread's slot in the chunk of a tile's list that ends at hi_
-    // COMPACT: entry (hi_ - c_) + tid of the compacted list -> its list position (fetch_pos) -> id, reach word (fetch_id with that position).
-    // Two dependent loads: the position is requested a chunk before the id (three chunks before the slot is staged), so that no wait for it
-    // sits behind the gathers of another chunk.
+    // COMPACT: entry (hi_ - c_) + tid of the compacted list -> its list position (fetch_pos) -> id, reach word (fetch_id with that position):
+    // two dependent loads.
     auto fetch_pos = [&](u32 hi_, const int tid) -> u32 {
         const u32 c_ = min(hi_, (u32)CH);
         return ((u32)tid < c_) ? cposp[(hi_ - c_) + tid] : 0u;
@@ -478,11 +480,10 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
     // The tile's descriptor carries its deepest contributor (from the forward), so the ids of the first two chunks are
     // requested before anything else and the pixel loads of tile_begin overlap them: the per-tile dependent chain is
     // descriptor -> ids -> gathers.
-    u32 gid0p = 0u, gid1p = 0u, pos2 = 0u;                   // (COMPACT: list positions of the slots of chunks 0, 1, 2)
+    u32 gid0p = 0u, gid1p = 0u;                              // (COMPACT: list positions of the slots of chunks 0, 1)
     if (COMPACT) {
         gid0p = fetch_pos(hi0, tid);
         if (hi0 > CH) gid1p = fetch_pos(hi0 - CH, tid);
-        if (hi0 > 2 * CH) pos2 = fetch_pos(hi0 - 2 * CH, tid);
     }
     const uint2 gid0r = fetch_id(A.rx, hi0, gid0p, tid);
     uint2 gid1 = (hi0 > CH) ? fetch_id(A.rx, hi0 - CH, gid1p, tid) : make_uint2(0xFFFFFFFFu, 0u);      // ids of chunk 1, in flight with chunk 0's
@@ -510,7 +511,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         rec = make_rec(raw0, slot_of(raw0, gid0.x != 0xFFFFFFFFu, A), gid0.y, A, hi0 - min(hi0, (u32)CH), min(hi0, (u32)CH), gid0p, tid,
                        -0.5f * LOG2E, -LOG2E);
     }
-    asm volatile("" :: "v"(gid1.x), "v"(gid1.y), "v"(gid1p), "v"(pos2));    // complete before the loop: a pending load on the entry edge costs a vmcnt(0) at every loop top
+    asm volatile("" :: "v"(gid1.x), "v"(gid1.y), "v"(gid1p));    // complete before the loop: a pending load on the entry edge costs a vmcnt(0) at every loop top
     gid1 = decode_id(gid1, 1u);
 
     const int row = lane >> 4, li = lane & 15;
@@ -545,11 +546,12 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         PH_MARK(2);    // barrier 1
         __builtin_amdgcn_s_setprio(PRIO_GROUPS);
         const u32 nx_cnt = min(lo, (u32)CH), nx_lo = lo - nx_cnt;                      // chunk k+1 = [nx_lo, lo)
-        Raw raw_n = fetch(lo > 0 ? gid1.x : 0xFFFFFFFFu);                           // gathers of chunk k+1
-        u32 gid2p = pos2;
-        const uint2 gid2 = (nx_lo > 0) ? fetch_id(A.rx, nx_lo, gid2p, ptid) : make_uint2(0xFFFFFFFFu, 0u);   // ids of chunk k+2 (as fetched: decode_id)
-        u32 pos3 = 0u;                                                               // COMPACT: positions of chunk k+3 = [.., nx2_lo)
-        if (COMPACT) { const u32 nx2_lo = nx_lo - min(nx_lo, (u32)CH); if (nx2_lo > 0) pos3 = fetch_pos(nx2_lo, ptid); }
+        // ids of chunk k+2 (as fetched: decode_id), then the gathers of chunk k+1.  COMPACT: the position comes first and the id load waits
+        // for it -- in front of the gathers, so that the wait does not drain them (fetching the position a chunk earlier still, in a
+        // third stage, measured 1.8 % slower at sm 1.0 and no faster at sm 0.5: profiles/r05/ab_blend_bwd.txt section 12)
+        u32 gid2p = (COMPACT && nx_lo > 0) ? fetch_pos(nx_lo, ptid) : 0u;
+        const uint2 gid2 = (nx_lo > 0) ? fetch_id(A.rx, nx_lo, gid2p, ptid) : make_uint2(0xFFFFFFFFu, 0u);
+        Raw raw_n = fetch(lo > 0 ? gid1.x : 0xFFFFFFFFu);
 
         // The per-(splat, block) work: one block row (4 pixels = two packed pairs) per step; four independent scan chains
         // interleave without pipeline bubbles.  `s` is the lane's splat, (bx0, by0) its block origin, pixb its block's
@@ -808,7 +810,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         float c_half = -0.5f * LOG2E, c_one = -LOG2E;
         asm volatile("" : "+v"(c_half), "+v"(c_one)
                         : "v"(gid2.x), "v"(gid2.y), "v"(raw_n.q0.x), "v"(raw_n.q0.y), "v"(raw_n.q0.z), "v"(raw_n.q0.w), "v"(raw_n.q1.x), "v"(raw_n.q1.y),
-                          "v"(raw_n.q1.z), "v"(raw_n.q1.w), "v"(raw_n.q2.x), "v"(raw_n.q2.y), "v"(e_n), "v"(gid2p), "v"(pos3));
+                          "v"(raw_n.q1.z), "v"(raw_n.q1.w), "v"(raw_n.q2.x), "v"(raw_n.q2.y), "v"(e_n), "v"(gid2p));
         if (lo > 0) rec = make_rec(raw_n, e_n, gid1.y, A, nx_lo, nx_cnt, gid1p, wtid, c_half, c_one);
         PH_MARK(1);
         // ---- one record per staged instance of the round's segments: the wave copies it sits in added in fixed order.  The record holds
@@ -842,7 +844,7 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
         {
             u32 one = 1u;
             asm volatile("" : "+v"(one) : "v"(gid2.x), "v"(gid2.y));
-            gid1 = decode_id(gid2, one); gid1p = gid2p; pos2 = pos3;
+            gid1 = decode_id(gid2, one); gid1p = gid2p;
         }
         if (lo == 0) break;
         hi = lo;
@@ -945,8 +947,8 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
     __shared__ u32 s_cnt[4];                                 // stock tile rule: record-holding instances staged by each wave (this chunk)
     // Stock tile rule on the tile-binned path (test_keep): 40 % of the list positions hold instances without a gradient record.
     // The backward stages its chunks from a COMPACTED list of the record-holding positions, written here as they are staged
-    // (u32 positions in the upper half of the tile's own slice of the words, behind the n reach words), so that its 176-slot
-    // chunks hold 176 live splats (62 k instead of 93 k wave-chunks on config 3).  tile_aux[slot] = {compact entries in front of
+    // (u32 positions in the upper half of the tile's own slice of the words, behind the n reach words), so that its
+    // chunks hold live splats only (62 k instead of 93 k wave-chunks on config 3 with 176-slot chunks; 50 k with 224 / 240).  tile_aux[slot] = {compact entries in front of
     // the deepest contributor, compact entries, list positions staged, -}.
     u32 n_live_run = 0, n_staged = 0;
     u32* const cpos = reinterpret_cast<u32*>(reach_mask + (size_t)range.x * 8u) + n;
