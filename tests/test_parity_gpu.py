@@ -920,26 +920,33 @@ def test_dense_scene_against_oracle(monkeypatch):
             assert torch.equal(g_d[k], g_z[k]), k
 
 
-def test_wide_chunks_that_overflow_a_wave_copy():
-    """The backward stages 256 splats per chunk and keeps, per wave, 160 slots for the ones that reach the wave's quadrant (blend.hip,
-    WCHUNK / WSLOTS); a chunk in which more than 160 reach some quadrant runs its group phase twice, once per half.  A scene of huge,
-    faint splats on a 4 x 3-tile image: ~400 instances in every tile (below the density at which the launcher falls back to 176-splat
-    chunks), every splat reaching every quadrant, walks that go deep into the lists -- every full chunk overflows.  Against the oracle to
-    the ordinary bars; the host re-derives that the case is what it claims."""
+@pytest.mark.parametrize("tile_bounds", ["opacity", "aabb"])
+def test_wide_chunks_that_overflow_a_wave_copy(tile_bounds):
+    """The backward stages 224 (240 on sparse scenes) splats per chunk and keeps, per wave, 176 (168) slots for the ones that reach the
+    wave's quadrant (blend.hip, BCHUNK / BSLOTS, WCHUNK / WSLOTS; 8 slots fewer with the stock tile rule, whose chunks are staged
+    from the compacted lists); a chunk in which more splats than that reach some quadrant runs its group phase twice, once per half.
+    A scene of huge, faint splats on a 4 x 3-tile image: ~400 instances in every tile, every splat reaching every quadrant, walks
+    that go deep into the lists -- every full chunk overflows.  Against the oracle to the ordinary bars, with both tile rules; the host
+    re-derives that the case is what it claims."""
     import numpy as np
     from oracle import raster_oracle as O
     from scenes import oracle_settings
     from analysis_geometries import sub_masks, quadrant_groups
     scene, cam = make_case(420, 64, 48, 8.0, 1, seed=21)
     scene["opacities"] = scene["opacities"] * 0.2
-    rep = compare(scene, cam, 1)
+    rep = compare(scene, cam, 1, tile_bounds=tile_bounds)
     _report({k: rep[k] for k in ("num_rendered", "image_max_err", "n_contrib_mismatch_frac", "grad_rel_fp32", "grad_rel_fp64")})
     assert_report(rep)
     T = 12
-    assert 300 * T < rep["num_rendered"][0] <= 480 * T, rep["num_rendered"]       # the wide geometry's side of BWD_DENSE_PER_TILE
+    assert rep["num_rendered"][0] > 300 * T, rep["num_rendered"]
     g = torch.randn(3, 48, 64, generator=torch.Generator().manual_seed(1))
-    _, _, v = run_hip(scene, cam, 1, g)
-    s = oracle_settings(cam, 1)
+    _, g_b, v = run_hip(scene, cam, 1, g, tile_bounds=tile_bounds)
+    _, g_r, v_r = run_hip(scene, cam, 1, g, tile_bounds=tile_bounds, binning="radix")       # the radix path's lists feed the same backward
+    assert torch.equal(v["point_list"], v_r["point_list"])
+    for k in g_b:                           # (stock tile rule: the tile-binned path stages its chunks from the compacted lists, the radix path
+        if g_b[k] is not None:              # from the full ones -- other chunk boundaries, other scan groups: equal to rounding, not to the bit)
+            assert torch.equal(g_b[k], g_r[k]) if tile_bounds == "opacity" else rel_err(g_b[k], g_r[k]) < 1e-5, k
+    s = oracle_settings(cam, 1, tile_bounds=tile_bounds)
     P = scene["means3D"].shape[0]
     with torch.no_grad():
         pre = O.preprocess(scene["means3D"], torch.zeros(P, 3), torch.zeros(3), scene["shs"], None, scene["opacities"], scene["scales"],
@@ -950,11 +957,11 @@ def test_wide_chunks_that_overflow_a_wave_copy():
     for t in range(T):
         ty, tx = divmod(t, 4)
         hi0 = int(nc[ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16].max())          # the tile's deepest contributor: where its chunks start
-        two_chunks += hi0 > 256
-        ids = pl[ranges[t, 0] + max(0, hi0 - 256):ranges[t, 0] + hi0]            # the first (deepest) chunk
+        two_chunks += hi0 > 240
+        ids = pl[ranges[t, 0] + max(0, hi0 - 224):ranges[t, 0] + hi0]            # (at least) the first, deepest chunk of either geometry
         n = ids.size
         m = sub_masks(xy[ids, 0], xy[ids, 1], conic[ids, 0], conic[ids, 1], conic[ids, 2], op[ids], np.full(n, tx * 16.0), np.full(n, ty * 16.0), 4, 4)
-        overflowing += max(int(m[:, q].any(1).sum()) for q in quadrant_groups(4, 4)) > 160
+        overflowing += max(int(m[:, q].any(1).sum()) for q in quadrant_groups(4, 4)) > 176
     assert overflowing >= 6 and two_chunks >= 3, (overflowing, two_chunks)
 
 
