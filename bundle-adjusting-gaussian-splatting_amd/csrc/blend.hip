@@ -944,6 +944,7 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
     list_t* const lists = reinterpret_cast<list_t*>(lds_raw + LDS_LISTS);
     u32* const masks = reinterpret_cast<u32*>(lds_raw + LDS_MASKS);
     __shared__ int s_live[4];
+    __shared__ int s_ill[4];                                 // this chunk: did wave w stage a splat with an ill-conditioned conic
     __shared__ u32 s_cnt[4];                                 // stock tile rule: record-holding instances staged by each wave (this chunk)
     // Stock tile rule on the tile-binned path (test_keep): 40 % of the list positions hold instances without a gradient record.
     // The backward stages its chunks from a COMPACTED list of the record-holding positions, written here as they are staged
@@ -1025,7 +1026,9 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
             ill = conic_ill_conditioned(co.x, co.y, co.z);
             live_rec = has_rec;
         }
-        needle |= (__ballot(ill) != 0ull);                   // (a scalar register, not a lane's)
+        const bool wave_ill = __ballot(ill) != 0ull;
+        needle |= wave_ill;                                  // (a scalar register, not a lane's)
+        if (lane == 0) s_ill[wave] = wave_ill ? 1 : 0;
         const u64 rec_b = __ballot(live_rec);
         if (test_keep && lane == 0) s_cnt[wave] = (u32)__popcll(rec_b);
         n_staged = base + cnt;
@@ -1083,7 +1086,11 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
             return w;
         };
         u32 last_off = 0xFFFFFFFFu;                          // byte offset of the record of this chunk's last contributor (per pixel)
-        auto step = [&](int i, const SplatW& s) {
+        // PTEST: with the `power <= 0` test.  It cannot fail for a well-conditioned conic (the bound above conic_ill_conditioned), so a chunk
+        // without an ill-conditioned splat walks without it: one vector instruction of 23 per step (the backward has skipped the test on
+        // such TILES since round 4, on this kernel's flag)
+        auto step = [&](auto ptest_tag, int i, const SplatW& s) {
+            constexpr bool PTEST = decltype(ptest_tag)::value;
             const float dx = s.x - pxf, dy = s.y - pyf;
             const float p2 = pair_power2(dx, dy, s.ap, s.bp, s.cp);
             const float G = __builtin_amdgcn_exp2f(p2);
@@ -1095,26 +1102,33 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
             // as on its vector units).  EXEC is all ones here: 256-thread workgroups, only wave-uniform control flow above.
             {
                 float t0, t1;
-                asm volatile(
+#define FWD_STEP_TAIL                                                                                                  \
+                    "v_sub_f32 %[t0], 1.0, %[al]\n\t"                                                                  \
+                    "v_mul_f32 %[t1], %[al], %[T]\n\t"                                                                 \
+                    "v_mul_f32 %[t0], %[T], %[t0]\n\t"                                                                 \
+                    "v_cmp_ngt_f32 vcc, 0x38d1b717, %[t0]\n\t"           /* !(1e-4 > T (1 - alpha)): composite; else stop */   \
+                    "v_cndmask_b32_e64 %[T], -|%[T]|, %[t0], vcc\n\t"     /* (a finished pixel, T < 0, lands here too and stays as it is) */ \
+                    "s_mov_b64 exec, vcc\n\t"                            /* (vcc is 0 in inactive lanes; s_and would clobber SCC, which holds the compiler's loop test) */ \
+                    "v_fmac_f32 %[cr], %[t1], %[r]\n\t"                                                                \
+                    "v_fmac_f32 %[cg], %[t1], %[g]\n\t"                                                                \
+                    "v_fmac_f32 %[cb], %[t1], %[b]\n\t"                                                                \
+                    "v_fmac_f32 %[dq], %[t1], %[z]\n\t"                                                                \
+                    "v_mov_b32 %[last], %[pos]\n\t"                                                                    \
+                    "s_mov_b64 exec, -1"
+#define FWD_STEP_OPERANDS                                                                                              \
+                    : [T] "+v"(Tq), [cr] "+v"(Cr), [cg] "+v"(Cg), [cb] "+v"(Cb), [dq] "+v"(Dq), [last] "+v"(last_off),   \
+                      [t0] "=&v"(t0), [t1] "=&v"(t1)                                                                     \
+                    : [p2] "v"(p2), [al] "v"(alpha), [r] "v"(s.r), [g] "v"(s.g), [b] "v"(s.b), [z] "v"(s.z), [pos] "v"(s.pos) \
+                    : "vcc"
+                if (PTEST) asm volatile(
                     "v_cmpx_ge_f32 vcc, 0, %[p2]\n\t"
                     "v_cmpx_le_f32 vcc, 0x3b808081, %[al]\n\t"          // 1 / 255
-                    "v_sub_f32 %[t0], 1.0, %[al]\n\t"
-                    "v_mul_f32 %[t1], %[al], %[T]\n\t"
-                    "v_mul_f32 %[t0], %[T], %[t0]\n\t"
-                    "v_cmp_ngt_f32 vcc, 0x38d1b717, %[t0]\n\t"           // !(1e-4 > T (1 - alpha)): composite; else stop
-                    "v_cndmask_b32_e64 %[T], -|%[T]|, %[t0], vcc\n\t"     // (a finished pixel, T < 0, lands here too and stays as it is)
-                    "s_mov_b64 exec, vcc\n\t"                                // (vcc is 0 in inactive lanes; s_and would clobber SCC,
-                                                                              //  which holds the compiler's loop test)
-                    "v_fmac_f32 %[cr], %[t1], %[r]\n\t"
-                    "v_fmac_f32 %[cg], %[t1], %[g]\n\t"
-                    "v_fmac_f32 %[cb], %[t1], %[b]\n\t"
-                    "v_fmac_f32 %[dq], %[t1], %[z]\n\t"
-                    "v_mov_b32 %[last], %[pos]\n\t"
-                    "s_mov_b64 exec, -1"
-                    : [T] "+v"(Tq), [cr] "+v"(Cr), [cg] "+v"(Cg), [cb] "+v"(Cb), [dq] "+v"(Dq), [last] "+v"(last_off),
-                      [t0] "=&v"(t0), [t1] "=&v"(t1)
-                    : [p2] "v"(p2), [al] "v"(alpha), [r] "v"(s.r), [g] "v"(s.g), [b] "v"(s.b), [z] "v"(s.z), [pos] "v"(s.pos)
-                    : "vcc");
+                    FWD_STEP_TAIL FWD_STEP_OPERANDS);
+                else asm volatile(
+                    "v_cmpx_le_f32 vcc, 0x3b808081, %[al]\n\t"
+                    FWD_STEP_TAIL FWD_STEP_OPERANDS);
+#undef FWD_STEP_TAIL
+#undef FWD_STEP_OPERANDS
                 (void)i;
             }
 #else           // the pair counters live in the plain C++ form of the step (a row past the end of its list composites the sentinel: not counted)
@@ -1152,36 +1166,40 @@ blend_fwd_rows_kernel(int W, int H, int grid_x, int T, uint4* __restrict__ tile_
         // stays live until its record has been composited; with one pair per trip the next pair's addresses therefore needed
         // registers of their own and two v_mov per trip to rotate them (2 of 49 vector instructions).  Over two pairs the roles
         // alternate and the rotation is a renaming.  (Reads run up to 9 entries past Lmax: the next list or the 16 bytes of padding.)
-        u32 ra, rb;
-        addr2((u32)mypairs[0], ra, rb);
-        SplatW S0 = load(ra);
-        u32 two = (u32)mypairs[1];                           // entries 2, 3
-        for (int i = 0; i < Lmax; i += 4) {
-            const SplatW S1 = load(rb);
-            u32 ra2, rb2;
-            addr2(two, ra2, rb2);
-            u32 nxt = (u32)mypairs[(i >> 1) + 2];            // entries i + 4, i + 5
-            __builtin_amdgcn_sched_barrier(0);
-            step(i, S0);
-            __builtin_amdgcn_sched_barrier(0);
-            const SplatW S2 = load(ra2);
-            __builtin_amdgcn_sched_barrier(0);
-            step(i + 1, S1);
-            asm("" : "+v"(nxt));                             // (keeps the zero extension with the load, not behind the loop's phi)
-            __builtin_amdgcn_sched_barrier(0);
-            const SplatW S3 = load(rb2);
-            u32 ra3, rb3;
-            addr2(nxt, ra3, rb3);
-            u32 nxt2 = (u32)mypairs[(i >> 1) + 3];           // entries i + 6, i + 7
-            __builtin_amdgcn_sched_barrier(0);
-            step(i + 2, S2);
-            __builtin_amdgcn_sched_barrier(0);
-            S0 = load(ra3);
-            __builtin_amdgcn_sched_barrier(0);
-            step(i + 3, S3);
-            asm("" : "+v"(nxt2));
-            two = nxt2; rb = rb3;
-        }
+        auto walk = [&](auto ptest_tag) {
+            u32 ra, rb;
+            addr2((u32)mypairs[0], ra, rb);
+            SplatW S0 = load(ra);
+            u32 two = (u32)mypairs[1];                           // entries 2, 3
+            for (int i = 0; i < Lmax; i += 4) {
+                const SplatW S1 = load(rb);
+                u32 ra2, rb2;
+                addr2(two, ra2, rb2);
+                u32 nxt = (u32)mypairs[(i >> 1) + 2];            // entries i + 4, i + 5
+                __builtin_amdgcn_sched_barrier(0);
+                step(ptest_tag, i, S0);
+                __builtin_amdgcn_sched_barrier(0);
+                const SplatW S2 = load(ra2);
+                __builtin_amdgcn_sched_barrier(0);
+                step(ptest_tag, i + 1, S1);
+                asm("" : "+v"(nxt));                             // (keeps the zero extension with the load, not behind the loop's phi)
+                __builtin_amdgcn_sched_barrier(0);
+                const SplatW S3 = load(rb2);
+                u32 ra3, rb3;
+                addr2(nxt, ra3, rb3);
+                u32 nxt2 = (u32)mypairs[(i >> 1) + 3];           // entries i + 6, i + 7
+                __builtin_amdgcn_sched_barrier(0);
+                step(ptest_tag, i + 2, S2);
+                __builtin_amdgcn_sched_barrier(0);
+                S0 = load(ra3);
+                __builtin_amdgcn_sched_barrier(0);
+                step(ptest_tag, i + 3, S3);
+                asm("" : "+v"(nxt2));
+                two = nxt2; rb = rb3;
+            }
+        };
+        // (wave-uniform: the four flags were written before the barrier that published the chunk)
+        if (s_ill[0] | s_ill[1] | s_ill[2] | s_ill[3]) walk(std::true_type{}); else walk(std::false_type{});
         // record offset -> slot (/ 48: x 43691 >> 21, exact below 2^17 slots) -> 1-based list position
         if (last_off != 0xFFFFFFFFu) last = base + ((last_off * 43691u) >> 21) + 1u;
     }
