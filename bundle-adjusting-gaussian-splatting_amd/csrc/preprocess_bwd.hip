@@ -83,6 +83,7 @@ __device__ __forceinline__ void sum_records(u32 nrec, u32 first, const float* __
     }
     if (!LIVE && nrec > 0 && nrec <= SUM_COOP) {
         const float4* rec = reinterpret_cast<const float4*>(partials + (size_t)first * PART_FLOATS);
+        // (four records per trip with the missing ones read again and dropped: 0.0608 -> 0.0635 ms, profiles/r05/ab_k1.txt)
         u32 r = 0;
         for (; r + 1 < nrec; r += 2) {
             const float4 a0 = rec[RQ * r], b0 = rec[RQ * r + 1], c0 = rec[RQ * r + 2];
@@ -603,14 +604,15 @@ pose_reduce_kernel(const float* __restrict__ slab, int nblocks, float* __restric
     const int t = blockIdx.x;                            // slab column
     double acc = 0.0;
     int b = threadIdx.x;
-    for (; b + 7 * 256 < nblocks; b += 8 * 256) {
+    // (rows past the end read as zero INSIDE the batch: a remainder loop of single loads -- 1954 rows are 7.6 per thread, so most threads
+    // took it -- was seven dependent round trips, 6.5 us of a kernel that needs one; the order of the additions is unchanged)
+    for (; b < nblocks; b += 8 * 256) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(b + u * 256) * POSE_VALS + t];
+        for (int u = 0; u < 8; ++u) v[u] = (b + u * 256 < nblocks) ? slab[(size_t)(b + u * 256) * POSE_VALS + t] : 0.f;
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += (double)v[u];
     }
-    for (; b < nblocks; b += 256) acc += (double)slab[(size_t)b * POSE_VALS + t];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
