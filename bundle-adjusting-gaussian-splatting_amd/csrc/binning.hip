@@ -191,11 +191,21 @@ __device__ __forceinline__ u32 ord_load_counts(const u32* __restrict__ tile_tota
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int span0 = wave * 64 * per;
-#pragma unroll 8
-    for (int j = 0; j < ORD_PER; ++j) {                      // load order: tile span0 + j * 64 + lane
-        const int t = span0 + j * 64 + lane;
-        const u32 v = (j < per && t < T) ? tile_total[t] : 0u;
-        if (j < per) tr[ord_pad(j * 64 + lane)] = v;
+    // (all loads of a batch of eight before the first LDS store: `tr` reaches this function as a plain pointer, the compiler keeps every
+    // load behind the store before it, and the batch was eight dependent round trips in the one workgroup the emission launch waits for)
+#pragma unroll
+    for (int j0 = 0; j0 < ORD_PER; j0 += 8) {                // load order: tile span0 + j * 64 + lane
+        u32 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u, t = span0 + j * 64 + lane;
+            v[u] = (j < per && t < T) ? tile_total[t] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u;
+            if (j < per) tr[ord_pad(j * 64 + lane)] = v[u];
+        }
     }
     lds_wave_sync();
     u32 sum = 0;
@@ -342,6 +352,18 @@ emit_binned_kernel(int P, int per_block, int grid_x, int T, const uint2* __restr
     static_assert(BIN_THREADS == 1024, "build_tile_desc is written for 1024 threads");
     extern __shared__ u32 cur[];                             // T slot cursors (the descriptor workgroup: its transposes)
     __shared__ u32 s_gb[513];                                // first instance of every group of 64 tiles; [512] = instance count
+    // the first eight tiles' cursor inputs of every thread (all of them up to 8192 tiles) are requested before the group bases -- one
+    // memory round trip for both -- and in one batch: as a loop of `load, load, store` with a run-time trip count the cursor
+    // initialisation was eight dependent round trips in a 21 us kernel
+    const bool emitter = blockIdx.x != gridDim.x - 1;
+    const u32* prow = pre + (size_t)blockIdx.x * T;
+    u32 ls0[8], pr0[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int t = threadIdx.x + u * BIN_THREADS;
+        ls0[u] = (emitter && t < T) ? tile_lstart[t] : 0u;
+        pr0[u] = (emitter && t < T) ? prow[t] : 0u;
+    }
     group_bases(group_total, (T + 63) >> 6, s_gb);
     if (blockIdx.x == gridDim.x - 1) {
         // the workgroup behind the last block of Gaussians: heavy-first descriptor list, the ranges array, the instance count
@@ -362,9 +384,25 @@ emit_binned_kernel(int P, int per_block, int grid_x, int T, const uint2* __restr
         return;
     }
     if (s_gb[512] > capacity) return;                        // the lists do not fit the buffer: nothing is written (the caller reruns)
-    const u32* prow = pre + (size_t)blockIdx.x * T;
     // u32 cursors: a tile's ids go to the first half of its own slice of `words` (u32 index 2 * first instance + position)
-    for (int t = threadIdx.x; t < T; t += BIN_THREADS) cur[t] = 2u * (s_gb[t >> 6] + tile_lstart[t]) + prow[t];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int t = threadIdx.x + u * BIN_THREADS;
+        if (t < T) cur[t] = 2u * (s_gb[t >> 6] + ls0[u]) + pr0[u];
+    }
+    for (int t0 = threadIdx.x + 8 * BIN_THREADS; t0 < T; t0 += 8 * BIN_THREADS) {       // (more than 8192 tiles: 4K images)
+        u32 ls[8], pr[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = t0 + u * BIN_THREADS;
+            ls[u] = t < T ? tile_lstart[t] : 0u; pr[u] = t < T ? prow[t] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = t0 + u * BIN_THREADS;
+            if (t < T) cur[t] = 2u * (s_gb[t >> 6] + ls[u]) + pr[u];
+        }
+    }
     __syncthreads();
     (void)depth_key;
     (void)walk_block<true>(cur, P, per_block, grid_x, rect, tiles_touched, keep, reinterpret_cast<u32*>(words));
