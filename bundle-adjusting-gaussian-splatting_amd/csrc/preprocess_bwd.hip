@@ -604,14 +604,15 @@ pose_reduce_kernel(const float* __restrict__ slab, int nblocks, float* __restric
     const int t = blockIdx.x;                            // slab column
     double acc = 0.0;
     int b = threadIdx.x;
-    // (rows past the end read as zero INSIDE the batch: a remainder loop of single loads -- 1954 rows are 7.6 per thread, so most threads
-    // took it -- was seven dependent round trips, 6.5 us of a kernel that needs one; the order of the additions is unchanged)
+    // (rows past the end INSIDE the batch, read at a clamped index and dropped afterwards: a remainder loop of single loads -- 1954 rows are
+    // 7.6 per thread, so most threads took it -- was seven dependent round trips, 6.5 us of a kernel that needs one.  No `in range ? load : 0`:
+    // the compiler makes that a branch per load with a wait behind each.  The order of the additions is unchanged.)
     for (; b < nblocks; b += 8 * 256) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (b + u * 256 < nblocks) ? slab[(size_t)(b + u * 256) * POSE_VALS + t] : 0.f;
+        for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)min(b + u * 256, nblocks - 1) * POSE_VALS + t];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += (double)v[u];
+        for (int u = 0; u < 8; ++u) acc += (b + u * 256 < nblocks) ? (double)v[u] : 0.0;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
