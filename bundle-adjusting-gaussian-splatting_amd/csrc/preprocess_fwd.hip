@@ -354,15 +354,14 @@ __device__ __forceinline__ void k1_load_camera(CamConst& cam, const float* __res
                                                const float* __restrict__ intrinsic, const float* __restrict__ campos_p,
                                                const float* __restrict__ shift_factors)
 {
-    if (threadIdx.x < 16) {
-        cam.v[threadIdx.x] = viewmatrix[threadIdx.x];
-        cam.m[threadIdx.x] = projmatrix[threadIdx.x];
-        cam.k[threadIdx.x] = intrinsic[threadIdx.x];
-    }
-    if (threadIdx.x < 3) {
-        cam.campos[threadIdx.x] = campos_p[threadIdx.x];
-        cam.sf[threadIdx.x] = shift_factors ? shift_factors[threadIdx.x] : 0.0f;
-    }
+    // all five loads first (clamped indices, every thread: 51 distinct words), then the LDS stores: written as `cam.x[t] = ptr[t]` pairs under
+    // their `if`s this was three dependent round trips at the start of a workgroup that lives as long as the whole launch
+    const int t16 = min((int)threadIdx.x, 15), t3 = min((int)threadIdx.x, 2);
+    const float v = viewmatrix[t16], m = projmatrix[t16], k = intrinsic[t16];
+    const float c = campos_p[t3];
+    const float sfv = (shift_factors ? shift_factors : campos_p)[t3];
+    if (threadIdx.x < 16) { cam.v[threadIdx.x] = v; cam.m[threadIdx.x] = m; cam.k[threadIdx.x] = k; }
+    if (threadIdx.x < 3) { cam.campos[threadIdx.x] = c; cam.sf[threadIdx.x] = shift_factors ? sfv : 0.0f; }
 }
 
 template <bool SPLIT>
