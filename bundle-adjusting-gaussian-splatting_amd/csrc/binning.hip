@@ -27,7 +27,7 @@
 template <bool EMIT>
 __device__ __forceinline__ u32 walk_block(u32* cnt, int P, int per_block, int grid_x, const uint2* __restrict__ rect,
                                           const u32* __restrict__ tiles_touched, const u64* __restrict__ keep,
-                                          u32* __restrict__ ids)
+                                          u32* __restrict__ ids, const int y_lo = 0, const int y_hi = 0x7FFF)
 {
     const int lane = threadIdx.x & 63;
     const int per_thread = per_block / BIN_THREADS;
@@ -51,15 +51,15 @@ __device__ __forceinline__ u32 walk_block(u32* cnt, int P, int per_block, int gr
             const int w = (int)(rc.y & 0xFFFF) - (int)(rc.x & 0xFFFF), h = (int)(rc.y >> 16) - (int)(rc.x >> 16);
             mine += nt;                                     // a large rectangle emits every tile: nt is its area
             if (nt > 0) {                                   // (the id alone is emitted: WordSrc, binning_common.h)
-                if (rect_small(w, h)) walk_mask<EMIT>(cnt, rc, kpv[u], grid_x, (u32)g, ids);
-                else if (nt <= BIN_COOP) walk_rect<EMIT>(cnt, rc, grid_x, lane, false, (u32)g, ids);
+                if (rect_small(w, h)) walk_mask<EMIT>(cnt, rc, kpv[u], grid_x, (u32)g, ids, y_lo, y_hi);
+                else if (nt <= BIN_COOP) walk_rect<EMIT>(cnt, rc, grid_x, lane, false, (u32)g, ids, y_lo, y_hi);
             }
             u64 big = __ballot(nt > BIN_COOP);              // never a small rectangle (at most 64 tiles)
             while (big) {
                 const int src = __ffsll((long long)big) - 1;
                 big &= big - 1;
                 const uint2 brc = make_uint2((u32)__shfl((int)rc.x, src), (u32)__shfl((int)rc.y, src));
-                walk_rect<EMIT>(cnt, brc, grid_x, lane, true, (u32)__shfl((int)(u32)g, src), ids);
+                walk_rect<EMIT>(cnt, brc, grid_x, lane, true, (u32)__shfl((int)(u32)g, src), ids, y_lo, y_hi);
             }
         }
     }
@@ -337,6 +337,12 @@ tile_desc_kernel(const u32* __restrict__ tile_total, const uint2* __restrict__ r
     build_tile_desc<ORD_PER>(tile_total, ranges, T, tile_desc, n_active, tr_all, s_cur, s_wave);
 }
 
+#ifndef EMIT_BANDS_MAX
+#define EMIT_BANDS_MAX 8
+#endif
+#ifndef EMIT_BAND_PER_TILE
+#define EMIT_BAND_PER_TILE 500                              // instances per tile (scene average) served by one band of the emission
+#endif
 // ------------------------------------------------------------------------------------------------ 4. emit_binned
 // The workgroup behind the last block of Gaussians builds the tile descriptor list (build_tile_desc) beside the emission.
 template <int ORD_PER>
@@ -405,7 +411,18 @@ emit_binned_kernel(int P, int per_block, int grid_x, int T, const uint2* __restr
     }
     __syncthreads();
     (void)depth_key;
-    (void)walk_block<true>(cur, P, per_block, grid_x, rect, tiles_touched, keep, reinterpret_cast<u32*>(words));
+    // Dense scenes: the emission in BANDS of tile rows, one pass over the block's Gaussians per band.  A tile's list is written 4 bytes at
+    // a time by 245 workgroups through eight L2s; with thousands of instances per tile the partial lines of all 8160 lists do not stay in
+    // the L2s until their neighbours arrive -- at sm 2.0 the launch wrote 525 MB to memory for 58 MB of ids (PMC, profiles/r05/ab_dense.txt).
+    // A band's lists do.  The order inside a (block, tile) group was arbitrary before and still is; the per-tile sort follows.
+    const int grid_y = T / grid_x;
+    const u32 per_band = (u32)T * (u32)EMIT_BAND_PER_TILE;
+    const int bands = min(EMIT_BANDS_MAX, max(1, (int)((s_gb[512] + per_band - 1u) / per_band)));
+    for (int bd = 0; bd < bands; ++bd) {
+        const int y_lo = bd * grid_y / bands, y_hi = (bd + 1 == bands) ? 0x7FFF : (bd + 1) * grid_y / bands;
+        (void)walk_block<true>(cur, P, per_block, grid_x, rect, tiles_touched, keep, reinterpret_cast<u32*>(words), y_lo, y_hi);
+        if (bd + 1 < bands) __syncthreads();                 // (keeps the workgroup's waves in one band; nothing depends on it)
+    }
 }
 
 // (5. the per-tile sorts: tile_sort.h, run by each tile's own blend_fwd workgroup since round 4 -- the kernel that used to launch

@@ -58,11 +58,14 @@ __device__ __forceinline__ WordSrc tile_words(const void* words, const u32 first
     WordSrc w; w.ids = reinterpret_cast<const u32*>(words) + first; w.keys = keys; return w;
 }
 
+// [y_lo, y_hi): the band of tile rows this pass of the emission serves (the count takes all rows)
 template <bool EMIT>
-__device__ __forceinline__ void walk_rect(u32* cnt, uint2 rc, int grid_x, int lane, bool coop, u32 id, u32* __restrict__ ids)
+__device__ __forceinline__ void walk_rect(u32* cnt, uint2 rc, int grid_x, int lane, bool coop, u32 id, u32* __restrict__ ids,
+                                          const int y_lo = 0, const int y_hi = 0x7FFF)
 {
-    const int minx = rc.x & 0xFFFF, miny = rc.x >> 16, w = (int)(rc.y & 0xFFFF) - minx, h = (int)(rc.y >> 16) - miny;
-    const int nt = w * h;
+    const int minx = rc.x & 0xFFFF, w = (int)(rc.y & 0xFFFF) - minx;
+    const int miny = max((int)(rc.x >> 16), y_lo), h = min((int)(rc.y >> 16), y_hi) - miny;
+    const int nt = w * h;                                    // (<= 0: the rectangle has no row in the band)
     for (int k = coop ? lane : 0; k < nt; k += coop ? 64 : 1) {
         const int dy = k / w, dx = k - dy * w;
         const u32 t = (u32)((miny + dy) * grid_x + minx + dx);
@@ -72,10 +75,17 @@ __device__ __forceinline__ void walk_rect(u32* cnt, uint2 rc, int grid_x, int la
 }
 // A rectangle of at most 8 x 8 tiles: the set bits of its tile mask (GeomView::keep), no division.
 template <bool EMIT>
-__device__ __forceinline__ void walk_mask(u32* cnt, uint2 rc, u64 m, int grid_x, u32 id, u32* __restrict__ ids)
+__device__ __forceinline__ void walk_mask(u32* cnt, uint2 rc, u64 m, int grid_x, u32 id, u32* __restrict__ ids,
+                                          const int y_lo = 0, const int y_hi = 0x7FFF)
 {
     const int minx = rc.x & 0xFFFF, miny = rc.x >> 16;
     const u32 t0 = (u32)(miny * grid_x + minx);
+    if (EMIT) {                                              // mask rows (8 bits each) outside the band
+        const int lo = min(8, max(0, y_lo - miny)), hi = min(8, max(0, y_hi - miny));
+        const u64 below_hi = hi >= 8 ? ~0ull : ((1ull << (8 * hi)) - 1ull);
+        const u64 below_lo = lo >= 8 ? ~0ull : ((1ull << (8 * lo)) - 1ull);
+        m &= below_hi & ~below_lo;
+    }
     while (m) {
         const int bit = __ffsll((long long)m) - 1;
         m &= m - 1ull;
