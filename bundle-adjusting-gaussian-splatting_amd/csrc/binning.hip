@@ -340,8 +340,8 @@ tile_desc_kernel(const u32* __restrict__ tile_total, const uint2* __restrict__ r
 #ifndef EMIT_BANDS_MAX
 #define EMIT_BANDS_MAX 8
 #endif
-#ifndef EMIT_BAND_PER_TILE
-#define EMIT_BAND_PER_TILE 500                              // instances per tile (scene average) served by one band of the emission
+#ifndef EMIT_OPEN_BYTES
+#define EMIT_OPEN_BYTES (3u << 20)                          // bytes of partially written lines per XCD that a band of the emission may keep open
 #endif
 // ------------------------------------------------------------------------------------------------ 4. emit_binned
 // The workgroup behind the last block of Gaussians builds the tile descriptor list (build_tile_desc) beside the emission.
@@ -415,9 +415,14 @@ emit_binned_kernel(int P, int per_block, int grid_x, int T, const uint2* __restr
     // a time by 245 workgroups through eight L2s; with thousands of instances per tile the partial lines of all 8160 lists do not stay in
     // the L2s until their neighbours arrive -- at sm 2.0 the launch wrote 525 MB to memory for 58 MB of ids (PMC, profiles/r05/ab_dense.txt).
     // A band's lists do.  The order inside a (block, tile) group was arbitrary before and still is; the per-tile sort follows.
+    // How many: the lines one XCD's workgroups have open -- half a byte per instance (4 bytes, eight XCDs) plus a line per tile -- should fit
+    // EMIT_OPEN_BYTES of its L2; but every band is another pass over the block's Gaussians, which only pays while a Gaussian has more than a
+    // tile or so per pass: 5 M Gaussians @4K (3.8 tiles each, 32 400 tiles) would need six bands and is slower with any number of them.
     const int grid_y = T / grid_x;
-    const u32 per_band = (u32)T * (u32)EMIT_BAND_PER_TILE;
-    const int bands = min(EMIT_BANDS_MAX, max(1, (int)((s_gb[512] + per_band - 1u) / per_band)));
+    const u32 total = s_gb[512];
+    const u32 open_bytes = total / 2u + (u32)T * 128u;
+    int bands = min(EMIT_BANDS_MAX, max(1, (int)((open_bytes + EMIT_OPEN_BYTES - 1u) / EMIT_OPEN_BYTES)));
+    if ((unsigned long long)bands * (unsigned long long)P * 4ull > (unsigned long long)total * 3ull) bands = 1;     // < 4/3 tiles per Gaussian and pass
     for (int bd = 0; bd < bands; ++bd) {
         const int y_lo = bd * grid_y / bands, y_hi = (bd + 1 == bands) ? 0x7FFF : (bd + 1) * grid_y / bands;
         (void)walk_block<true>(cur, P, per_block, grid_x, rect, tiles_touched, keep, reinterpret_cast<u32*>(words), y_lo, y_hi);
