@@ -55,15 +55,18 @@ __device__ __forceinline__ void sum_records(u32 nrec, u32 first, const float* __
     if (LIVE && nrec > 0 && nrec <= SUM_COOP) {
         // the Gaussian's <= 64 marks first (consecutive bytes, all requested before the first is looked at), then its live records two
         // at a time as below
-        u64 lm = 0ull;
-        const unsigned char* lp = live + first;
-        for (u32 r = 0; r < nrec; r += 8) {
-            u32 b[8];
-#pragma unroll
-            for (u32 u = 0; u < 8; ++u) b[u] = lp[min(r + u, nrec - 1)];
-#pragma unroll
-            for (u32 u = 0; u < 8; ++u) lm |= (u64)((b[u] != 0u && r + u < nrec) ? 1u : 0u) << (r + u);
-        }
+        // 64 bytes from the Gaussian's first mark on, as four 16-byte loads at whatever alignment, all in flight at once (bytes past its last
+        // mark belong to the next Gaussians or to the 256 bytes of slack behind the map, bags_backward_workspace_size).  Until the end of round 5
+        // this was a loop of eight byte loads per trip: four dependent round trips for the 30 records of a Gaussian at sm 2.0.
+        // A mark is 0 or 1: the four of a word gather into four bits with one multiplication.
+        struct __attribute__((packed, aligned(1))) U4 { u32 x, y, z, w; };
+        const U4* lp = reinterpret_cast<const U4*>(live + first);
+        const U4 c0 = lp[0], c1 = lp[1], c2 = lp[2], c3 = lp[3];
+        auto nib = [](u32 w) -> u64 { return (u64)(((w * 0x00204081u) >> 21) & 0xFu); };
+        u64 lm = nib(c0.x) | (nib(c0.y) << 4) | (nib(c0.z) << 8) | (nib(c0.w) << 12) | (nib(c1.x) << 16) | (nib(c1.y) << 20) | (nib(c1.z) << 24) |
+                 (nib(c1.w) << 28) | (nib(c2.x) << 32) | (nib(c2.y) << 36) | (nib(c2.z) << 40) | (nib(c2.w) << 44) | (nib(c3.x) << 48) |
+                 (nib(c3.y) << 52) | (nib(c3.z) << 56) | (nib(c3.w) << 60);
+        lm &= (nrec >= 64u) ? ~0ull : ((1ull << nrec) - 1ull);
         const float4* rec = reinterpret_cast<const float4*>(partials + (size_t)first * PART_FLOATS);
         while (lm) {
             const u32 r = (u32)__builtin_ctzll(lm); lm &= lm - 1ull;
@@ -71,6 +74,9 @@ __device__ __forceinline__ void sum_records(u32 nrec, u32 first, const float* __
             const u32 r1 = two ? (u32)__builtin_ctzll(lm) : r; if (two) lm &= lm - 1ull;
             const float4 a0 = rec[RQ * r], b0 = rec[RQ * r + 1], c0 = rec[RQ * r + 2];
             const float4 a1 = rec[RQ * r1], b1 = rec[RQ * r1 + 1], c1 = rec[RQ * r1 + 2];
+            // (both records requested before either is added: left alone the compiler sinks the second one's loads into `if (two)`, behind
+            // the first one's wait)
+            asm volatile("" :: "v"(a1.x), "v"(b1.x), "v"(c1.x));
             s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
             s1.x += b0.x; s1.y += b0.y; s1.z += b0.z; s1.w += b0.w;
             s2.x += c0.x; s2.y += c0.y; s2.z += c0.z;
