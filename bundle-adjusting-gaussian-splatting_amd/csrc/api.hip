@@ -227,7 +227,9 @@ size_t bags_backward_workspace_size(int32_t P, int64_t I)
 {
     const size_t part = align_up((size_t)(I > 0 ? I : 1) * PART_FLOATS * sizeof(float), 256);
     const size_t slab = align_up((size_t)(cdiv(P > 0 ? P : 1, 256)) * POSE_VALS * sizeof(float), 256);
-    const size_t live = align_up((size_t)(I > 0 ? I : 1), 256);          // dense-scene mode: one byte per record
+    // dense-scene mode: one byte per record, + the 64 bytes preprocess_bwd reads from a Gaussian's first mark on (launch_blend_bwd clears
+    // the same number of bytes)
+    const size_t live = align_up((size_t)(I > 0 ? I : 1) + 64, 256);
     return part + slab + live + 256;
 }
 

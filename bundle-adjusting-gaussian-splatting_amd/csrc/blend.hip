@@ -874,7 +874,10 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     // Dense scenes (long tile lists, most of each list behind the deepest contributor): clearing the record array with one
     // streaming memset is cheaper than the per-tile zero loops, which gather an id and two geometry lines per dead instance.
     if (!bwd_dense_mode(n_records, T, dense_per_tile_arg)) live_map = nullptr;
-    if (live_map) { hipError_t e = hipMemsetAsync(live_map, 0, (size_t)n_records, st); if (e != hipSuccess) return e; }
+    // (the map is carved 256-byte aligned, in 256-byte units, with room for the 64 bytes preprocess_bwd reads from a mark on --
+    // bags_backward_workspace_size: a fill of whole units is ONE launch of the runtime's fill kernel; with the odd tail it was two, ~5.5 us
+    // each -- and the bytes behind the last mark are zero rather than arbitrary)
+    if (live_map) { hipError_t e = hipMemsetAsync(live_map, 0, ((size_t)n_records + 64 + 255) / 256 * 256, st); if (e != hipSuccess) return e; }
 #define BWD_LAUNCH_(ABS_, CMP_, SPARSE_)                                                                                             \
     hipLaunchKernelGGL((blend_bwd_scan_kernel<ABS_, CMP_, SPARSE_>), dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T, \
                        im.tile_desc, b.point_list, reinterpret_cast<const unsigned char*>(b.reach_mask), binned ? 8u : 4u, g.g2d,    \
