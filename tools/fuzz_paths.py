@@ -24,13 +24,17 @@ def main():
                                                          "keeps a byte per record instead of zero records; 1 forces that mode, -1 the other)")
     ap.add_argument("--cross-dense", action="store_true", help="differential runs only: the tile-binned run in dense-scene mode, the radix run "
                                                                "without it -- the gradients must still be bit-identical")
+    ap.add_argument("--only", default="", help="comma-separated trial numbers: every scene is still drawn (the generator's state is the same as in "
+                                               "the full run) but only these are run -- to look at a failure of an earlier run again")
     args = ap.parse_args()
+    only = {int(x) for x in args.only.split(",") if x.strip()}
+    cut = 3000 if only else 300
     from bags_raster import rasterizer as _R
     _R.DENSE_PER_TILE = args.dense
     rng = torch.Generator().manual_seed(args.seed)
     U = lambda a, b: float(torch.empty(1).uniform_(a, b, generator=rng))
     I = lambda a, b: int(torch.randint(a, b, (1,), generator=rng))
-    bad = []
+    bad, soft = [], []
     paths_hit = {}                                           # sort path (csrc/tile_sort.h) -> lists that took it, over all trials
     for trial in range(args.trials):
         P = max(1, int(math.exp(U(math.log(3000.0) if args.long else 0.0, math.log(60000.0 if args.long else 40000.0)))))
@@ -58,6 +62,8 @@ def main():
         if I(0, 3) == 0:
             scene["opacities"] = scene["opacities"] * 0.05    # long lists that do not saturate
         g = torch.randn(3, H, W, generator=rng)
+        if only and trial not in only:
+            continue
         if args.oracle:
             try:
                 rep = compare(scene, cam, deg, check_fp64=True, **kw)
@@ -65,8 +71,20 @@ def main():
                     assert_report(rep, grad_tol=3e-4, skip_zero=("campos",))
                     print(f"  I = {rep['num_rendered'][0]}: ok", flush=True)
                 except AssertionError as e:
-                    print(f"  I = {rep['num_rendered'][0]}: MISMATCH {str(e)[:300]}", flush=True)
-                    bad.append(dict(tag, why=str(e)[:300]))
+                    # Two things a small random scene does that the kernels are not responsible for (seed 311 of round 5 has both): the fp32
+                    # and the fp64 oracle disagree with EACH OTHER by more than assert_report's 2e-3 cap (one flipped alpha / transmittance
+                    # threshold weighs more among 2500 Gaussians than among 500 k), and the device's v_exp_f32 decides such a pair differently
+                    # from the oracle's libm exp on a pixel or two (n_contrib).  Second look: at most two such pixels, and for the "other
+                    # oracle" bound 1.5 x what the oracles differ by themselves; everything else as strict as before.  Reported apart.
+                    o = rep.get("oracle32_vs_64", {})
+                    relaxed = {k: (3e-4, max(2e-3, 1.5 * float(v))) for k, v in o.items()}
+                    try:
+                        assert_report(rep, grad_tol=3e-4, skip_zero=("campos",), tol_override=relaxed, n_contrib_mismatch=2.5 / (W * H))
+                        print(f"  I = {rep['num_rendered'][0]}: ok on second look (threshold pair): {str(e)[:120]}", flush=True)
+                        soft.append(dict(tag, why=str(e)[:120]))
+                    except AssertionError as e2:
+                        print(f"  I = {rep['num_rendered'][0]}: MISMATCH {str(e2)[:cut]}", flush=True)
+                        bad.append(dict(tag, why=str(e2)[:300]))
             except Exception as e:
                 print(f"  EXCEPTION {type(e).__name__}: {str(e)[:200]}", flush=True)
                 bad.append(dict(tag, why=f"exception {type(e).__name__}"))
@@ -119,7 +137,7 @@ def main():
         except Exception as e:                               # (an exception of the op, not a device fault)
             print(f"  EXCEPTION {type(e).__name__}: {str(e)[:200]}", flush=True)
             bad.append(dict(tag, why=f"exception {type(e).__name__}"))
-    print(json.dumps({"trials": args.trials, "failures": bad, "sort_paths": paths_hit}))
+    print(json.dumps({"trials": args.trials, "failures": bad, "threshold_pairs": soft, "sort_paths": paths_hit}))
 
 
 if __name__ == "__main__":
