@@ -281,6 +281,26 @@ __device__ __forceinline__ void for_each_word_256(const WordSrc words_in, const 
             if (base + 256u * j < n) f(((u64)key[j] << 32) | (u64)id[j]);
     }
 }
+// The same over words whose keys were stashed by an earlier pass (slab_prepare): id and key of an entry are two INDEPENDENT coalesced
+// loads -- one memory round trip per batch instead of two, and no gather.  The stash was written by other waves of this workgroup:
+// read at agent scope (L2), like the scratch words of level 2.
+template <typename F>
+__device__ __forceinline__ void for_each_stashed_word_256(const WordSrc words_in, const u32* __restrict__ stash, const u32 start, const u32 n,
+                                                          const u32 tid, F f)
+{
+    for (u32 base = tid; base < n; base += 256u * 8u) {
+        u32 id[8], key[8];
+#pragma unroll
+        for (u32 j = 0; j < 8; ++j) {
+            const u32 i = min(base + 256u * j, n - 1);
+            id[j] = words_in.ids[start + i];
+            key[j] = __hip_atomic_load(&stash[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (u32 j = 0; j < 8; ++j)
+            if (base + 256u * j < n) f(((u64)key[j] << 32) | (u64)id[j]);
+    }
+}
 // ---- the two-level sort of a list of TSORT_BLOCK < n <= TSORT_LARGE entries, one function per level.  (Round 5 ran level 2 lazily
 // from blend_fwd -- a dense tile's walk ends after a fraction of its list and nothing behind the tile's deepest contributor needs an
 // ORDER -- and measured it slower: blend.hip, profiles/r05/ab_dense.txt.)
@@ -294,8 +314,25 @@ __device__ __forceinline__ u32 slab_prepare(const u32 n, const u32 start, const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 K = min((u32)TS_SLABS_MAX, (n + TSORT_WAVE / 2 - 1) / (TSORT_WAVE / 2));
     u32 kmin = 0xFFFFFFFFu, kmax = 0u;
-    for_each_word_256(words_in, start, n, (u32)tid, [&](const u64 w) { const u32 key = (u32)(w >> 32); kmin = min(kmin, key); kmax = max(kmax, key); });
+    // The first pass gathers every entry's key by its id (two dependent round trips per batch, 64 lines per wave load) and leaves the keys
+    // in the SECOND half of the tile's own slice of the words buffer -- its first half holds the unsorted ids, the second is free until
+    // the compacted positions are written after the sort (blend.hip) -- so that the two passes below read id and key side by side.
+    // (Round 5, timing build: level 1 was three quarters of what a dense scene's sort costs, and that 43 % / 61 % of blend_fwd at 1800 /
+    // 4000 entries per tile: profiles/r05/ab_dense.txt 9.)
+    u32* const stash = const_cast<u32*>(words_in.ids) + start + n;
+    for (u32 base = tid; base < n; base += 256u * 8u) {
+        u32 id[8], key[8];
+#pragma unroll
+        for (u32 j = 0; j < 8; ++j) id[j] = words_in.ids[start + min(base + 256u * j, n - 1)];
+#pragma unroll
+        for (u32 j = 0; j < 8; ++j) key[j] = words_in.keys[id[j]];
+#pragma unroll
+        for (u32 j = 0; j < 8; ++j)
+            if (base + 256u * j < n) { kmin = min(kmin, key[j]); kmax = max(kmax, key[j]); stash[base + 256u * j] = key[j]; }
+    }
     kmin = wave_min(kmin); kmax = wave_max(kmax);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stash is complete (read back by the other waves through the L2)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();                                  // the previous list's state is no longer in use
     if (lane == 0) { s_red[wave] = kmin; s_red[4 + wave] = kmax; }
     for (u32 i = tid; i <= TS_SLABS_MAX; i += 256) slab_cnt[i] = 0u;
@@ -304,7 +341,7 @@ __device__ __forceinline__ u32 slab_prepare(const u32 n, const u32 start, const 
     kmin = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
     kmax = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
     const float scale = (float)K / ((float)(kmax - kmin) + 1.0f);
-    for_each_word_256(words_in, start, n, (u32)tid, [&](const u64 w) {
+    for_each_stashed_word_256(words_in, stash, start, n, (u32)tid, [&](const u64 w) {
         atomicAdd(&slab_cnt[min(K - 1, (u32)((float)((u32)(w >> 32) - kmin) * scale))], 1u);
     });
     __syncthreads();
@@ -316,7 +353,7 @@ __device__ __forceinline__ u32 slab_prepare(const u32 n, const u32 start, const 
     __syncthreads();
     if (s_bad != 0u) return 0u;
     // ---- words grouped by slab in the scratch array (order inside a slab arbitrary)
-    for_each_word_256(words_in, start, n, (u32)tid, [&](const u64 w) {
+    for_each_stashed_word_256(words_in, stash, start, n, (u32)tid, [&](const u64 w) {
         const u32 k = min(K - 1, (u32)((float)((u32)(w >> 32) - kmin) * scale));
         scratch[start + slab_start[k] + atomicAdd(&slab_cnt[k], 1u)] = w;
     });
