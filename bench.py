@@ -39,6 +39,7 @@ for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
 import torch  # noqa: E402
 
 HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: 8 TB/s spec
+CLOCK_HZ = 2.4e9           # MI355X_MICROARCH.md: max clock 2400 MHz (the chip holds less under load: fractions of issue cycles are lower bounds)
 P_DEFAULT, W_DEFAULT, H_DEFAULT, SM_DEFAULT, DEG = 500_000, 1920, 1080, 0.5, 3
 
 
@@ -293,13 +294,21 @@ def main():
     world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    def die(reason, ranks=0):
+        """A multi-rank run that cannot start: ONE JSON line on stdout (the driver keeps the tail of stdout: a failed SCALE run must
+        say why there, not only on some rank's stderr), then a non-zero exit from this process -- never a re-exec, never a smaller
+        bench under the same --gpus."""
+        print(json.dumps({"error": reason, "rccl_ranks": ranks, "n_gpus": args.gpus, "rank": rank,
+                          "backend": args.backend, "world_size_env": env_world}), flush=True)
+        raise SystemExit(2)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        die(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the rasterizer has no CPU path")
+        die("bench.py needs an MI355X: the rasterizer has no CPU path")
     if world > 1 and args.backend == "nccl" and torch.cuda.device_count() < world:
         # one rank per GPU over RCCL: two ranks on one device would deadlock or fail inside the first collective -- say so instead
-        raise SystemExit(f"--gpus {world} over RCCL needs {world} visible GPUs, this node shows {torch.cuda.device_count()}")
+        die(f"--gpus {world} over RCCL needs {world} visible GPUs, this node shows {torch.cuda.device_count()}")
     local = local % max(torch.cuda.device_count(), 1)      # gloo self-test: several ranks may share one GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -308,17 +317,24 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(args.backend)
-        # the ranks that actually take part in a collective, counted BY a collective: the figure printed as rccl_ranks.  Fewer
-        # than --gpus (a launcher that started fewer processes, a communicator that split) is an error, never a smaller bench.
-        ones = torch.ones(1, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(ones)
-        ranks_seen = int(ones.item())
+        import datetime
+        ranks_seen = 0
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=180))
+            else:
+                dist.init_process_group(args.backend, timeout=datetime.timedelta(seconds=180))
+            # the ranks that actually take part in a collective, counted BY a collective: the figure printed as rccl_ranks.  Fewer
+            # than --gpus (a launcher that started fewer processes, a communicator that split) is an error, never a smaller bench.
+            ones = torch.ones(1, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(ones)
+            if args.backend == "nccl":
+                torch.cuda.synchronize()
+            ranks_seen = int(ones.item())
+        except Exception as e:                                 # RCCL / rendezvous failure: every rank says so on stdout and exits non-zero
+            die(f"process group ({args.backend}) did not come up: {type(e).__name__}: {str(e)[:400]}", ranks_seen)
         if dist.get_world_size() != args.gpus or ranks_seen != args.gpus:
-            raise SystemExit(f"--gpus {args.gpus}: the process group holds {dist.get_world_size()} ranks, {ranks_seen} answered the first all-reduce")
+            die(f"--gpus {args.gpus}: the process group holds {dist.get_world_size()} ranks, {ranks_seen} answered the first all-reduce", ranks_seen)
 
     from bags_raster import _lib
     from bags_raster.sharding import GradAllReducer, PipelinedExchange
@@ -615,13 +631,22 @@ def main():
                                    "library_build": build,
                                    "traffic_commit": None if tj is None else (tj["build"].split("commit=")[-1] if "commit=" in tj["build"] else None),
                                    "traffic_build": None if tj is None else tj["build"], "traffic_stale": None if tj is not None else stale,
-                                   "note": "this kernel is bound by vector-instruction throughput, not by HBM (DESIGN.md section 3: at one "
-                                           "workgroup per CU it already runs at 82 % of a single wave's issue rate; HBM traffic stays near "
-                                           "its algorithmic bytes); PMC source: " + str(src)}
+                                   "binding_resource": "valu_issue",
+                                   "note": "SURVEY 8(d) defines this block against HBM; the kernel itself is bound by vector-instruction "
+                                           "issue (roofline_valu.valu_issue_frac; DESIGN.md section 3), its HBM traffic stays near the "
+                                           "algorithmic bytes.  The step's HBM-bound kernels are judged in roofline_k1 / roofline_k9; "
+                                           "PMC source: " + str(src)}
                 # the blend kernels are VALU bound.  flop_frac = contributing (pixel, splat) pairs of forward +
                 # backward x ~100 flop / (t_fwd + t_bwd) / 157.3 TFLOP/s; the pair counts come from a DIAG_PAIRS build of the
                 # same workload (tools/diag_pairs.sh -> profiles/rNN/pairs.json).
                 rv = {"kernel": dom, "valu_insts_per_launch": va, "peak_tflops": 157.3}
+                if tj is not None and tj[dom].get("active_inst_valu_quads"):
+                    # the binding resource of this kernel: share of the chip's SIMD cycles in which a vector instruction issues.
+                    # SQ_ACTIVE_INST_VALU counts quad-cycles (x 4 = cycles); 256 CUs x 4 SIMDs; the clock is the part's maximum
+                    # (MI355X_MICROARCH.md: 2400 MHz) -- under this load the chip holds less, so the true fraction is HIGHER
+                    rv.update(valu_issue_frac=tj[dom]["active_inst_valu_quads"] * 4.0 / (stages[dom] * 1e-3 * CLOCK_HZ * 1024),
+                              clock_ghz_assumed=CLOCK_HZ / 1e9, active_inst_valu_quads=tj[dom]["active_inst_valu_quads"],
+                              counters_from=src)
                 for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
                     try:
                         pj = json.load(open(os.path.join(ROOT, "profiles", rnd, "pairs.json")))
@@ -631,11 +656,24 @@ def main():
                             rv.update(pairs_evaluated=pp["bwd_pairs_evaluated"], pairs_contributing=pp["bwd_pairs_contributing"],
                                       lane_fill=pp["bwd_entries"] / max(1.0, 64.0 * pp["bwd_wave_steps"]) if "bwd_entries" in pp else None,
                                       flop_frac=(pp["fwd_pairs_contributing"] + pp["bwd_pairs_contributing"]) * 100.0 / t_blend / 157.3e12,
+                                      lane_instr_per_evaluated_pair=(va * 64.0 / pp["bwd_pairs_evaluated"]) if va else None,
                                       source="profiles/" + rnd + "/pairs.json")
                             break
                     except (OSError, ValueError, KeyError):
                         continue
                 out["roofline_valu"] = rv
+                # The two kernels of the step that ARE HBM-bound, each against the 8 TB/s peak: algorithmic bytes of the stage (SURVEY 8d
+                # split: K1 reads a visible Gaussian's 236 input bytes and writes 48, a culled one costs 28; K9 re-reads the 236,
+                # reads 92 of intermediates + records and writes 236 of gradients + 2) over the stage's mean time, and the counter
+                # traffic of the same launch (2 x FETCH + WRITE of the stamped PMC file) as a ratio to the algorithmic bytes
+                for nm, stg in (("roofline_k1", "preprocess_fwd"), ("roofline_k9", "preprocess_bwd")):
+                    if stages.get(stg):
+                        ab_, t_ = alg[stg], stages[stg] * 1e-3
+                        tr_ = (2 * tj[stg]["fetch_bytes"] + tj[stg]["write_bytes"]) if (tj is not None and stg in tj and "fetch_bytes" in tj[stg]) else None
+                        out[nm] = {"bound": "hbm", "kernel": stg, "achieved": ab_ / t_ / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                   "frac": ab_ / t_ / HBM_PEAK, "alg_bytes_per_launch": ab_, "mean_launch_ms": stages[stg],
+                                   "traffic": tr_, "traffic_over_alg": (tr_ / ab_) if tr_ else None,
+                                   "note": "stage time from the 10-step all-stage hipEvent pass behind the timed region"}
                 out["roofline_atomic"] = {"global_float_atomics_per_step": 0,
                                           "note": "gradients are reduced through per-wave LDS copies and one 48-B record per instance"}
             dev_ms = sum(stages.values())

@@ -11,12 +11,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # tests).  Not a fallback: a missing file still raises.
 LIB_PATH = os.environ.get("BAGS_RASTER_LIB") or os.path.join(_HERE, "libbags_raster.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 TILES_AABB, TILES_OPACITY = 0, 1
 DEPTH_Z, DEPTH_DISTANCE = 0, 1
 BINNING_AUTO, BINNING_RADIX = 0, 1
 CLAMP_GRAD_STOCK, CLAMP_GRAD_EXACT = 0, 1
 CONIC_GRAD_STOCK, CONIC_GRAD_EXACT = 0, 1
+BWD_ALL, BWD_BLEND, BWD_PREPROCESS = 0, 1, 2
 
 c_fp = C.c_void_p  # device pointers travel as integers
 
@@ -50,7 +51,8 @@ class BagsBackwardArgs(C.Structure):
                 ("grad_colors_precomp", c_fp), ("grad_opacities", c_fp), ("grad_scales", c_fp), ("grad_rotations", c_fp),
                 ("grad_cov3D_precomp", c_fp), ("grad_viewmatrix", c_fp), ("grad_projmatrix", c_fp),
                 ("grad_intrinsic", c_fp), ("grad_campos", c_fp), ("grad_shift_factors", c_fp),
-                ("binning_capacity", C.c_int64), ("accumulate", C.c_int32), ("dense_per_tile", C.c_int32), ("grad_shs_rest", c_fp)]
+                ("binning_capacity", C.c_int64), ("accumulate", C.c_int32), ("dense_per_tile", C.c_int32), ("grad_shs_rest", c_fp),
+                ("phase", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class BagsDebugViews(C.Structure):

@@ -204,6 +204,27 @@ LAZY_RECOVER = False
 # (BagsBackwardArgs.accumulate) and hands autograd None for them -- no flat buffer, no add pass per tensor and view.  The sums are
 # what autograd's own accumulation gives; tensor hooks on those parameters do not see the per-view gradients.
 ACCUMULATE_IN_PLACE = False
+
+
+class AccumulationGate:
+    """Orders the per-Gaussian halves of the backwards of ONE optimisation step whose views run on SEVERAL streams.
+
+    With ACCUMULATE_IN_PLACE the backward of view k reads, adds to and writes the gradient buffers view k-1 wrote: a read-modify-write
+    that two streams must not interleave, and whose ORDER decides the rounding of the sums.  While a gate is installed
+    (``rasterizer.ACCUMULATION_GATE = AccumulationGate()``; bags_raster.sharding.ViewShardedRenderer does it for its batch) every
+    backward runs as two calls of the library -- BAGS_BWD_BLEND (the per-tile half, ~85 % of the time, no shared state), then
+    BAGS_BWD_PREPROCESS behind the event the previous backward recorded after ITS second half -- so the sums are formed in the order
+    the backwards were CALLED in, i.e. bit for bit what the same calls give on one stream, while everything else of the views
+    overlaps freely.  ``reset()`` at the start of a step (nothing to wait for)."""
+
+    def __init__(self):
+        self.event = None
+
+    def reset(self) -> None:
+        self.event = None
+
+
+ACCUMULATION_GATE: Optional[AccumulationGate] = None
 # BagsBackwardArgs.dense_per_tile: 0 = the library's threshold (instances per tile, scene average) for the backward's dense-scene
 # mode (a byte per gradient record instead of zero records), < 0 never, > 0 that threshold.  Results do not depend on it;
 # tools/fuzz_paths.py forces both paths with it.
@@ -549,8 +570,24 @@ class _RasterizeGaussians(torch.autograd.Function):
                                       _ptr(g_intr), _ptr(g_campos), _ptr(g_shift), fw.capacity, 1 if in_place is not None else 0, int(DENSE_PER_TILE),
                                       _ptr(g_sh_rest))
             state = _state_of(fw)
-            L.check(lib.bags_backward(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(args), stream),
-                    "bags_backward")
+            gate = ACCUMULATION_GATE
+            if gate is None:
+                L.check(lib.bags_backward(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(args), stream),
+                        "bags_backward")
+            else:
+                # views of one step on several streams (AccumulationGate): the per-tile half now, the per-Gaussian half -- the one
+                # that adds into the shared gradient buffers -- behind the previous backward's
+                ts = torch.cuda.current_stream(dev)
+                args.phase = L.BWD_BLEND
+                L.check(lib.bags_backward(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(args), stream),
+                        "bags_backward (blend half)")
+                if gate.event is not None:
+                    ts.wait_event(gate.event)
+                args.phase = L.BWD_PREPROCESS
+                L.check(lib.bags_backward(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(args), stream),
+                        "bags_backward (per-Gaussian half)")
+                gate.event = torch.cuda.Event()
+                gate.event.record(ts)
         if g_campos is not None:
             g_campos = g_campos.reshape(ctx.shapes["campos"])
         if in_place is not None:                              # already added into the parameters' .grad: nothing for autograd to add

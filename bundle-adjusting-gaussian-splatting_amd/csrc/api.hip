@@ -293,7 +293,7 @@ static int enqueue_finish(const BagsSettings* s, const BagsInputs* in, const Geo
         if (in->P == 0) HIP_TRY(launch_binned_empty(g, im, gx * gy, st));      // no prepare phase ran: an all-empty tile list
         if (I > 0 && in->P > 0) {
             ProfScope ps(ST_TILE_SORT, st);
-            HIP_TRY(launch_binned_finish(g, im, in->P, gx, gx * gy, b.words, b.scratch, b.point_list, (u32)I, n_dev, st, speculative));
+            HIP_TRY(launch_binned_finish(g, im, in->P, gx, gx * gy, b.words, (u32)I, st, speculative));
         } else if (in->P > 0) {
             HIP_TRY(launch_binned_desc_only(im, gx * gy, st));                   // nothing to emit: only the (all-empty) tile list
         }
@@ -412,6 +412,7 @@ int bags_backward(const BagsSettings* s, const BagsInputs* in, const BagsState* 
     if (cap < I) return fail(BAGS_ERR_ARG, "binning_capacity %lld < num_rendered %lld", (long long)cap, (long long)I);
     if (!stt->binning || stt->binning_bytes < bags_binning_size(cap, W, H)) return fail(BAGS_ERR_SIZE, "binning buffer too small");
     if (!a->workspace || a->workspace_bytes < bags_backward_workspace_size(in->P, I)) return fail(BAGS_ERR_SIZE, "backward workspace too small");
+    if (a->phase < BAGS_BWD_ALL || a->phase > BAGS_BWD_PREPROCESS) return fail(BAGS_ERR_ARG, "phase %d is not BAGS_BWD_ALL / _BLEND / _PREPROCESS", a->phase);
     if (in->shs_rest ? ((a->grad_shs != nullptr) != (a->grad_shs_rest != nullptr)) : (a->grad_shs_rest != nullptr))
         return fail(BAGS_ERR_ARG, "grad_shs_rest goes with inputs.shs_rest, and then grad_shs (features_dc) and grad_shs_rest are given together");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -422,12 +423,14 @@ int bags_backward(const BagsSettings* s, const BagsInputs* in, const BagsState* 
     float* partials = reinterpret_cast<float*>(ws);
     float* slab = reinterpret_cast<float*>(ws + align_up((size_t)(I > 0 ? I : 1) * PART_FLOATS * sizeof(float), 256));
     unsigned char* live_map = reinterpret_cast<unsigned char*>(slab) + align_up((size_t)(cdiv(in->P > 0 ? in->P : 1, 256)) * POSE_VALS * sizeof(float), 256);
+    // the dense-scene mode (a byte per gradient record instead of zero records) is decided HERE, once: both launchers get the map or null
     const bool dense = I > 0 && bwd_dense_mode(I, cdiv(W, BAGS_TILE) * cdiv(H, BAGS_TILE), a->dense_per_tile);
-    if (I > 0) {
+    if (I > 0 && a->phase != BAGS_BWD_PREPROCESS) {
         { ProfScope ps(ST_BLEND_BWD, st); HIP_TRY(launch_blend_bwd(*s, g, b, im, a->grad_color, partials, a->grad_means2D_densify != nullptr, use_binned(s, in->P), st,
-                                                                  I, a->dense_per_tile, live_map)); }
+                                                                  I, dense ? live_map : nullptr)); }
         DEBUG_SYNC(s, st, "blend_bwd");
     }
+    if (a->phase == BAGS_BWD_BLEND) return BAGS_OK;          // the per-Gaussian half comes with a second call (BAGS_BWD_PREPROCESS)
     int nblocks = 0;
     { ProfScope ps(ST_PRE_BWD, st); HIP_TRY(launch_preprocess_bwd(*s, *in, g, nullptr, partials, slab, &nblocks, *a, st, use_binned(s, in->P), dense ? live_map : nullptr)); }
     DEBUG_SYNC(s, st, "preprocess_bwd");

@@ -174,8 +174,8 @@ hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinV
 // (radix path) it is gathered from g.inst_off
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
                             const float* grad_color, float* partials, bool want_abs, bool binned, hipStream_t st,
-                            long long n_records = 0, int dense_per_tile = 0,       // instance count, BagsBackwardArgs.dense_per_tile
-                            unsigned char* live_map = nullptr);           // one byte per record (dense-scene mode), or null
+                            long long n_records = 0,                      // instance count
+                            unsigned char* live_map = nullptr);           // one byte per record (dense-scene mode: the caller's decision), or null
 bool bwd_dense_mode(long long n_records, int T, int dense_per_tile);      // does a backward of this size run in dense-scene mode?
 hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, const int32_t* radii_or_null,
                                  const float* partials, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a, hipStream_t st,
@@ -221,8 +221,8 @@ hipError_t launch_binned_desc_only(const ImgView& im, int T, hipStream_t st);
 // (the (block, tile) counts themselves come from launch_preprocess_fwd(count_into = &im))
 hipError_t launch_binned_prepare(const GeomView& g, const ImgView& im, int P, int grid_x, int T, hipStream_t st, u32* host_count = nullptr,
                                  bool count_now = true);
-hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int grid_x, int T, u64* words, u64* scratch, u32* point_list,
-                                u32 capacity, const u32* n_dev, hipStream_t st, bool deliver_count = false);
+hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int grid_x, int T, u64* words, u32 capacity, hipStream_t st,
+                                bool deliver_count = false);
 hipError_t launch_debug_keys_ranges(const uint2* ranges, const u32* point_list, const u32* depth_key, int T, u64* out, hipStream_t st);
 hipError_t launch_debug_keys(const u32* tile_sorted, const u32* point_list, const u32* depth_key, long long I, u64* out, hipStream_t st);
 hipError_t launch_unpack_rect(const uint2* rect, int P, u32* out, hipStream_t st);

@@ -497,8 +497,8 @@ hipError_t launch_binned_empty(const GeomView& g, const ImgView& im, int T, hipS
     return launch_binned_desc_only(im, T, st);
 }
 
-hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int grid_x, int T, u64* words, u64* scratch, u32* point_list,
-                                u32 capacity, const u32* n_dev, hipStream_t st, bool deliver_count)
+hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int grid_x, int T, u64* words, u32 capacity, hipStream_t st,
+                                bool deliver_count)
 {
     const int per = binned_per_block(P), B = cdiv(P, per);
     // T slot cursors (up to 128 KB at 32768 tiles: one workgroup per CU); the descriptor workgroup's transposes fit beside
@@ -510,7 +510,7 @@ hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int
                 im.tile_total, im.tile_desc, im.n_active, g.num_rendered, g.block_total, B, g.block_base, deliver_count ? 1 : 0); }
     switch (ord_per_for(T)) { case 8: EM_LAUNCH(8) break; case 16: EM_LAUNCH(16) break; default: EM_LAUNCH(32) }
 #undef EM_LAUNCH
-    (void)scratch; (void)point_list; (void)n_dev;            // blend_fwd sorts every tile's list itself (tile_sort.h)
+    // (blend_fwd sorts every tile's list itself: tile_sort.h)
     return e != hipSuccess ? e : hipGetLastError();
 }
 

@@ -862,9 +862,11 @@ bool bwd_dense_mode(long long n_records, int T, int dense_per_tile_arg)
     const long long thr = dense_per_tile_arg == 0 ? BWD_DENSE_PER_TILE : dense_per_tile_arg;
     return thr > 0 && n_records > thr * (long long)T;
 }
+// live_map: the caller's ONE decision about the dense-scene mode (bags_backward: bwd_dense_mode) -- the byte map, or null.  The same
+// pointer goes to launch_preprocess_bwd, so the kernel that marks records and the kernel that reads the marks cannot disagree.
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
                             const float* grad_color, float* partials, bool want_abs, bool binned, hipStream_t st,
-                            long long n_records, int dense_per_tile_arg, unsigned char* live_map)
+                            long long n_records, unsigned char* live_map)
 {
     const int gx = cdiv(s.image_width, BAGS_TILE), gy = cdiv(s.image_height, BAGS_TILE);
     const int T = gx * gy;
@@ -873,7 +875,6 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     const bool compact = binned && s.tile_bounds != BAGS_TILES_OPACITY;
     // Dense scenes (long tile lists, most of each list behind the deepest contributor): clearing the record array with one
     // streaming memset is cheaper than the per-tile zero loops, which gather an id and two geometry lines per dead instance.
-    if (!bwd_dense_mode(n_records, T, dense_per_tile_arg)) live_map = nullptr;
     // (the map is carved 256-byte aligned, in 256-byte units, with room for the 64 bytes preprocess_bwd reads from a mark on --
     // bags_backward_workspace_size: a fill of whole units is ONE launch of the runtime's fill kernel; with the odd tail it was two, ~5.5 us
     // each -- and the bytes behind the last mark are zero rather than arbitrary)
@@ -883,7 +884,7 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
                        im.tile_desc, b.point_list, reinterpret_cast<const unsigned char*>(b.reach_mask), binned ? 8u : 4u, g.g2d,    \
                        binned ? nullptr : g.inst_off, g.block_base, s.bg, im.final_T, im.n_contrib, grad_color, partials, \
                        compact ? 1 : 0, im.tile_aux, live_map)
-    // The chunk geometry follows the SCENE, not dense_per_tile_arg: forcing the dense-scene mode on or off leaves the arithmetic
+    // The chunk geometry follows the SCENE, not the dense-scene decision: forcing the dense-scene mode on or off leaves the arithmetic
     // untouched, so the two modes stay bit-identical (tests, tools/fuzz_paths.py --cross-dense)
     const bool sparse = n_records <= (long long)BWD_SPARSE_PER_TILE * T;
 #define BWD_LAUNCH(ABS_, CMP_) do { if (sparse) BWD_LAUNCH_(ABS_, CMP_, true); else BWD_LAUNCH_(ABS_, CMP_, false); } while (0)

@@ -104,9 +104,8 @@ __device__ __forceinline__ void wave_sort_words(const u64 (&e)[PER], u32 n, u32 
     }
 }
 
-// One WAVE per tile for lists of up to TSORT_WAVE entries: independent waves, no workgroup barriers (role of the
-// workgroups behind the long-list ones in tile_sort_kernel: four tiles per 256-thread workgroup, one per wave, each with
-// its own quarter of the workgroup's LDS; neighbouring descriptors hold lists of similar length).
+// One WAVE for a list of up to TSORT_WAVE entries: no workgroup barriers, only wave-level synchronisation (blend_fwd calls it from
+// wave 0 of the tile's workgroup; the other three waves wait at the barrier behind the sort).
 #define TS_PER (TSORT_WAVE / 64)
 template <int PER>
 __device__ __forceinline__ void sort_wave_list(u32 n, u32 start, const WordSrc words_in, u32* __restrict__ point_list, u64* t, u32* cnt,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BAGS_ABI_VERSION 8
+#define BAGS_ABI_VERSION 9
 #define BAGS_TILE 16
 
 enum { BAGS_OK = 0, BAGS_ERR_ARG = -1, BAGS_ERR_HIP = -2, BAGS_ERR_SIZE = -3, BAGS_ERR_DEVICE = -4 };
@@ -61,6 +61,7 @@ enum { BAGS_CLAMP_GRAD_STOCK = 0, BAGS_CLAMP_GRAD_EXACT = 1 };
  * det >= 0.09 (the 0.3 px dilation), so the two differ by at most 1.2e-5 relative on one Gaussian's dL/dcov2D (measured 2e-7 on the
  * gradient tensors of a scene of small splats, tests/test_oracle_cpu.py).  Forward values do not depend on this switch. */
 enum { BAGS_CONIC_GRAD_STOCK = 0, BAGS_CONIC_GRAD_EXACT = 1 };
+enum { BAGS_BWD_ALL = 0, BAGS_BWD_BLEND = 1, BAGS_BWD_PREPROCESS = 2 };   /* BagsBackwardArgs.phase (ABI 9) */
 
 /* GaussianRasterizationSettings (gaussian_renderer/__init__.py:50-65) */
 typedef struct BagsSettings {
@@ -150,6 +151,14 @@ typedef struct BagsBackwardArgs {
      * do not depend on it (ABI 8; the field was reserved1 = 0 before, and rounds 3-4 read an environment variable here). */
     int32_t dense_per_tile;
     float* grad_shs_rest;            /* (P,M-1,3), with inputs.shs_rest: grad_shs is then the (P,1,3) gradient of features_dc (ABI 7) */
+    /* (ABI 9) Which half of the backward this call enqueues.  BAGS_BWD_ALL (0): everything, as before.  BAGS_BWD_BLEND: the per-tile
+     * half only (blend_bwd: dL/dimage -> one partial-gradient record per instance, in the workspace).  BAGS_BWD_PREPROCESS: the
+     * per-Gaussian half only (preprocess_bwd + pose_reduce: records -> every output above); same workspace, same arguments, after a
+     * BLEND call.  The split exists for callers that differentiate several views of one step on several streams with `accumulate`:
+     * the read-modify-write of the shared gradient buffers must run in view order, so the second half of view k waits for the
+     * second half of view k-1 (an event between two calls) while its first half -- 85 % of the backward's time -- does not. */
+    int32_t phase;
+    int32_t reserved2;               /* 0 */
 } BagsBackwardArgs;
 
 /* integer artefacts for bit-exact parity checks (all device pointers, any may be NULL) */

@@ -131,6 +131,9 @@ def compare(scene, cam, deg, seed=1, check_fp64=True, **kw):
     # thresholds, so an ulp of difference in exp() flips a (pixel, splat) pair in any one implementation.
     rep["image_max_err"] = img_err.max().item()
     rep["image_bad_frac"] = (img_err > 1e-5).float().mean().item()
+    # the same as COUNTS of pixels, which is what assert_report holds to zero (or to a documented number of threshold pixels)
+    rep["image_bad_pixels"] = int((img_err > 1e-5).any(0).sum())
+    rep["depth_bad_pixels"], rep["weights_bad_pixels"] = int((d_err > 1e-4).sum()), int((w_err > 1e-4).sum())
     return rep
 
 
@@ -184,11 +187,13 @@ def compare_sampled(scene, cam, deg, tiles, seed=1, check_fp64=False, return_gra
     img_err = ((outs[0] - st32.image).abs() / (1.0 + st32.image.abs()))[m3]
     rep["image_max_err_fp32"] = rep["image_max_err"] = img_err.max().item()
     rep["image_bad_frac"] = (img_err > 1e-5).float().mean().item()
+    rep["image_bad_pixels"] = int((img_err.view(3, -1) > 1e-5).any(0).sum())
     d_err = ((outs[2] - st32.depth_img).abs() / (1.0 + st32.depth_img.abs()))[mask[None]]
     w_err = (outs[3] - st32.weights).abs()[mask[None]]
     rep["depth_max_err"], rep["weights_max_err"] = d_err.max().item(), w_err.max().item()
     rep["depth_bad_frac"] = (d_err > 1e-4).float().mean().item()
     rep["weights_bad_frac"] = (w_err > 1e-4).float().mean().item()
+    rep["depth_bad_pixels"], rep["weights_bad_pixels"] = int((d_err > 1e-4).sum()), int((w_err > 1e-4).sum())
     rep["mean2D_max_err"] = (outs[4] - st32.mean2D).abs().max().item()
     rep["grad_rel_fp32"] = {k: rel_err(grads[k], gr32[k]) for k in GRAD_NAMES if grads.get(k) is not None and k in gr32}
     gr64 = None
@@ -266,18 +271,31 @@ def assert_ill_conditioned(rep, slack=3.0, floor=1e-4):
             assert rep["grad_rel_fp64"][k] <= slack * ref + floor, f"grad[{k}]: {rep['grad_rel_fp64'][k]:.3e} vs oracle32 {ref:.3e}"
 
 
-def assert_report(rep, grad_tol=1e-4, img_tol=1e-5, skip_zero=(), tol_override=None, n_contrib_mismatch=0.0):
+def assert_image_bars(rep, threshold_pixels=0, mean2D_tol=1e-3):
+    """The float OUTPUTS of a report (compare / compare_sampled): image |d| <= 1e-5 (1 + |x|), depth and weights <= 1e-4, on EVERY
+    compared pixel.  threshold_pixels: how many pixels may sit on a flipped threshold pair instead -- alpha within an ulp of 1/255 or
+    T (1 - alpha) of 1e-4, decided differently by the oracle's libm exp and the device's v_exp_f32; such a pixel changes by up to one
+    splat's contribution (bounded at 5e-3 / 5e-2 / 2e-2 below).  0 by default; a test passes a number only for pixels it documents
+    (round 5 accepted 2e-4 of the pixels on every case while every report but the full-size config 3 showed none)."""
+    bad = (rep["image_bad_pixels"], rep["depth_bad_pixels"], rep["weights_bad_pixels"])
+    assert max(bad) <= threshold_pixels, (bad, threshold_pixels, rep["image_max_err"])
+    if threshold_pixels == 0:
+        assert rep["image_max_err"] <= 1e-5 and rep["depth_max_err"] <= 1e-4 and rep["weights_max_err"] <= 1e-4
+    else:
+        assert rep["image_max_err"] <= 5e-3 and rep["depth_max_err"] <= 5e-2 and rep["weights_max_err"] <= 2e-2
+    assert rep["mean2D_max_err"] <= mean2D_tol
+
+
+def assert_report(rep, grad_tol=1e-4, skip_zero=(), tol_override=None, n_contrib_mismatch=0.0, threshold_pixels=0):
     """n_contrib_mismatch: fraction of pixels whose last contributor may differ from the oracle's.  0 by default -- n_contrib is an
     integer artefact; a test passes an allowance only where a documented threshold pair exists (T (1 - alpha) within an ulp of
-    1e-4, or alpha of 1/255, decided differently by the oracle's libm exp and the device's v_exp_f32)."""
+    1e-4, or alpha of 1/255, decided differently by the oracle's libm exp and the device's v_exp_f32).  threshold_pixels: the same
+    for the float outputs (assert_image_bars)."""
     for k in INT_KEYS:
         assert rep[k], f"{k} failed: {rep}"
     assert rep["num_rendered"][0] == rep["num_rendered"][1]
     assert rep["n_contrib_mismatch_frac"] <= n_contrib_mismatch, rep["n_contrib_mismatch_frac"]
-    # image: |d| <= 1e-5 (1+|x|) against the oracle; at most 2e-4 of the pixels may sit on a flipped threshold pair
-    assert rep["image_bad_frac"] <= 2e-4 and rep["image_max_err"] <= 5e-3, (rep["image_bad_frac"], rep["image_max_err"])
-    assert rep["depth_bad_frac"] <= 2e-4 and rep["weights_bad_frac"] <= 2e-4, (rep["depth_bad_frac"], rep["weights_bad_frac"])
-    assert rep["depth_max_err"] <= 5e-2 and rep["weights_max_err"] <= 2e-2 and rep["mean2D_max_err"] <= 1e-3
+    assert_image_bars(rep, threshold_pixels)
     # gradients: <= 1e-4 relative to the closer oracle (fp32 / fp64 walk), never worse than 2e-3 to the other one
     # (the two oracles themselves differ by that much when one of them flips a threshold pair: 'oracle32_vs_64')
     g32, g64 = rep.get("grad_rel_fp32", {}), rep.get("grad_rel_fp64", rep.get("grad_rel_fp32", {}))

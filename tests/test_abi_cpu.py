@@ -45,7 +45,7 @@ def test_struct_layout_matches_header(lib):
     assert C.sizeof(_lib.BagsInputs) == 8 + 9 * 8 + 8          # + shs_rest (ABI 7)
     assert C.sizeof(_lib.BagsState) == 6 * 8
     assert C.sizeof(_lib.BagsForwardOut) == 5 * 8
-    assert C.sizeof(_lib.BagsBackwardArgs) == 4 * 8 + 14 * 8 + 8 + 8 + 8  # + binning_capacity (ABI 4), accumulate + dense_per_tile (ABI 6 / 8), grad_shs_rest (ABI 7)
+    assert C.sizeof(_lib.BagsBackwardArgs) == 4 * 8 + 14 * 8 + 8 + 8 + 8 + 8  # + binning_capacity (ABI 4), accumulate + dense_per_tile (ABI 6 / 8), grad_shs_rest (ABI 7), phase + reserved2 (ABI 9)
     assert C.sizeof(_lib.BagsDebugViews) == 8 * 8
 
 

@@ -312,7 +312,10 @@ def test_full_size_config3_against_oracle():
     # opacity-aware tile bounds (default); the stock 3-sigma rule gives 3 450 308 on this scene (~3.7 M)
     assert rep["num_rendered"][0] == rep["num_rendered"][1] == 2074322
     assert rep["n_contrib_mismatch_frac"] == 0.0, rep["n_contrib_mismatch_frac"]     # 2 073 600 pixels, every one identical
-    assert_report(rep, tol_override={"shift_factors": (1e-3, 1e-2)})     # measured: 3.8e-4 vs fp32, 5.0e-3 vs fp64
+    # float outputs: TWO of the 2 073 600 pixels sit on a flipped threshold pair (a middle splat whose alpha lies within an ulp of
+    # 1/255: the pixel's last contributor -- n_contrib, asserted identical above -- is not affected): image 2.8e-3 there, depth on
+    # the same two pixels, weights on one (profiles/r05/parity_reports.jsonl); every other pixel is held to 1e-5 / 1e-4
+    assert_report(rep, tol_override={"shift_factors": (1e-3, 1e-2)}, threshold_pixels=2)     # shift: measured 3.8e-4 vs fp32, 5.0e-3 vs fp64
     for k, e in rep["grad_rel_fp32"].items():
         if k != "shift_factors":
             assert e <= 1e-4, (k, e)
@@ -342,18 +345,17 @@ def test_full_size_config3_aabb():
     assert min(rep["grad_rel_fp32"]["shift_factors"], rep["grad_rel_fp64"]["shift_factors"]) <= 1e-3
 
 
-def _assert_sampled(rep, grad_tol=1e-4, worst_tol=2e-3, skip=(), nc_tol=0.0):
+def _assert_sampled(rep, grad_tol=1e-4, worst_tol=2e-3, skip=(), nc_tol=0.0, threshold_pixels=0):
     """Bars of assert_report for a compare_sampled() report (the full-size configurations): integers bit-exact over ALL
-    Gaussians / instances, n_contrib identical on the sampled pixels (nc_tol = 0 unless the caller says why not), image on the
-    sampled tiles, every gradient <= grad_tol relative to the closer oracle (fp32 walk / fp64 replay)."""
-    from parity import INT_KEYS
+    Gaussians / instances, n_contrib identical on the sampled pixels (nc_tol = 0 unless the caller says why not), image / depth /
+    weights on EVERY sampled pixel (threshold_pixels = 0 unless the caller documents a pixel on a flipped threshold pair), every
+    gradient <= grad_tol relative to the closer oracle (fp32 walk / fp64 replay)."""
+    from parity import INT_KEYS, assert_image_bars
     for k in INT_KEYS:
         assert rep[k], f"{k} failed: {rep}"
     assert rep["num_rendered"][0] == rep["num_rendered"][1]
     assert rep["n_contrib_mismatch_frac"] <= nc_tol, rep["n_contrib_mismatch_frac"]
-    assert rep["image_bad_frac"] <= 2e-4 and rep["image_max_err"] <= 5e-3, (rep["image_bad_frac"], rep["image_max_err"])
-    assert rep["depth_bad_frac"] <= 2e-4 and rep["weights_bad_frac"] <= 2e-4
-    assert rep["mean2D_max_err"] <= 2e-3
+    assert_image_bars(rep, threshold_pixels, mean2D_tol=2e-3)
     g32, g64 = rep["grad_rel_fp32"], rep.get("grad_rel_fp64", rep["grad_rel_fp32"])
     for k in g32:
         if k in skip:
@@ -378,12 +380,15 @@ def test_full_size_config4_views():
     scene = synth_scene(2_000_000, 0, 0.5, 3)
     cams = sphere_views(200, W, H, noise=0.15, seed=55)
     for k in (0, 99, 199):
-        rep = compare_sampled(scene, cams[k], 3, sample_tiles(W, H, 96, seed=k), seed=k + 1, check_fp64=True)
-        print(k, {n: rep[n] for n in ("num_rendered", "instances_in_sample", "n_contrib_mismatch_frac", "image_max_err",
+        # the middle view on the REFERENCE's own instance list (tile_bounds="aabb": the stock 3-sigma square the CUDA op behind
+        # gaussian_renderer/__init__.py:110-121 bins with), the other two on the default list
+        tb = "aabb" if k == 99 else "opacity"
+        rep = compare_sampled(scene, cams[k], 3, sample_tiles(W, H, 96, seed=k), seed=k + 1, check_fp64=True, tile_bounds=tb)
+        print(k, tb, {n: rep[n] for n in ("num_rendered", "instances_in_sample", "n_contrib_mismatch_frac", "image_max_err",
                                       "image_bad_frac", "grad_rel_fp32", "grad_rel_fp64", "oracle32_vs_64")})
         from parity import dump_report
-        dump_report(f"test_full_size_config4_views[k={k}]", rep)
-        assert rep["num_rendered"][0] > 3_000_000, rep["num_rendered"]
+        dump_report(f"test_full_size_config4_views[k={k},{tb}]", rep)
+        assert rep["num_rendered"][0] > (6_000_000 if tb == "aabb" else 3_000_000), rep["num_rendered"]
         # n_contrib: identical at k = 0 and k = 99; at k = 199 ONE of the 24 576 sampled pixels (4.1e-5) ends its list one splat
         # earlier or later than the oracle's -- a pair whose alpha sits within an ulp of 1/255 (the kernels evaluate exp as
         # exp2 of a pre-scaled power, torch's CPU exp is another implementation); the image agrees to 5e-7 there
@@ -391,8 +396,9 @@ def test_full_size_config4_views():
 
 
 @pytest.mark.timeout(900)
-def test_full_size_config5_4k_with_distortion():
-    """BASELINE config 5: 5 M Gaussians at 3840x2160, SH degree 3, NON-ZERO radial distortion parameters (the
+@pytest.mark.parametrize("tile_bounds", ["opacity", "aabb"])
+def test_full_size_config5_4k_with_distortion(tile_bounds):
+    """BASELINE config 5 (on the default instance list and on the reference's own, tile_bounds="aabb"): 5 M Gaussians at 3840x2160, SH degree 3, NON-ZERO radial distortion parameters (the
     shift_factors polynomial, train.py:125,210-222; decision D2).  theta comes from the libm-free atan on both sides, so
     the integer artefacts stay bit-exact with distortion switched on: radii, rectangles, depth bits for all 5 M
     Gaussians, the sorted (key, id) list of all ~22 M instances, the 32 400 tile ranges.  Image, n_contrib and every
@@ -409,12 +415,12 @@ def test_full_size_config5_4k_with_distortion():
         big_host = psutil.virtual_memory().available > 48e9
     except ImportError:
         big_host = False
-    rep = compare_sampled(scene, cam, 3, sample_tiles(W, H, 256, seed=5), seed=6, check_fp64=big_host, shift=sf)
+    rep = compare_sampled(scene, cam, 3, sample_tiles(W, H, 256, seed=5), seed=6, check_fp64=big_host, shift=sf, tile_bounds=tile_bounds)
     print({n: rep.get(n) for n in ("num_rendered", "instances_in_sample", "n_contrib_mismatch_frac", "image_max_err",
                                    "image_bad_frac", "grad_rel_fp32", "grad_rel_fp64", "oracle32_vs_64")})
     from parity import dump_report
-    dump_report("test_full_size_config5_4k_with_distortion", rep)
-    assert rep["num_rendered"][0] > 15_000_000, rep["num_rendered"]
+    dump_report(f"test_full_size_config5_4k_with_distortion[{tile_bounds}]", rep)
+    assert rep["num_rendered"][0] > (30_000_000 if tile_bounds == "aabb" else 15_000_000), rep["num_rendered"]
     # at 4K the fp32 pixel grid (ulp 2.4e-4 px at x = 3800) makes any fp32 rasterizer sit at ~1e-3 from fp64; without the
     # fp64 replay the bar against the fp32 oracle alone is 3e-4
     _assert_sampled(rep, grad_tol=1e-4 if big_host else 3e-4, nc_tol=1e-4)   # 65 536 sampled pixels; see config 4 for why not 0
@@ -597,6 +603,38 @@ def test_tile_bound_modes_render_the_same():
             # ulps; behind the conic -> cov2D -> Sigma chain the strongly anisotropic splats of this scene amplify that.
             tol = 2e-6 if k in ("shs", "opacities", "means2D", "means2D_densify") else 1e-4
             assert rel_err(g_t[k], g_a[k]) < tol, (k, rel_err(g_t[k], g_a[k]))
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("P,W,H,shift", [(500_000, 1920, 1080, None), (5_000_000, 3840, 2160, (0.02, -0.01, 0.005))])
+def test_tile_bound_modes_render_the_same_at_full_size(P, W, H, shift):
+    """The headline runs on the default instance list (tile_bounds="opacity"), the reference's CUDA op on the stock 3-sigma list
+    ("aabb", gaussian_renderer/__init__.py:110-121).  The claim that the one stands in for the other -- every pair the default rule
+    drops has alpha < 1/255 on all 256 pixels of its tile -- is asserted HERE at BASELINE config 3 and config 5 size (with the
+    distortion parameters on), not only on the 6 000-Gaussian scene above: image, radii, depth, weights, mean2D, n_contrib and
+    final_T `torch.equal`; the gradients are the same sums in another order (a Gaussian's per-tile records: more of them, the
+    extra ones zero).  No oracle involved: two runs of the product."""
+    from bags_raster.synth import look_at_origin_camera, synth_scene
+    scene, cam = synth_scene(P, 0, 0.5, 3), look_at_origin_camera(W, H)
+    gimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(11))
+    sf = None if shift is None else torch.tensor(shift)
+    o_t, g_t, v_t = run_hip(scene, cam, 3, gimg, tile_bounds="opacity", shift=sf)
+    o_a, g_a, v_a = run_hip(scene, cam, 3, gimg, tile_bounds="aabb", shift=sf)
+    print({"instances": (v_t["num_rendered"], v_a["num_rendered"])})
+    assert v_t["num_rendered"] < 0.7 * v_a["num_rendered"], (v_t["num_rendered"], v_a["num_rendered"])
+    for name, a, b in zip(("image", "radii", "depth", "weights", "mean2D"), o_t, o_a):
+        assert torch.equal(a, b), name
+    assert torch.equal(v_t["n_contrib"] > 0, v_a["n_contrib"] > 0)          # (positions differ: they index two different lists)
+    assert torch.equal(v_t["final_T"], v_a["final_T"])
+    assert torch.equal(v_t["depth_bits"], v_a["depth_bits"])
+    worst = {}
+    for k in g_a:
+        if g_a[k] is not None:
+            worst[k] = rel_err(g_t[k], g_a[k])
+            # summation order only.  shift_factors: a near-cancelling sum over all Gaussians (test_full_size_config3_against_oracle)
+            assert worst[k] < (2e-3 if k == "shift_factors" else 2e-5), (k, worst[k])
+    print(worst)
 
 
 @pytest.mark.gpu
@@ -1074,13 +1112,17 @@ def test_frozen_camera_mode_against_oracle(tile_bounds):
         assert rel_err(g_f[k], g_p[k]) <= 1e-6, (k, rel_err(g_f[k], g_p[k]))     # the same sums with and without the pose Jacobians beside them
 
 
-def test_frozen_camera_mode_at_config2_size():
-    """BASELINE config 2 itself: 500 k Gaussians, 1920x1080, SH degree 3, fixed pose.  Integers bit-exact for all Gaussians and
-    instances, image / n_contrib / Gaussian gradients on 96 sampled tiles (the cotangent is zero elsewhere)."""
+@pytest.mark.parametrize("tile_bounds", ["opacity", "aabb"])
+def test_frozen_camera_mode_at_config2_size(tile_bounds):
+    """BASELINE config 2 itself: 500 k Gaussians, 1920x1080, SH degree 3, fixed pose -- on the default instance list and on the
+    reference's own (tile_bounds="aabb").  Integers bit-exact for all Gaussians and instances, image / n_contrib / Gaussian
+    gradients on 96 sampled tiles (the cotangent is zero elsewhere)."""
     scene, cam = make_case(500_000, 1920, 1080, 0.5, 3, seed=0)
-    rep = compare_sampled(scene, cam, 3, sample_tiles(1920, 1080, 96, seed=7), frozen_camera=True)
+    rep = compare_sampled(scene, cam, 3, sample_tiles(1920, 1080, 96, seed=7), frozen_camera=True, tile_bounds=tile_bounds)
     _report({n: rep[n] for n in ("num_rendered", "instances_in_sample", "n_contrib_mismatch_frac", "image_max_err", "grad_rel_fp32")})
-    assert rep["num_rendered"][0] == 2_074_322
+    from parity import dump_report
+    dump_report(f"test_frozen_camera_mode_at_config2_size[{tile_bounds}]", rep)
+    assert rep["num_rendered"][0] == (3_450_308 if tile_bounds == "aabb" else 2_074_322)
     assert set(rep["grad_rel_fp32"]) == {"means3D", "means2D", "shs", "opacities", "scales", "rotations"}
     _assert_sampled(rep)
 

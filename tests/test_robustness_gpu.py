@@ -47,3 +47,7 @@ def test_both_modes_of_the_backward_match_the_oracle(dense):
     none does; gradients against the CPU oracle either way."""
     out = _run("fuzz_paths.py", "--trials", "10", "--seed", "11", "--oracle", "--dense", dense)
     assert out["trials"] == 10 and out["failures"] == [], out["failures"]
+    # the tool's "second look" (a trial whose only disagreement is a pixel or two on a flipped alpha / transmittance threshold, with
+    # the gradient bars widened to what the two oracles differ by themselves) must stay the exception: the seed is pinned, so the
+    # number of trials that may land there is too -- a regression between 1e-4 and 3e-4 on several trials fails here
+    assert len(out["threshold_pairs"]) <= 1, out["threshold_pairs"]

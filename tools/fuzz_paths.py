@@ -75,11 +75,13 @@ def main():
                     # and the fp64 oracle disagree with EACH OTHER by more than assert_report's 2e-3 cap (one flipped alpha / transmittance
                     # threshold weighs more among 2500 Gaussians than among 500 k), and the device's v_exp_f32 decides such a pair differently
                     # from the oracle's libm exp on a pixel or two (n_contrib).  Second look: at most two such pixels, and for the "other
-                    # oracle" bound 1.5 x what the oracles differ by themselves; everything else as strict as before.  Reported apart.
+                    # oracle" bound 1.5 x what the oracles differ by themselves; everything else as strict as before.  Reported apart
+                    # ("threshold_pairs"), and the pytest that runs this mode bounds how many trials of its pinned seed may land there.
                     o = rep.get("oracle32_vs_64", {})
                     relaxed = {k: (3e-4, max(2e-3, 1.5 * float(v))) for k, v in o.items()}
                     try:
-                        assert_report(rep, grad_tol=3e-4, skip_zero=("campos",), tol_override=relaxed, n_contrib_mismatch=2.5 / (W * H))
+                        assert_report(rep, grad_tol=3e-4, skip_zero=("campos",), tol_override=relaxed, n_contrib_mismatch=2.5 / (W * H),
+                                      threshold_pixels=2)
                         print(f"  I = {rep['num_rendered'][0]}: ok on second look (threshold pair): {str(e)[:120]}", flush=True)
                         soft.append(dict(tag, why=str(e)[:120]))
                     except AssertionError as e2:
