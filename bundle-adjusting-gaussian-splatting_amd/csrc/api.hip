@@ -230,9 +230,7 @@ size_t bags_backward_workspace_size(int32_t P, int64_t I)
     // dense-scene mode: one byte per record, + the 64 bytes preprocess_bwd reads from a Gaussian's first mark on (launch_blend_bwd clears
     // the same number of bytes)
     const size_t live = align_up((size_t)(I > 0 ? I : 1) + 64, 256);
-    // preprocess_bwd's own reduction of the slab rows: completion counters (1 + groups words) and the groups' fp64 sums
-    const size_t pose = align_up((size_t)(1 + pose_groups(P)) * sizeof(u32), 256) + align_up((size_t)pose_groups(P) * POSE_VALS * sizeof(double), 256);
-    return part + slab + live + pose + 256;
+    return part + slab + live + 256;
 }
 
 // tile-binned lists (binning.hip) unless the caller asked for the radix path or the problem is outside their limits
@@ -426,27 +424,18 @@ int bags_backward(const BagsSettings* s, const BagsInputs* in, const BagsState* 
     float* slab = reinterpret_cast<float*>(ws + align_up((size_t)(I > 0 ? I : 1) * PART_FLOATS * sizeof(float), 256));
     unsigned char* live_map = reinterpret_cast<unsigned char*>(slab) + align_up((size_t)(cdiv(in->P > 0 ? in->P : 1, 256)) * POSE_VALS * sizeof(float), 256);
     // the dense-scene mode (a byte per gradient record instead of zero records) is decided HERE, once: both launchers get the map or null
-    u32* pose_cnt = reinterpret_cast<u32*>(live_map + align_up((size_t)(I > 0 ? I : 1) + 64, 256));
-    const int n_pose_cnt = 1 + pose_groups(in->P);
-    double* pose_grp = reinterpret_cast<double*>(reinterpret_cast<char*>(pose_cnt) + align_up((size_t)n_pose_cnt * sizeof(u32), 256));
     const bool dense = I > 0 && bwd_dense_mode(I, cdiv(W, BAGS_TILE) * cdiv(H, BAGS_TILE), a->dense_per_tile);
     if (I > 0 && a->phase != BAGS_BWD_PREPROCESS) {
         { ProfScope ps(ST_BLEND_BWD, st); HIP_TRY(launch_blend_bwd(*s, g, b, im, a->grad_color, partials, a->grad_means2D_densify != nullptr, use_binned(s, in->P), st,
-                                                                  I, dense ? live_map : nullptr, pose_cnt, n_pose_cnt)); }
+                                                                  I, dense ? live_map : nullptr)); }
         DEBUG_SYNC(s, st, "blend_bwd");
-    }
-    else if (a->phase != BAGS_BWD_PREPROCESS && in->P > 0) {
-        HIP_TRY(hipMemsetAsync(pose_cnt, 0, (size_t)n_pose_cnt * sizeof(u32), st));      // no instance, no blend_bwd launch to clear them
     }
     if (a->phase == BAGS_BWD_BLEND) return BAGS_OK;          // the per-Gaussian half comes with a second call (BAGS_BWD_PREPROCESS)
     int nblocks = 0;
-    { ProfScope ps(ST_PRE_BWD, st); HIP_TRY(launch_preprocess_bwd(*s, *in, g, nullptr, partials, slab, &nblocks, *a, st, use_binned(s, in->P), dense ? live_map : nullptr,
-                                                                   pose_cnt, pose_grp)); }
+    { ProfScope ps(ST_PRE_BWD, st); HIP_TRY(launch_preprocess_bwd(*s, *in, g, nullptr, partials, slab, &nblocks, *a, st, use_binned(s, in->P), dense ? live_map : nullptr)); }
     DEBUG_SYNC(s, st, "preprocess_bwd");
-    if (in->P == 0) {                                        // no Gaussian, no preprocess_bwd launch: the pose gradients are zeros
-        ProfScope ps(ST_POSE_REDUCE, st); HIP_TRY(launch_pose_reduce(slab, 0, *a, st));
-        DEBUG_SYNC(s, st, "pose_reduce");
-    }
+    { ProfScope ps(ST_POSE_REDUCE, st); HIP_TRY(launch_pose_reduce(slab, nblocks, *a, st)); }
+    DEBUG_SYNC(s, st, "pose_reduce");
     if (s->debug) {
         const size_t P = (size_t)in->P;
         const ScanItem items[] = {{"grad_means3D", a->grad_means3D, 3 * P}, {"grad_means2D", a->grad_means2D, 3 * P},

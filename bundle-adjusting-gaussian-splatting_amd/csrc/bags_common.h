@@ -26,11 +26,6 @@ typedef uint64_t u64;
 #endif                                    // one 48-byte partial-gradient record per sorted instance (11 sums), densely packed:
                                           // every byte of every line is written, and K8a streams 25 % less than with 64-B slots
 #define POSE_VALS 40                      // pose-gradient slab row (35 used)
-// The slab rows are reduced INSIDE preprocess_bwd (round 6): the last workgroup of every POSE_GS consecutive ones to finish adds the group's
-// rows (fp64, fixed order), the last group to finish adds the group sums and writes the five pose tensors.  Counters: [0] groups done,
-// [1 + g] workgroups of group g done; cleared by blend_bwd's first workgroup (or a memset when there is no instance).
-#define POSE_GS 64
-static inline int pose_groups(int P) { const int nb = ((P > 0 ? P : 1) + 255) / 256; return (nb + POSE_GS - 1) / POSE_GS; }
 #define KEY_CULLED 0xFFFFFFFFu
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -180,12 +175,11 @@ hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinV
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
                             const float* grad_color, float* partials, bool want_abs, bool binned, hipStream_t st,
                             long long n_records = 0,                      // instance count
-                            unsigned char* live_map = nullptr,            // one byte per record (dense-scene mode: the caller's decision), or null
-                            u32* pose_cnt = nullptr, int n_pose_cnt = 0); // preprocess_bwd's completion counters, cleared here
+                            unsigned char* live_map = nullptr);           // one byte per record (dense-scene mode: the caller's decision), or null
 bool bwd_dense_mode(long long n_records, int T, int dense_per_tile);      // does a backward of this size run in dense-scene mode?
 hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, const int32_t* radii_or_null,
                                  const float* partials, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a, hipStream_t st,
-                                 bool binned, const unsigned char* live_map = nullptr, u32* pose_cnt = nullptr, double* pose_grp = nullptr);
+                                 bool binned, const unsigned char* live_map = nullptr);
 hipError_t launch_pose_reduce(const float* pose_slab, int nblocks, const BagsBackwardArgs& a, hipStream_t st);
 // loss.hip: fused L1 + SSIM terms and their image gradient
 size_t loss_workspace_bytes(int C, int H, int W);

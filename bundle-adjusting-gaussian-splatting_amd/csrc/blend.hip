@@ -276,11 +276,8 @@ blend_bwd_scan_kernel(int W, int H, int grid_x, int T, const uint4* __restrict__
                       const float4* __restrict__ g2d, const u32* __restrict__ inst_off, const u32* __restrict__ block_base,
                       const float* __restrict__ bg, const float* __restrict__ final_T, const u32* __restrict__ n_contrib,
                       const float* __restrict__ grad_color, float* __restrict__ partials,
-                      const int test_keep, const uint4* __restrict__ tile_aux, unsigned char* __restrict__ live_map,
-                      u32* __restrict__ pose_cnt, const int n_pose_cnt)
+                      const int test_keep, const uint4* __restrict__ tile_aux, unsigned char* __restrict__ live_map)
 {
-    // (preprocess_bwd, the next launch, counts its finished workgroups in these words: cleared here so that no fill launch is needed)
-    if (blockIdx.x == 0) for (int i = threadIdx.x; i < n_pose_cnt; i += 256) pose_cnt[i] = 0u;
     // One workgroup per tile that holds at least one instance, heavy tiles first (slot_of_vblock).  Tried and dropped:
     // persistent workgroups that run the chunk pipeline over the flattened (tile, chunk) sequence, with the next tile's
     // ids and gathers in flight during the current tile's last chunk (static b, b+G, ... walk or per-XCD ticket counters).
@@ -869,7 +866,7 @@ bool bwd_dense_mode(long long n_records, int T, int dense_per_tile_arg)
 // pointer goes to launch_preprocess_bwd, so the kernel that marks records and the kernel that reads the marks cannot disagree.
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
                             const float* grad_color, float* partials, bool want_abs, bool binned, hipStream_t st,
-                            long long n_records, unsigned char* live_map, u32* pose_cnt, int n_pose_cnt)
+                            long long n_records, unsigned char* live_map)
 {
     const int gx = cdiv(s.image_width, BAGS_TILE), gy = cdiv(s.image_height, BAGS_TILE);
     const int T = gx * gy;
@@ -886,7 +883,7 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     hipLaunchKernelGGL((blend_bwd_scan_kernel<ABS_, CMP_, SPARSE_>), dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T, \
                        im.tile_desc, b.point_list, reinterpret_cast<const unsigned char*>(b.reach_mask), binned ? 8u : 4u, g.g2d,    \
                        binned ? nullptr : g.inst_off, g.block_base, s.bg, im.final_T, im.n_contrib, grad_color, partials, \
-                       compact ? 1 : 0, im.tile_aux, live_map, pose_cnt, n_pose_cnt)
+                       compact ? 1 : 0, im.tile_aux, live_map)
     // The chunk geometry follows the SCENE, not the dense-scene decision: forcing the dense-scene mode on or off leaves the arithmetic
     // untouched, so the two modes stay bit-identical (tests, tools/fuzz_paths.py --cross-dense)
     const bool sparse = n_records <= (long long)BWD_SPARSE_PER_TILE * T;

@@ -183,8 +183,6 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                       const u32* __restrict__ tiles_touched, const u32* __restrict__ inst_off, const u32* __restrict__ local_off,
                       const u32* __restrict__ block_base, int per_block, const float* __restrict__ shjac,
                       const float* __restrict__ partials, const unsigned char* __restrict__ live_map, float* __restrict__ pose_slab,
-                      u32* __restrict__ pose_cnt, double* __restrict__ pose_grp, float* __restrict__ g_view, float* __restrict__ g_proj,
-                      float* __restrict__ g_intr, float* __restrict__ g_campos, float* __restrict__ g_shift,
                       float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_densify,
                       float* __restrict__ g_shs, float* __restrict__ g_shs_rest, float* __restrict__ g_colors, float* __restrict__ g_opac,
                       float* __restrict__ g_scales, float* __restrict__ g_rot, float* __restrict__ g_cov3D)
@@ -598,60 +596,7 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
         const int t = threadIdx.x;
         float r = (t < 35) ? (wpose[0][t] + wpose[1][t]) + (wpose[2][t] + wpose[3][t]) : 0.f;
         if (t < 9) r += (wpose[0][35 + t] + wpose[1][35 + t]) + (wpose[2][35 + t] + wpose[3][35 + t]);
-        // agent scope: written through to where the workgroup (on any XCD) that reduces this group will read it -- no fence.  A release
-        // fence here would be `buffer_wbl2`: a write-back of every dirty line of this XCD's L2, i.e. of the gradient rows the kernel has
-        // just stored, once per workgroup (round 4's fused epilogue, profiles/r04/ab_pose_fold.txt: 60 -> 69 us)
-        __hip_atomic_store(&pose_slab[(size_t)blockIdx.x * POSE_VALS + t], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // ---- 6. rows -> the five pose tensors, inside this launch (round 6; until then pose_reduce_kernel: a 5 us launch at the end of every
-    // backward).  Two levels, each "the last to finish does the sum": the workgroups of a group of POSE_GS count themselves, the last one
-    // adds the group's rows; the groups count themselves, the last one adds the group sums.  Everything in fp64 and in a fixed order (rows
-    // in row order by four slices, slices in slice order, groups in group order): which workgroup does a sum varies, what it computes does not.
-    __shared__ u32 s_last;
-    __shared__ double s_part[4][64];
-    const int nblocks = (int)gridDim.x, grp = (int)blockIdx.x / POSE_GS, ngroups = (nblocks + POSE_GS - 1) / POSE_GS;
-    const int row0 = grp * POSE_GS, rows = min(POSE_GS, nblocks - row0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this workgroup's row has arrived ...
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(&pose_cnt[1 + grp], 1u) == (u32)rows - 1u) ? 1u : 0u;     // ... before it is counted
-    __syncthreads();
-    if (s_last == 0u) return;
-    {
-        const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;          // slab column, slice of POSE_GS / 4 rows
-        constexpr int RS = POSE_GS / 4;
-        float v[RS];
-#pragma unroll
-        for (int u = 0; u < RS; ++u)                                    // (every load in flight at once; clamped, dropped below)
-            v[u] = __hip_atomic_load(&pose_slab[(size_t)(row0 + min(sl * RS + u, rows - 1)) * POSE_VALS + min(c, POSE_VALS - 1)],
-                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        double acc = 0.0;
-#pragma unroll
-        for (int u = 0; u < RS; ++u) acc += (sl * RS + u < rows) ? (double)v[u] : 0.0;
-        s_part[sl][c] = acc;
-    }
-    __syncthreads();
-    if (threadIdx.x < POSE_VALS) {
-        const int t = threadIdx.x;
-        __hip_atomic_store(&pose_grp[(size_t)grp * POSE_VALS + t], ((s_part[0][t] + s_part[1][t]) + s_part[2][t]) + s_part[3][t],
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(&pose_cnt[0], 1u) == (u32)ngroups - 1u) ? 1u : 0u;
-    __syncthreads();
-    if (s_last == 0u || threadIdx.x >= 35) return;
-    {
-        const int t = threadIdx.x;
-        double acc = 0.0;
-        for (int g0 = 0; g0 < ngroups; g0 += 8) {
-            double w[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                w[u] = __hip_atomic_load(&pose_grp[(size_t)min(g0 + u, ngroups - 1) * POSE_VALS + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc += (g0 + u < ngroups) ? w[u] : 0.0;
-        }
-        pose_write_out(t, (float)acc, g_view, g_proj, g_intr, g_campos, g_shift);
+        pose_slab[(size_t)blockIdx.x * POSE_VALS + t] = r;
     }
 }
 
@@ -688,7 +633,7 @@ pose_reduce_kernel(const float* __restrict__ slab, int nblocks, float* __restric
 
 hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, const int32_t*,
                                  const float* partials_records, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a,
-                                 hipStream_t st, bool binned, const unsigned char* live_map, u32* pose_cnt, double* pose_grp)
+                                 hipStream_t st, bool binned, const unsigned char* live_map)
 {
     const int P = in.P;
     const int nb = cdiv(P, 256);
@@ -701,8 +646,7 @@ hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, co
                        in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, s.viewmatrix, s.projmatrix, \
                        s.intrinsic, s.campos, in.opacities, g.rec_count, binned ? nullptr : g.inst_off, g.local_off, g.block_base, \
                        binned_per_block(P), g.shjac, partials, live_map, \
-                       pose_slab, pose_cnt, pose_grp, a.grad_viewmatrix, a.grad_projmatrix, a.grad_intrinsic, a.grad_campos, a.grad_shift_factors, \
-                       a.grad_means3D, a.grad_means2D, a.grad_means2D_densify, a.grad_shs, in.shs_rest ? a.grad_shs_rest : nullptr, \
+                       pose_slab, a.grad_means3D, a.grad_means2D, a.grad_means2D_densify, a.grad_shs, in.shs_rest ? a.grad_shs_rest : nullptr, \
                        a.grad_colors_precomp, a.grad_opacities, a.grad_scales, a.grad_rotations, a.grad_cov3D_precomp);
 #define PRE_BWD_PICK if (in.cov3D_precomp) { PRE_BWD_LAUNCH(true) } else { PRE_BWD_LAUNCH(false) }
     if (live_map) {
