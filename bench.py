@@ -266,6 +266,8 @@ def main():
     ap.add_argument("--host-wait", default="forward", choices=("forward", "lazy"),
                     help="forward (the operator's default): every forward reads its instance count before it returns, the image "
                          "it returns is always the true render; lazy (opt-in): the count is read at the entry of the backward")
+    ap.add_argument("--no-prealloc", action="store_true", help="A/B: the operator without rasterizer.PREALLOCATE_BACKWARD (the backward's buffers "
+                                                                "allocated by the forward while it waits for its instance count)")
     ap.add_argument("--no-lazy-leg", action="store_true", help="skip the extra timed leg in the other host-wait mode")
     ap.add_argument("--no-median-leg", action="store_true", help="skip the 50-step leg with one hipEvent per step (median)")
     ap.add_argument("--fixed-pose", action="store_true", help="config 2 exactly: no pose/intrinsic gradients requested")
@@ -344,6 +346,8 @@ def main():
     assert R.HOST_WAIT == "forward" and not R.LAZY_RECOVER, "the operator's defaults changed: the bench line must say so"
     R.HOST_WAIT = args.host_wait
     R.DENSE_PER_TILE = args.dense_per_tile
+    if args.no_prealloc:
+        R.PREALLOCATE_BACKWARD = False
     # ONE view per rank per exchange at every N (BASELINE configs 3-5: one view per GPU per iteration), so that the driver's
     # N = 1, 2, 4, 8 curve compares like with like; the V = 4 figure (the cubemap step renders 5 views per iteration,
     # utils/cubemap_utils.py:229,263-265) is a second leg of the same run, also at every N.
@@ -566,7 +570,7 @@ def main():
             "config": {"workload": f"{cfg_name}: synth({P}, seed 0, sm {args.sm}), "
                                    f"{V} camera{'s' if V > 1 else ''}/rank/step @{W}x{H}, SH deg 3, fwd+bwd"
                                    f"{'' if args.fixed_pose else ' incl. pose/intrinsic gradients'}",
-                       "P": P, "visible_G": G, "instances_I": I, "host_wait": args.host_wait, "tile_bounds": args.tile_bounds, "binning": args.binning, "width": W, "height": H,
+                       "P": P, "visible_G": G, "instances_I": I, "host_wait": args.host_wait, "prealloc_backward": bool(R.PREALLOCATE_BACKWARD), "tile_bounds": args.tile_bounds, "binning": args.binning, "width": W, "height": H,
                        "views_per_rank_per_exchange": V,
                        "settle_steps": max(0, args.settle_steps) // max(1, V) * max(1, V),   # untimed view renders before the warm-up
                        "parallelism": f"view-sharded x{world}" + (

@@ -175,7 +175,7 @@ LAST_NUM_RENDERED = 0      # instance count of the most recent forward whose cou
 class _Forwarded:
     """Everything backward (and the parity tests) need from one forward call."""
     __slots__ = ("packed", "geom", "binning", "image", "num_rendered", "capacity", "H", "W", "pending", "outs", "stream",
-                 "key", "__weakref__")
+                 "key", "pre", "waiting", "__weakref__")
 
 
 # Speculative forward (bags_forward_prepare_async + bags_forward_finish_speculative): the instance counts of earlier calls
@@ -204,6 +204,14 @@ LAZY_RECOVER = False
 # (BagsBackwardArgs.accumulate) and hands autograd None for them -- no flat buffer, no add pass per tensor and view.  The sums are
 # what autograd's own accumulation gives; tensor hooks on those parameters do not see the per-view gradients.
 ACCUMULATE_IN_PLACE = False
+
+
+# A forward that waits for its instance count (HOST_WAIT = "forward") has nothing to do while it waits: K1, the prefix and the emission
+# have to run before the count exists (~85 us at 500 k Gaussians).  With this switch it allocates, in that wait, what its BACKWARD will
+# need (the gradient buffers and the record workspace, sized for the capacity the forward was enqueued with) and keeps them in the
+# context: the host's path from "count has arrived" to "blend_bwd launched" -- which the device covers with blend_fwd alone -- loses
+# its ~15 allocator calls.  Nothing else changes; a forward that is never differentiated hands the buffers back when its context dies.
+PREALLOCATE_BACKWARD = True
 
 
 class AccumulationGate:
@@ -387,10 +395,38 @@ def _resolve(lib, fw: "_Forwarded") -> None:
     fw.outs = None
 
 
-def _run_forward(lib, pk: _Packed, H: int, W: int, speculate: bool = True, lazy: bool = False):
+def _finish_wait(lib, fw: "_Forwarded") -> None:
+    """Second half of a waiting speculative forward: the host reads the instance count (the device is meanwhile busy with phase 2) and
+    redoes phase 2 on an exact buffer if the guess was too small.  No-op for every other kind of forward."""
+    global LAST_NUM_RENDERED
+    if fw.waiting is None:
+        return
+    pinned, cap, out = fw.waiting
+    fw.waiting = None
+    pk, dev = fw.packed, fw.packed.device
+    n = _await_count(pinned, fw.stream)
+    _pinned.give(pinned)
+    _note_count(fw.key, n)
+    fw.num_rendered = LAST_NUM_RENDERED = n
+    if n <= cap:
+        return
+    # guess too small (scene changed abruptly): redo the second phase on an exact buffer; phase 1 results stay valid
+    with torch.cuda.device(dev), torch.cuda.stream(fw.stream):
+        fw.binning = _bytes(lib.bags_binning_size(n, fw.W, fw.H), dev)
+        state = _state_of(fw)
+        L.check(lib.bags_forward_finish(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(out), n, fw.stream.cuda_stream),
+                "bags_forward_finish")
+    fw.capacity = n
+
+
+def _run_forward(lib, pk: _Packed, H: int, W: int, speculate: bool = True, lazy: bool = False, prealloc=None, defer_wait: bool = False):
+    """prealloc(capacity) -> anything: called once both phases of a waiting speculative forward are enqueued, before the host starts
+    to wait for the instance count; its result is kept as fw.pre (PREALLOCATE_BACKWARD).  defer_wait: return before that wait; the
+    caller finishes its own bookkeeping first and then calls _finish_wait(lib, fw) -- everything the host does AFTER the count has
+    arrived sits between the device's blend_fwd and its blend_bwd."""
     dev, P = pk.device, pk.P
     fw = _Forwarded()
-    fw.packed, fw.H, fw.W, fw.pending, fw.outs = pk, H, W, None, None
+    fw.packed, fw.H, fw.W, fw.pending, fw.outs, fw.pre, fw.waiting = pk, H, W, None, None, None, None
     fw.geom = _bytes(lib.bags_geom_size(P), dev)
     fw.image = _bytes(lib.bags_image_size(W, H), dev)
     color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
@@ -429,18 +465,12 @@ def _run_forward(lib, pk: _Packed, H: int, W: int, speculate: bool = True, lazy:
             fw.pending = (pinned, weakref.finalize(fw, _abandon, pinned, key, cap))
             return fw, (color, radii, depth, weights, mean2D)
         # phase 2 is already queued behind the count: the device does not wait for us while we wait for the word
-        n = _await_count(pinned, fw.stream)
-        _pinned.give(pinned)
-        _note_count(key, n)
-        fw.num_rendered = LAST_NUM_RENDERED = n
-        if n <= cap:
-            return fw, (color, radii, depth, weights, mean2D)
-        # guess too small (scene changed abruptly): redo the second phase on an exact buffer; phase 1 results stay valid
-        fw.binning = _bytes(lib.bags_binning_size(n, W, H), dev)
-        state.binning, state.binning_bytes = fw.binning.data_ptr(), fw.binning.numel()
-        L.check(lib.bags_forward_finish(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(out), n, stream),
-                "bags_forward_finish")
-        fw.capacity = n
+        if prealloc is not None:
+            fw.pre = prealloc(cap)
+        fw.num_rendered = None
+        fw.waiting = (pinned, cap, out)
+        if not defer_wait:
+            _finish_wait(lib, fw)
         return fw, (color, radii, depth, weights, mean2D)
     n = C.c_int64(0)
     L.check(lib.bags_forward_prepare(C.byref(pk.settings), C.byref(pk.inputs), C.byref(state), C.byref(out),
@@ -460,6 +490,39 @@ def _state_of(fw: _Forwarded) -> L.BagsState:
                        fw.image.data_ptr(), fw.image.numel())
 
 
+def _alloc_backward(lib, need, k, shapes, P, dev, ws_instances, gaussian_grads=True):
+    """The tensors a backward writes: the Gaussian-parameter gradients carved out of ONE buffer (64-float aligned slices, so that the
+    view-sharded exchange is a single collective over it -- bags_raster/sharding.py finds the common storage; to autograd they are
+    ordinary tensors), the per-view gradients, and the record workspace for `ws_instances` instances."""
+    def new(shape, flag):
+        return torch.empty(shape, dtype=torch.float32, device=dev) if flag else None
+    want = _wanted(need, k, shapes, P)
+    if not gaussian_grads:                                    # (they accumulate in place: ACCUMULATE_IN_PLACE)
+        want = [(n, sh, False) for n, sh, _ in want]
+    sizes = {n: (math.prod(sh) if f else 0) for n, sh, f in want}
+    total = sum((v + 63) // 64 * 64 for v in sizes.values())
+    flat = torch.empty(total, dtype=torch.float32, device=dev) if total else None
+    carved, off = {}, 0
+    for n, sh, f in want:
+        carved[n] = flat[off:off + sizes[n]].view(sh) if f else None
+        off += (sizes[n] + 63) // 64 * 64
+    del flat
+    return dict(carved=carved, means2D=new((P, 3), need[1]), densify=new((P, 3), need[2]), shift=new((3,), need[3]),
+                view=new((4, 4), need[10]), proj=new((4, 4), need[11]), intr=new((4, 4), need[12]), campos=new((3,), need[13]),
+                ws=_bytes(lib.bags_backward_workspace_size(P, ws_instances), dev), ws_instances=int(ws_instances))
+
+
+def _wanted(need, k, shapes, P):
+    return [("means3D", (P, 3), need[0]),
+            ("sh", shapes["sh"], need[4] and k["shs"] is not None),
+            ("sh_rest", shapes["sh_rest"], need[15] and k["shs_rest"] is not None),
+            ("col", (P, 3), need[5] and k["colors_precomp"] is not None),
+            ("opac", shapes["opac"], need[6]),
+            ("scales", (P, 3), need[7] and k["scales"] is not None),
+            ("rot", (P, 4), need[8] and k["rotations"] is not None),
+            ("cov", (P, 6), need[9] and k["cov3D_precomp"] is not None)]
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, means2D_densify, shift_factors, sh, colors_precomp, opacities, scales, rotations,
@@ -469,18 +532,24 @@ class _RasterizeGaussians(torch.autograd.Function):
         with torch.cuda.device(means3D.device):
             pk = _Packed(raster_settings, means3D, means2D, shift_factors, sh, colors_precomp, opacities, scales,
                          rotations, cov3Ds_precomp, viewmatrix, projmatrix, intrinsic, campos, sh_rest)
+            shapes = dict(sh=None if sh is None else sh.shape, sh_rest=None if sh_rest is None else sh_rest.shape,
+                          opac=opacities.shape, campos=campos.shape)
+            need = tuple(ctx.needs_input_grad)
+            pre = None
+            if PREALLOCATE_BACKWARD and any(need) and not ACCUMULATE_IN_PLACE:
+                pre = lambda cap: _alloc_backward(lib, need, pk.keep, shapes, pk.P, pk.device, cap)    # noqa: E731
             fw, outs = _run_forward(lib, pk, int(raster_settings.image_height), int(raster_settings.image_width),
-                                    lazy=any(ctx.needs_input_grad))
+                                    lazy=any(need), prealloc=pre, defer_wait=True)
         ctx.fw = fw
         # (weak: the op must not keep the caller's parameters alive; only used by ACCUMULATE_IN_PLACE)
         ctx.leaves = (tuple(None if t is None else weakref.ref(t) for t in
                             (means3D, sh, sh_rest, colors_precomp, opacities, scales, rotations, cov3Ds_precomp))
                       if ACCUMULATE_IN_PLACE else None)
-        ctx.shapes = dict(sh=None if sh is None else sh.shape, sh_rest=None if sh_rest is None else sh_rest.shape,
-                          opac=opacities.shape, campos=campos.shape)
+        ctx.shapes = shapes
         color, radii, depth, weights, mean2D = outs
         ctx.mark_non_differentiable(radii, depth, weights, mean2D)
         ctx.set_materialize_grads(False)     # no zero-fill kernels for the four outputs nobody differentiates
+        _finish_wait(lib, fw)                # (HOST_WAIT = "forward": the count is read last, when nothing else is left to do here)
         return color, radii, depth, weights, mean2D
 
     @staticmethod
@@ -496,20 +565,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             if gc.dtype != torch.float32 or not gc.is_contiguous():
                 gc = gc.to(torch.float32).contiguous()
 
-            def new(shape, flag):
-                return torch.empty(shape, dtype=torch.float32, device=dev) if flag else None
             k = pk.keep
-            # The gradients of the replicated Gaussian parameters are carved out of ONE buffer (64-float aligned slices), so
-            # the view-sharded exchange is a single RCCL all-reduce over it instead of one per tensor
-            # (bags_raster/sharding.py finds the common storage); to autograd they are ordinary tensors.
-            want = [("means3D", (P, 3), need[0]),
-                    ("sh", ctx.shapes["sh"], need[4] and k["shs"] is not None),
-                    ("sh_rest", ctx.shapes["sh_rest"], need[15] and k["shs_rest"] is not None),
-                    ("col", (P, 3), need[5] and k["colors_precomp"] is not None),
-                    ("opac", ctx.shapes["opac"], need[6]),
-                    ("scales", (P, 3), need[7] and k["scales"] is not None),
-                    ("rot", (P, 4), need[8] and k["rotations"] is not None),
-                    ("cov", (P, 6), need[9] and k["cov3D_precomp"] is not None)]
+            want = _wanted(need, k, ctx.shapes, P)
             # ACCUMULATE_IN_PLACE: every wanted Gaussian gradient has a running sum to be added into
             in_place = None
             if ACCUMULATE_IN_PLACE and ctx.leaves is not None:       # (the flag was already set when this forward ran)
@@ -526,17 +583,15 @@ class _RasterizeGaussians(torch.autograd.Function):
                     tgt[n] = g
                 if tgt:
                     in_place = tgt
-            if in_place is not None:
-                carved = {n: in_place.get(n) for n, _, _ in want}
-            else:
-                sizes = {n: (math.prod(sh) if f else 0) for n, sh, f in want}
-                total = sum((v + 63) // 64 * 64 for v in sizes.values())
-                flat = torch.empty(total, dtype=torch.float32, device=dev) if total else None
-                carved, off = {}, 0
-                for n, sh, f in want:
-                    carved[n] = flat[off:off + sizes[n]].view(sh) if f else None
-                    off += (sizes[n] + 63) // 64 * 64
-                del flat
+            # what the forward allocated while it waited for its count (PREALLOCATE_BACKWARD), or the same allocations now.  A lazy
+            # forward's workspace is sized for the speculative capacity (>= the count unless the forward overflowed): its count is read
+            # below, after the allocations, so that only the struct fill and the call itself sit between the count's arrival and the
+            # first backward kernel's launch (tools/trace_gaps.sh: ~40 us of Python there showed up as idle device in front of blend_bwd)
+            ws_for = fw.capacity if fw.pending is not None else fw.num_rendered
+            pre, fw.pre = fw.pre, None
+            if pre is None or pre["ws_instances"] < ws_for:
+                pre = _alloc_backward(lib, need, k, ctx.shapes, P, dev, ws_for, gaussian_grads=in_place is None)
+            carved = {n: in_place.get(n) for n, _, _ in want} if in_place is not None else pre["carved"]
             g_means3D, g_sh, g_col, g_opac = carved["means3D"], carved["sh"], carved["col"], carved["opac"]
             g_sh_rest = carved["sh_rest"]
             if k["shs_rest"] is not None and (g_sh is None) != (g_sh_rest is None):
@@ -546,20 +601,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                 else:
                     g_sh_rest = torch.zeros(ctx.shapes["sh_rest"], dtype=torch.float32, device=dev)
             g_scales, g_rot, g_cov = carved["scales"], carved["rot"], carved["cov"]
-            g_means2D = new((P, 3), need[1])
-            g_densify = new((P, 3), need[2])
-            g_shift = new((3,), need[3])
-            g_view = new((4, 4), need[10])
-            g_proj = new((4, 4), need[11])
-            g_intr = new((4, 4), need[12])
-            g_campos = new((3,), need[13])
-            # A lazy forward's instance count is read HERE, not inside the forward and not at the top of this function: every
-            # allocation above happens while the device is still busy with the forward, and only the struct fill and the call
-            # itself sit between the count's arrival and the first backward kernel's launch (on a slow host the ~40 us of
-            # Python in between showed up as idle device in front of blend_bwd, tools/trace_gaps.sh).  The workspace is
-            # therefore sized for the speculative capacity (>= the count unless the forward overflowed).
-            ws_for = fw.capacity if fw.pending is not None else fw.num_rendered
-            ws = _bytes(lib.bags_backward_workspace_size(P, ws_for), dev)
+            g_means2D, g_densify, g_shift = pre["means2D"], pre["densify"], pre["shift"]
+            g_view, g_proj, g_intr, g_campos = pre["view"], pre["proj"], pre["intr"], pre["campos"]
+            ws, ws_for = pre["ws"], pre["ws_instances"]
+            del pre
             stream = torch.cuda.current_stream(dev).cuda_stream
             _resolve(lib, fw)
             if fw.num_rendered > ws_for:                         # overflow: the exact redo found more instances than the capacity
