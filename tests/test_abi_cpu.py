@@ -58,6 +58,22 @@ def test_error_path_reports_message(lib):
     assert rc == -1 and b"empty image" in lib.bags_last_error()      # argument validation, no GPU touched
 
 
+def test_backward_phase_is_validated(lib):
+    """ABI 9: BagsBackwardArgs.phase selects the per-tile half, the per-Gaussian half, or both; anything else is an argument error
+    (reported before anything is enqueued: no GPU touched)."""
+    assert (_lib.BWD_ALL, _lib.BWD_BLEND, _lib.BWD_PREPROCESS) == (0, 1, 2)
+    # a syntactically complete call whose only defect is the phase: host pointers are fine, validation never dereferences them
+    buf = (C.c_char * 4096)()
+    addr = C.addressof(buf)
+    s = _lib.BagsSettings(16, 16, 0.5, 0.5, 1.0, 0, 1, 0, 0, 0, 1, 0, 0, 0, addr, addr, addr, addr, addr)
+    i = _lib.BagsInputs(0, None, None, None, None, None, None, None, None, None, None)
+    st = _lib.BagsState(addr, 1 << 40, addr, 1 << 40, addr, 1 << 40)
+    a = _lib.BagsBackwardArgs()
+    a.grad_color, a.workspace, a.workspace_bytes, a.phase = addr, addr, 1 << 40, 3
+    rc = lib.bags_backward(C.byref(s), C.byref(i), C.byref(st), C.byref(a), None)
+    assert rc == -1 and b"phase" in lib.bags_last_error(), (rc, lib.bags_last_error())
+
+
 def test_operator_api_surface_and_argument_errors():
     import inspect
     import diff_gaussian_rasterization as dgr

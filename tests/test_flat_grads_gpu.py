@@ -149,3 +149,66 @@ def test_views_accumulate_in_place_like_autograd():
     for a, b in zip(pv_ref, pv_acc):
         for k in a:
             assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_streams", [1, 2, 3])
+def test_views_on_several_streams_accumulate_in_view_order(n_streams):
+    """ABI 9: bags_backward in two halves (BagsBackwardArgs.phase) + rasterizer.AccumulationGate.  The views of one step run on
+    n_streams streams with their gradients accumulating in place; the per-Gaussian half of every backward waits for the one before
+    it, so the sums are formed in the order the backwards were CALLED in -- bit for bit what the same calls give on ONE stream without a
+    gate, and what autograd's own accumulation gives (test_views_accumulate_in_place_like_autograd).  n_streams = 1: the two-halves
+    path alone (BAGS_BWD_BLEND, then BAGS_BWD_PREPROCESS) against the one-call backward."""
+    import math
+    from bags_raster import GaussianRasterizationSettings, GaussianRasterizer, rasterizer as R
+    from bags_raster.synth import sphere_views, synth_scene
+    from scenes import camera_tensors
+    dev = torch.device("cuda")
+    P, W, H, deg, V = 5000, 256, 176, 3, 4
+    scene = synth_scene(P, 9, 1.5, deg)
+    cams = sphere_views(V, W, H, noise=0.05)
+    cots = [torch.randn(3, H, W, generator=torch.Generator().manual_seed(20 + v)).to(dev) for v in range(V)]
+    base = {k: v.to(dev) for k, v in scene.items()}
+
+    def run(streams, gate):
+        saved = (R.ACCUMULATE_IN_PLACE, R.ACCUMULATION_GATE, R.HOST_WAIT)
+        R.ACCUMULATE_IN_PLACE, R.ACCUMULATION_GATE = True, gate
+        try:
+            leaves = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+            cur = torch.cuda.current_stream()
+            per_view = []
+            for rep in range(3):                              # (the second call of a shape on takes the speculative forward)
+                if gate is not None:
+                    gate.reset()
+                for p in leaves.values():
+                    p.grad = None
+                per_view = []
+                for s in streams:
+                    s.wait_stream(cur)
+                for v, (cam, cot) in enumerate(zip(cams, cots)):
+                    with torch.cuda.stream(streams[v % len(streams)]):
+                        ct = {k: t.clone().requires_grad_(True) for k, t in camera_tensors(cam, dev).items()}
+                        m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
+                        st = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5),
+                                                           tanfovy=math.tan(cam.FoVy * 0.5), bg=torch.zeros(3, device=dev),
+                                                           scale_modifier=1.0, viewmatrix=ct["viewmatrix"], projmatrix=ct["projmatrix"],
+                                                           intrinsic=ct["intrinsic"], sh_degree=deg, campos=ct["campos"])
+                        img = GaussianRasterizer(st)(means3D=leaves["means3D"], means2D=m2, shs=leaves["shs"], opacities=leaves["opacities"],
+                                                     scales=leaves["scales"], rotations=leaves["rotations"])[0]
+                        img.backward(cot)
+                        per_view.append((ct, m2))
+                for s in streams:
+                    cur.wait_stream(s)
+                torch.cuda.synchronize()
+            return ({k: p.grad.clone() for k, p in leaves.items()},
+                    [{**{k: t.grad.clone() for k, t in ct.items()}, "means2D": m2.grad.clone()} for ct, m2 in per_view])
+        finally:
+            R.ACCUMULATE_IN_PLACE, R.ACCUMULATION_GATE, R.HOST_WAIT = saved
+    g_ref, pv_ref = run([torch.cuda.current_stream()], None)
+    streams = [torch.cuda.current_stream()] if n_streams == 1 else [torch.cuda.Stream() for _ in range(n_streams)]
+    g_new, pv_new = run(streams, R.AccumulationGate())
+    for k in g_ref:
+        assert torch.equal(g_ref[k], g_new[k]), k
+    for a, b in zip(pv_ref, pv_new):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
