@@ -68,8 +68,10 @@ def test_parity_shift_factors_extension():
     _report(rep)
     assert_report(rep)
     scene, cam = make_case(20000, 400, 304, 1.0, 3, seed=10)
-    rep = compare(scene, cam, 3, shift=torch.tensor([-0.03, 0.02, 0.015]))
-    _report({k: rep[k] for k in ("num_rendered", "image_max_err", "grad_rel_fp32", "grad_rel_fp64", "oracle32_vs_64")})
+    # (the larger scene against the fp32 oracle alone: its fp64 replay was 40 s of the suite's CPU time, and config 5 at full size runs
+    # with the distortion on as well)
+    rep = compare(scene, cam, 3, shift=torch.tensor([-0.03, 0.02, 0.015]), check_fp64=False)
+    _report({k: rep[k] for k in ("num_rendered", "image_max_err", "grad_rel_fp32")})
     assert_report(rep)
 
 
