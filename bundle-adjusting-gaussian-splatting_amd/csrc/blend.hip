@@ -886,7 +886,13 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
                        compact ? 1 : 0, im.tile_aux, live_map)
     // The chunk geometry follows the SCENE, not the dense-scene decision: forcing the dense-scene mode on or off leaves the arithmetic
     // untouched, so the two modes stay bit-identical (tests, tools/fuzz_paths.py --cross-dense)
-    const bool sparse = n_records <= (long long)BWD_SPARSE_PER_TILE * T;
+    // (stock tile rule on the tile-binned path: the chunks are staged from the compacted list of record holders -- ~60 % of the list's
+    // instances on the bench scene, the instances the opacity rule keeps -- so it is THEIR density that picks the geometry)
+#ifndef COMPACT_DENSITY_NUM
+#define COMPACT_DENSITY_NUM 3
+#endif
+    const long long per_tile_x5 = compact ? n_records * COMPACT_DENSITY_NUM : n_records * 5;
+    const bool sparse = per_tile_x5 <= 5ll * BWD_SPARSE_PER_TILE * T;
 #define BWD_LAUNCH(ABS_, CMP_) do { if (sparse) BWD_LAUNCH_(ABS_, CMP_, true); else BWD_LAUNCH_(ABS_, CMP_, false); } while (0)
     if (want_abs) { if (compact) BWD_LAUNCH(true, true); else BWD_LAUNCH(true, false); }
     else          { if (compact) BWD_LAUNCH(false, true); else BWD_LAUNCH(false, false); }

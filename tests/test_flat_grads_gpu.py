@@ -212,3 +212,59 @@ def test_views_on_several_streams_accumulate_in_view_order(n_streams):
     for a, b in zip(pv_ref, pv_new):
         for k in a:
             assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.gpu
+def test_backward_twice_on_one_forward_and_forward_without_backward():
+    """rasterizer.PREALLOCATE_BACKWARD (round 6): a waiting forward allocates its backward's buffers while it waits for the instance
+    count.  They belong to the FIRST backward of that forward: a second backward on the same graph (retain_graph) must get buffers of
+    its own (the first call's tensors are the caller's gradients by then), with the same values; a forward that is never
+    differentiated, and one under no_grad, simply give the buffers back; the switch itself does not change a bit."""
+    import math
+    from bags_raster import GaussianRasterizationSettings, GaussianRasterizer, rasterizer as R
+    from bags_raster.synth import look_at_origin_camera, synth_scene
+    from scenes import camera_tensors
+    dev = torch.device("cuda")
+    P, W, H, deg = 4000, 200, 136, 2
+    scene = synth_scene(P, 3, 1.5, deg)
+    cam = look_at_origin_camera(W, H)
+    cot = torch.randn(3, H, W, generator=torch.Generator().manual_seed(5)).to(dev)
+
+    def forward(leaves, ct):
+        st = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+                                           bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=ct["viewmatrix"],
+                                           projmatrix=ct["projmatrix"], intrinsic=ct["intrinsic"], sh_degree=deg, campos=ct["campos"])
+        return GaussianRasterizer(st)(means3D=leaves["means3D"], means2D=torch.zeros(P, 3, device=dev, requires_grad=True), shs=leaves["shs"],
+                                      opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"])[0]
+
+    def grads(prealloc, twice):
+        saved = R.PREALLOCATE_BACKWARD
+        R.PREALLOCATE_BACKWARD = prealloc
+        try:
+            out = None
+            for _ in range(2):                                   # (the second call of a shape takes the speculative, waiting forward)
+                leaves = {k: v.to(dev).clone().requires_grad_(True) for k, v in scene.items()}
+                ct = {k: v.clone().requires_grad_(True) for k, v in camera_tensors(cam, dev).items()}
+                img = forward(leaves, ct)
+                ins = list(leaves.values()) + list(ct.values())
+                g1 = torch.autograd.grad(img, ins, cot, retain_graph=twice)
+                g2 = torch.autograd.grad(img, ins, cot) if twice else g1
+                out = (g1, g2)
+            return out
+        finally:
+            R.PREALLOCATE_BACKWARD = saved
+    (a1, a2), (b1, _), (c1, _) = grads(True, True), grads(True, False), grads(False, False)
+    for x, y, z, w in zip(a1, a2, b1, c1):
+        assert torch.equal(x, y) and torch.equal(x, z) and torch.equal(x, w)
+        assert x.data_ptr() != y.data_ptr()                      # the second backward did not write into the first one's result
+    # never differentiated / no_grad: nothing to assert but that they run and leave the next differentiated call intact
+    leaves = {k: v.to(dev).clone().requires_grad_(True) for k, v in scene.items()}
+    ct = {k: v.clone().requires_grad_(True) for k, v in camera_tensors(cam, dev).items()}
+    img = forward(leaves, ct)
+    with torch.no_grad():
+        img2 = forward(leaves, ct)
+    assert torch.equal(img.detach(), img2)
+    del img, img2
+    (d1, _) = grads(True, False)
+    for x, y in zip(a1, d1):
+        assert torch.equal(x, y)
