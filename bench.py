@@ -12,8 +12,8 @@ value = N * V * P * K / max-over-ranks time ("weak" scaling: per-GPU work is fix
 the 4-view figure is a second leg of the same run, "v4").
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (blend_bwd): algorithmic bytes per launch / mean launch time, timed with hipEvents on the
-                launch stream inside the timed region (bags_profile_*), against the 8 TB/s HBM peak
+  roofline      dominant kernel (blend_bwd): algorithmic bytes per launch / mean launch time, timed with hipEvents attached to the
+                kernel's dispatch on the launch stream inside the timed region (bags_profile_*), against the 8 TB/s HBM peak
   op_roofline   the same for the whole fwd+bwd with SURVEY.md 8d's B_alg = G*850 + (P-G)*28 + I*168 + H*W*40
   cpu_baseline  the CPU oracle (oracle/raster_oracle.py, PyTorch autograd, fp32) on a bounded sample of the same workload
   pose_grad_rel_err_vs_fp32_oracle / _vs_fp64_oracle / pose_grad_parity
@@ -257,6 +257,9 @@ def main():
                          "clocks (0: none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage hipEvents in the timed region")
+    ap.add_argument("--profile-stride", type=int, default=4,
+                    help="the dominant kernel carries its timing events on every n-th step of the timed region (reported as "
+                         "roofline.launches_timed; 1 = every step)")
     ap.add_argument("--no-aabb-leg", action="store_true", help="skip the second timed leg with the stock tile rule")
     ap.add_argument("--tile-bounds", default="opacity", choices=("opacity", "aabb"),
                     help="opacity: bin a Gaussian into the tiles its alpha >= 1/255 ellipse can reach (default; same image and "
@@ -445,8 +448,11 @@ def main():
     if finish is not None:
         finish()
     _lib.profile_read()
-    # timed region: only the dominant kernel (blend_bwd) is bracketed by hipEvents -- a full per-stage breakdown costs
-    # ~40 event records (~0.09 ms of stream bubbles) per step and is taken in a separate short pass below
+    # timed region: only the dominant kernel (blend_bwd) is timed, by hipEvents ATTACHED TO ITS OWN DISPATCH (hipExtLaunchKernelGGL in
+    # csrc/blend.hip: start / stop ride on the kernel's completion signal, on the stream it is launched on) -- no event packet sits
+    # between the step's launches.  (Until round 6 two hipEventRecord calls bracketed it: 10-25 us of bubbles per step inside the very
+    # region they measured.)  A full per-stage breakdown (~14 bracketing records per step) is taken in a separate short pass below.
+    _lib.profile_stride(max(1, args.profile_stride))
     _lib.profile_enable(0 if args.no_profile else 1)
     ex_events.clear()
     elapsed = timed_leg(full_step, args.steps, dist, dev, finish=finish)
@@ -521,7 +527,8 @@ def main():
         fns_a, _ = make_views([cam0], "aabb")
         settle(lambda: fns_a[0](True), max(3, min(60, args.settle_steps)))   # the setup above left the device idle: settle again
         _lib.profile_read()
-        _lib.profile_enable(0 if args.no_profile else 1)          # blend_bwd bracketed inside this leg's timed region too
+        _lib.profile_stride(max(1, args.profile_stride))
+        _lib.profile_enable(0 if args.no_profile else 1)          # blend_bwd timed inside this leg's timed region too
         el = timed_leg(lambda: fns_a[0](True), args.steps, None, dev)
         _lib.profile_enable(0)
         pa = _lib.profile_read()
@@ -632,6 +639,9 @@ def main():
                                    "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic,
                                    "traffic_uncorrected": None if tj is None else tj[dom]["fetch_bytes"] + tj[dom]["write_bytes"],
                                    "alg_bytes_per_launch": alg[dom], "mean_launch_ms": stages[dom],
+                                   "launches_timed": int(prof_dom.get(dom, (0.0, 0))[1]), "launches_in_timed_region": args.steps * V,
+                                   "timing": "hipEvents attached to the kernel's dispatch (hipExtLaunchKernelGGL) on the launch stream, "
+                                             f"every {max(1, args.profile_stride)}-th step of the timed region",
                                    "library_build": build,
                                    "traffic_commit": None if tj is None else (tj["build"].split("commit=")[-1] if "commit=" in tj["build"] else None),
                                    "traffic_build": None if tj is None else tj["build"], "traffic_stale": None if tj is not None else stale,

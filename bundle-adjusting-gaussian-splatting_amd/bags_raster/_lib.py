@@ -94,6 +94,7 @@ SYMBOLS = {
     "bags_debug_views": (C.c_int, [C.POINTER(BagsSettings), C.POINTER(BagsInputs), C.POINTER(BagsState), C.c_int64,
                                    C.POINTER(BagsDebugViews), C.c_void_p]),
     "bags_profile_enable": (C.c_int, [C.c_int]),
+    "bags_profile_stride": (C.c_int, [C.c_int]),
     "bags_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "bags_loss_workspace_size": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "bags_loss_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
@@ -148,6 +149,11 @@ def check(rc: int, what: str) -> None:
 def profile_enable(mode) -> None:
     """0/False off, 1 dominant kernel only, 2/True every stage."""
     load().bags_profile_enable(2 if mode is True else int(mode))
+
+
+def profile_stride(n: int) -> None:
+    """mode 1: only every n-th launch of the dominant kernel carries timing events."""
+    load().bags_profile_stride(int(n))
 
 
 def profile_read():

@@ -175,7 +175,8 @@ hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinV
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
                             const float* grad_color, float* partials, bool want_abs, bool binned, hipStream_t st,
                             long long n_records = 0,                      // instance count
-                            unsigned char* live_map = nullptr);           // one byte per record (dense-scene mode: the caller's decision), or null
+                            unsigned char* live_map = nullptr,            // one byte per record (dense-scene mode: the caller's decision), or null
+                            hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);   // attached to the kernel's dispatch when given
 bool bwd_dense_mode(long long n_records, int T, int dense_per_tile);      // does a backward of this size run in dense-scene mode?
 hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, const GeomView& g, const int32_t* radii_or_null,
                                  const float* partials, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a, hipStream_t st,

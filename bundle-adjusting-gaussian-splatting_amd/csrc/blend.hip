@@ -17,6 +17,7 @@
 // issue at 96 % with a third of the lanes contributing; they are in the git history).
 #include "bags_common.h"
 #include "tile_sort.h"
+#include <hip/hip_ext.h>
 #include <type_traits>
 
 #define LOG2E 1.4426950408889634f
@@ -866,7 +867,7 @@ bool bwd_dense_mode(long long n_records, int T, int dense_per_tile_arg)
 // pointer goes to launch_preprocess_bwd, so the kernel that marks records and the kernel that reads the marks cannot disagree.
 hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinView& b, const ImgView& im,
                             const float* grad_color, float* partials, bool want_abs, bool binned, hipStream_t st,
-                            long long n_records, unsigned char* live_map)
+                            long long n_records, unsigned char* live_map, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const int gx = cdiv(s.image_width, BAGS_TILE), gy = cdiv(s.image_height, BAGS_TILE);
     const int T = gx * gy;
@@ -879,11 +880,15 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     // bags_backward_workspace_size: a fill of whole units is ONE launch of the runtime's fill kernel; with the odd tail it was two, ~5.5 us
     // each -- and the bytes behind the last mark are zero rather than arbitrary)
     if (live_map) { hipError_t e = hipMemsetAsync(live_map, 0, ((size_t)n_records + 64 + 255) / 256 * 256, st); if (e != hipSuccess) return e; }
+    // (ev_start / ev_stop: the stage profiler's events ride on this dispatch -- bags_backward says why)
+#define BWD_ARGS_ s.image_width, s.image_height, gx, T, im.tile_desc, (const u32*)b.point_list,                                          \
+                  reinterpret_cast<const unsigned char*>(b.reach_mask), (u32)(binned ? 8u : 4u), (const float4*)g.g2d,                  \
+                  (const u32*)(binned ? nullptr : g.inst_off), (const u32*)g.block_base, (const float*)s.bg, (const float*)im.final_T,  \
+                  (const u32*)im.n_contrib, grad_color, partials, (int)(compact ? 1 : 0), (const uint4*)im.tile_aux, live_map
 #define BWD_LAUNCH_(ABS_, CMP_, SPARSE_)                                                                                             \
-    hipLaunchKernelGGL((blend_bwd_scan_kernel<ABS_, CMP_, SPARSE_>), dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T, \
-                       im.tile_desc, b.point_list, reinterpret_cast<const unsigned char*>(b.reach_mask), binned ? 8u : 4u, g.g2d,    \
-                       binned ? nullptr : g.inst_off, g.block_base, s.bg, im.final_T, im.n_contrib, grad_color, partials, \
-                       compact ? 1 : 0, im.tile_aux, live_map)
+    do { if (ev_start || ev_stop) hipExtLaunchKernelGGL((blend_bwd_scan_kernel<ABS_, CMP_, SPARSE_>), dim3(grid), dim3(256), 0, st,     \
+                                                        ev_start, ev_stop, 0, BWD_ARGS_);                                             \
+         else hipLaunchKernelGGL((blend_bwd_scan_kernel<ABS_, CMP_, SPARSE_>), dim3(grid), dim3(256), 0, st, BWD_ARGS_); } while (0)
     // The chunk geometry follows the SCENE, not the dense-scene decision: forcing the dense-scene mode on or off leaves the arithmetic
     // untouched, so the two modes stay bit-identical (tests, tools/fuzz_paths.py --cross-dense)
     // (stock tile rule on the tile-binned path: the chunks are staged from the compacted list of record holders -- ~60 % of the list's
@@ -898,6 +903,7 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
     else          { if (compact) BWD_LAUNCH(false, true); else BWD_LAUNCH(false, false); }
 #undef BWD_LAUNCH
 #undef BWD_LAUNCH_
+#undef BWD_ARGS_
     return hipGetLastError();
 }
 

@@ -222,13 +222,16 @@ int bags_backward(const BagsSettings*, const BagsInputs*, const BagsState*, cons
 int bags_debug_views(const BagsSettings*, const BagsInputs*, const BagsState*, int64_t num_rendered,
                      const BagsDebugViews*, void* stream);
 
-/* Opt-in per-stage device timing (hipEvents recorded on the caller's stream around each kernel group):
- * bench.py's roofline leg.  mode 0 = off (default; the hot path records nothing), 1 = only the dominant kernel
- * (blend_bwd: two events per step), 2 = every stage (each event pair costs a few microseconds of stream bubble).
- * bags_profile_read synchronises on the recorded events, returns the number of stages, fills up to `max_stages`
- * entries (stage name, summed milliseconds, number of timed intervals) and clears the accumulators. */
+/* Opt-in per-stage device timing on the caller's stream: bench.py's roofline leg.  mode 0 = off (default; the hot path records
+ * nothing), 1 = only the dominant kernel (blend_bwd), by a start / stop hipEvent pair ATTACHED TO THE KERNEL'S DISPATCH
+ * (hipExtLaunchKernelGGL: no packet between the step's launches; round 5 bracketed it with two hipEventRecord calls, 10-25 us of
+ * bubbles per step inside the region being timed), 2 = every stage, bracketed by recorded events (each pair costs a few microseconds
+ * of stream bubble: for a separate, untimed pass).  bags_profile_stride(n): in mode 1 only every n-th launch carries events (the mean
+ * launch time of a steady loop needs no more; n = 1 by default).  bags_profile_read synchronises on the events, returns the number of
+ * stages, fills up to `max_stages` entries (stage name, summed milliseconds, number of timed intervals) and clears the accumulators. */
 #define BAGS_PROFILE_MAX_STAGES 16
 int bags_profile_enable(int mode);
+int bags_profile_stride(int n);
 int bags_profile_read(int max_stages, const char** names, double* total_ms, int64_t* calls);
 
 /* Fused photometric loss terms.  Replaces the reference's l1_loss + ssim pair
