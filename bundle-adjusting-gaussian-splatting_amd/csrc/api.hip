@@ -87,19 +87,31 @@ static hipEvent_t prof_event()
     }
     hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
 }
+thread_local hipEvent_t g_attach_start = nullptr, g_attach_stop = nullptr;     // (bags_common.h: launch_k)
 struct ProfScope {
-    hipStream_t st; int stage; hipEvent_t a = nullptr;
-    // (mode 1 -- the dominant kernel alone, inside bench.py's timed region -- does not bracket: its events ride on the kernel's own
-    // dispatch, see bags_backward)
-    ProfScope(int stage_, hipStream_t st_) : st(st_), stage(stage_) {
-        if (g_prof_mode == 2) { a = prof_event(); (void)hipEventRecord(a, st); }
+    hipStream_t st; int stage; hipEvent_t a = nullptr, b = nullptr; bool attached = false;
+    // mode 2 (every stage, bench.py's separate untimed pass).  attach: the stage is ONE kernel -- the events ride on its dispatch (no
+    // packet of their own: what they report is the kernel's time, as rocprofv3 does); otherwise the stage is bracketed by two recorded
+    // events.  Mode 1 (the dominant kernel alone, inside bench.py's timed region) is handled in bags_backward.
+    ProfScope(int stage_, hipStream_t st_, bool attach = false) : st(st_), stage(stage_) {
+        if (g_prof_mode != 2) return;
+        a = prof_event();
+        if (attach) { b = prof_event(); attached = true; g_attach_start = a; g_attach_stop = b; }
+        else (void)hipEventRecord(a, st);
     }
     ~ProfScope() {
-        if (a) {
-            hipEvent_t b = prof_event(); (void)hipEventRecord(b, st);
+        if (!a) return;
+        if (attached) {
+            const bool taken = (g_attach_start == nullptr && g_attach_stop == nullptr);
+            g_attach_start = nullptr; g_attach_stop = nullptr;
             std::lock_guard<std::mutex> lk(g_prof_mutex);
-            g_prof_pending.push_back({stage, a, b});
+            if (taken) g_prof_pending.push_back({stage, a, b});
+            else { g_prof_free.push_back(a); g_prof_free.push_back(b); }       // the launcher launched nothing
+            return;
         }
+        b = prof_event(); (void)hipEventRecord(b, st);
+        std::lock_guard<std::mutex> lk(g_prof_mutex);
+        g_prof_pending.push_back({stage, a, b});
     }
 };
 
@@ -253,7 +265,7 @@ static int enqueue_prepare(const BagsSettings* s, const BagsInputs* in, const Ge
                            hipStream_t st, u32* host_count = nullptr, bool* host_written = nullptr)
 {
     const bool binned = use_binned(s, in->P);
-    { ProfScope ps(ST_PRE_FWD, st);
+    { ProfScope ps(ST_PRE_FWD, st, true);
       HIP_TRY(launch_preprocess_fwd(*s, *in, g, out->radii, out->mean2D, st, binned ? &im : nullptr, cdiv(s->image_width, BAGS_TILE))); }
     DEBUG_SYNC(s, st, "preprocess_fwd");
     if (binned) {
@@ -261,7 +273,8 @@ static int enqueue_prepare(const BagsSettings* s, const BagsInputs* in, const Ge
         const int gx = cdiv(s->image_width, BAGS_TILE), gy = cdiv(s->image_height, BAGS_TILE);
         // host_count given (device-visible pinned word, speculative forward): no ranges_order launch -- the emission launch of
         // the second phase computes the ranges itself and delivers the count there
-        { ProfScope ps(ST_OFFSETS, st); HIP_TRY(launch_binned_prepare(g, im, in->P, gx, gx * gy, st, host_count, host_count == nullptr)); }
+        { ProfScope ps(ST_OFFSETS, st, host_count != nullptr);          // (one kernel unless the count is wanted now: then ranges_order follows)
+          HIP_TRY(launch_binned_prepare(g, im, in->P, gx, gx * gy, st, host_count, host_count == nullptr)); }
         if (host_count && host_written) *host_written = true;
         DEBUG_SYNC(s, st, "tile count / prefix / ranges");
         return BAGS_OK;
@@ -296,13 +309,13 @@ static int enqueue_finish(const BagsSettings* s, const BagsInputs* in, const Geo
     if (use_binned(s, in->P)) {
         if (in->P == 0) HIP_TRY(launch_binned_empty(g, im, gx * gy, st));      // no prepare phase ran: an all-empty tile list
         if (I > 0 && in->P > 0) {
-            ProfScope ps(ST_TILE_SORT, st);
+            ProfScope ps(ST_TILE_SORT, st, true);
             HIP_TRY(launch_binned_finish(g, im, in->P, gx, gx * gy, b.words, (u32)I, st, speculative));
         } else if (in->P > 0) {
             HIP_TRY(launch_binned_desc_only(im, gx * gy, st));                   // nothing to emit: only the (all-empty) tile list
         }
         DEBUG_SYNC(s, st, "emit / tile sort");
-        { ProfScope ps(ST_BLEND_FWD, st); HIP_TRY(launch_blend_fwd(*s, g, b, im, *out, st, n_dev, (u32)I, I > 0 && in->P > 0)); }
+        { ProfScope ps(ST_BLEND_FWD, st, true); HIP_TRY(launch_blend_fwd(*s, g, b, im, *out, st, n_dev, (u32)I, I > 0 && in->P > 0)); }
         DEBUG_SYNC(s, st, "blend_fwd");
         return scan_forward(s, in, g, out, st);
     }
@@ -318,7 +331,7 @@ static int enqueue_finish(const BagsSettings* s, const BagsInputs* in, const Geo
       HIP_TRY(launch_tile_ranges(b.tile_sorted, I, b.ranges, gx * gy, st, n_dev, I > 0));
       HIP_TRY(launch_tile_order(b.ranges, gx * gy, im.tile_desc, im.n_active, st)); }
     DEBUG_SYNC(s, st, "tile ranges");
-    { ProfScope ps(ST_BLEND_FWD, st); HIP_TRY(launch_blend_fwd(*s, g, b, im, *out, st)); }
+    { ProfScope ps(ST_BLEND_FWD, st, true); HIP_TRY(launch_blend_fwd(*s, g, b, im, *out, st)); }
     DEBUG_SYNC(s, st, "blend_fwd");
     return scan_forward(s, in, g, out, st);
 }
@@ -437,16 +450,16 @@ int bags_backward(const BagsSettings* s, const BagsInputs* in, const BagsState* 
         // box of round 5), i.e. the measurement slowed down what it measured.
         hipEvent_t ea = nullptr, eb = nullptr;
         if (g_prof_mode == 1 && (g_prof_seq++ % (unsigned long long)g_prof_stride) == 0ull) { ea = prof_event(); eb = prof_event(); }
-        { ProfScope ps(ST_BLEND_BWD, st); HIP_TRY(launch_blend_bwd(*s, g, b, im, a->grad_color, partials, a->grad_means2D_densify != nullptr, use_binned(s, in->P), st,
+        { ProfScope ps(ST_BLEND_BWD, st, true); HIP_TRY(launch_blend_bwd(*s, g, b, im, a->grad_color, partials, a->grad_means2D_densify != nullptr, use_binned(s, in->P), st,
                                                                   I, dense ? live_map : nullptr, ea, eb)); }
         if (ea) { std::lock_guard<std::mutex> lk(g_prof_mutex); g_prof_pending.push_back({ST_BLEND_BWD, ea, eb}); }
         DEBUG_SYNC(s, st, "blend_bwd");
     }
     if (a->phase == BAGS_BWD_BLEND) return BAGS_OK;          // the per-Gaussian half comes with a second call (BAGS_BWD_PREPROCESS)
     int nblocks = 0;
-    { ProfScope ps(ST_PRE_BWD, st); HIP_TRY(launch_preprocess_bwd(*s, *in, g, nullptr, partials, slab, &nblocks, *a, st, use_binned(s, in->P), dense ? live_map : nullptr)); }
+    { ProfScope ps(ST_PRE_BWD, st, true); HIP_TRY(launch_preprocess_bwd(*s, *in, g, nullptr, partials, slab, &nblocks, *a, st, use_binned(s, in->P), dense ? live_map : nullptr)); }
     DEBUG_SYNC(s, st, "preprocess_bwd");
-    { ProfScope ps(ST_POSE_REDUCE, st); HIP_TRY(launch_pose_reduce(slab, nblocks, *a, st)); }
+    { ProfScope ps(ST_POSE_REDUCE, st, true); HIP_TRY(launch_pose_reduce(slab, nblocks, *a, st)); }
     DEBUG_SYNC(s, st, "pose_reduce");
     if (s->debug) {
         const size_t P = (size_t)in->P;

@@ -148,6 +148,25 @@ struct ImgView {
     u32*   group_total;      // [512] instances per group of 64 tiles
 };
 
+// ---- kernel launches that can carry the stage profiler's events ON THEIR OWN DISPATCH (hipExtLaunchKernelGGL: the timestamps of the
+// kernel's completion signal) instead of between two hipEventRecord packets.  The profiler (api.hip: ProfScope) parks a start / stop pair
+// in these two thread-local words right before it calls a launcher whose stage is ONE kernel; the first LAUNCH_K of that launcher takes
+// them.  Without a pair parked this is hipLaunchKernelGGL.
+#include <hip/hip_ext.h>
+extern thread_local hipEvent_t g_attach_start, g_attach_stop;
+template <typename... KArgs, typename... Args>
+static inline void launch_k(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args)
+{
+    if (g_attach_start || g_attach_stop) {
+        hipEvent_t ea = g_attach_start, eb = g_attach_stop;
+        g_attach_start = nullptr; g_attach_stop = nullptr;
+        hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)lds, st, ea, eb, 0, static_cast<KArgs>(args)...);
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, lds, st, static_cast<KArgs>(args)...);
+    }
+}
+#define LAUNCH_K(kernel, grid, block, lds, st, ...) launch_k(kernel, grid, block, lds, st, __VA_ARGS__)
+
 int radix_items_for(long long n);
 int radix_blocks_for(long long n);
 size_t carve_geom(void* base, int P, GeomView* v);

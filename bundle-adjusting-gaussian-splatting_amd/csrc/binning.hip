@@ -477,7 +477,7 @@ hipError_t launch_binned_prepare(const GeomView& g, const ImgView& im, int P, in
 {
     const int per = binned_per_block(P), B = cdiv(P, per), T2 = (T + 1) / 2;
     (void)grid_x;                                             // (the counts came with K1: launch_preprocess_fwd(count_into))
-    hipLaunchKernelGGL(tile_prefix_kernel, dim3(cdiv(T2, PFX_WORDS)), dim3(1024), 0, st, im.cnt_rows, B, T, T2, im.pre, im.tile_total,
+    LAUNCH_K(tile_prefix_kernel, dim3(cdiv(T2, PFX_WORDS)), dim3(1024), 0, st, im.cnt_rows, B, T, T2, im.pre, im.tile_total,
                        im.tile_lstart, im.group_total, g.num_rendered + 2, count_now ? nullptr : host_count);
     // count_now: the caller needs the instance count before the second phase is enqueued (bags_forward_prepare hands it to the
     // host): tile ranges, count and block bases by ranges_order, one more launch.  Otherwise (speculative forward) the emission
@@ -505,7 +505,7 @@ hipError_t launch_binned_finish(const GeomView& g, const ImgView& im, int P, int
     hipError_t e = hipSuccess;
 #define EM_LAUNCH(PER) { const size_t lds = (size_t)T * 4 > ord_tr_bytes(PER) ? (size_t)T * 4 : ord_tr_bytes(PER);              \
         e = big_lds(emit_binned_kernel<PER>, lds);                                                                                \
-        if (e == hipSuccess) hipLaunchKernelGGL(emit_binned_kernel<PER>, dim3(B + 1), dim3(BIN_THREADS), lds, st, P, per, grid_x, T, g.rect, \
+        if (e == hipSuccess) LAUNCH_K(emit_binned_kernel<PER>, dim3(B + 1), dim3(BIN_THREADS), lds, st, P, per, grid_x, T, g.rect, \
                 g.tiles_touched, g.keep, im.pre, im.ranges, im.tile_lstart, im.group_total, g.depth_key, words, capacity,   \
                 im.tile_total, im.tile_desc, im.n_active, g.num_rendered, g.block_total, B, g.block_base, deliver_count ? 1 : 0); }
     switch (ord_per_for(T)) { case 8: EM_LAUNCH(8) break; case 16: EM_LAUNCH(16) break; default: EM_LAUNCH(32) }

@@ -17,7 +17,6 @@
 // issue at 96 % with a third of the lanes contributing; they are in the git history).
 #include "bags_common.h"
 #include "tile_sort.h"
-#include <hip/hip_ext.h>
 #include <type_traits>
 
 #define LOG2E 1.4426950408889634f
@@ -888,7 +887,7 @@ hipError_t launch_blend_bwd(const BagsSettings& s, const GeomView& g, const BinV
 #define BWD_LAUNCH_(ABS_, CMP_, SPARSE_)                                                                                             \
     do { if (ev_start || ev_stop) hipExtLaunchKernelGGL((blend_bwd_scan_kernel<ABS_, CMP_, SPARSE_>), dim3(grid), dim3(256), 0, st,     \
                                                         ev_start, ev_stop, 0, BWD_ARGS_);                                             \
-         else hipLaunchKernelGGL((blend_bwd_scan_kernel<ABS_, CMP_, SPARSE_>), dim3(grid), dim3(256), 0, st, BWD_ARGS_); } while (0)
+         else LAUNCH_K((blend_bwd_scan_kernel<ABS_, CMP_, SPARSE_>), dim3(grid), dim3(256), 0, st, BWD_ARGS_); } while (0)
     // The chunk geometry follows the SCENE, not the dense-scene decision: forcing the dense-scene mode on or off leaves the arithmetic
     // untouched, so the two modes stay bit-identical (tests, tools/fuzz_paths.py --cross-dense)
     // (stock tile rule on the tile-binned path: the chunks are staged from the compacted list of record holders -- ~60 % of the list's
@@ -1269,7 +1268,7 @@ hipError_t launch_blend_fwd(const BagsSettings& s, const GeomView& g, const BinV
     const int T = gx * gy;
     if (T == 0) return hipSuccess;
     const int grid = cdiv(T, TILE_RUN) * TILE_RUN;
-    hipLaunchKernelGGL(blend_fwd_rows_kernel<0>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
+    LAUNCH_K(blend_fwd_rows_kernel<0>, dim3(grid), dim3(256), 0, st, s.image_width, s.image_height, gx, T,
                        im.tile_desc, b.point_list, sort_here ? b.words : nullptr, g.depth_key, b.scratch,
                        reinterpret_cast<unsigned char*>(b.reach_mask), b.words ? 8u : 4u, g.g2d, s.bg, out.color, out.depth, out.weights,
                        im.final_T, im.n_contrib, n_dev, capacity, (b.words && s.tile_bounds != BAGS_TILES_OPACITY) ? 1 : 0, im.tile_aux);

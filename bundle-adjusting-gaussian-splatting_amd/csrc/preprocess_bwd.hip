@@ -640,7 +640,7 @@ hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, co
     *nblocks_out = nb;
     if (P == 0) return hipSuccess;
     const float* partials = partials_records;
-#define PRE_BWD_LAUNCH(COV)     hipLaunchKernelGGL((preprocess_bwd_kernel<COV, ACC_, LIVE_>), dim3(nb), dim3(256), 0, st, P, s.sh_coeffs, s.sh_degree, s.image_width, \
+#define PRE_BWD_LAUNCH(COV)     LAUNCH_K((preprocess_bwd_kernel<COV, ACC_, LIVE_>), dim3(nb), dim3(256), 0, st, P, s.sh_coeffs, s.sh_degree, s.image_width, \
                        s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, (s.clamp_grad == BAGS_CLAMP_GRAD_EXACT) ? 0 : 1, \
                        (s.conic_grad == BAGS_CONIC_GRAD_EXACT) ? 0 : 1, in.means3D, in.shift_factors, in.shs, \
                        in.colors_precomp, in.scales, in.rotations, in.cov3D_precomp, s.viewmatrix, s.projmatrix, \
@@ -681,7 +681,7 @@ hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, co
 
 hipError_t launch_pose_reduce(const float* pose_slab, int nblocks, const BagsBackwardArgs& a, hipStream_t st)
 {
-    hipLaunchKernelGGL(pose_reduce_kernel, dim3(35), dim3(256), 0, st, pose_slab, nblocks, a.grad_viewmatrix,
+    LAUNCH_K(pose_reduce_kernel, dim3(35), dim3(256), 0, st, pose_slab, nblocks, a.grad_viewmatrix,
                        a.grad_projmatrix, a.grad_intrinsic, a.grad_campos, a.grad_shift_factors);
     return hipGetLastError();
 }

@@ -473,17 +473,17 @@ hipError_t launch_preprocess_fwd(const BagsSettings& s, const BagsInputs& in, co
             if (e != hipSuccess) return e;
         }
 #define LAUNCH_COUNT(SP)                                                                                                       \
-        hipLaunchKernelGGL(preprocess_fwd_count_kernel<SP>, dim3(B), dim3(BIN_THREADS), lds, st, A, s.viewmatrix, s.projmatrix,  \
+        LAUNCH_K(preprocess_fwd_count_kernel<SP>, dim3(B), dim3(BIN_THREADS), lds, st, A, s.viewmatrix, s.projmatrix,  \
                            s.intrinsic, s.campos, in.shift_factors, O, per, grid_x, T2, count_into->cnt_rows, g.local_off, g.block_total)
         if (in.shs_rest) LAUNCH_COUNT(true); else LAUNCH_COUNT(false);
 #undef LAUNCH_COUNT
         return hipGetLastError();
     }
     if (in.shs_rest)
-        hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(cdiv(P, 256)), dim3(256), 0, st, A, s.viewmatrix, s.projmatrix, s.intrinsic,
+        LAUNCH_K(preprocess_fwd_kernel<true>, dim3(cdiv(P, 256)), dim3(256), 0, st, A, s.viewmatrix, s.projmatrix, s.intrinsic,
                            s.campos, in.shift_factors, O);
     else
-        hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(cdiv(P, 256)), dim3(256), 0, st, A, s.viewmatrix, s.projmatrix, s.intrinsic,
+        LAUNCH_K(preprocess_fwd_kernel<false>, dim3(cdiv(P, 256)), dim3(256), 0, st, A, s.viewmatrix, s.projmatrix, s.intrinsic,
                            s.campos, in.shift_factors, O);
     return hipGetLastError();
 }
