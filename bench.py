@@ -252,9 +252,10 @@ def main():
     ap.add_argument("--width", type=int, default=W_DEFAULT)
     ap.add_argument("--height", type=int, default=H_DEFAULT)
     ap.add_argument("--sm", type=float, default=SM_DEFAULT)
-    ap.add_argument("--settle-steps", type=int, default=300,
+    ap.add_argument("--settle-steps", type=int, default=1500,
                     help="untimed view renders before the warm-up steps, so that the timed region runs at the device's steady "
-                         "clocks (0: none)")
+                         "clocks (0: none).  1500 (~1 s): with 300 the first timed leg still read 3-6 us per step above the legs behind "
+                         "it (profiles/r06/ab_settle_raw.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage hipEvents in the timed region")
     ap.add_argument("--profile-stride", type=int, default=4,
