@@ -210,7 +210,9 @@ ACCUMULATE_IN_PLACE = False
 # have to run before the count exists (~85 us at 500 k Gaussians).  With this switch it allocates, in that wait, what its BACKWARD will
 # need (the gradient buffers and the record workspace, sized for the capacity the forward was enqueued with) and keeps them in the
 # context: the host's path from "count has arrived" to "blend_bwd launched" -- which the device covers with blend_fwd alone -- loses
-# its ~15 allocator calls.  Nothing else changes; a forward that is never differentiated hands the buffers back when its context dies.
+# its ~15 allocator calls (~60 us of host time; on the pool's hosts that path was already shorter than blend_fwd, so the step time did not
+# move: profiles/r06/ab_round6.txt 7 -- it is insurance for slower hosts).  Nothing else changes; a forward that is never differentiated
+# hands the buffers back when its context dies.
 PREALLOCATE_BACKWARD = True
 
 
@@ -219,8 +221,9 @@ class AccumulationGate:
 
     With ACCUMULATE_IN_PLACE the backward of view k reads, adds to and writes the gradient buffers view k-1 wrote: a read-modify-write
     that two streams must not interleave, and whose ORDER decides the rounding of the sums.  While a gate is installed
-    (``rasterizer.ACCUMULATION_GATE = AccumulationGate()``; bags_raster.sharding.ViewShardedRenderer does it for its batch) every
-    backward runs as two calls of the library -- BAGS_BWD_BLEND (the per-tile half, ~85 % of the time, no shared state), then
+    (``rasterizer.ACCUMULATION_GATE = AccumulationGate()``; the caller that spreads the views over streams installs it --
+    tools/bench_cu_partition.py, tests/test_flat_grads_gpu.py; ViewShardedRenderer keeps its views on one stream, where no gate is
+    needed: DESIGN.md section 6 has the measurements that decided that) every backward runs as two calls of the library -- BAGS_BWD_BLEND (the per-tile half, ~85 % of the time, no shared state), then
     BAGS_BWD_PREPROCESS behind the event the previous backward recorded after ITS second half -- so the sums are formed in the order
     the backwards were CALLED in, i.e. bit for bit what the same calls give on one stream, while everything else of the views
     overlaps freely.  ``reset()`` at the start of a step (nothing to wait for)."""

@@ -61,6 +61,7 @@ static int debug_scan(const BagsSettings* s, hipStream_t st, u32* counters, cons
 
 // ---------------------------------------------------------------------------------------------- stage profiler
 // Opt-in (bags_profile_enable): a start/stop hipEvent pair per stage per call, resolved in bags_profile_read.
+#include <atomic>
 #include <mutex>
 #include <vector>
 enum Stage { ST_PRE_FWD, ST_DEPTH_SORT, ST_OFFSETS, ST_EMIT, ST_TILE_SORT, ST_RANGES, ST_BLEND_FWD, ST_BLEND_BWD,
@@ -73,7 +74,7 @@ struct ProfInterval { int stage; hipEvent_t a, b; };
 static std::mutex g_prof_mutex;
 static int g_prof_mode = 0;          // 0 off, 1 dominant kernel only (blend_bwd), 2 every stage
 static int g_prof_stride = 1;        // mode 1: every n-th launch of the dominant kernel carries events (bags_profile_stride)
-static unsigned long long g_prof_seq = 0;
+static std::atomic<unsigned long long> g_prof_seq{0};
 static std::vector<ProfInterval> g_prof_pending;
 static std::vector<hipEvent_t> g_prof_free;
 static double g_prof_ms[ST_COUNT];
@@ -449,7 +450,7 @@ int bags_backward(const BagsSettings* s, const BagsInputs* in, const BagsState* 
         // gap: they cost the timed region 10-25 us per step (0.605 against 0.594 ms on one device, 0.637 against 0.611 on the driver's
         // box of round 5), i.e. the measurement slowed down what it measured.
         hipEvent_t ea = nullptr, eb = nullptr;
-        if (g_prof_mode == 1 && (g_prof_seq++ % (unsigned long long)g_prof_stride) == 0ull) { ea = prof_event(); eb = prof_event(); }
+        if (g_prof_mode == 1 && (g_prof_seq.fetch_add(1, std::memory_order_relaxed) % (unsigned long long)g_prof_stride) == 0ull) { ea = prof_event(); eb = prof_event(); }
         { ProfScope ps(ST_BLEND_BWD, st, true); HIP_TRY(launch_blend_bwd(*s, g, b, im, a->grad_color, partials, a->grad_means2D_densify != nullptr, use_binned(s, in->P), st,
                                                                   I, dense ? live_map : nullptr, ea, eb)); }
         if (ea) { std::lock_guard<std::mutex> lk(g_prof_mutex); g_prof_pending.push_back({ST_BLEND_BWD, ea, eb}); }
@@ -519,7 +520,7 @@ int bags_profile_enable(int mode)
 int bags_profile_stride(int n)
 {
     g_prof_stride = n < 1 ? 1 : n;
-    g_prof_seq = 0;
+    g_prof_seq.store(0, std::memory_order_relaxed);
     return BAGS_OK;
 }
 
