@@ -95,3 +95,27 @@ def test_settings_reject_unknown_modes_before_touching_the_device():
     with pytest.raises(RuntimeError, match="AMD GPU"):                                             # CPU tensors: no fallback
         GaussianRasterizer(st)(means3D=z(2, 3), means2D=z(2, 3), opacities=z(2, 1), shs=z(2, 1, 3), scales=z(2, 3), rotations=z(2, 4))
 
+
+
+def test_bench_reports_a_failed_start_as_one_json_line():
+    """bench.py on a box where it cannot run (here: no GPU) or with a rank count that does not match its launcher must say why on
+    STDOUT as one JSON line -- the driver keeps the tail of stdout of a failed SCALE run -- and exit non-zero; it never re-executes
+    itself and never runs a smaller bench under the same --gpus."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if __import__("torch").cuda.is_available():
+        import pytest
+        pytest.skip("needs a box without a GPU (the error path of a box with one is the rank-count check below)")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    msg = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "error" in msg and msg["rccl_ranks"] == 0 and msg["n_gpus"] == 1
+    # a launcher that started another number of ranks than --gpus says
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 2
+    msg = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "WORLD_SIZE=3" in msg["error"] and msg["n_gpus"] == 2
