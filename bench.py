@@ -284,6 +284,9 @@ def main():
                     help="N > 1, one view per exchange: go through the flat bucket (zero + accumulate) instead of all-reducing the "
                          "op's own gradient buffer")
     ap.add_argument("--no-v4-leg", action="store_true", help="skip the second timed leg with 4 views per rank per exchange")
+    ap.add_argument("--no-factored-sh", action="store_true",
+                    help="v4 leg: every view's backward writes its full SH-gradient rows (read-modify-write from the second view on) instead "
+                         "of dL/dcolour alone with ONE pass forming the step's rows (rasterizer.FactoredSH, ABI 10; same sums bit for bit)")
     ap.add_argument("--exchange", default="all_reduce", choices=("all_reduce", "reduce_scatter", "sparse"),
                     help="one ncclAllReduce of the flat gradient bucket, ncclReduceScatter + ncclAllGather, or only the rows some "
                          "rank touched (falls back to the dense all-reduce when more than 70 %% of the rows were)")
@@ -375,6 +378,7 @@ def main():
     def make_leg(v_per_rank, leaves=None, overlap=False):
         """(full_step, finish, reducer-or-pipe, exchange event list, params) of a leg with v_per_rank views behind one exchange."""
         fns, params = make_views(views_of(v_per_rank), args.tile_bounds, leaves)
+        leaf_of = dict(zip(scene.keys(), params))
         red = pip = None
         if world > 1 or v_per_rank > 1:
             if overlap:
@@ -401,10 +405,17 @@ def main():
                 return radii_
             if adopt:
                 # several views per rank: the first view's gradient buffer is adopted as the accumulator (p.grad starts as None,
-                # autograd adds the later views into it in place): no bucket zero pass, no add for the first view
+                # autograd adds the later views into it in place): no bucket zero pass, no add for the first view.  The SH gradients
+                # stay factored (dL/dcolour per view) until the step's last backward has run: one pass then forms their rows, in the
+                # first view's buffer (rasterizer.FactoredSH; needs the in-kernel accumulation of the other gradients)
+                fs = R.FactoredSH() if (R.ACCUMULATE_IN_PLACE and not args.no_factored_sh) else None
+                R.FACTORED_SH = fs
                 radii_ = fns[0](True)
                 for f_ in fns[1:]:
                     radii_ = f_(False)
+                R.FACTORED_SH = None
+                if fs is not None:
+                    fs.finish(leaf_of["means3D"], leaf_of["shs"])
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 red.all_reduce_adopted()
@@ -491,9 +502,10 @@ def main():
         v4 = {"views_per_rank_per_exchange": 4, "steps": k4, "ms_per_step": el4 / k4 * 1e3, "ms_per_view": el4 / k4 / 4 * 1e3,
               "value": world * 4 * P * k4 / el4,
               "exchange_ms": (sum(a.elapsed_time(b) for a, b in ev4) / len(ev4)) if ev4 else 0.0,
-              "accumulate_in_place": bool(R.ACCUMULATE_IN_PLACE),
+              "accumulate_in_place": bool(R.ACCUMULATE_IN_PLACE), "factored_sh": bool(R.ACCUMULATE_IN_PLACE and not args.no_factored_sh),
               "note": "four views per rank (fwd+bwd; the first view's gradient buffer is adopted as the accumulator and views 2-4 add "
-                      "into it inside the backward kernel; --bucket-always: the flat bucket and autograd's add passes) behind one exchange"}
+                      "into it inside the backward kernel, the SH gradients as dL/dcolour per view with one pass forming the step's rows; "
+                      "--bucket-always: the flat bucket and autograd's add passes) behind one exchange"}
         R.ACCUMULATE_IN_PLACE = False
     def settle(fn, n):
         for _ in range(n):

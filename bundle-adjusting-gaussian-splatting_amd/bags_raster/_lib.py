@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # tests).  Not a fallback: a missing file still raises.
 LIB_PATH = os.environ.get("BAGS_RASTER_LIB") or os.path.join(_HERE, "libbags_raster.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 TILES_AABB, TILES_OPACITY = 0, 1
 DEPTH_Z, DEPTH_DISTANCE = 0, 1
 BINNING_AUTO, BINNING_RADIX = 0, 1
@@ -52,12 +52,19 @@ class BagsBackwardArgs(C.Structure):
                 ("grad_cov3D_precomp", c_fp), ("grad_viewmatrix", c_fp), ("grad_projmatrix", c_fp),
                 ("grad_intrinsic", c_fp), ("grad_campos", c_fp), ("grad_shift_factors", c_fp),
                 ("binning_capacity", C.c_int64), ("accumulate", C.c_int32), ("dense_per_tile", C.c_int32), ("grad_shs_rest", c_fp),
-                ("phase", C.c_int32), ("reserved2", C.c_int32)]
+                ("phase", C.c_int32), ("reserved2", C.c_int32), ("grad_dldc", c_fp)]
 
 
 class BagsDebugViews(C.Structure):
     _fields_ = [("tiles_touched", c_fp), ("rect", c_fp), ("depth_bits", c_fp), ("point_list", c_fp),
                 ("keys_sorted", c_fp), ("ranges", c_fp), ("n_contrib", c_fp), ("final_T", c_fp)]
+
+
+MAX_SH_VIEWS = 16
+
+
+class BagsShViews(C.Structure):
+    _fields_ = [("n_views", C.c_int32), ("reserved", C.c_int32), ("campos", c_fp * MAX_SH_VIEWS), ("dldc", c_fp * MAX_SH_VIEWS)]
 
 
 # every symbol include/bags_raster.h declares: (restype, argtypes)
@@ -91,6 +98,8 @@ SYMBOLS = {
                                                   C.POINTER(BagsForwardOut), C.c_int64, C.c_void_p]),
     "bags_backward": (C.c_int, [C.POINTER(BagsSettings), C.POINTER(BagsInputs), C.POINTER(BagsState),
                                 C.POINTER(BagsBackwardArgs), C.c_void_p]),
+    "bags_sh_gradient_from_views": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(BagsShViews), C.c_void_p, C.c_void_p,
+                                              C.c_int32, C.c_void_p]),
     "bags_debug_views": (C.c_int, [C.POINTER(BagsSettings), C.POINTER(BagsInputs), C.POINTER(BagsState), C.c_int64,
                                    C.POINTER(BagsDebugViews), C.c_void_p]),
     "bags_profile_enable": (C.c_int, [C.c_int]),

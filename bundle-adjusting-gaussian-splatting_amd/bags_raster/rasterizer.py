@@ -236,6 +236,74 @@ class AccumulationGate:
 
 
 ACCUMULATION_GATE: Optional[AccumulationGate] = None
+
+
+class FactoredSH:
+    """The SH gradients of the views of ONE optimisation step, kept factored until the step's last backward has run (ABI 10).
+
+    dL/dshs of one view is, per Gaussian, the outer product of the SH basis at the direction from that view's camera and the
+    three floats dL/dcolour -- and writing that 192-byte row (and, when the views accumulate, reading it first) is two thirds of the
+    traffic of a backward's per-Gaussian half.  While an instance is installed (``rasterizer.FACTORED_SH = FactoredSH()``) every
+    backward of the SH colour path writes only its (P,3) dL/dcolour and hands autograd None for ``shs`` / ``shs_rest``;
+    ``finish(means3D, shs[, shs_rest])`` then forms the rows of all the step's views in one kernel -- 12 bytes read per Gaussian
+    and view, every row written once -- into ``shs.grad`` (added, in view order, to a gradient that is already there: exactly the
+    sums, bit for bit, that the same backwards leave with ACCUMULATE_IN_PLACE).  Tensor hooks on the SH parameters see nothing
+    before ``finish``.  One instance per step; ``finish`` clears it for the next."""
+
+    def __init__(self):
+        self.views = []            # (campos (3,), dL/dcolour (P,3), active sh degree, stream) per backward, in call order
+        self.target = None         # (shs slice, shs_rest slice) of the first backward's gradient buffer, lent for the finished rows
+
+    def finish(self, means3D: torch.Tensor, shs: torch.Tensor, shs_rest: Optional[torch.Tensor] = None) -> None:
+        views, self.views = self.views, []
+        lent, self.target = self.target, None
+        if not views:
+            return
+        lib = L.load()
+        dev, P = means3D.device, means3D.shape[0]
+        deg = views[0][2]
+        if any(v[2] != deg for v in views):
+            raise RuntimeError("FactoredSH.finish: the views of one step were rendered with different sh_degree")
+        M = shs.shape[1] + (shs_rest.shape[1] if shs_rest is not None else 0)
+        targets = []
+        for j, p_ in enumerate((shs, shs_rest)):
+            if p_ is None:
+                targets.append(None)
+                continue
+            fresh = p_.grad is None
+            if fresh:
+                slot = lent[j] if lent is not None else None
+                p_.grad = slot if (slot is not None and tuple(slot.shape) == tuple(p_.shape)) else torch.empty_like(p_, memory_format=torch.contiguous_format)
+            if p_.grad.dtype != torch.float32 or not p_.grad.is_contiguous() or p_.grad.device != dev:
+                raise RuntimeError("FactoredSH.finish: the SH parameters' gradients must be contiguous fp32 tensors on the op's device")
+            targets.append((p_.grad, fresh))
+        if shs_rest is not None and targets[0][1] != targets[1][1]:
+            raise RuntimeError("FactoredSH.finish: shs and shs_rest must both hold a gradient, or neither")
+        accumulate = 0 if targets[0][1] else 1
+        m3 = means3D.detach()
+        if m3.dtype != torch.float32 or not m3.is_contiguous():
+            m3 = m3.to(torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            cur = torch.cuda.current_stream(dev)
+            for v in views:                                   # the views' backwards may have run on other streams
+                if v[3] != cur:
+                    cur.wait_stream(v[3])
+            for b in range(0, len(views), L.MAX_SH_VIEWS):
+                part = views[b:b + L.MAX_SH_VIEWS]
+                sv = L.BagsShViews()
+                sv.n_views = len(part)
+                for j, v in enumerate(part):
+                    sv.campos[j], sv.dldc[j] = v[0].data_ptr(), v[1].data_ptr()
+                L.check(lib.bags_sh_gradient_from_views(P, M, deg, m3.data_ptr(), C.byref(sv), targets[0][0].data_ptr(),
+                                                        None if targets[1] is None else targets[1][0].data_ptr(), accumulate, cur.cuda_stream),
+                        "bags_sh_gradient_from_views")
+                accumulate = 1
+                for v in part:                                # the factored tensors are read on `cur`: tell their allocator streams
+                    if v[3] != cur:
+                        v[1].record_stream(cur)
+
+
+FACTORED_SH: Optional[FactoredSH] = None
 # BagsBackwardArgs.dense_per_tile: 0 = the library's threshold (instances per tile, scene average) for the backward's dense-scene
 # mode (a byte per gradient record instead of zero records), < 0 never, > 0 that threshold.  Results do not depend on it;
 # tools/fuzz_paths.py forces both paths with it.
@@ -570,12 +638,14 @@ class _RasterizeGaussians(torch.autograd.Function):
 
             k = pk.keep
             want = _wanted(need, k, ctx.shapes, P)
+            # FactoredSH: this view's SH gradient stays factored (12 bytes per Gaussian); FactoredSH.finish forms the rows of the whole step
+            fsh = FACTORED_SH if (FACTORED_SH is not None and k["shs"] is not None and (need[4] or need[15])) else None
             # ACCUMULATE_IN_PLACE: every wanted Gaussian gradient has a running sum to be added into
             in_place = None
             if ACCUMULATE_IN_PLACE and ctx.leaves is not None:       # (the flag was already set when this forward ran)
                 tgt = {}
                 for (n, sh, f), ref in zip(want, ctx.leaves):
-                    if not f:
+                    if not f or (fsh is not None and n in ("sh", "sh_rest")):
                         continue
                     t = ref() if ref is not None else None
                     g = None if t is None else t.grad
@@ -597,7 +667,15 @@ class _RasterizeGaussians(torch.autograd.Function):
             carved = {n: in_place.get(n) for n, _, _ in want} if in_place is not None else pre["carved"]
             g_means3D, g_sh, g_col, g_opac = carved["means3D"], carved["sh"], carved["col"], carved["opac"]
             g_sh_rest = carved["sh_rest"]
-            if k["shs_rest"] is not None and (g_sh is None) != (g_sh_rest is None):
+            g_dldc = None
+            if fsh is not None:
+                g_dldc = torch.empty(P, 3, dtype=torch.float32, device=dev)
+                # the step's first backward (nothing accumulated yet) lends its carved SH slices to finish(): the finished gradient then
+                # sits in the same flat buffer as the other parameters' (GradAllReducer.all_reduce_adopted: ONE collective over it)
+                if in_place is None and fsh.target is None:
+                    fsh.target = (g_sh, g_sh_rest)
+                g_sh = g_sh_rest = None
+            if g_dldc is None and k["shs_rest"] is not None and (g_sh is None) != (g_sh_rest is None):
                 # the library writes the pair or neither (one staged pass over both): the unwanted half goes to a scratch tensor
                 if g_sh is None:
                     g_sh = torch.zeros(ctx.shapes["sh"], dtype=torch.float32, device=dev)
@@ -617,6 +695,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                       _ptr(g_scales), _ptr(g_rot), _ptr(g_cov), _ptr(g_view), _ptr(g_proj),
                                       _ptr(g_intr), _ptr(g_campos), _ptr(g_shift), fw.capacity, 1 if in_place is not None else 0, int(DENSE_PER_TILE),
                                       _ptr(g_sh_rest))
+            args.grad_dldc = _ptr(g_dldc)
             state = _state_of(fw)
             gate = ACCUMULATION_GATE
             if gate is None:
@@ -636,6 +715,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                         "bags_backward (per-Gaussian half)")
                 gate.event = torch.cuda.Event()
                 gate.event.record(ts)
+        if g_dldc is not None:                                # (the op's campos tensor is kept alive by the entry: finish reads it)
+            fsh.views.append((k["campos"], g_dldc, int(pk.settings.sh_degree), torch.cuda.current_stream(dev)))
+            g_sh = g_sh_rest = None
         if g_campos is not None:
             g_campos = g_campos.reshape(ctx.shapes["campos"])
         if in_place is not None:                              # already added into the parameters' .grad: nothing for autograd to add

@@ -324,11 +324,18 @@ class ViewShardedRenderer:
     the same collective on the same bucket."""
 
     def __init__(self, params: Sequence[torch.Tensor], render_fn: Callable[[object], torch.Tensor], group=None,
-                 mode: str = "all_reduce"):
+                 mode: str = "all_reduce", sh_params: Optional[Sequence[torch.Tensor]] = None):
+        """sh_params (optional): ``(means3D, shs)`` or ``(means3D, features_dc, features_rest)`` -- the leaves the rasterizer is called
+        with.  With them the SH gradients of the rank's views stay factored (rasterizer.FactoredSH: 12 bytes per Gaussian and view) and
+        one pass forms the step's rows before the exchange -- the same sums bit for bit, a third less traffic per view from the second
+        view of a rank on."""
         self.params = list(params)
         self.render_fn = render_fn
         self.group = group
         self.reducer = GradAllReducer(self.params, group, mode)
+        self.sh_params = tuple(sh_params) if sh_params is not None else None
+        if self.sh_params is not None and len(self.sh_params) not in (2, 3):
+            raise ValueError("sh_params must be (means3D, shs) or (means3D, features_dc, features_rest)")
 
     def step(self, views: Sequence[object]) -> Dict[str, object]:
         world = _world(self.group)
@@ -339,15 +346,19 @@ class ViewShardedRenderer:
         # the parameters' .grad are the (zeroed) bucket slices: where the rasterizer is called on the leaves themselves its backward
         # adds into them inside the kernel (rasterizer.ACCUMULATE_IN_PLACE) instead of through one autograd add pass per tensor and view
         from . import rasterizer as _R
-        saved = _R.ACCUMULATE_IN_PLACE
+        saved = (_R.ACCUMULATE_IN_PLACE, _R.FACTORED_SH)
         _R.ACCUMULATE_IN_PLACE = True
+        fs = _R.FactoredSH() if (self.sh_params is not None and self.sh_params[0].is_cuda) else None
+        _R.FACTORED_SH = fs
         try:
             for v in mine:
                 loss = self.render_fn(views[v])
                 loss.backward()                  # grads of this rank's views accumulate in the bucket
                 losses.append(loss.detach())
         finally:
-            _R.ACCUMULATE_IN_PLACE = saved
+            _R.ACCUMULATE_IN_PLACE, _R.FACTORED_SH = saved
+        if fs is not None:
+            fs.finish(*self.sh_params)           # the step's SH-gradient rows, added into the bucket's (zeroed) slices
         self.reducer.all_reduce()
         total = torch.stack(losses).sum() if losses else torch.zeros((), device=self.params[0].device)
         if world > 1:

@@ -431,6 +431,8 @@ int bags_backward(const BagsSettings* s, const BagsInputs* in, const BagsState* 
     if (!stt->binning || stt->binning_bytes < bags_binning_size(cap, W, H)) return fail(BAGS_ERR_SIZE, "binning buffer too small");
     if (!a->workspace || a->workspace_bytes < bags_backward_workspace_size(in->P, I)) return fail(BAGS_ERR_SIZE, "backward workspace too small");
     if (a->phase < BAGS_BWD_ALL || a->phase > BAGS_BWD_PREPROCESS) return fail(BAGS_ERR_ARG, "phase %d is not BAGS_BWD_ALL / _BLEND / _PREPROCESS", a->phase);
+    if (a->grad_dldc && (!in->shs || in->colors_precomp || a->grad_shs || a->grad_shs_rest))
+        return fail(BAGS_ERR_ARG, "grad_dldc (factored SH gradient) goes with inputs.shs and WITHOUT grad_shs / grad_shs_rest");
     if (in->shs_rest ? ((a->grad_shs != nullptr) != (a->grad_shs_rest != nullptr)) : (a->grad_shs_rest != nullptr))
         return fail(BAGS_ERR_ARG, "grad_shs_rest goes with inputs.shs_rest, and then grad_shs (features_dc) and grad_shs_rest are given together");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -474,6 +476,23 @@ int bags_backward(const BagsSettings* s, const BagsInputs* in, const BagsState* 
                                   {"grad_campos", a->grad_campos, 3}, {"grad_shift_factors", a->grad_shift_factors, 3}};
         return debug_scan(s, st, g.num_rendered + 8, items, 15, "the backward", fail);
     }
+    return BAGS_OK;
+}
+
+int bags_sh_gradient_from_views(int32_t P, int32_t M, int32_t sh_degree, const float* means3D, const BagsShViews* views,
+                                float* grad_shs, float* grad_shs_rest, int32_t accumulate, void* stream)
+{
+    if (P < 0) return fail(BAGS_ERR_ARG, "sh_gradient_from_views: P < 0");
+    if (!views || views->n_views < 0 || views->n_views > BAGS_MAX_SH_VIEWS)
+        return fail(BAGS_ERR_ARG, "sh_gradient_from_views: n_views must be 0..%d (more views: a second call with accumulate = 1)", BAGS_MAX_SH_VIEWS);
+    if (sh_degree < 0 || sh_degree > 3 || M < 1 || (sh_degree + 1) * (sh_degree + 1) > M)
+        return fail(BAGS_ERR_ARG, "sh_gradient_from_views: sh_degree %d needs %d coefficients, M = %d", sh_degree, (sh_degree + 1) * (sh_degree + 1), M);
+    if (grad_shs_rest && M < 2) return fail(BAGS_ERR_ARG, "sh_gradient_from_views: grad_shs_rest needs M >= 2");
+    if (P == 0 || views->n_views == 0) return BAGS_OK;
+    if (!means3D || !grad_shs) return fail(BAGS_ERR_ARG, "sh_gradient_from_views: means3D / grad_shs must be given");
+    for (int v = 0; v < views->n_views; ++v)
+        if (!views->campos[v] || !views->dldc[v]) return fail(BAGS_ERR_ARG, "sh_gradient_from_views: view %d has a NULL campos / dldc", v);
+    HIP_TRY(launch_sh_grad_from_views(P, M, sh_degree, means3D, *views, grad_shs, grad_shs_rest, accumulate, reinterpret_cast<hipStream_t>(stream)));
     return BAGS_OK;
 }
 

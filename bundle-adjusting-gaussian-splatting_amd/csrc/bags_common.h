@@ -201,6 +201,8 @@ hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, co
                                  const float* partials, float* pose_slab, int* nblocks_out, const BagsBackwardArgs& a, hipStream_t st,
                                  bool binned, const unsigned char* live_map = nullptr);
 hipError_t launch_pose_reduce(const float* pose_slab, int nblocks, const BagsBackwardArgs& a, hipStream_t st);
+hipError_t launch_sh_grad_from_views(int P, int M, int deg, const float* means3D, const BagsShViews& views, float* g_shs, float* g_shs_rest,
+                                     int accumulate, hipStream_t st);
 // loss.hip: fused L1 + SSIM terms and their image gradient
 size_t loss_workspace_bytes(int C, int H, int W);
 hipError_t launch_loss_fwd(const float* img, const float* gt, int C, int H, int W, void* ws, float* out_terms, hipStream_t st,

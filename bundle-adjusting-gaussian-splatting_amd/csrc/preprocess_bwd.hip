@@ -184,7 +184,8 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
                       const u32* __restrict__ block_base, int per_block, const float* __restrict__ shjac,
                       const float* __restrict__ partials, const unsigned char* __restrict__ live_map, float* __restrict__ pose_slab,
                       float* __restrict__ g_means3D, float* __restrict__ g_means2D, float* __restrict__ g_densify,
-                      float* __restrict__ g_shs, float* __restrict__ g_shs_rest, float* __restrict__ g_colors, float* __restrict__ g_opac,
+                      float* __restrict__ g_shs, float* __restrict__ g_shs_rest, float* __restrict__ g_dldc, float* __restrict__ g_colors,
+                      float* __restrict__ g_opac,
                       float* __restrict__ g_scales, float* __restrict__ g_rot, float* __restrict__ g_cov3D)
 {
     // A wave's life in this kernel is a handful of memory round trips, not arithmetic (55 % of the wave cycles were spent
@@ -458,6 +459,8 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
             if (cl & 1u) drgb[0] = 0.f;
             if (cl & 2u) drgb[1] = 0.f;
             if (cl & 4u) drgb[2] = 0.f;
+            // factored SH gradient (BagsBackwardArgs.grad_dldc): the row basis x dL/dcolour is formed later, for all views of the step at once
+            if (g_dldc) { g_dldc[3 * (size_t)i] = drgb[0]; g_dldc[3 * (size_t)i + 1] = drgb[1]; g_dldc[3 * (size_t)i + 2] = drgb[2]; }
             const float ex = x - cpx, ey = y - cpy, ez = z - cpz;
             const float il = 1.0f / sqrtf(ex * ex + ey * ey + ez * ez);
             const float ux_ = ex * il, uy_ = ey * il, uz_ = ez * il;
@@ -494,6 +497,8 @@ preprocess_bwd_kernel(int P, int M, int deg, int W, int H, float tanfovx, float 
             dmx += px_; dmy += py_; dmz += pz_;
             cp0 = -px_; cp1 = -py_; cp2 = -pz_;
         }
+    } else if (i < P && g_dldc && !colors_precomp) {      // a culled Gaussian: no colour gradient
+        g_dldc[3 * (size_t)i] = 0.f; g_dldc[3 * (size_t)i + 1] = 0.f; g_dldc[3 * (size_t)i + 2] = 0.f;
     } else if (i < P && g_shs && !colors_precomp) {       // a culled Gaussian: its gradient row is zero
         float* gsh = g_shs_rest ? g_shs + 3 * (size_t)i : g_shs + (size_t)i * M * 3;
         float* gsr = g_shs_rest ? g_shs_rest + (size_t)i * (M - 1) * 3 : gsh + 3;
@@ -647,6 +652,7 @@ hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, co
                        s.intrinsic, s.campos, in.opacities, g.rec_count, binned ? nullptr : g.inst_off, g.local_off, g.block_base, \
                        binned_per_block(P), g.shjac, partials, live_map, \
                        pose_slab, a.grad_means3D, a.grad_means2D, a.grad_means2D_densify, a.grad_shs, in.shs_rest ? a.grad_shs_rest : nullptr, \
+                       (in.shs && !in.colors_precomp) ? a.grad_dldc : nullptr, \
                        a.grad_colors_precomp, a.grad_opacities, a.grad_scales, a.grad_rotations, a.grad_cov3D_precomp);
 #define PRE_BWD_PICK if (in.cov3D_precomp) { PRE_BWD_LAUNCH(true) } else { PRE_BWD_LAUNCH(false) }
     if (live_map) {
@@ -676,6 +682,144 @@ hipError_t launch_preprocess_bwd(const BagsSettings& s, const BagsInputs& in, co
     }
 #undef PRE_BWD_PICK
 #undef PRE_BWD_LAUNCH
+    return hipGetLastError();
+}
+
+// ---- (ABI 10) SH-gradient rows of several views from their factored form.  One 256-thread workgroup per SHV_G = 128 Gaussians, view
+// after view: threads 0..127 form their Gaussian's basis at the view's direction (the very expressions preprocess_bwd_kernel uses: same
+// file, same flags, same bits) and stage 16 + 3 floats; then the workgroup's 128 rows leave as whole lines, thread t owning float4
+// number k * 256 + t of the span for ALL views -- the running sums of a step live in registers (six or seven float4s per thread: with
+// 256 Gaussians per workgroup the thirteen float4s and their index arithmetic did not fit 128 registers), the rows are written once.
+#define SHV_G 128
+struct ShViewPtrs { const float* campos[BAGS_MAX_SH_VIEWS]; const float* dldc[BAGS_MAX_SH_VIEWS]; };
+template <bool SPLIT>
+__global__ void __launch_bounds__(256, SPLIT ? 3 : 4)      // (split: 45-float rows, dearer index arithmetic: 19 spilled registers at four per CU)
+sh_grad_from_views_kernel(int P, int deg, const float* __restrict__ means3D, const ShViewPtrs V, int n_views,
+                          float* __restrict__ g_shs, float* __restrict__ g_shs_rest, int accumulate)
+{
+    __shared__ float srow[SHV_G][20];
+    const int i = blockIdx.x * SHV_G + (threadIdx.x & (SHV_G - 1));
+    const size_t ic = (size_t)(i < P ? i : P - 1);
+    const float x = means3D[3 * ic], y = means3D[3 * ic + 1], z = means3D[3 * ic + 2];
+    const int nb = (deg + 1) * (deg + 1);
+    // the float4s of the workgroup's span(s) this thread owns: concatenated (P,16,3): 6 of one span of 128 x 48 floats; split: 1 of the DC
+    // span (128 x 3 floats = 96 float4s: threads 0..95) + 6 of the (P,15,3) span (128 x 45 floats = 1440 float4s: the last round partial)
+    constexpr int NK = SPLIT ? 7 : 6;
+    float4 acc[NK];
+    bool first = (accumulate == 0);
+    for (int v = 0; v < n_views; ++v) {
+        __syncthreads();                                  // the previous view's rows have been consumed
+        if (threadIdx.x < SHV_G) {
+            const float cpx = V.campos[v][0], cpy = V.campos[v][1], cpz = V.campos[v][2];
+            const float* dl = V.dldc[v] + 3 * ic;
+            const float d0 = dl[0], d1 = dl[1], d2 = dl[2];
+            const float ex = x - cpx, ey = y - cpy, ez = z - cpz;
+            const float il = 1.0f / sqrtf(ex * ex + ey * ey + ez * ez);
+            const float ux_ = ex * il, uy_ = ey * il, uz_ = ez * il;
+            float bs[16];
+            sh_basis(deg, ux_, uy_, uz_, bs);
+            float4* d4 = reinterpret_cast<float4*>(&srow[threadIdx.x][0]);
+            const bool on = i < P;
+            d4[0] = make_float4(bs[0], nb > 1 ? bs[1] : 0.f, nb > 1 ? bs[2] : 0.f, nb > 1 ? bs[3] : 0.f);
+            d4[1] = make_float4(nb > 4 ? bs[4] : 0.f, nb > 4 ? bs[5] : 0.f, nb > 4 ? bs[6] : 0.f, nb > 4 ? bs[7] : 0.f);
+            d4[2] = make_float4(nb > 4 ? bs[8] : 0.f, nb > 9 ? bs[9] : 0.f, nb > 9 ? bs[10] : 0.f, nb > 9 ? bs[11] : 0.f);
+            d4[3] = make_float4(nb > 9 ? bs[12] : 0.f, nb > 9 ? bs[13] : 0.f, nb > 9 ? bs[14] : 0.f, nb > 9 ? bs[15] : 0.f);
+            d4[4] = make_float4(on ? d0 : 0.f, on ? d1 : 0.f, on ? d2 : 0.f, 0.f);
+        }
+        __syncthreads();
+        // products of this view for the float4s the thread owns; the first view starts the sums (or adds to the buffers' content)
+        auto add = [&](const int k, const u32 R, const u32 t0, const u32 el, float* __restrict__ out, const size_t first_f, const size_t total) {
+            float o4[4];
+#pragma unroll
+            for (u32 u = 0; u < 4; ++u) {
+                const u32 f = el * 4u + u, row = f / R, r = f - row * R, t = t0 + r / 3u, c = r - 3u * (r / 3u);
+                o4[u] = srow[row][t] * srow[row][16u + c];
+            }
+            if (first) acc[k] = make_float4(o4[0], o4[1], o4[2], o4[3]);
+            else {
+                if (v == 0) {                                // accumulate: the running sums start from what the buffers hold
+                    const size_t g0 = first_f + (size_t)el * 4u;
+                    if (g0 + 3 < total) acc[k] = *reinterpret_cast<const float4*>(out + g0);
+                    else acc[k] = make_float4(g0 < total ? out[g0] : 0.f, g0 + 1 < total ? out[g0 + 1] : 0.f, g0 + 2 < total ? out[g0 + 2] : 0.f, 0.f);
+                }
+                acc[k].x = o4[0] + acc[k].x; acc[k].y = o4[1] + acc[k].y; acc[k].z = o4[2] + acc[k].z; acc[k].w = o4[3] + acc[k].w;
+            }
+        };
+        if (SPLIT) {
+            if (threadIdx.x < (u32)(SHV_G * 3 / 4)) add(0, 3u, 0u, threadIdx.x, g_shs, (size_t)blockIdx.x * SHV_G * 3u, (size_t)P * 3u);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const u32 el = (u32)k * 256u + threadIdx.x;
+                if (el * 4u < (u32)SHV_G * 45u) add(1 + k, 45u, 1u, el, g_shs_rest, (size_t)blockIdx.x * SHV_G * 45u, (size_t)P * 45u);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) add(k, 48u, 0u, (u32)k * 256u + threadIdx.x, g_shs, (size_t)blockIdx.x * SHV_G * 48u, (size_t)P * 48u);
+        }
+        first = false;
+    }
+    auto put = [&](const int k, const u32 el, float* __restrict__ out, const size_t first_f, const size_t total) {
+        const size_t g0 = first_f + (size_t)el * 4u;
+        if (g0 + 3 < total) *reinterpret_cast<float4*>(out + g0) = acc[k];
+        else {
+            if (g0 < total) out[g0] = acc[k].x;
+            if (g0 + 1 < total) out[g0 + 1] = acc[k].y;
+            if (g0 + 2 < total) out[g0 + 2] = acc[k].z;
+        }
+    };
+    if (n_views <= 0) return;
+    if (SPLIT) {
+        if (threadIdx.x < (u32)(SHV_G * 3 / 4)) put(0, threadIdx.x, g_shs, (size_t)blockIdx.x * SHV_G * 3u, (size_t)P * 3u);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const u32 el = (u32)k * 256u + threadIdx.x;
+            if (el * 4u < (u32)SHV_G * 45u) put(1 + k, el, g_shs_rest, (size_t)blockIdx.x * SHV_G * 45u, (size_t)P * 45u);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) put(k, (u32)k * 256u + threadIdx.x, g_shs, (size_t)blockIdx.x * SHV_G * 48u, (size_t)P * 48u);
+    }
+}
+// any other M (fewer stored coefficients): a thread per Gaussian writes its own row; the same products in the same order
+__global__ void __launch_bounds__(256)
+sh_grad_from_views_generic_kernel(int P, int M, int deg, const float* __restrict__ means3D, const ShViewPtrs V, int n_views,
+                                  float* __restrict__ g_shs, float* __restrict__ g_shs_rest, int accumulate)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P || n_views <= 0) return;
+    const float x = means3D[3 * (size_t)i], y = means3D[3 * (size_t)i + 1], z = means3D[3 * (size_t)i + 2];
+    const int nb = (deg + 1) * (deg + 1);
+    float* gsh = g_shs_rest ? g_shs + 3 * (size_t)i : g_shs + (size_t)i * M * 3;
+    float* gsr = g_shs_rest ? g_shs_rest + (size_t)i * (M - 1) * 3 : gsh + 3;
+    for (int v = 0; v < n_views; ++v) {
+        const float cpx = V.campos[v][0], cpy = V.campos[v][1], cpz = V.campos[v][2];
+        const float* dl = V.dldc[v] + 3 * (size_t)i;
+        const float d[3] = {dl[0], dl[1], dl[2]};
+        const float ex = x - cpx, ey = y - cpy, ez = z - cpz;
+        const float il = 1.0f / sqrtf(ex * ex + ey * ey + ez * ez);
+        float bs[16];
+        sh_basis(deg, ex * il, ey * il, ez * il, bs);
+        const bool add = accumulate != 0 || v > 0;
+        for (int t = 0; t < M; ++t) {
+            float* gr = (t == 0) ? gsh : gsr + 3 * (t - 1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float o = (t < nb) ? bs[t] * d[c] : 0.f;
+                gr[c] = add ? o + gr[c] : o;
+            }
+        }
+    }
+}
+hipError_t launch_sh_grad_from_views(int P, int M, int deg, const float* means3D, const BagsShViews& views, float* g_shs, float* g_shs_rest,
+                                     int accumulate, hipStream_t st)
+{
+    if (P == 0 || views.n_views <= 0) return hipSuccess;
+    ShViewPtrs V;
+    for (int v = 0; v < BAGS_MAX_SH_VIEWS; ++v) { V.campos[v] = views.campos[v < views.n_views ? v : 0]; V.dldc[v] = views.dldc[v < views.n_views ? v : 0]; }
+    const int nbk = cdiv(P, 256), nbs = cdiv(P, SHV_G);
+    if (M == 16 && g_shs_rest) hipLaunchKernelGGL(sh_grad_from_views_kernel<true>, dim3(nbs), dim3(256), 0, st, P, deg, means3D, V, views.n_views, g_shs, g_shs_rest, accumulate);
+    else if (M == 16) hipLaunchKernelGGL(sh_grad_from_views_kernel<false>, dim3(nbs), dim3(256), 0, st, P, deg, means3D, V, views.n_views, g_shs, g_shs_rest, accumulate);
+    else hipLaunchKernelGGL(sh_grad_from_views_generic_kernel, dim3(nbk), dim3(256), 0, st, P, M, deg, means3D, V, views.n_views, g_shs, g_shs_rest, accumulate);
     return hipGetLastError();
 }
 

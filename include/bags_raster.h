@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BAGS_ABI_VERSION 9
+#define BAGS_ABI_VERSION 10
 #define BAGS_TILE 16
 
 enum { BAGS_OK = 0, BAGS_ERR_ARG = -1, BAGS_ERR_HIP = -2, BAGS_ERR_SIZE = -3, BAGS_ERR_DEVICE = -4 };
@@ -159,6 +159,14 @@ typedef struct BagsBackwardArgs {
      * second half of view k-1 (an event between two calls) while its first half -- 85 % of the backward's time -- does not. */
     int32_t phase;
     int32_t reserved2;               /* 0 */
+    /* (ABI 10) Factored SH gradient, for steps that differentiate SEVERAL views into the same Gaussians.  dL/dshs of one view is an
+     * outer product per Gaussian -- basis(direction from that view's camera) x dL/dcolour, 16 x 3 floats made of 3 -- and writing
+     * (and, with `accumulate`, first reading) that 192-byte row is two thirds of the per-Gaussian half's traffic.  With grad_dldc
+     * non-NULL (and grad_shs / grad_shs_rest NULL) the backward writes only the (P,3) dL/dcolour (after the colour clamp; zero for a
+     * culled Gaussian) here; bags_sh_gradient_from_views then forms the gradient rows of ALL the step's views in one pass, reading
+     * 12 bytes per Gaussian and view and writing each row once.  Same products, added in view order: bit-identical to V backwards
+     * with `accumulate`.  SH colour path only (inputs.shs given). */
+    float* grad_dldc;
 } BagsBackwardArgs;
 
 /* integer artefacts for bit-exact parity checks (all device pointers, any may be NULL) */
@@ -217,6 +225,22 @@ int bags_forward_finish_speculative(const BagsSettings*, const BagsInputs*, cons
                                     int64_t capacity, void* stream);
 /* Backward of the whole op from dL/dimage. */
 int bags_backward(const BagsSettings*, const BagsInputs*, const BagsState*, const BagsBackwardArgs*, void* stream);
+
+/* (ABI 10) The SH-gradient rows of up to BAGS_MAX_SH_VIEWS views of one step from their factored form (BagsBackwardArgs.grad_dldc):
+ *   grad_shs[g][t][c] (+)= sum over the views v, in order, of basis_t(normalize(means3D[g] - campos_v)) * dldc_v[g][c]
+ * for the active degree's coefficients (the others are written as zeros / left as they are when accumulating).  M = coefficients
+ * per Gaussian in grad_shs ((P,M,3)), or -- grad_shs_rest non-NULL -- grad_shs is (P,1,3) and grad_shs_rest (P,M-1,3) (the pair
+ * of BagsInputs.shs_rest).  accumulate != 0: the views are added, in order, to what the buffers hold; else the first view overwrites.
+ * More than BAGS_MAX_SH_VIEWS views: call again with accumulate = 1 for the next batch (the order of the additions is preserved). */
+#define BAGS_MAX_SH_VIEWS 16
+typedef struct BagsShViews {
+    int32_t n_views;
+    int32_t reserved;
+    const float* campos[BAGS_MAX_SH_VIEWS];   /* (3) each: the campos tensor the view's op call was given */
+    const float* dldc[BAGS_MAX_SH_VIEWS];     /* (P,3) each: that view's BagsBackwardArgs.grad_dldc */
+} BagsShViews;
+int bags_sh_gradient_from_views(int32_t P, int32_t M, int32_t sh_degree, const float* means3D, const BagsShViews* views,
+                                float* grad_shs, float* grad_shs_rest, int32_t accumulate, void* stream);
 
 /* Copies integer artefacts out of the state buffers (parity tests / debugging). */
 int bags_debug_views(const BagsSettings*, const BagsInputs*, const BagsState*, int64_t num_rendered,

@@ -45,7 +45,8 @@ def test_struct_layout_matches_header(lib):
     assert C.sizeof(_lib.BagsInputs) == 8 + 9 * 8 + 8          # + shs_rest (ABI 7)
     assert C.sizeof(_lib.BagsState) == 6 * 8
     assert C.sizeof(_lib.BagsForwardOut) == 5 * 8
-    assert C.sizeof(_lib.BagsBackwardArgs) == 4 * 8 + 14 * 8 + 8 + 8 + 8 + 8  # + binning_capacity (ABI 4), accumulate + dense_per_tile (ABI 6 / 8), grad_shs_rest (ABI 7), phase + reserved2 (ABI 9)
+    assert C.sizeof(_lib.BagsBackwardArgs) == 4 * 8 + 14 * 8 + 8 + 8 + 8 + 8 + 8  # + binning_capacity (ABI 4), accumulate + dense_per_tile (ABI 6 / 8), grad_shs_rest (ABI 7), phase + reserved2 (ABI 9), grad_dldc (ABI 10)
+    assert C.sizeof(_lib.BagsShViews) == 8 + 2 * 16 * 8                         # (ABI 10)
     assert C.sizeof(_lib.BagsDebugViews) == 8 * 8
 
 
@@ -72,6 +73,26 @@ def test_backward_phase_is_validated(lib):
     a.grad_color, a.workspace, a.workspace_bytes, a.phase = addr, addr, 1 << 40, 3
     rc = lib.bags_backward(C.byref(s), C.byref(i), C.byref(st), C.byref(a), None)
     assert rc == -1 and b"phase" in lib.bags_last_error(), (rc, lib.bags_last_error())
+
+
+def test_factored_sh_gradient_arguments_are_validated(lib):
+    """ABI 10: bags_sh_gradient_from_views / BagsBackwardArgs.grad_dldc argument errors (reported before anything is enqueued)."""
+    buf = (C.c_char * 4096)()
+    addr = C.addressof(buf)
+    v = _lib.BagsShViews()
+    v.n_views = 17
+    assert lib.bags_sh_gradient_from_views(10, 16, 3, addr, C.byref(v), addr, None, 0, None) == -1 and b"n_views" in lib.bags_last_error()
+    v.n_views = 1
+    assert lib.bags_sh_gradient_from_views(10, 4, 3, addr, C.byref(v), addr, None, 0, None) == -1 and b"coefficients" in lib.bags_last_error()
+    assert lib.bags_sh_gradient_from_views(10, 16, 3, addr, C.byref(v), addr, None, 0, None) == -1 and b"NULL campos" in lib.bags_last_error()
+    assert lib.bags_sh_gradient_from_views(0, 16, 3, None, C.byref(v), None, None, 0, None) == 0          # nothing to do
+    # grad_dldc together with grad_shs: refused
+    s = _lib.BagsSettings(16, 16, 0.5, 0.5, 1.0, 0, 1, 0, 0, 0, 1, 0, 0, 0, addr, addr, addr, addr, addr)
+    i = _lib.BagsInputs(4, addr, None, None, addr, None, addr, addr, addr, None, None)
+    st = _lib.BagsState(addr, 1 << 40, addr, 1 << 40, addr, 1 << 40)
+    a = _lib.BagsBackwardArgs()
+    a.grad_color, a.workspace, a.workspace_bytes, a.grad_shs, a.grad_dldc = addr, addr, 1 << 40, addr, addr
+    assert lib.bags_backward(C.byref(s), C.byref(i), C.byref(st), C.byref(a), None) == -1 and b"grad_dldc" in lib.bags_last_error()
 
 
 def test_operator_api_surface_and_argument_errors():

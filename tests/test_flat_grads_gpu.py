@@ -268,3 +268,103 @@ def test_backward_twice_on_one_forward_and_forward_without_backward():
     (d1, _) = grads(True, False)
     for x, y in zip(a1, d1):
         assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,deg,split,P", [(16, 3, False, 3001), (16, 3, True, 3001), (16, 1, True, 700), (9, 2, False, 515), (4, 1, True, 130)])
+def test_factored_sh_gradient_equals_the_accumulated_one(M, deg, split, P):
+    """ABI 10: rasterizer.FactoredSH.  Every view's backward writes only dL/dcolour (P,3); finish() forms the SH-gradient rows of the
+    whole step in one kernel.  Same products (basis at the view's direction x dL/dcolour), added in view order: the result must be
+    bit for bit what the same backwards leave with ACCUMULATE_IN_PLACE (and with autograd's own accumulation) -- for the concatenated
+    (P,M,3) tensor and for the features_dc / features_rest pair, M = 16 (whole-line kernel) and smaller M (row kernel), an active
+    degree below the stored one, P not a multiple of the workgroup's 128 Gaussians, a second step accumulating on top of the first;
+    every other gradient untouched by the switch."""
+    import math
+    from bags_raster import GaussianRasterizationSettings, GaussianRasterizer, rasterizer as R
+    from bags_raster.synth import sphere_views, synth_scene
+    from scenes import camera_tensors
+    dev = torch.device("cuda")
+    W, H, V = 176, 128, 3
+    g = torch.Generator().manual_seed(M * 100 + deg)
+    scene = synth_scene(P, 11, 1.5, 3)
+    scene["shs"] = (torch.randn(P, M, 3, generator=g) * 0.3)
+    cams = sphere_views(V, W, H, noise=0.05)
+    cots = [torch.randn(3, H, W, generator=torch.Generator().manual_seed(30 + v)).to(dev) for v in range(V)]
+
+    def run(factored, steps=2):
+        saved = (R.ACCUMULATE_IN_PLACE, R.FACTORED_SH)
+        R.ACCUMULATE_IN_PLACE = True
+        try:
+            leaves = {k: v.to(dev).clone().requires_grad_(True) for k, v in scene.items() if k != "shs"}
+            if split:
+                dc = scene["shs"][:, :1].contiguous().to(dev).requires_grad_(True)
+                rest = scene["shs"][:, 1:].contiguous().to(dev).requires_grad_(True)
+            else:
+                dc, rest = scene["shs"].to(dev).clone().requires_grad_(True), None
+            per_view = []
+            for step in range(steps):                           # the second step accumulates on top of the first one's gradients
+                fs = R.FactoredSH() if factored else None
+                R.FACTORED_SH = fs
+                for cam, cot in zip(cams, cots):
+                    ct = {k: t.clone().requires_grad_(True) for k, t in camera_tensors(cam, dev).items()}
+                    st = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+                                                       bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=ct["viewmatrix"],
+                                                       projmatrix=ct["projmatrix"], intrinsic=ct["intrinsic"], sh_degree=deg, campos=ct["campos"])
+                    img = GaussianRasterizer(st)(means3D=leaves["means3D"], means2D=torch.zeros(P, 3, device=dev, requires_grad=True), shs=dc, shs_rest=rest,
+                                                 opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"])[0]
+                    img.backward(cot)
+                    per_view.append({k: t.grad.clone() for k, t in ct.items()})
+                R.FACTORED_SH = None
+                if fs is not None:
+                    assert dc.grad is None or step > 0                       # nothing reaches the SH parameters before finish()
+                    fs.finish(leaves["means3D"], dc, rest)
+            out = {k: v.grad.clone() for k, v in leaves.items()}
+            out["dc"] = dc.grad.clone()
+            if rest is not None:
+                out["rest"] = rest.grad.clone()
+            return out, per_view
+        finally:
+            R.ACCUMULATE_IN_PLACE, R.FACTORED_SH = saved
+    g_ref, pv_ref = run(False)
+    g_fac, pv_fac = run(True)
+    for k in g_ref:
+        assert torch.equal(g_ref[k], g_fac[k]), (k, float((g_ref[k] - g_fac[k]).abs().max()))
+    for a, b in zip(pv_ref, pv_fac):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    assert float(g_ref["dc"].abs().max()) > 0
+
+
+@pytest.mark.gpu
+def test_view_sharded_step_with_factored_sh_equals_the_plain_step():
+    """ViewShardedRenderer(sh_params=...): the rank's views keep their SH gradients factored and one pass forms the step's rows in the
+    bucket's slices before the exchange.  Single process (the exchange is a no-op): every gradient in the bucket bit-identical to the
+    same step without sh_params, the bucket still bound (ONE collective would follow)."""
+    from bags_raster import GaussianRasterizer
+    from bags_raster.sharding import ViewShardedRenderer
+    from bags_raster.synth import sphere_views
+    dev = torch.device("cuda", 0)
+    scene, _ = make_case(4000, 192, 128, 1.5, 3, seed=23)
+    cams = sphere_views(3, 192, 128, noise=0.05)
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+    cot = torch.randn(3, 128, 192, generator=torch.Generator().manual_seed(4)).to(dev)
+
+    def run(factored):
+        leaves = {k: v.to(dev).clone().requires_grad_(True) for k, v in scene.items()}
+        P = leaves["means3D"].shape[0]
+
+        def render_fn(cam):
+            img = GaussianRasterizer(hip_settings(cam, 3, dev))(
+                means3D=leaves["means3D"], means2D=torch.zeros(P, 3, device=dev, requires_grad=True), means2D_densify=None, shift_factors=None,
+                shs=leaves["shs"], colors_precomp=None, opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"],
+                cov3D_precomp=None)[0]
+            return (img * cot).sum()
+        r = ViewShardedRenderer([leaves[k] for k in names], render_fn,
+                                sh_params=(leaves["means3D"], leaves["shs"]) if factored else None)
+        for _ in range(2):                                          # second step: the bucket is zeroed and bound again
+            out = r.step(cams)
+        assert r.reducer.bucket.bound() and out["views"] == [0, 1, 2]
+        return {k: leaves[k].grad.clone() for k in names}
+    a, b = run(False), run(True)
+    for k in names:
+        assert torch.equal(a[k], b[k]), k
