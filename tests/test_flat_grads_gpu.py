@@ -152,8 +152,8 @@ def test_views_accumulate_in_place_like_autograd():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_streams", [1, 2, 3])
-def test_views_on_several_streams_accumulate_in_view_order(n_streams):
+@pytest.mark.parametrize("n_streams,factored", [(1, False), (2, False), (3, False), (2, True)])
+def test_views_on_several_streams_accumulate_in_view_order(n_streams, factored):
     """ABI 9: bags_backward in two halves (BagsBackwardArgs.phase) + rasterizer.AccumulationGate.  The views of one step run on
     n_streams streams with their gradients accumulating in place; the per-Gaussian half of every backward waits for the one before
     it, so the sums are formed in the order the backwards were CALLED in -- bit for bit what the same calls give on ONE stream without a
@@ -170,7 +170,7 @@ def test_views_on_several_streams_accumulate_in_view_order(n_streams):
     cots = [torch.randn(3, H, W, generator=torch.Generator().manual_seed(20 + v)).to(dev) for v in range(V)]
     base = {k: v.to(dev) for k, v in scene.items()}
 
-    def run(streams, gate):
+    def run(streams, gate, factored_sh=False):
         saved = (R.ACCUMULATE_IN_PLACE, R.ACCUMULATION_GATE, R.HOST_WAIT)
         R.ACCUMULATE_IN_PLACE, R.ACCUMULATION_GATE = True, gate
         try:
@@ -183,6 +183,8 @@ def test_views_on_several_streams_accumulate_in_view_order(n_streams):
                 for p in leaves.values():
                     p.grad = None
                 per_view = []
+                fs = R.FactoredSH() if factored_sh else None         # (with the gate: finish() waits for the views' streams itself)
+                R.FACTORED_SH = fs
                 for s in streams:
                     s.wait_stream(cur)
                 for v, (cam, cot) in enumerate(zip(cams, cots)):
@@ -197,6 +199,9 @@ def test_views_on_several_streams_accumulate_in_view_order(n_streams):
                                                      scales=leaves["scales"], rotations=leaves["rotations"])[0]
                         img.backward(cot)
                         per_view.append((ct, m2))
+                R.FACTORED_SH = None
+                if fs is not None:
+                    fs.finish(leaves["means3D"], leaves["shs"])
                 for s in streams:
                     cur.wait_stream(s)
                 torch.cuda.synchronize()
@@ -204,9 +209,10 @@ def test_views_on_several_streams_accumulate_in_view_order(n_streams):
                     [{**{k: t.grad.clone() for k, t in ct.items()}, "means2D": m2.grad.clone()} for ct, m2 in per_view])
         finally:
             R.ACCUMULATE_IN_PLACE, R.ACCUMULATION_GATE, R.HOST_WAIT = saved
+            R.FACTORED_SH = None
     g_ref, pv_ref = run([torch.cuda.current_stream()], None)
     streams = [torch.cuda.current_stream()] if n_streams == 1 else [torch.cuda.Stream() for _ in range(n_streams)]
-    g_new, pv_new = run(streams, R.AccumulationGate())
+    g_new, pv_new = run(streams, R.AccumulationGate(), factored_sh=factored)
     for k in g_ref:
         assert torch.equal(g_ref[k], g_new[k]), k
     for a, b in zip(pv_ref, pv_new):
